@@ -1,0 +1,183 @@
+"""Golden-case definitions + deterministic input generators (numpy only).
+
+Shared by make_golden.py (reference side, build container only) and the parity tests
+(oracle side / HIP side, anywhere).  Inputs are pure functions of the case dict, so the
+.npz fixtures hold expected outputs only.
+"""
+import numpy as np
+
+from oracle import weights as W
+from oracle.qwen3_ref import Qwen3Cfg
+
+
+def trim_like(g):
+    """Fixture-size rule shared by generator and tests: 2-D arrays above 16384 elements keep rows [:32]."""
+    g = np.asarray(g)
+    if g.ndim == 2 and g.size > 16384:
+        return g[:32].copy()
+    return g.copy()
+
+
+def _unit_rows(name, shape, seed):
+    x = W.normal(name, shape, seed, std=1.0)
+    return (x / np.linalg.norm(x, axis=-1, keepdims=True)).astype(np.float32)
+
+
+# ------------------------------------------------------------------ item Q-Former -------------
+def item_inputs(case):
+    """field_embeddings [B,F,E] unit-norm rows; masks cover: all-ones (row 0), fully masked with
+    zero vectors (row 1: what padded history slots look like, train_item_individual_token_joint.py:
+    568-575), fully masked with NON-zero vectors (row 2: SURVEY I3 uniform-softmax probe),
+    non-contiguous partial masks (rest); masked fields of rows >=3 are exact zeros
+    (models/qformer_utils.py:116)."""
+    c, s = case["cfg"], case["seed"]
+    B, Fn, E = case["B"], c["F"], c["E"]
+    x = _unit_rows("item/x", (B, Fn, E), s)
+    mask = (W.uniform("item/mask", (B, Fn), s, 0, 1) < 0.7).astype(np.int64)
+    mask[:, 0] |= (mask.sum(1) == 0)
+    mask[0] = 1
+    if B > 2:
+        mask[1] = 0
+        mask[2] = 0
+    for b in range(B):
+        if b != 2:
+            x[b][mask[b] == 0] = 0.0
+    return x, mask
+
+
+def triplet_reps(case):
+    c, s = case["cfg"], case["seed"]
+    return (W.normal("item/pos", (case["B"], c["E"]), s, std=0.05),
+            W.normal("item/neg", (case["B"], c["E"]), s, std=0.05))
+
+
+def item_grad_keys(c, heads=True):
+    L = c["L"]
+    last_cross = max(i for i in range(L) if i % 2 == 0)
+    keys = ["query_embeddings",
+            "qformer.embeddings.LayerNorm.weight",
+            "qformer.encoder.layer.0.attention.self.query.weight",
+            "qformer.encoder.layer.0.attention.self.key.bias",
+            "qformer.encoder.layer.0.attention.output.LayerNorm.bias",
+            "qformer.encoder.layer.0.crossattention.self.key.weight",
+            f"qformer.encoder.layer.{last_cross}.crossattention.self.value.weight",
+            f"qformer.encoder.layer.{last_cross}.crossattention.output.dense.weight",
+            f"qformer.encoder.layer.{L - 1}.intermediate_query.dense.weight",
+            f"qformer.encoder.layer.{L - 1}.output_query.dense.bias",
+            f"qformer.encoder.layer.{L - 1}.output_query.LayerNorm.weight"]
+    if heads:
+        keys += ["item_representation_head.weight", "reconstruction_head.weight", "reconstruction_head.bias",
+                 "field_projection.weight", "field_projection.bias"]
+    return keys
+
+
+# ------------------------------------------------------------------ user Q-Former -------------
+def user_inputs(case):
+    """tokens [B,T,E] ~ 0.8*N(0,1), ragged right-padded masks (float, as the
+    reference's collate builds them, training/user_qformer_training.py:155-161), padded rows zero."""
+    c, s = case["cfg"], case["seed"]
+    B, T, E = case["B"], case["T"], c["E"]
+    x = W.normal("user/x", (B, T, E), s, std=0.8)
+    lens = np.maximum(1, (W.uniform("user/len", (B,), s, 0.3, 1.0) * T).astype(np.int64))
+    lens[0] = T
+    mask = (np.arange(T)[None, :] < lens[:, None]).astype(np.float32)
+    x = x * mask[..., None]
+    tgt = W.normal("user/tgt", (B, c["n_pred"], E), s, std=0.8)
+    return x, mask, tgt
+
+
+def user_grad_keys(c):
+    L = c["L"]
+    return ["query_embeddings",
+            "qformer.encoder.layer.0.crossattention.self.key.weight",
+            f"qformer.encoder.layer.{L - 1}.crossattention.self.query.weight",
+            f"qformer.encoder.layer.{L - 1}.crossattention.self.value.bias",
+            f"qformer.encoder.layer.{L - 1}.output_query.dense.weight",
+            "prediction_head.0.weight", "prediction_head.2.weight", "prediction_head.3.bias"]
+
+
+# ------------------------------------------------------------------ joint ----------------------
+def qwen_cfg(case) -> Qwen3Cfg:
+    q = case["qwen"]
+    return Qwen3Cfg(hidden_size=q["D"], num_hidden_layers=q["L"], num_attention_heads=q["nq"],
+                    num_key_value_heads=q["nkv"], head_dim=q["hd"], intermediate_size=q["I"],
+                    vocab_size=q["vocab"], rope_theta=1e6, rms_norm_eps=1e-6)
+
+
+def _padding_mask(name, B, S, seed, side):
+    npad = (W.uniform(name, (B,), seed, 0.0, 0.3) * S).astype(np.int64)
+    npad[0] = 0
+    am = np.ones((B, S), dtype=np.int64)
+    for b in range(B):
+        if npad[b]:
+            if side == "left":
+                am[b, :npad[b]] = 0
+            else:
+                am[b, S - npad[b]:] = 0
+    return am
+
+
+def joint_inputs(case):
+    """Batch layout of MultiModalDataCollator (:295-323): input_ids with each special token exactly
+    once in the non-pad region, attention_mask, history field embeddings/masks (some history slots
+    fully masked zeros, :568-575), positive, negatives, negative_masks."""
+    c, s = case["cfg"], case["seed"]
+    B, S, hist, Qi = case["B"], case["S"], case["hist"], c["Q"]
+    first = case["first_special_id"]
+    am = _padding_mask("joint/pad", B, S, s, case["pad_side"])
+    ids = (W.uniform("joint/ids", (B, S), s, 0, 1) * first).astype(np.int64).clip(0, first - 1)
+    for b in range(B):
+        real = np.nonzero(am[b])[0]
+        rng = np.random.Generator(np.random.Philox(key=s * 1000 + b))
+        slots = rng.choice(real, size=hist * Qi, replace=False)
+        for t, p in enumerate(slots):
+            ids[b, p] = first + t
+    if case.get("drop_one_special", False):     # truncated prompt: a special token that never appears
+        ids[B - 1][ids[B - 1] == first + hist * Qi - 1] = 1
+    x = _unit_rows("joint/hfe", (B, hist, c["F"], c["E"]), s)
+    hmask = (W.uniform("joint/hmask", (B, hist, c["F"]), s, 0, 1) < 0.8).astype(np.int64)
+    hmask[..., 0] = 1
+    hmask[1:, hist - 1, :] = 0                    # padded history slot
+    x = x * hmask[..., None]
+    pos = _unit_rows("joint/pos", (B, case["D"]), s)
+    neg = _unit_rows("joint/neg", (B, case["N"], case["D"]), s)
+    nmask = np.ones((B, case["N"]), dtype=bool)
+    nmask[B - 1, case["N"] - 2:] = False
+    neg[B - 1, case["N"] - 2:] = 0.0
+    return ids, am, x.astype(np.float32), hmask, pos, neg, nmask
+
+
+def qwen_inputs(case):
+    q, s = case["qwen"], case["seed"]
+    x = W.normal("qwen/x", (case["B"], case["S"], q["D"]), s, std=0.05)
+    am = _padding_mask("qwen/pad", case["B"], case["S"], s, case["pad_side"])
+    return x, am
+
+
+def qwen_grad_keys():
+    return ["layers.0.self_attn.q_proj.weight", "layers.0.self_attn.k_norm.weight",
+            "layers.1.mlp.down_proj.weight", "layers.1.input_layernorm.weight", "norm.weight"]
+
+
+# ------------------------------------------------------------------ case table ----------------
+_TINYQ = dict(D=256, L=2, nq=4, nkv=2, hd=128, I=512, vocab=96)
+
+ALL = {
+    # BASELINE configs[0] exactly (C1): L2 Q4 H256 nh4 I1024 F8 E256 B16
+    "item_c1": dict(kind="item", seed=11, B=16, cfg=dict(H=256, L=2, nh=4, I=1024, Q=4, F=8, E=256)),
+    # shrunken C2: cross layers {0,2}, plain layer 1, Q=32, F=14, E != H
+    "item_c2s": dict(kind="item", seed=12, B=4, cfg=dict(H=128, L=3, nh=2, I=512, Q=32, F=14, E=256)),
+    # joint-shaped item Q-Former: Q=2 (C4's Q_item)
+    "item_q2": dict(kind="item", seed=13, B=6, cfg=dict(H=128, L=2, nh=2, I=256, Q=2, F=14, E=128)),
+    # shrunken C3: cross every layer, Q=64, ragged T
+    "user_t96": dict(kind="user", seed=21, B=3, T=96, cfg=dict(H=128, L=2, nh=2, I=256, Q=64, E=128, n_pred=4)),
+    "user_t8": dict(kind="user", seed=22, B=2, T=8, cfg=dict(H=128, L=2, nh=2, I=256, Q=64, E=192, n_pred=2)),
+    # Qwen3 decoder alone, right padding (no fully-masked query rows) and left padding
+    "qwen_right": dict(kind="qwen", seed=31, B=3, S=40, pad_side="right", qwen=_TINYQ),
+    "qwen_left": dict(kind="qwen", seed=32, B=3, S=40, pad_side="left", qwen=_TINYQ),
+    # joint: item Q-Former (H == D) -> injection -> Qwen3 -> mean-pool -> InfoNCE / MRR
+    "joint_right": dict(kind="joint", seed=41, B=3, S=48, hist=3, N=7, D=256, first_special_id=90, pad_side="right",
+                        cfg=dict(H=256, L=2, nh=4, I=512, Q=2, F=5, E=192), qwen=_TINYQ, drop_one_special=True),
+    "joint_left": dict(kind="joint", seed=42, B=3, S=48, hist=3, N=7, D=256, first_special_id=90, pad_side="left",
+                       cfg=dict(H=256, L=2, nh=4, I=512, Q=2, F=5, E=192), qwen=_TINYQ),
+}
