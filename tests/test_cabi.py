@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library builds, loads and exports exactly what include/unirec_hip.h declares
+(no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+from unirec_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "unirec_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ur_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_bound_and_exported():
+    names = _declared()
+    assert "ur_gemm" in names and "ur_version" in names
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in unirec_hip.h but not exported by libunirec_hip.so"
+        assert n in _lib.SIGNATURES, f"{n} declared in unirec_hip.h but not bound in unirec_amd/_lib.py"
+    extra = set(_lib.SIGNATURES) - set(names)
+    assert not extra, f"bound but not declared in the header: {extra}"
+
+
+def test_loader_binds_and_reports_version():
+    lib = _lib.load()
+    assert lib.ur_version() == _lib.ABI_VERSION
+    assert isinstance(lib.ur_last_error(), bytes)
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    """Argument validation happens on the host before any launch, so it is testable here."""
+    lib = _lib.load()
+    a = _lib.GemmArgs()
+    a.M, a.N, a.K = 8, 8, 12          # K not a multiple of 8
+    a.R = a.S = a.C = 256
+    a.ldr = a.lds = 16
+    a.ldc = 8
+    a.r_kcontig = a.s_kcontig = 1
+    rc = lib.ur_gemm(ctypes.byref(a), None, 0, None)
+    assert rc < 0 and b"multiples of 8" in lib.ur_last_error()
+    assert lib.ur_layernorm_fwd(None, 1, None, None, None, None, None, None, None, 4, 12, 1e-5, 0.0, 0, 0.0, 0, None) < 0
+
+
+def test_product_path_has_no_oracle_import():
+    """The oracle is test infrastructure: nothing under unirec_amd/ may import it."""
+    pkg = os.path.join(ROOT, "unirec_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)

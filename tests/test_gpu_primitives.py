@@ -1,0 +1,224 @@
+"""GPU: every primitive of the C ABI against a plain PyTorch fp32 reference of the same op.
+Integer-valued operands make the MFMA layout checks EXACT (a wrong fragment map cannot hide)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from unirec_amd import hip  # noqa: E402
+
+DEV = "cuda"
+
+
+def _ints(shape, lo=-3, hi=4, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).to(torch.float32)
+
+
+def _randn(shape, seed=0, std=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(shape, generator=g) * std
+
+
+def _bf(x):
+    return x.to(DEV).to(torch.bfloat16).contiguous()
+
+
+def _ref_gemm(Rm, Sm):  # Rm [M,K], Sm [N,K] (logical), fp32
+    return Rm.double() @ Sm.double().t()
+
+
+LAYOUTS = [(True, True), (True, False), (False, False), (False, True)]
+SHAPES = [(128, 128, 64), (256, 384, 128), (200, 136, 72), (64, 16, 1024), (1000, 48, 256), (8, 8, 8),
+          (384, 1024, 4096), (130, 260, 200)]
+
+
+@pytest.mark.parametrize("rk,sk", LAYOUTS)
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_exact_integer(M, N, K, rk, sk):
+    if (not rk and M % 8) or (not sk and N % 8):
+        pytest.skip("K-strided operand needs the contiguous dim % 8 == 0")
+    Rm, Sm = _ints((M, K), seed=1), _ints((N, K), seed=2)
+    R = _bf(Rm if rk else Rm.t())
+    S = _bf(Sm if sk else Sm.t())
+    ref = _ref_gemm(Rm, Sm)
+    out32 = hip.gemm(R, S, r_kcontig=rk, s_kcontig=sk, out_f32=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out32.double().cpu(), ref), f"max err {(out32.double().cpu() - ref).abs().max()}"
+    if ref.abs().max() < 256:   # exactly representable in bf16
+        out16 = hip.gemm(R, S, r_kcontig=rk, s_kcontig=sk)
+        assert torch.equal(out16.double().cpu(), ref)
+
+
+@pytest.mark.parametrize("rk,sk", LAYOUTS)
+def test_gemm_random_tolerance(rk, sk):
+    M, N, K = 512, 768, 1024
+    Rm, Sm = _randn((M, K), 3), _randn((N, K), 4, std=0.05)
+    R = _bf(Rm if rk else Rm.t())
+    S = _bf(Sm if sk else Sm.t())
+    Rq = (R if rk else R.t()).float().cpu()
+    Sq = (S if sk else S.t()).float().cpu()
+    ref = _ref_gemm(Rq, Sq)
+    out = hip.gemm(R, S, r_kcontig=rk, s_kcontig=sk, out_f32=True).double().cpu()
+    assert (out - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-4
+
+
+def test_gemm_epilogues():
+    M, N, K = 200, 136, 256
+    Rm, Sm = _randn((M, K), 5), _randn((N, K), 6, std=0.1)
+    R, S = _bf(Rm), _bf(Sm)
+    bias = _randn((N,), 7).to(DEV)
+    res = _bf(_randn((M, N), 8))
+    aux = _bf(_randn((M, N), 9))
+    base = 0.5 * (R.float() @ S.float().t()) + bias
+    # bias + residual + gelu second output
+    g = torch.empty((M, N), dtype=torch.bfloat16, device=DEV)
+    out = hip.gemm(R, S, alpha=0.5, bias=bias, residual=res, gelu_out=g)
+    want = base + res.float()
+    assert torch.allclose(out.float(), want, rtol=1e-2, atol=1e-2)
+    assert torch.allclose(g.float(), torch.nn.functional.gelu(out.float()), rtol=1e-2, atol=1e-2)
+    # multiply by gelu'(aux)
+    out2 = hip.gemm(R, S, alpha=0.5, bias=bias, gelu_grad_aux=aux)
+    a = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(a).sum().backward()
+    assert torch.allclose(out2.float(), base * a.grad, rtol=2e-2, atol=2e-2)
+    # f32 out with bias
+    out3 = hip.gemm(R, S, alpha=0.5, bias=bias, out_f32=True)
+    assert torch.allclose(out3, base, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("rk,sk", [(True, True), (True, False)])
+def test_gemm_second_pair_lora(rk, sk):
+    M, N, K, r = 300, 264, 192, 16
+    Rm, Sm = _ints((M, K), seed=1), _ints((N, K), seed=2)
+    R2m, S2m = _ints((M, r), seed=3), _ints((N, r), seed=4)
+    R, R2 = _bf(Rm), _bf(R2m)
+    S = _bf(Sm if sk else Sm.t())
+    S2 = _bf(S2m if sk else S2m.t())
+    ref = _ref_gemm(Rm, Sm) + _ref_gemm(R2m, S2m)
+    out = hip.gemm(R, S, r_kcontig=rk, s_kcontig=sk, R2=R2, S2=S2, out_f32=True)
+    assert torch.equal(out.double().cpu(), ref)
+
+
+@pytest.mark.parametrize("split", [2, 5, 16])
+def test_gemm_splitk_tn(split):
+    # dW = dY^T X : reduction over the token dim, both operands K-strided
+    Mred, N, Kp = 1000, 136, 264
+    dY, X = _ints((Mred, N), seed=1), _ints((Mred, Kp), seed=2)
+    ref = dY.double().t() @ X.double()
+    out = hip.gemm(_bf(dY), _bf(X), r_kcontig=False, s_kcontig=False, out_f32=True, split_k=split)
+    assert torch.equal(out.double().cpu(), ref)
+    out2 = hip.gemm(_bf(dY), _bf(X), r_kcontig=False, s_kcontig=False, out_f32=True, split_k=split)
+    assert torch.equal(out, out2), "split-K reduction must be deterministic"
+
+
+def test_gemm_rejects_bad_arguments():
+    from unirec_amd._lib import UniRecHipError
+    R, S = _bf(_randn((16, 12))), _bf(_randn((8, 12)))
+    with pytest.raises(UniRecHipError):
+        hip.gemm(R, S)   # K = 12 not a multiple of 8
+
+
+@pytest.mark.parametrize("M,H", [(5, 128), (64, 256), (300, 768), (1000, 1024), (17, 2048)])
+def test_layernorm_fwd_bwd(M, H):
+    y, res = _bf(_randn((M, H), 1)), _bf(_randn((M, H), 2))
+    gamma = (1 + 0.1 * _randn((H,), 3)).to(DEV)
+    beta = (0.1 * _randn((H,), 4)).to(DEV)
+    out, z, mean, rstd = hip.layernorm_fwd(y, gamma, beta, 1e-12, residual=res)
+    zf = (y.float() + res.float()).to(torch.bfloat16).float().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(zf, (H,), gr, br, 1e-12)
+    assert torch.equal(z.float(), zf.detach())
+    assert torch.allclose(out.float(), ref, rtol=1e-2, atol=2e-2)
+    dout = _bf(_randn((M, H), 5))
+    ref.backward(dout.float())
+    dg, db, dbias = (torch.empty(H, device=DEV) for _ in range(3))
+    dz, dy = hip.layernorm_bwd(dout, z, mean, rstd, gamma, dg, db, dbias)
+    assert dy.data_ptr() == dz.data_ptr()
+    assert torch.allclose(dz.float(), zf.grad, rtol=2e-2, atol=2e-2)
+    scale = math.sqrt(M)
+    assert torch.allclose(dg, gr.grad, rtol=1e-2, atol=2e-2 * scale)
+    assert torch.allclose(db, br.grad, rtol=1e-2, atol=2e-2 * scale)
+    assert torch.allclose(dbias, dz.float().sum(0), rtol=1e-3, atol=1e-3 * scale)
+
+
+def test_layernorm_broadcast_rows_and_dropout():
+    Q, H, B = 8, 256, 5
+    qe = _bf(_randn((Q, H), 1))
+    gamma, beta = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
+    out, z, mean, rstd = hip.layernorm_fwd(qe, gamma, beta, 1e-12, M=B * Q)
+    ref = torch.nn.functional.layer_norm(qe.float(), (H,))
+    assert torch.allclose(out.float().view(B, Q, H), ref.expand(B, Q, H), rtol=1e-2, atol=2e-2)
+    # dropout: mask is deterministic in (seed, index); kept elements are scaled by 1/(1-p)
+    p = 0.25
+    o1, _, _, _ = hip.layernorm_fwd(qe, gamma, beta, 1e-12, M=B * Q, p_post=p, seed_post=123)
+    o2, _, _, _ = hip.layernorm_fwd(qe, gamma, beta, 1e-12, M=B * Q, p_post=p, seed_post=123)
+    o3, _, _, _ = hip.layernorm_fwd(qe, gamma, beta, 1e-12, M=B * Q, p_post=p, seed_post=124)
+    assert torch.equal(o1, o2) and not torch.equal(o1, o3)
+    kept = o1.float() != 0
+    frac = 1.0 - kept.float().mean().item()
+    assert abs(frac - p) < 0.03
+    assert torch.allclose(o1.float()[kept], (out.float() / (1 - p))[kept], rtol=2e-2, atol=2e-2)
+    # pre-dropout + backward consistency: dy == dz * mask / (1-p)
+    y, res = _bf(_randn((B * Q, H), 2)), _bf(_randn((B * Q, H), 3))
+    o, z, mean, rstd = hip.layernorm_fwd(y, gamma, beta, 1e-12, residual=res, p_pre=p, seed_pre=77)
+    mask_scale = ((z.float() - res.float()) / y.float()).round(decimals=1)   # ~0 or ~1/(1-p)
+    dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    dz, dy = hip.layernorm_bwd(_bf(_randn((B * Q, H), 4)), z, mean, rstd, gamma, dg, db, p_pre=p, seed_pre=77)
+    dropped = mask_scale.abs() < 0.5
+    assert (dy.float()[dropped] == 0).all()
+    assert torch.allclose(dy.float()[~dropped], dz.float()[~dropped] / (1 - p), rtol=2e-2, atol=1e-3)
+
+
+def test_batch_reduce_and_colsum():
+    nb, rows, H = 37, 4, 64
+    x = _bf(_randn((nb * rows, H), 1))
+    out = hip.batch_reduce(x, nb, rows, H)
+    assert torch.allclose(out, x.float().view(nb, rows, H).sum(0), rtol=1e-5, atol=1e-4)
+    y = _bf(_randn((1000, 136), 2))
+    assert torch.allclose(hip.colsum(y), y.float().sum(0), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,D", [(7, 128), (513, 1024), (64, 256)])
+def test_rmsnorm_fwd_bwd(M, D):
+    x = _bf(_randn((M, D), 1))
+    w = (1 + 0.1 * _randn((D,), 2)).to(DEV)
+    out, rstd = hip.rmsnorm_fwd(x, w, 1e-6)
+    xf = x.float().requires_grad_(True)
+    ref = w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6))
+    assert torch.allclose(out.float(), ref, rtol=1e-2, atol=1e-2)
+    dout, add = _bf(_randn((M, D), 3)), _bf(_randn((M, D), 4))
+    ref.backward(dout.float())
+    dx = hip.rmsnorm_bwd(dout, x, w, rstd, add=add)
+    assert torch.allclose(dx.float(), xf.grad + add.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_elementwise_and_adamw():
+    a32 = _randn((1000003,), 1).to(DEV)
+    b = hip.cast_f32_to_bf16(a32)
+    assert torch.equal(b, a32.to(torch.bfloat16))
+    assert torch.equal(hip.cast_bf16_to_f32(b), b.float())
+    x, y = _bf(_randn((4096,), 2)), _bf(_randn((4096,), 3))
+    assert torch.equal(hip.add_bf16(x, y), (x.float() + y.float()).to(torch.bfloat16))
+    M, I = 33, 96
+    gu = _bf(_randn((M, 2 * I), 4))
+    act = hip.swiglu_fwd(gu, I)
+    guf = gu.float().requires_grad_(True)
+    ref = torch.nn.functional.silu(guf[:, :I]) * guf[:, I:]
+    assert torch.allclose(act.float(), ref, rtol=1e-2, atol=1e-2)
+    d = _bf(_randn((M, I), 5))
+    ref.backward(d.float())
+    assert torch.allclose(hip.swiglu_bwd(d, gu, I).float(), guf.grad, rtol=2e-2, atol=2e-2)
+    # AdamW vs torch.optim.AdamW, 3 steps
+    n = 10007
+    p0, gs = _randn((n,), 6).to(DEV), [_randn((n,), 10 + i).to(DEV) for i in range(3)]
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p, m, v = p0.clone(), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for i, g in enumerate(gs):
+        pt.grad = g.clone()
+        opt.step()
+        hip.adamw_step(p, g * 4.0, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, i + 1, grad_scale=0.25)
+    assert torch.allclose(p, pt.detach(), rtol=1e-5, atol=1e-6)

@@ -1,0 +1,87 @@
+"""ctypes binding of libunirec_hip.so (the C ABI declared in include/unirec_hip.h).
+
+Fails loudly: there is no CPU / eager fallback for the product path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libunirec_hip.so")
+ABI_VERSION = 1
+
+c_void_p, c_int, c_i64, c_u64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
+
+
+class GemmArgs(ctypes.Structure):
+    """Mirror of ur_gemm_args (include/unirec_hip.h)."""
+    _fields_ = [("R", c_void_p), ("ldr", c_i64), ("r_kcontig", c_int),
+                ("S", c_void_p), ("lds", c_i64), ("s_kcontig", c_int),
+                ("K", c_int),
+                ("R2", c_void_p), ("ldr2", c_i64), ("S2", c_void_p), ("lds2", c_i64), ("K2", c_int),
+                ("C", c_void_p), ("ldc", c_i64), ("c_f32", c_int),
+                ("M", c_int), ("N", c_int),
+                ("alpha", c_float),
+                ("bias", c_void_p),
+                ("residual", c_void_p), ("ldres", c_i64),
+                ("gelu_out", c_void_p), ("ldg", c_i64),
+                ("gelu_grad_aux", c_void_p), ("ldaux", c_i64),
+                ("split_k", c_int)]
+
+
+# name -> (restype, argtypes).  Every symbol include/unirec_hip.h declares must appear here
+# (tests/test_cabi.py cross-checks the header against this table and the built library).
+SIGNATURES = {
+    "ur_version": (c_int, []),
+    "ur_last_error": (ctypes.c_char_p, []),
+    "ur_gemm_workspace_bytes": (c_i64, [ctypes.POINTER(GemmArgs)]),
+    "ur_gemm": (c_int, [ctypes.POINTER(GemmArgs), c_void_p, c_i64, c_void_p]),
+    "ur_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int, c_int, c_float, c_float, c_u64, c_float, c_u64, c_void_p]),
+    "ur_layernorm_bwd_workspace_bytes": (c_i64, [c_int]),
+    "ur_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_int, c_int, c_float, c_u64, c_float, c_u64, c_void_p, c_i64, c_void_p]),
+    "ur_batch_reduce": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
+    "ur_batch_reduce_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
+    "ur_rmsnorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "ur_rmsnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ur_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
+    "ur_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
+    "ur_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "ur_swiglu_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ur_swiglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ur_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float, c_float,
+                              c_int, c_float, c_void_p]),
+}
+
+_lib = None
+
+
+class UniRecHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UniRecHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C unirec_amd/csrc`).  The UniRec MI355X path has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.ur_version()
+    if v != ABI_VERSION:
+        raise UniRecHipError(f"libunirec_hip.so ABI version {v} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ur_last_error().decode("utf-8", "replace")
+        raise UniRecHipError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,106 @@
+// Shared device/host helpers for the UniRec MI355X (gfx950 / CDNA4) hot-path library.
+// Wave = 64 lanes everywhere; no CUDA compatibility paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+typedef uint16_t bf16_t;   // raw bfloat16 bits (matches torch.bfloat16 storage)
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define UR_WAVE 64
+
+// ---- error plumbing (C ABI: 0 ok, <0 invalid argument, >0 HIP error code) -------------------
+extern thread_local char g_ur_err[512];
+#define UR_FAIL(code, ...)                                   \
+  do {                                                       \
+    snprintf(g_ur_err, sizeof(g_ur_err), __VA_ARGS__);       \
+    return (code);                                           \
+  } while (0)
+#define UR_REQUIRE(cond, ...)                                \
+  do {                                                       \
+    if (!(cond)) UR_FAIL(-1, __VA_ARGS__);                   \
+  } while (0)
+#define UR_CHECK_LAUNCH(name)                                                        \
+  do {                                                                               \
+    hipError_t e_ = hipGetLastError();                                               \
+    if (e_ != hipSuccess) UR_FAIL((int)e_, "%s: launch failed: %s", name, hipGetErrorString(e_)); \
+  } while (0)
+#define UR_ALIGNED16(p) ((((uintptr_t)(p)) & 15) == 0)
+
+// ---- bf16 <-> f32 ---------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  // round-to-nearest-even; NaN stays NaN (guide: integer trick loses NaNs, so guard it)
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// ---- wave / block reductions -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// sum over the lanes that share (lane / W) for power-of-two W <= 64
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int W>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- counter-based RNG for dropout (mask is a pure function of (seed, element index), so the
+// backward regenerates it instead of storing it; independent of grid shape and rank count) ------
+__device__ __forceinline__ uint32_t ur_hash2(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+// keep-probability test: returns scale (1/(1-p)) if kept, 0 if dropped.  thr = p * 2^32.
+__device__ __forceinline__ float ur_dropout_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
+  return (ur_hash2(seed, idx) >= thr) ? inv_keep : 0.0f;
+}
+static inline uint32_t ur_drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  if (t < 0) t = 0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}
+
+// ---- math -------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad_f(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+static inline int ur_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

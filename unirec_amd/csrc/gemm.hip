@@ -1,0 +1,344 @@
+// bf16 MFMA GEMM for every Linear on the hot path (forward, dX and dW), gfx950 only.
+//
+//   C[m][n] = alpha * ( sum_k R(m,k) * S(n,k)  +  sum_k2 R2(m,k2) * S2(n,k2) )   (+ epilogue)
+//
+// R gives C's rows, S gives C's columns.  Each operand is either "K-contiguous" (stored [rows][K],
+// the nn.Linear [out,in] weight layout and the activation layout) or "K-strided" (stored [K][rows]),
+// so all three Linear products run on tensors exactly as they lie in HBM -- no transposed copies:
+//   forward  Y  = X W^T      : R = X  [M,K]  kc ;  S = W  [N,K]  kc
+//   dX       dX = dY W       : R = dY [M,N]  kc ;  S = W  [N(red),K'] k-strided
+//   dW       dW = dY^T X     : R = dY [M(red),N] k-strided ; S = X [M(red),K'] k-strided
+// The second (R2,S2,K2) range is the LoRA low-rank term: R2 = x A^T (rank r), S2 = B, so the
+// B-product is accumulated in the same MFMA accumulators as the base GEMM (no extra pass over Y).
+//
+// Tiling: 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4
+// v_mfma_f32_16x16x32_bf16 tiles.  The weight-side operand S is the MFMA "A" (row) operand and the
+// token-side operand R the "B" (column) operand, so each lane ends up with 4 CONSECUTIVE n for one
+// m: packed 8-byte (bf16) / 16-byte (f32) stores into row-major C.
+// Staging: global -> registers -> LDS, double-buffered, next tile's global loads issued before the
+// current tile's MFMAs (issue-early / write-late).  K-contiguous tiles: 128-B rows with 16-B chunk
+// XOR swizzle (conflict-free ds_read_b128).  K-strided tiles: [k][128] rows padded to 288 B with the
+// k-row slot permutation rho(k) = k ^ ((k>>1)&4), read with ds_read_b64_tr_b16 (hardware
+// transpose) conflict-free.
+#include "common.cuh"
+#include "unirec_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int KC_ROWB = 128;               // K-contiguous tile row bytes (64 bf16)
+constexpr int KC_BYTES = 128 * KC_ROWB;    // 16 KiB
+constexpr int KS_ROWB = 288;               // K-strided tile row bytes (128 bf16 + 32 B pad)
+constexpr int KS_BYTES = BK * KS_ROWB;     // 18 KiB
+
+struct GemmP {
+  const bf16_t* R; const bf16_t* S; long ldr, lds; int K;
+  const bf16_t* R2; const bf16_t* S2; long ldr2, lds2; int K2;
+  void* C; long ldc; int M, N; float alpha;
+  const float* bias; const bf16_t* res; long ldres;
+  bf16_t* gelu_out; long ldg; const bf16_t* aux; long ldaux;
+  int ksplit_len; long slab_stride;
+  int gm, gn;
+};
+
+__device__ __forceinline__ int rho(int k) { return k ^ ((k >> 1) & 4); }
+
+// ---- global -> register staging of one 128 x 64 operand tile (4 x 16 B per thread) -----------
+template <bool KC>
+__device__ __forceinline__ void g2r(uint4 (&v)[4], const bf16_t* __restrict__ base, long ld, int rows_total,
+                                    int row0, int k0, int kend, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int c = tid + i * 256;
+    uint4 z = make_uint4(0, 0, 0, 0);
+    if (KC) {
+      int row = c >> 3, kc = c & 7;
+      int grow = row0 + row, gk = k0 + kc * 8;
+      if (grow < rows_total && gk < kend) z = *reinterpret_cast<const uint4*>(base + (long)grow * ld + gk);
+    } else {
+      int kr = c >> 4, cc = c & 15;
+      int gk = k0 + kr, gcol = row0 + cc * 8;
+      if (gk < kend && gcol < rows_total) z = *reinterpret_cast<const uint4*>(base + (long)gk * ld + gcol);
+    }
+    v[i] = z;
+  }
+}
+
+template <bool KC>
+__device__ __forceinline__ void r2s(const uint4 (&v)[4], char* tile, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int c = tid + i * 256;
+    int off;
+    if (KC) {
+      int row = c >> 3, kc = c & 7;
+      off = row * KC_ROWB + ((kc ^ (row & 7)) << 4);
+    } else {
+      int kr = c >> 4, cc = c & 15;
+      off = rho(kr) * KS_ROWB + cc * 16;
+    }
+    *reinterpret_cast<uint4*>(tile + off) = v[i];
+  }
+}
+
+// ---- LDS -> MFMA fragment: lane holds [idx = base16 + (lane&15)][k = 32*kk + 8*(lane>>4) + 0..7]
+template <bool KC>
+__device__ __forceinline__ bf16x8 lds_frag(const char* tile, int idx0, int kk, int lane) {
+  if (KC) {
+    int idx = idx0 + (lane & 15);
+    int chunk = kk * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(tile + idx * KC_ROWB + ((chunk ^ (idx & 7)) << 4));
+  } else {
+    int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    int ka = kk * 32 + 8 * g + q;
+    int col = idx0 + 4 * pp;
+    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+    const char* pa = tile + rho(ka) * KS_ROWB + col * 2;
+    const char* pb = tile + rho(ka + 4) * KS_ROWB + col * 2;
+    bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pa);
+    bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pb);
+    bf16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+  }
+}
+
+template <bool RK, bool SK, bool OUTF32>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int S_BYTES = SK ? KC_BYTES : KS_BYTES;
+  constexpr int R_BYTES = RK ? KC_BYTES : KS_BYTES;
+  constexpr int STAGE = S_BYTES + R_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // XCD-aware tile order: blocks sharing (id % 8) sit on one XCD (speed only); give each XCD a
+  // contiguous run of tiles, column-tile fastest, so an R panel is re-read from that XCD's L2.
+  const int nwg = p.gm * p.gn;
+  int id = blockIdx.x;
+  {
+    int q = nwg >> 3, r = nwg & 7, x = id & 7;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+  }
+  const int bm = id / p.gn, bn = id - bm * p.gn;
+  const int m0 = bm * BM, n0 = bn * BN;
+  const int z = blockIdx.z;
+
+  int kbeg = z * p.ksplit_len;
+  int kend = min(p.K, kbeg + p.ksplit_len);
+  const int nt1 = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+  const int nt2 = (p.K2 > 0) ? (p.K2 + BK - 1) / BK : 0;
+  const int nt = nt1 + nt2;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 sreg[4], rreg[4];
+  auto load_tile = [&](int t) {
+    if (t < nt1) {
+      int k0 = kbeg + t * BK;
+      g2r<SK>(sreg, p.S, p.lds, p.N, n0, k0, kend, tid);
+      g2r<RK>(rreg, p.R, p.ldr, p.M, m0, k0, kend, tid);
+    } else {
+      int k0 = (t - nt1) * BK;
+      g2r<SK>(sreg, p.S2, p.lds2, p.N, n0, k0, p.K2, tid);
+      g2r<RK>(rreg, p.R2, p.ldr2, p.M, m0, k0, p.K2, tid);
+    }
+  };
+
+  if (nt > 0) {
+    load_tile(0);
+    r2s<SK>(sreg, smem, tid);
+    r2s<RK>(rreg, smem + S_BYTES, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const char* sb = smem + (t & 1) * STAGE;
+    const char* rb = sb + S_BYTES;
+    if (t + 1 < nt) load_tile(t + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 sf[4], rf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sf[i] = lds_frag<SK>(sb, wc * 64 + i * 16, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rf[j] = lds_frag<RK>(rb, wr * 64 + j * 16, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[i], rf[j], acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) {
+      char* nb = smem + ((t + 1) & 1) * STAGE;
+      r2s<SK>(sreg, nb, tid);
+      r2s<RK>(rreg, nb + S_BYTES, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds n = n0 + wc*64 + i*16 + (lane>>4)*4 + 0..3, m = m0 + wr*64 + j*16 + (lane&15)
+  const int nq = (lane >> 4) * 4, ml = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + wc * 64 + i * 16 + nq;
+    if (n >= p.N) continue;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+      b4[0] = bb.x; b4[1] = bb.y; b4[2] = bb.z; b4[3] = bb.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wr * 64 + j * 16 + ml;
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha + b4[e];
+      if (OUTF32) {
+        float* c = reinterpret_cast<float*>(p.C) + (long)z * p.slab_stride + (long)m * p.ldc + n;
+        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        if (p.res) {
+          const uint2 r = *reinterpret_cast<const uint2*>(p.res + (long)m * p.ldres + n);
+          v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
+        }
+        if (p.aux) {
+          const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
+          v[0] *= gelu_erf_grad_f(bf_lo(a.x)); v[1] *= gelu_erf_grad_f(bf_hi(a.x));
+          v[2] *= gelu_erf_grad_f(bf_lo(a.y)); v[3] *= gelu_erf_grad_f(bf_hi(a.y));
+        }
+        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
+        *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        if (p.gelu_out) {
+          // GELU of the bf16-ROUNDED pre-activation, so backward's gelu'(u) sees the same u
+          float u0 = bf2f(f2bf(v[0])), u1 = bf2f(f2bf(v[1])), u2 = bf2f(f2bf(v[2])), u3 = bf2f(f2bf(v[3]));
+          bf16_t* g = p.gelu_out + (long)m * p.ldg + n;
+          *reinterpret_cast<uint2*>(g) = make_uint2(pack_bf2(gelu_erf_f(u0), gelu_erf_f(u1)),
+                                                     pack_bf2(gelu_erf_f(u2), gelu_erf_f(u3)));
+        }
+      }
+    }
+  }
+}
+
+// deterministic split-K combine: C[m][n] = sum_z slab[z][m][n]  (f32, vectorised)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, long total4, long slab4,
+                                     int splits) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float4* w4 = reinterpret_cast<const float4*>(ws);
+  float4* c4 = reinterpret_cast<float4*>(C);
+  for (; i < total4; i += stride) {
+    float4 a = w4[i];
+    for (int z = 1; z < splits; ++z) {
+      float4 b = w4[i + (long)z * slab4];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    c4[i] = a;
+  }
+}
+
+template <bool RK, bool SK, bool OUTF32>
+int launch(const GemmP& p, int splits, hipStream_t st) {
+  constexpr int S_BYTES = SK ? KC_BYTES : KS_BYTES;
+  constexpr int R_BYTES = RK ? KC_BYTES : KS_BYTES;
+  constexpr int SMEM = 2 * (S_BYTES + R_BYTES);
+  static bool attr_set = false;   // idempotent; a race only repeats the call
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RK, SK, OUTF32>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) UR_FAIL((int)e, "ur_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  dim3 grid(p.gm * p.gn, 1, splits);
+  hipLaunchKernelGGL((gemm_kernel<RK, SK, OUTF32>), grid, dim3(256), SMEM, st, p);
+  UR_CHECK_LAUNCH("ur_gemm");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t ur_gemm_workspace_bytes(const ur_gemm_args* a) {
+  if (!a || a->split_k <= 1) return 0;
+  return (int64_t)a->split_k * a->M * a->ldc * (int64_t)sizeof(float);
+}
+
+extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, void* stream) {
+  UR_REQUIRE(a != nullptr, "ur_gemm: null args");
+  UR_REQUIRE(a->M >= 0 && a->N >= 0 && a->K >= 0 && a->K2 >= 0, "ur_gemm: negative dimension");
+  if (a->M == 0 || a->N == 0) return 0;
+  UR_REQUIRE(a->R && a->S && a->C, "ur_gemm: null operand");
+  UR_REQUIRE((a->K % 8) == 0 && (a->K2 % 8) == 0, "ur_gemm: K (%d) and K2 (%d) must be multiples of 8", a->K, a->K2);
+  UR_REQUIRE((a->N % 4) == 0 && (a->ldc % 4) == 0, "ur_gemm: N (%d) and ldc (%ld) must be multiples of 4", a->N, (long)a->ldc);
+  UR_REQUIRE((a->ldr % 8) == 0 && (a->lds % 8) == 0, "ur_gemm: ldr/lds must be multiples of 8 elements");
+  UR_REQUIRE(a->r_kcontig || (a->M % 8) == 0, "ur_gemm: K-strided R needs M %% 8 == 0 (M=%d)", a->M);
+  UR_REQUIRE(a->s_kcontig || (a->N % 8) == 0, "ur_gemm: K-strided S needs N %% 8 == 0 (N=%d)", a->N);
+  UR_REQUIRE(UR_ALIGNED16(a->R) && UR_ALIGNED16(a->S) && UR_ALIGNED16(a->C), "ur_gemm: operands must be 16-byte aligned");
+  UR_REQUIRE(a->ldr >= (a->r_kcontig ? a->K : a->M) && a->lds >= (a->s_kcontig ? a->K : a->N) && a->ldc >= a->N,
+             "ur_gemm: leading dimension smaller than row length");
+  if (a->K2 > 0) {
+    UR_REQUIRE(a->R2 && a->S2 && UR_ALIGNED16(a->R2) && UR_ALIGNED16(a->S2), "ur_gemm: bad second operand pair");
+    UR_REQUIRE((a->ldr2 % 8) == 0 && (a->lds2 % 8) == 0, "ur_gemm: ldr2/lds2 must be multiples of 8");
+    UR_REQUIRE(a->ldr2 >= (a->r_kcontig ? a->K2 : a->M) && a->lds2 >= (a->s_kcontig ? a->K2 : a->N),
+               "ur_gemm: second-pair leading dimension too small");
+  }
+  const int splits = a->split_k > 1 ? a->split_k : 1;
+  if (splits > 1) {
+    UR_REQUIRE(a->c_f32 && !a->bias && !a->residual && !a->gelu_out && !a->gelu_grad_aux && a->K2 == 0,
+               "ur_gemm: split_k needs f32 output and no epilogue / second pair");
+    UR_REQUIRE(workspace && workspace_bytes >= ur_gemm_workspace_bytes(a) && UR_ALIGNED16(workspace),
+               "ur_gemm: split_k workspace too small (%lld < %lld)", (long long)workspace_bytes,
+               (long long)ur_gemm_workspace_bytes(a));
+  }
+  if (a->c_f32) {
+    UR_REQUIRE(!a->residual && !a->gelu_out && !a->gelu_grad_aux, "ur_gemm: f32 output supports alpha/bias only");
+  } else {
+    UR_REQUIRE(!a->residual || ((a->ldres % 4) == 0 && (((uintptr_t)a->residual) & 7) == 0), "ur_gemm: residual misaligned");
+    UR_REQUIRE(!a->gelu_out || ((a->ldg % 4) == 0 && (((uintptr_t)a->gelu_out) & 7) == 0), "ur_gemm: gelu_out misaligned");
+    UR_REQUIRE(!a->gelu_grad_aux || ((a->ldaux % 4) == 0 && (((uintptr_t)a->gelu_grad_aux) & 7) == 0), "ur_gemm: aux misaligned");
+  }
+  UR_REQUIRE(!a->bias || UR_ALIGNED16(a->bias), "ur_gemm: bias must be 16-byte aligned");
+
+  GemmP p;
+  p.R = (const bf16_t*)a->R; p.S = (const bf16_t*)a->S; p.ldr = a->ldr; p.lds = a->lds; p.K = a->K;
+  p.R2 = (const bf16_t*)a->R2; p.S2 = (const bf16_t*)a->S2; p.ldr2 = a->ldr2; p.lds2 = a->lds2; p.K2 = a->K2;
+  p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.alpha = a->alpha;
+  p.bias = a->bias; p.res = (const bf16_t*)a->residual; p.ldres = a->ldres;
+  p.gelu_out = (bf16_t*)a->gelu_out; p.ldg = a->ldg; p.aux = (const bf16_t*)a->gelu_grad_aux; p.ldaux = a->ldaux;
+  p.gm = ur_cdiv(a->M, BM); p.gn = ur_cdiv(a->N, BN);
+  p.slab_stride = 0;
+  if (splits > 1) {
+    int tiles = ur_cdiv(a->K, BK);
+    p.ksplit_len = ur_cdiv(tiles, splits) * BK;
+    p.slab_stride = (long)a->M * a->ldc;
+    p.C = workspace;
+  } else {
+    p.ksplit_len = a->K > 0 ? ur_cdiv(a->K, BK) * BK : BK;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  const bool rk = a->r_kcontig != 0, sk = a->s_kcontig != 0, f32 = a->c_f32 != 0;
+  if (rk && sk) rc = f32 ? launch<true, true, true>(p, splits, st) : launch<true, true, false>(p, splits, st);
+  else if (rk && !sk) rc = f32 ? launch<true, false, true>(p, splits, st) : launch<true, false, false>(p, splits, st);
+  else if (!rk && !sk) rc = f32 ? launch<false, false, true>(p, splits, st) : launch<false, false, false>(p, splits, st);
+  else rc = f32 ? launch<false, true, true>(p, splits, st) : launch<false, true, false>(p, splits, st);
+  if (rc) return rc;
+  if (splits > 1) {
+    long total = (long)a->M * a->ldc;
+    UR_REQUIRE((total % 4) == 0, "ur_gemm: split_k output size must be a multiple of 4");
+    long total4 = total / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, (float*)a->C,
+                       total4, total4, splits);
+    UR_CHECK_LAUNCH("ur_gemm(splitk_reduce)");
+  }
+  return 0;
+}

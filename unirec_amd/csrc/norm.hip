@@ -1,0 +1,405 @@
+// LayerNorm / RMSNorm forward+backward and batch reductions (HBM-bound, one wave per row,
+// 16-byte vector loads, wave-shuffle row reductions, f32 statistics).  gfx950 only.
+#include "common.cuh"
+#include "unirec_hip.h"
+
+namespace {
+
+constexpr int ROWS_PER_BLOCK = 4;   // 256 threads = 4 waves = 4 rows in flight per block
+
+struct Drop {
+  uint32_t thr; float inv_keep; uint64_t seed;
+  __device__ __forceinline__ bool on() const { return thr != 0; }
+};
+static Drop make_drop(float p, uint64_t seed) {
+  Drop d; d.thr = (p > 0.f) ? ur_drop_threshold(p) : 0u; d.inv_keep = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f; d.seed = seed;
+  return d;
+}
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  f[0] = bf_lo(u.x); f[1] = bf_hi(u.x); f[2] = bf_lo(u.y); f[3] = bf_hi(u.y);
+  f[4] = bf_lo(u.z); f[5] = bf_hi(u.z); f[6] = bf_lo(u.w); f[7] = bf_hi(u.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+}
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ y, int y_rows,
+                                                     const bf16_t* __restrict__ res, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                     bf16_t* __restrict__ zsave, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int M, int H, float eps, Drop pre,
+                                                     Drop post) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += gridDim.x * ROWS_PER_BLOCK) {
+    const long yoff = (long)(row % y_rows) * H, roff = (long)row * H;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e0 = (lane + i * 64) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+      if (e0 < H) {
+        unpack8(*reinterpret_cast<const uint4*>(y + yoff + e0), v[i]);
+        if (pre.on()) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[i][e] *= ur_dropout_scale(pre.seed, (uint64_t)(roff + e0 + e), pre.thr, pre.inv_keep);
+        }
+        if (res) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(res + roff + e0), r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[i][e] += r[e];
+        }
+        if (zsave) {   // round z to bf16 first so forward and backward see the same z
+          uint4 pk = pack8(v[i]);
+          *reinterpret_cast<uint4*>(zsave + roff + e0) = pk;
+          unpack8(pk, v[i]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      }
+    }
+    const float mu = wave_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e0 = (lane + i * 64) * 8;
+      if (e0 < H) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mu; q += d * d; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)H + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e0 = (lane + i * 64) * 8;
+      if (e0 < H) {
+        float g[8], b[8], o[8];
+        load8f(gamma + e0, g); load8f(beta + e0, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+          if (post.on()) o[e] *= ur_dropout_scale(post.seed, (uint64_t)(roff + e0 + e), post.thr, post.inv_keep);
+        }
+        *reinterpret_cast<uint4*>(out + roff + e0) = pack8(o);
+      }
+    }
+  }
+}
+
+// backward: per-wave column partials (dgamma, dbeta, dbias) go to workspace [nwaves_total][3][H]
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ z,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, bf16_t* __restrict__ dz,
+                                                     bf16_t* __restrict__ dy, float* __restrict__ part, int M, int H,
+                                                     Drop pre, Drop post) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float pg[NCH][8], pb[NCH][8], pd[NCH][8];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pg[i][e] = 0.f; pb[i][e] = 0.f; pd[i][e] = 0.f; }
+
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += gridDim.x * ROWS_PER_BLOCK) {
+    const long roff = (long)row * H;
+    const float mu = mean[row], rs = rstd[row];
+    float go[NCH][8], xh[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e0 = (lane + i * 64) * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { go[i][e] = 0.f; xh[i][e] = 0.f; }
+      if (e0 < H) {
+        float zz[8], g[8];
+        unpack8(*reinterpret_cast<const uint4*>(dout + roff + e0), go[i]);
+        unpack8(*reinterpret_cast<const uint4*>(z + roff + e0), zz);
+        load8f(gamma + e0, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (post.on()) go[i][e] *= ur_dropout_scale(post.seed, (uint64_t)(roff + e0 + e), post.thr, post.inv_keep);
+          xh[i][e] = (zz[e] - mu) * rs;
+          pg[i][e] += go[i][e] * xh[i][e];
+          pb[i][e] += go[i][e];
+          go[i][e] *= g[e];                       // g = dout * gamma
+          s1 += go[i][e];
+          s2 += go[i][e] * xh[i][e];
+        }
+      }
+    }
+    const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e0 = (lane + i * 64) * 8;
+      if (e0 < H) {
+        float d[8], dd[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          d[e] = rs * (go[i][e] - m1 - xh[i][e] * m2);
+          dd[e] = d[e];
+        }
+        const uint4 pk = pack8(d);
+        *reinterpret_cast<uint4*>(dz + roff + e0) = pk;
+        if (pre.on()) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dd[e] *= ur_dropout_scale(pre.seed, (uint64_t)(roff + e0 + e), pre.thr, pre.inv_keep);
+          if (dy) *reinterpret_cast<uint4*>(dy + roff + e0) = pack8(dd);
+        } else if (dy && dy != dz) {
+          *reinterpret_cast<uint4*>(dy + roff + e0) = pk;
+        }
+        float dr[8];
+        unpack8(pre.on() ? pack8(dd) : pk, dr);   // bias grad sums the bf16 values the dense bwd will see
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pd[i][e] += dr[e];
+      }
+    }
+  }
+  float* base = part + (long)(blockIdx.x * ROWS_PER_BLOCK + wave) * 3 * H;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int e0 = (lane + i * 64) * 8;
+    if (e0 < H) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        base[e0 + e] = pg[i][e];
+        base[H + e0 + e] = pb[i][e];
+        base[2 * H + e0 + e] = pd[i][e];
+      }
+    }
+  }
+}
+
+// out[k][c] = sum_p part[p][k][c]   (k in 0..nout-1), out pointers may be null
+__global__ void colpart_reduce_kernel(const float* __restrict__ part, int nparts, int ncols_total, float* o0, float* o1,
+                                      float* o2, int H) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols_total) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += part[(long)p * ncols_total + c];
+  const int k = c / H, h = c - k * H;
+  float* o = (k == 0) ? o0 : (k == 1 ? o1 : o2);
+  if (o) o[h] = s;
+}
+
+// ---- batch reduce: out[r*H + h] = sum_b in[(b*rows + r)*H + h] ---------------------------------
+__global__ void batch_reduce_stage1(const bf16_t* __restrict__ in, float* __restrict__ part, int nb, long rh8,
+                                    int per_slice) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;   // 8-element chunk of the [rows*H] vector
+  if (c >= rh8) return;
+  const int slice = blockIdx.y;
+  const int b0 = slice * per_slice, b1 = min(nb, b0 + per_slice);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = b0; b < b1; ++b) {
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(in + ((long)b * rh8 + c) * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += f[e];
+  }
+  float* o = part + ((long)slice * rh8 + c) * 8;
+  *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+__global__ void batch_reduce_stage2(const float* __restrict__ part, float* __restrict__ out, long n, int nslices) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nslices; ++k) s += part[(long)k * n + i];
+  out[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void rms_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ w,
+                                                      bf16_t* __restrict__ out, float* __restrict__ rstd, int M, int D,
+                                                      float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += gridDim.x * ROWS_PER_BLOCK) {
+    const long roff = (long)row * D;
+    float v[NCH][8];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e0 = (lane + i * 64) * 8;
+      if (e0 < D) {
+        unpack8(*reinterpret_cast<const uint4*>(x + roff + e0), v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) q += v[i][e] * v[i][e];
+      }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) rstd[row] = rs;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e0 = (lane + i * 64) * 8;
+      if (e0 < D) {
+        float g[8], o[8];
+        load8f(w + e0, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = g[e] * (v[i][e] * rs);
+        *reinterpret_cast<uint4*>(out + roff + e0) = pack8(o);
+      }
+    }
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void rms_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
+                                                      const float* __restrict__ w, const float* __restrict__ rstd,
+                                                      const bf16_t* __restrict__ add, bf16_t* __restrict__ dx, int M,
+                                                      int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < M; row += gridDim.x * ROWS_PER_BLOCK) {
+    const long roff = (long)row * D;
+    const float rs = rstd[row];
+    float g[NCH][8], xh[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e0 = (lane + i * 64) * 8;
+      if (e0 < D) {
+        float ww[8];
+        unpack8(*reinterpret_cast<const uint4*>(dout + roff + e0), g[i]);
+        unpack8(*reinterpret_cast<const uint4*>(x + roff + e0), xh[i]);
+        load8f(w + e0, ww);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g[i][e] *= ww[e]; xh[i][e] *= rs; s += g[i][e] * xh[i][e]; }
+      }
+    }
+    const float m = wave_sum(s) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int e0 = (lane + i * 64) * 8;
+      if (e0 < D) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - xh[i][e] * m);
+        if (add) {
+          float a[8];
+          unpack8(*reinterpret_cast<const uint4*>(add + roff + e0), a);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] += a[e];
+        }
+        *reinterpret_cast<uint4*>(dx + roff + e0) = pack8(o);
+      }
+    }
+  }
+}
+
+inline int nch_for(int H) { int c = ur_cdiv(H, 512); return c <= 1 ? 1 : (c <= 2 ? 2 : 4); }
+inline int row_grid(int M, int cap) { int g = ur_cdiv(M, ROWS_PER_BLOCK); return g < cap ? (g > 0 ? g : 1) : cap; }
+constexpr int LN_BWD_BLOCKS = 128;
+
+}  // namespace
+
+#define UR_NCH_DISPATCH(H, CALL)                  \
+  switch (nch_for(H)) {                           \
+    case 1: { constexpr int NCH = 1; CALL; } break; \
+    case 2: { constexpr int NCH = 2; CALL; } break; \
+    default: { constexpr int NCH = 4; CALL; } break; \
+  }
+
+extern "C" int ur_layernorm_fwd(const void* y, int32_t y_rows, const void* residual, const float* gamma,
+                                const float* beta, void* out, void* z_save, float* mean, float* rstd, int32_t M,
+                                int32_t H, float eps, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
+                                void* stream) {
+  UR_REQUIRE(M >= 0 && H > 0 && (H % 8) == 0 && H <= 2048, "ur_layernorm_fwd: need H %% 8 == 0 and H <= 2048 (H=%d)", H);
+  if (M == 0) return 0;
+  UR_REQUIRE(y && gamma && beta && out && mean && rstd && y_rows > 0, "ur_layernorm_fwd: null argument");
+  UR_REQUIRE(UR_ALIGNED16(y) && UR_ALIGNED16(out) && UR_ALIGNED16(gamma) && UR_ALIGNED16(beta) &&
+             (!residual || UR_ALIGNED16(residual)) && (!z_save || UR_ALIGNED16(z_save)), "ur_layernorm_fwd: 16-byte alignment");
+  UR_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "ur_layernorm_fwd: dropout p out of range");
+  const Drop pre = make_drop(p_pre, seed_pre), post = make_drop(p_post, seed_post);
+  const int grid = row_grid(M, 4096);
+  UR_NCH_DISPATCH(H, hipLaunchKernelGGL((ln_fwd_kernel<NCH>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                        (const bf16_t*)y, y_rows, (const bf16_t*)residual, gamma, beta, (bf16_t*)out,
+                                        (bf16_t*)z_save, mean, rstd, M, H, eps, pre, post));
+  UR_CHECK_LAUNCH("ur_layernorm_fwd");
+  return 0;
+}
+
+extern "C" int64_t ur_layernorm_bwd_workspace_bytes(int32_t H) {
+  return (int64_t)LN_BWD_BLOCKS * ROWS_PER_BLOCK * 3 * H * (int64_t)sizeof(float);
+}
+
+extern "C" int ur_layernorm_bwd(const void* dout, const void* z, const float* mean, const float* rstd,
+                                const float* gamma, void* dz, void* dy, float* dgamma, float* dbeta, float* dbias,
+                                int32_t M, int32_t H, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
+                                void* workspace, int64_t workspace_bytes, void* stream) {
+  UR_REQUIRE(M >= 0 && H > 0 && (H % 8) == 0 && H <= 2048, "ur_layernorm_bwd: need H %% 8 == 0 and H <= 2048 (H=%d)", H);
+  UR_REQUIRE(dout && z && mean && rstd && gamma && dz && dgamma && dbeta, "ur_layernorm_bwd: null argument");
+  UR_REQUIRE(workspace && workspace_bytes >= ur_layernorm_bwd_workspace_bytes(H), "ur_layernorm_bwd: workspace too small");
+  UR_REQUIRE(UR_ALIGNED16(dout) && UR_ALIGNED16(z) && UR_ALIGNED16(dz) && UR_ALIGNED16(gamma) && (!dy || UR_ALIGNED16(dy)),
+             "ur_layernorm_bwd: 16-byte alignment");
+  UR_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "ur_layernorm_bwd: dropout p out of range");
+  const Drop pre = make_drop(p_pre, seed_pre), post = make_drop(p_post, seed_post);
+  const int grid = row_grid(M, LN_BWD_BLOCKS);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  UR_NCH_DISPATCH(H, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dout,
+                                        (const bf16_t*)z, mean, rstd, gamma, (bf16_t*)dz, (bf16_t*)dy, part, M, H, pre, post));
+  UR_CHECK_LAUNCH("ur_layernorm_bwd");
+  const int ncols = 3 * H;
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(ur_cdiv(ncols, 256)), dim3(256), 0, st, (const float*)part,
+                     grid * ROWS_PER_BLOCK, ncols, dgamma, dbeta, dbias, H);
+  UR_CHECK_LAUNCH("ur_layernorm_bwd(reduce)");
+  return 0;
+}
+
+static inline int br_slices(int nb) { return nb < 64 ? (nb > 0 ? nb : 1) : 64; }
+
+extern "C" int64_t ur_batch_reduce_workspace_bytes(int32_t nb, int32_t rows, int32_t H) {
+  return (int64_t)br_slices(nb) * rows * H * (int64_t)sizeof(float);
+}
+
+extern "C" int ur_batch_reduce(const void* in, float* out, int32_t nb, int32_t rows, int32_t H, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+  UR_REQUIRE(nb >= 0 && rows > 0 && H > 0 && ((long)rows * H) % 8 == 0, "ur_batch_reduce: rows*H must be a multiple of 8");
+  UR_REQUIRE(in && out && UR_ALIGNED16(in) && UR_ALIGNED16(out), "ur_batch_reduce: null / misaligned argument");
+  UR_REQUIRE(workspace && UR_ALIGNED16(workspace) && workspace_bytes >= ur_batch_reduce_workspace_bytes(nb, rows, H),
+             "ur_batch_reduce: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)rows * H, rh8 = n / 8;
+  const int ns = br_slices(nb);
+  const int per = ur_cdiv(nb > 0 ? nb : 1, ns);
+  hipLaunchKernelGGL(batch_reduce_stage1, dim3(ur_cdiv(rh8, 128), ns), dim3(128), 0, st, (const bf16_t*)in,
+                     (float*)workspace, nb, rh8, per);
+  UR_CHECK_LAUNCH("ur_batch_reduce(stage1)");
+  hipLaunchKernelGGL(batch_reduce_stage2, dim3(ur_cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, out, n, ns);
+  UR_CHECK_LAUNCH("ur_batch_reduce(stage2)");
+  return 0;
+}
+
+extern "C" int ur_rmsnorm_fwd(const void* x, const float* w, void* out, float* rstd, int32_t M, int32_t D, float eps,
+                              void* stream) {
+  UR_REQUIRE(M >= 0 && D > 0 && (D % 8) == 0 && D <= 2048, "ur_rmsnorm_fwd: need D %% 8 == 0 and D <= 2048 (D=%d)", D);
+  if (M == 0) return 0;
+  UR_REQUIRE(x && w && out && rstd && UR_ALIGNED16(x) && UR_ALIGNED16(w) && UR_ALIGNED16(out), "ur_rmsnorm_fwd: null / misaligned");
+  const int grid = row_grid(M, 8192);
+  UR_NCH_DISPATCH(D, hipLaunchKernelGGL((rms_fwd_kernel<NCH>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                        (const bf16_t*)x, w, (bf16_t*)out, rstd, M, D, eps));
+  UR_CHECK_LAUNCH("ur_rmsnorm_fwd");
+  return 0;
+}
+
+extern "C" int ur_rmsnorm_bwd(const void* dout, const void* x, const float* w, const float* rstd, const void* add,
+                              void* dx, int32_t M, int32_t D, void* stream) {
+  UR_REQUIRE(M >= 0 && D > 0 && (D % 8) == 0 && D <= 2048, "ur_rmsnorm_bwd: need D %% 8 == 0 and D <= 2048 (D=%d)", D);
+  if (M == 0) return 0;
+  UR_REQUIRE(dout && x && w && rstd && dx && UR_ALIGNED16(dout) && UR_ALIGNED16(x) && UR_ALIGNED16(w) && UR_ALIGNED16(dx) &&
+             (!add || UR_ALIGNED16(add)), "ur_rmsnorm_bwd: null / misaligned");
+  const int grid = row_grid(M, 8192);
+  UR_NCH_DISPATCH(D, hipLaunchKernelGGL((rms_bwd_kernel<NCH>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                        (const bf16_t*)dout, (const bf16_t*)x, w, rstd, (const bf16_t*)add, (bf16_t*)dx, M, D));
+  UR_CHECK_LAUNCH("ur_rmsnorm_bwd");
+  return 0;
+}

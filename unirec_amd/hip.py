@@ -1,0 +1,211 @@
+"""Tensor-level wrappers over the C ABI (include/unirec_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every computation is a
+call into libunirec_hip.so with raw ``data_ptr()``s.  All functions require CUDA(HIP) tensors and
+raise on anything else -- there is no eager fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs, check
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _need(t, dtype, name):
+    if not t.is_cuda:
+        raise _lib.UniRecHipError(f"{name}: expected a device tensor (the UniRec HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: expected a contiguous tensor")
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only scratch buffer per (device, tag); owned by the caller side (torch allocator)."""
+    key = (device, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------------
+def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=None, out_f32=False, alpha=1.0,
+         bias=None, residual=None, gelu_out=None, gelu_grad_aux=None, R2=None, S2=None, split_k=1):
+    """C[M,N] = alpha*(R(m,k) S(n,k) + R2 S2) + epilogue.  R/S are 2-D bf16 (row stride = stride(0))."""
+    lib = _lib.load()
+    for t, n in ((R, "R"), (S, "S")):
+        if t.dtype != BF16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+            raise ValueError(f"gemm: {n} must be a 2-D bf16 device tensor with unit inner stride")
+    if M is None:
+        M = R.shape[0] if r_kcontig else R.shape[1]
+    if N is None:
+        N = S.shape[0] if s_kcontig else S.shape[1]
+    if K is None:
+        K = R.shape[1] if r_kcontig else R.shape[0]
+    Ks = S.shape[1] if s_kcontig else S.shape[0]
+    if Ks != K:
+        raise ValueError(f"gemm: K mismatch R:{K} S:{Ks}")
+    if out is None:
+        out = torch.empty((M, N), dtype=F32 if out_f32 else BF16, device=R.device)
+    a = GemmArgs()
+    a.R, a.ldr, a.r_kcontig = R.data_ptr(), R.stride(0), int(r_kcontig)
+    a.S, a.lds, a.s_kcontig = S.data_ptr(), S.stride(0), int(s_kcontig)
+    a.K = K
+    if R2 is not None:
+        a.R2, a.ldr2, a.S2, a.lds2 = R2.data_ptr(), R2.stride(0), S2.data_ptr(), S2.stride(0)
+        a.K2 = R2.shape[1] if r_kcontig else R2.shape[0]
+    a.C, a.ldc, a.c_f32 = out.data_ptr(), out.stride(0), int(out.dtype == F32)
+    a.M, a.N, a.alpha = M, N, float(alpha)
+    a.bias = _p(bias)
+    if residual is not None:
+        a.residual, a.ldres = residual.data_ptr(), residual.stride(0)
+    if gelu_out is not None:
+        a.gelu_out, a.ldg = gelu_out.data_ptr(), gelu_out.stride(0)
+    if gelu_grad_aux is not None:
+        a.gelu_grad_aux, a.ldaux = gelu_grad_aux.data_ptr(), gelu_grad_aux.stride(0)
+    a.split_k = int(split_k)
+    ws, wsb = 0, 0
+    if split_k > 1:
+        wsb = lib.ur_gemm_workspace_bytes(ctypes.byref(a))
+        ws = workspace(wsb, R.device, "gemm").data_ptr()
+    check(lib.ur_gemm(ctypes.byref(a), ws, wsb, _stream()), "ur_gemm")
+    return out
+
+
+def layernorm_fwd(y, gamma, beta, eps, residual=None, save_z=True, p_pre=0.0, seed_pre=0, p_post=0.0, seed_post=0,
+                  M=None):
+    """Returns (out, z, mean, rstd).  y may have fewer rows than M (row m reads y[m % y.shape[0]])."""
+    lib = _lib.load()
+    _need(y, BF16, "y")
+    H = y.shape[-1]
+    y_rows = y.numel() // H
+    if M is None:
+        M = y_rows
+    dev = y.device
+    out = torch.empty((M, H), dtype=BF16, device=dev)
+    z = torch.empty((M, H), dtype=BF16, device=dev) if save_z else None
+    mean = torch.empty((M,), dtype=F32, device=dev)
+    rstd = torch.empty((M,), dtype=F32, device=dev)
+    check(lib.ur_layernorm_fwd(y.data_ptr(), y_rows, _p(residual), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), _p(z),
+                               mean.data_ptr(), rstd.data_ptr(), M, H, eps, p_pre, seed_pre, p_post, seed_post, _stream()),
+          "ur_layernorm_fwd")
+    return out, z, mean, rstd
+
+
+def layernorm_bwd(dout, z, mean, rstd, gamma, dgamma, dbeta, dbias=None, p_pre=0.0, seed_pre=0, p_post=0.0, seed_post=0,
+                  need_dy=True):
+    """Returns (dz, dy); dgamma/dbeta/dbias (f32 [H]) are overwritten in place."""
+    lib = _lib.load()
+    M, H = z.shape
+    dz = torch.empty_like(z)
+    dy = dz if (p_pre == 0.0 or not need_dy) else torch.empty_like(z)
+    wsb = lib.ur_layernorm_bwd_workspace_bytes(H)
+    ws = workspace(wsb, z.device, "ln")
+    check(lib.ur_layernorm_bwd(dout.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                               dz.data_ptr(), dy.data_ptr() if need_dy else 0, dgamma.data_ptr(), dbeta.data_ptr(), _p(dbias),
+                               M, H, p_pre, seed_pre, p_post, seed_post, ws.data_ptr(), wsb, _stream()), "ur_layernorm_bwd")
+    return dz, dy
+
+
+def batch_reduce(x, nb, rows, H, out=None):
+    lib = _lib.load()
+    _need(x, BF16, "x")
+    if out is None:
+        out = torch.empty((rows, H), dtype=F32, device=x.device)
+    wsb = lib.ur_batch_reduce_workspace_bytes(nb, rows, H)
+    ws = workspace(wsb, x.device, "br")
+    check(lib.ur_batch_reduce(x.data_ptr(), out.data_ptr(), nb, rows, H, ws.data_ptr(), wsb, _stream()), "ur_batch_reduce")
+    return out
+
+
+def colsum(x2d, out=None):
+    """f32 column sums of a contiguous bf16 [M,N] (bias gradients)."""
+    M, N = x2d.shape
+    o = batch_reduce(x2d, M, 1, N, out=None if out is None else out.view(1, N))
+    return o.view(N)
+
+
+def rmsnorm_fwd(x, w, eps):
+    lib = _lib.load()
+    _need(x, BF16, "x")
+    D = x.shape[-1]
+    M = x.numel() // D
+    out = torch.empty_like(x)
+    rstd = torch.empty((M,), dtype=F32, device=x.device)
+    check(lib.ur_rmsnorm_fwd(x.data_ptr(), w.data_ptr(), out.data_ptr(), rstd.data_ptr(), M, D, eps, _stream()), "ur_rmsnorm_fwd")
+    return out, rstd
+
+
+def rmsnorm_bwd(dout, x, w, rstd, add=None):
+    lib = _lib.load()
+    D = x.shape[-1]
+    M = x.numel() // D
+    dx = torch.empty_like(x)
+    check(lib.ur_rmsnorm_bwd(dout.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(add), dx.data_ptr(), M, D, _stream()),
+          "ur_rmsnorm_bwd")
+    return dx
+
+
+def cast_f32_to_bf16(src, dst=None):
+    lib = _lib.load()
+    _need(src, F32, "src")
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    check(lib.ur_cast_f32_to_bf16(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "ur_cast_f32_to_bf16")
+    return dst
+
+
+def cast_bf16_to_f32(src, dst=None):
+    lib = _lib.load()
+    _need(src, BF16, "src")
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=F32, device=src.device)
+    check(lib.ur_cast_bf16_to_f32(src.data_ptr(), dst.data_ptr(), src.numel(), _stream()), "ur_cast_bf16_to_f32")
+    return dst
+
+
+def add_bf16(a, b, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty_like(a)
+    check(lib.ur_add_bf16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "ur_add_bf16")
+    return out
+
+
+def swiglu_fwd(gu, I):
+    lib = _lib.load()
+    M = gu.numel() // (2 * I)
+    act = torch.empty((M, I), dtype=BF16, device=gu.device)
+    check(lib.ur_swiglu_fwd(gu.data_ptr(), act.data_ptr(), M, I, _stream()), "ur_swiglu_fwd")
+    return act
+
+
+def swiglu_bwd(dact, gu, I):
+    lib = _lib.load()
+    M = gu.numel() // (2 * I)
+    dgu = torch.empty_like(gu)
+    check(lib.ur_swiglu_bwd(dact.data_ptr(), gu.data_ptr(), dgu.data_ptr(), M, I, _stream()), "ur_swiglu_bwd")
+    return dgu
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    lib = _lib.load()
+    check(lib.ur_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), lr,
+                            beta1, beta2, eps, weight_decay, step, grad_scale, _stream()), "ur_adamw_step")
