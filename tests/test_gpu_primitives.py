@@ -163,11 +163,13 @@ def test_layernorm_broadcast_rows_and_dropout():
     assert torch.allclose(o1.float()[kept], (out.float() / (1 - p))[kept], rtol=2e-2, atol=2e-2)
     # pre-dropout + backward consistency: dy == dz * mask / (1-p)
     y, res = _bf(_randn((B * Q, H), 2)), _bf(_randn((B * Q, H), 3))
+    _, z0, _, _ = hip.layernorm_fwd(y, gamma, beta, 1e-12, p_pre=p, seed_pre=77)     # no residual: z0 = dropout(y)
+    dropped = (z0.float() == 0) & (y.float() != 0)
+    assert abs(dropped.float().mean().item() - p) < 0.03
     o, z, mean, rstd = hip.layernorm_fwd(y, gamma, beta, 1e-12, residual=res, p_pre=p, seed_pre=77)
-    mask_scale = ((z.float() - res.float()) / y.float()).round(decimals=1)   # ~0 or ~1/(1-p)
+    assert torch.equal(z.float()[dropped], res.float()[dropped])
     dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
     dz, dy = hip.layernorm_bwd(_bf(_randn((B * Q, H), 4)), z, mean, rstd, gamma, dg, db, p_pre=p, seed_pre=77)
-    dropped = mask_scale.abs() < 0.5
     assert (dy.float()[dropped] == 0).all()
     assert torch.allclose(dy.float()[~dropped], dz.float()[~dropped] / (1 - p), rtol=2e-2, atol=1e-3)
 

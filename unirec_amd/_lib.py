@@ -28,6 +28,21 @@ class GemmArgs(ctypes.Structure):
                 ("split_k", c_int)]
 
 
+class AttnArgs(ctypes.Structure):
+    """Mirror of ur_attn_args."""
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p), ("stats", c_void_p),
+                ("ldq", c_i64), ("ldk", c_i64), ("ldv", c_i64), ("ldo", c_i64),
+                ("key_mask", c_void_p),
+                ("B", c_int), ("Sq", c_int), ("Sk", c_int), ("nq", c_int), ("nkv", c_int), ("head_dim", c_int),
+                ("causal", c_int), ("scale", c_float), ("dropout_p", c_float), ("seed", c_u64)]
+
+
+class AttnBwdArgs(ctypes.Structure):
+    """Mirror of ur_attn_bwd_args."""
+    _fields_ = [("dout", c_void_p), ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
+                ("lddo", c_i64), ("lddq", c_i64), ("lddk", c_i64), ("lddv", c_i64), ("delta", c_void_p)]
+
+
 # name -> (restype, argtypes).  Every symbol include/unirec_hip.h declares must appear here
 # (tests/test_cabi.py cross-checks the header against this table and the built library).
 SIGNATURES = {
@@ -44,6 +59,8 @@ SIGNATURES = {
     "ur_batch_reduce_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "ur_rmsnorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ur_rmsnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ur_attn_fwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
+    "ur_attn_bwd": (c_int, [ctypes.POINTER(AttnArgs), ctypes.POINTER(AttnBwdArgs), c_void_p]),
     "ur_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),

@@ -1,0 +1,522 @@
+// Fused MFMA attention (forward + two-kernel backward) for BOTH attention shapes on the path:
+//   * Q-Former learned-query attention: small Q (<= 64 queries), K/V length T = Q (self), F (item
+//     cross) or hist*Q_item (user cross, up to 3200), head_dim 64, additive key mask with the
+//     reference's finfo.min semantics (a fully masked row is a UNIFORM softmax, not NaN) and
+//     attention-probability dropout.      models/qformer.py:169-275
+//   * Qwen3 causal GQA attention, head_dim 128, causal AND key-padding mask with SDPA semantics
+//     (a query row with no allowed key outputs 0).   transformers modeling_qwen3.py:185-208,244-280
+//
+// Structure (per wave = one 32-query block; a workgroup = NW waves sharing LDS K/V tiles):
+//   S^T = K Q^T with v_mfma_f32_32x32x16_bf16, KEYS on the MFMA rows -> every lane owns ONE query
+//   column, so the online-softmax row reductions are 16 in-register ops + one cross-half shuffle,
+//   and the P accumulators are directly the B operand of O^T += V^T P (no LDS round trip, no lane
+//   movement).  V^T (and K^T / Q^T / dO^T in the backward) fragments come from the plain row-major
+//   LDS tile through ds_read_b64_tr_b16.  K/V tiles are staged once per workgroup with coalesced
+//   16-byte loads; LDS rows are padded by 16 B so the ds_read_b128 row reads are conflict-free.
+// Backward = dQ kernel (same decomposition as forward) + dK/dV kernel (one 32-key block per wave,
+// looping over the query heads of its GQA group): no atomics, bitwise reproducible.
+#include "common.cuh"
+#include "unirec_hip.h"
+
+namespace {
+
+constexpr float NEG_INF = -__builtin_huge_valf();
+constexpr float F32_MIN = -3.4028234663852886e38f;   // torch.finfo(torch.float32).min
+constexpr int KT = 64;                                // keys (or queries, in dK/dV) staged per LDS tile
+
+template <int HD> struct Cfg {
+  static constexpr int ROWB = HD * 2 + 16;            // padded LDS row (bytes)
+  static constexpr int NS = HD / 16;                  // MFMA k-steps contracting over head_dim
+  static constexpr int NDT = HD / 32;                 // 32-wide head_dim tiles of an O^T/dQ^T/dK^T/dV^T accumulator
+  static constexpr int CH = HD / 8;                   // 16-byte chunks per row
+  static constexpr int TILE = KT * ROWB;
+};
+
+struct AttnP {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v; bf16_t* o; float* stats;
+  long ldq, ldk, ldv, ldo;
+  const uint8_t* kmask;
+  int B, Sq, Sk, nq, nkv, rep;
+  float scale; uint32_t drop_thr; float drop_inv; uint64_t seed;
+  // backward
+  const bf16_t* dout; bf16_t* dq; bf16_t* dk; bf16_t* dv; const float* delta;
+  long lddo, lddq, lddk, lddv;
+};
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+// accumulator register r of lane-half h  <->  row index inside the 32-row tile
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// rows [row0, row0+KT) x HD of a [S][ld] bf16 matrix -> LDS tile (zero-filled past S)
+template <int HD, int NT>
+__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* __restrict__ base, long ld, int row0, int S, int tid) {
+  constexpr int CH = Cfg<HD>::CH, ROWB = Cfg<HD>::ROWB;
+  for (int c = tid; c < KT * CH; c += NT) {
+    const int r = c / CH, cc = c - r * CH;
+    const int g = row0 + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (g < S) v = *reinterpret_cast<const uint4*>(base + (long)g * ld + cc * 8);
+    *reinterpret_cast<uint4*>(tile + r * ROWB + cc * 16) = v;
+  }
+}
+
+// row fragment: X[r0 + (lane&31)][16*s + 8*(lane>>5) + 0..7]   (MFMA A or B operand, k = head_dim)
+template <int HD>
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int r0, int s, int lane) {
+  return *reinterpret_cast<const bf16x8*>(tile + (r0 + (lane & 31)) * Cfg<HD>::ROWB + (2 * s + (lane >> 5)) * 16);
+}
+// transposed fragment: A[m = 32*dt + (lane&31)][k-element j] = X[r0 + 8*(j>>2) + 4*(lane>>5) + (j&3)][m]
+// (16 rows r0..r0+15 of X; k order matches an accumulator tile used as the B operand)
+template <int HD>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int r0, int dt, int lane) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+  const int h = lane >> 5, g16 = (lane >> 4) & 1, i = lane & 15;
+  const char* pa = tile + (r0 + 4 * h + (i >> 2)) * Cfg<HD>::ROWB + (32 * dt + 16 * g16 + 4 * (i & 3)) * 2;
+  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pa);
+  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(pa + 8 * Cfg<HD>::ROWB));
+  bf16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+// accumulator registers 8*s2 .. 8*s2+7 -> bf16 B-operand fragment of k-step s2
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s2) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(a[8 * s2 + j]);
+  return r;
+}
+// global row fragment (same element map as row_frag), zero when !ok
+__device__ __forceinline__ bf16x8 g_frag(const bf16_t* rowp, int s, int lane, bool ok) {
+  bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (!ok) return z;
+  return *reinterpret_cast<const bf16x8*>(rowp + 16 * s + 8 * (lane >> 5));
+}
+// store an O^T-layout accumulator set (lane = row of the output matrix, regs = head_dim) as bf16
+template <int HD>
+__device__ __forceinline__ void store_T(bf16_t* rowp, const f32x16 (&acc)[Cfg<HD>::NDT], float mul, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < Cfg<HD>::NDT; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int d = 32 * dt + 8 * rq + 4 * h;
+      *reinterpret_cast<uint2*>(rowp + d) = make_uint2(pack_bf2(acc[dt][4 * rq] * mul, acc[dt][4 * rq + 1] * mul),
+                                                       pack_bf2(acc[dt][4 * rq + 2] * mul, acc[dt][4 * rq + 3] * mul));
+    }
+}
+
+// key-state byte staged beside each tile: 0 = beyond Sk, 1 = masked by key_mask, 2 = valid
+__device__ __forceinline__ void stage_kstate(uint8_t* ks, const uint8_t* km, int k0, int Sk, int tid) {
+  if (tid < KT) {
+    const int key = k0 + tid;
+    ks[tid] = (key >= Sk) ? 0 : ((km == nullptr || km[key]) ? 2 : 1);
+  }
+}
+
+// masked, scaled score.  CAUSAL: SDPA semantics (-inf); else the Q-Former's additive finfo.min.
+template <bool CAUSAL>
+__device__ __forceinline__ float mask_score(float raw, float scale, uint8_t st, int key, int qpos) {
+  if (CAUSAL) return (st == 2 && key <= qpos) ? raw * scale : NEG_INF;
+  return st == 0 ? NEG_INF : (st == 2 ? raw * scale : F32_MIN);
+}
+
+// ================================================================================================
+template <int HD, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
+  using C = Cfg<HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ktile = smem;
+  char* vtile = smem + C::TILE;
+  uint8_t* kst = reinterpret_cast<uint8_t*>(smem + 2 * C::TILE);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int hq = blockIdx.y, b = blockIdx.z, kvh = hq / p.rep;
+  const int qblk = blockIdx.x * (32 * NW) + wave * 32;
+  const int q = qblk + (lane & 31);
+  const bool qok = q < p.Sq;
+
+  const bf16_t* qrow = p.q + ((long)b * p.Sq + (qok ? q : 0)) * p.ldq + (long)hq * HD;
+  bf16x8 qf[C::NS];
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) qf[s] = g_frag(qrow, s, lane, qok);
+
+  f32x16 o[C::NDT];
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt) o[dt] = zero16();
+  float m = NEG_INF, l = 0.f;
+
+  int kend = p.Sk;
+  if (CAUSAL) kend = min(p.Sk, (int)(blockIdx.x + 1) * (32 * NW));
+  const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * HD;
+  const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * HD;
+  const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
+  const uint64_t drow = ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
+
+  for (int k0 = 0; k0 < kend; k0 += KT) {
+    __syncthreads();
+    stage_tile<HD, NW * 64>(ktile, kb, p.ldk, k0, p.Sk, tid);
+    stage_tile<HD, NW * 64>(vtile, vb, p.ldv, k0, p.Sk, tid);
+    stage_kstate(kst, km, k0, p.Sk, tid);
+    __syncthreads();
+    if (qblk >= p.Sq) continue;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int kbase = k0 + 32 * sub;
+      if (kbase >= kend || (CAUSAL && kbase > qblk + 31)) break;
+      f32x16 s = zero16();
+#pragma unroll
+      for (int st = 0; st < C::NS; ++st)
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ktile, 32 * sub, st, lane), qf[st], s, 0, 0, 0);
+      float mx = NEG_INF;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = 32 * sub + acc_row(r, h);
+        s[r] = mask_score<CAUSAL>(s[r], p.scale, kst[kr], k0 + kr, q);
+        mx = fmaxf(mx, s[r]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m, mx);
+      const float muse = (mnew == NEG_INF) ? 0.f : mnew;
+      const float alpha = __expf(m - muse);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pr = __expf(s[r] - muse);
+        rs += pr;
+        if (!CAUSAL && p.drop_thr)
+          pr *= ur_dropout_scale(p.seed, drow + (uint64_t)(k0 + 32 * sub + acc_row(r, h)), p.drop_thr, p.drop_inv);
+        s[r] = pr;
+      }
+      rs += __shfl_xor(rs, 32, 64);
+      l = l * alpha + rs;
+      m = mnew;
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(s, s2);
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(vtile, 32 * sub + 16 * s2, dt, lane), pf, o[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (qok) {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    store_T<HD>(p.o + ((long)b * p.Sq + q) * p.ldo + (long)hq * HD, o, inv, lane);
+    if (h == 0) {
+      float* st = p.stats + (((long)b * p.nq + hq) * p.Sq + q) * 2;
+      st[0] = (m == NEG_INF) ? 0.f : m;
+      st[1] = inv;
+    }
+  }
+}
+
+// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+template <int HD>
+__global__ void attn_delta_kernel(AttnP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int LPR = HD / 8;           // lanes per row (16 B each)
+  constexpr int RPW = 64 / LPR;         // rows per wave
+  const long nrows = (long)p.B * p.Sq * p.nq;
+  const long row = ((long)blockIdx.x * 4 + wave) * RPW + lane / LPR;
+  float acc = 0.f;
+  long b = 0; int hq = 0, q = 0;
+  if (row < nrows) {
+    hq = (int)(row % p.nq); const long t = row / p.nq; q = (int)(t % p.Sq); b = t / p.Sq;
+    const int c = (lane % LPR) * 8;
+    const uint4 a = *reinterpret_cast<const uint4*>(p.dout + (b * p.Sq + q) * p.lddo + (long)hq * HD + c);
+    const uint4 o = *reinterpret_cast<const uint4*>(p.o + (b * p.Sq + q) * p.ldo + (long)hq * HD + c);
+    acc = bf_lo(a.x) * bf_lo(o.x) + bf_hi(a.x) * bf_hi(o.x) + bf_lo(a.y) * bf_lo(o.y) + bf_hi(a.y) * bf_hi(o.y) +
+          bf_lo(a.z) * bf_lo(o.z) + bf_hi(a.z) * bf_hi(o.z) + bf_lo(a.w) * bf_lo(o.w) + bf_hi(a.w) * bf_hi(o.w);
+  }
+  acc = group_sum<LPR>(acc);
+  if (row < nrows && (lane % LPR) == 0) const_cast<float*>(p.delta)[(b * p.nq + hq) * p.Sq + q] = acc;
+}
+
+// ================================================================================================
+// dQ: same decomposition as forward.  dQ^T[d][q] += K^T[d][key] * dS^T[key][q]
+template <int HD, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
+  using C = Cfg<HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ktile = smem;
+  char* vtile = smem + C::TILE;
+  uint8_t* kst = reinterpret_cast<uint8_t*>(smem + 2 * C::TILE);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int hq = blockIdx.y, b = blockIdx.z, kvh = hq / p.rep;
+  const int qblk = blockIdx.x * (32 * NW) + wave * 32;
+  const int q = qblk + (lane & 31);
+  const bool qok = q < p.Sq;
+  const long qtok = (long)b * p.Sq + (qok ? q : 0);
+
+  bf16x8 qf[C::NS], dof[C::NS];
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) {
+    qf[s] = g_frag(p.q + qtok * p.ldq + (long)hq * HD, s, lane, qok);
+    dof[s] = g_frag(p.dout + qtok * p.lddo + (long)hq * HD, s, lane, qok);
+  }
+  const long srow = ((long)b * p.nq + hq) * p.Sq + (qok ? q : 0);
+  const float m = p.stats[srow * 2], inv = qok ? p.stats[srow * 2 + 1] : 0.f, dlt = p.delta[srow];
+
+  f32x16 dq[C::NDT];
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt) dq[dt] = zero16();
+
+  int kend = p.Sk;
+  if (CAUSAL) kend = min(p.Sk, (int)(blockIdx.x + 1) * (32 * NW));
+  const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * HD;
+  const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * HD;
+  const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
+  const uint64_t drow = ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
+
+  for (int k0 = 0; k0 < kend; k0 += KT) {
+    __syncthreads();
+    stage_tile<HD, NW * 64>(ktile, kb, p.ldk, k0, p.Sk, tid);
+    stage_tile<HD, NW * 64>(vtile, vb, p.ldv, k0, p.Sk, tid);
+    stage_kstate(kst, km, k0, p.Sk, tid);
+    __syncthreads();
+    if (qblk >= p.Sq) continue;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int kbase = k0 + 32 * sub;
+      if (kbase >= kend || (CAUSAL && kbase > qblk + 31)) break;
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int st = 0; st < C::NS; ++st) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ktile, 32 * sub, st, lane), qf[st], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(vtile, 32 * sub, st, lane), dof[st], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kr = 32 * sub + acc_row(r, h);
+        const float sc = mask_score<CAUSAL>(s[r], p.scale, kst[kr], k0 + kr, q);
+        const float pr = (sc == NEG_INF) ? 0.f : __expf(sc - m) * inv;
+        float g = dp[r];
+        if (!CAUSAL && p.drop_thr) g *= ur_dropout_scale(p.seed, drow + (uint64_t)(k0 + kr), p.drop_thr, p.drop_inv);
+        s[r] = pr * (g - dlt) * p.scale;
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 df = acc_frag(s, s2);
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(ktile, 32 * sub + 16 * s2, dt, lane), df, dq[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (qok) store_T<HD>(p.dq + ((long)b * p.Sq + q) * p.lddq + (long)hq * HD, dq, 1.0f, lane);
+}
+
+// ================================================================================================
+// dK/dV: one 32-key block per wave (lane = key column).  Per 32-query sub-tile:
+//   S[q][key] = Q K^T, dP[q][key] = dO V^T (A = Q / dO rows from LDS, B = K / V fragments in registers)
+//   dV^T[d][key] += dO^T[d][q] * (P.drop)[q][key];   dK^T[d][key] += Q^T[d][q] * dS[q][key]
+template <int HD, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
+  using C = Cfg<HD>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* qtile = smem;
+  char* dotile = smem + C::TILE;
+  float* fst = reinterpret_cast<float*>(smem + 2 * C::TILE);   // [KT][4]: m, inv_l, delta, valid
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int kvh = blockIdx.y, b = blockIdx.z;
+  const int kblk = blockIdx.x * (32 * NW) + wave * 32;
+  const int key = kblk + (lane & 31);
+  const bool kok = key < p.Sk;
+  const long ktok = (long)b * p.Sk + (kok ? key : 0);
+
+  bf16x8 kf[C::NS], vf[C::NS];
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) {
+    kf[s] = g_frag(p.k + ktok * p.ldk + (long)kvh * HD, s, lane, kok);
+    vf[s] = g_frag(p.v + ktok * p.ldv + (long)kvh * HD, s, lane, kok);
+  }
+  uint8_t kstate = 0;
+  if (kok) kstate = (p.kmask == nullptr || p.kmask[(long)b * p.Sk + key]) ? 2 : 1;
+
+  f32x16 dk[C::NDT], dv[C::NDT];
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
+
+  const int qstart = CAUSAL ? ((int)(blockIdx.x * (32 * NW)) / KT) * KT : 0;
+  for (int hr = 0; hr < p.rep; ++hr) {
+    const int hq = kvh * p.rep + hr;
+    const bf16_t* qb = p.q + (long)b * p.Sq * p.ldq + (long)hq * HD;
+    const bf16_t* dob = p.dout + (long)b * p.Sq * p.lddo + (long)hq * HD;
+    const long sbase = ((long)b * p.nq + hq) * p.Sq;
+    for (int q0 = qstart; q0 < p.Sq; q0 += KT) {
+      __syncthreads();
+      stage_tile<HD, NW * 64>(qtile, qb, p.ldq, q0, p.Sq, tid);
+      stage_tile<HD, NW * 64>(dotile, dob, p.lddo, q0, p.Sq, tid);
+      if (tid < KT) {
+        const int qq = q0 + tid;
+        const bool ok = qq < p.Sq;
+        fst[tid * 4 + 0] = ok ? p.stats[(sbase + qq) * 2] : 0.f;
+        fst[tid * 4 + 1] = ok ? p.stats[(sbase + qq) * 2 + 1] : 0.f;
+        fst[tid * 4 + 2] = ok ? p.delta[sbase + qq] : 0.f;
+        fst[tid * 4 + 3] = ok ? 1.f : 0.f;
+      }
+      __syncthreads();
+      if (kblk >= p.Sk) continue;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const int qbase = q0 + 32 * sub;
+        if (qbase >= p.Sq) break;
+        if (CAUSAL && qbase + 31 < kblk) continue;        // every query of this sub-tile precedes every key
+        f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+        for (int st = 0; st < C::NS; ++st) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(qtile, 32 * sub, st, lane), kf[st], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dotile, 32 * sub, st, lane), vf[st], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qr = 32 * sub + acc_row(r, h);
+          const float4 f = *reinterpret_cast<const float4*>(fst + qr * 4);     // m, inv, delta, valid
+          const int qpos = q0 + qr;
+          const float sc = mask_score<CAUSAL>(s[r], p.scale, kstate, key, qpos);
+          float pr = (sc == NEG_INF || f.w == 0.f) ? 0.f : __expf(sc - f.x) * f.y;
+          float g = dp[r], pd = pr;
+          if (!CAUSAL && p.drop_thr) {
+            const float dsc = ur_dropout_scale(p.seed, (((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)qpos) * (uint64_t)p.Sk) + (uint64_t)key,
+                                               p.drop_thr, p.drop_inv);
+            g *= dsc; pd *= dsc;
+          }
+          s[r] = pd;                                  // P (with dropout) -> dV
+          dp[r] = pr * (g - f.z) * p.scale;           // dS               -> dK
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = acc_frag(s, s2), df = acc_frag(dp, s2);
+#pragma unroll
+          for (int dt = 0; dt < C::NDT; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(dotile, 32 * sub + 16 * s2, dt, lane), pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(qtile, 32 * sub + 16 * s2, dt, lane), df, dk[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (kok) {
+    store_T<HD>(p.dk + ((long)b * p.Sk + key) * p.lddk + (long)kvh * HD, dk, 1.0f, lane);
+    store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 1.0f, lane);
+  }
+}
+
+// ================================================================================================
+template <int HD> constexpr int fwd_smem() { return 2 * Cfg<HD>::TILE + 64; }
+template <int HD> constexpr int dkv_smem() { return 2 * Cfg<HD>::TILE + KT * 4 * (int)sizeof(float); }
+
+template <typename K>
+int set_smem(K kern, int bytes, const char* name) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) UR_FAIL((int)e, "%s: hipFuncSetAttribute: %s", name, hipGetErrorString(e));
+  return 0;
+}
+
+int fill(AttnP& p, const ur_attn_args* a) {
+  UR_REQUIRE(a && a->q && a->k && a->v && a->stats, "ur_attn: null argument");
+  UR_REQUIRE(a->B >= 0 && a->Sq > 0 && a->Sk > 0 && a->nq > 0 && a->nkv > 0 && (a->nq % a->nkv) == 0, "ur_attn: bad sizes");
+  UR_REQUIRE(a->head_dim == 64 || a->head_dim == 128, "ur_attn: head_dim must be 64 or 128 (got %d)", a->head_dim);
+  UR_REQUIRE((a->ldq % 8) == 0 && (a->ldk % 8) == 0 && (a->ldv % 8) == 0 && UR_ALIGNED16(a->q) && UR_ALIGNED16(a->k) && UR_ALIGNED16(a->v),
+             "ur_attn: q/k/v need 16-byte aligned rows");
+  UR_REQUIRE(a->ldq >= (int64_t)a->nq * a->head_dim && a->ldk >= (int64_t)a->nkv * a->head_dim && a->ldv >= (int64_t)a->nkv * a->head_dim,
+             "ur_attn: token stride smaller than heads*head_dim");
+  UR_REQUIRE(!a->causal || a->Sq == a->Sk, "ur_attn: causal mode needs Sq == Sk");
+  UR_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f && (!a->causal || a->dropout_p == 0.f), "ur_attn: bad dropout");
+  memset(&p, 0, sizeof(p));
+  p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.o = (bf16_t*)a->o; p.stats = a->stats;
+  p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.kmask = a->key_mask;
+  p.B = a->B; p.Sq = a->Sq; p.Sk = a->Sk; p.nq = a->nq; p.nkv = a->nkv; p.rep = a->nq / a->nkv;
+  p.scale = a->scale; p.seed = a->seed;
+  p.drop_thr = a->dropout_p > 0.f ? ur_drop_threshold(a->dropout_p) : 0u;
+  p.drop_inv = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
+  return 0;
+}
+
+template <int HD, bool CAUSAL, int NW>
+int launch_fwd(const AttnP& p, hipStream_t st) {
+  static bool once = false;
+  if (!once) { int rc = set_smem(&attn_fwd_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_fwd"); if (rc) return rc; once = true; }
+  dim3 grid(ur_cdiv(p.Sq, 32 * NW), p.nq, p.B);
+  hipLaunchKernelGGL((attn_fwd_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), fwd_smem<HD>(), st, p);
+  UR_CHECK_LAUNCH("ur_attn_fwd");
+  return 0;
+}
+template <int HD, bool CAUSAL, int NW>
+int launch_dq(const AttnP& p, hipStream_t st) {
+  static bool once = false;
+  if (!once) { int rc = set_smem(&attn_bwd_dq_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_bwd(dq)"); if (rc) return rc; once = true; }
+  dim3 grid(ur_cdiv(p.Sq, 32 * NW), p.nq, p.B);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), fwd_smem<HD>(), st, p);
+  UR_CHECK_LAUNCH("ur_attn_bwd(dq)");
+  return 0;
+}
+template <int HD, bool CAUSAL, int NW>
+int launch_dkv(const AttnP& p, hipStream_t st) {
+  static bool once = false;
+  if (!once) { int rc = set_smem(&attn_bwd_dkv_kernel<HD, CAUSAL, NW>, dkv_smem<HD>(), "ur_attn_bwd(dkv)"); if (rc) return rc; once = true; }
+  dim3 grid(ur_cdiv(p.Sk, 32 * NW), p.nkv, p.B);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), dkv_smem<HD>(), st, p);
+  UR_CHECK_LAUNCH("ur_attn_bwd(dkv)");
+  return 0;
+}
+
+inline int pick_nw(int S) { return S <= 32 ? 1 : (S <= 64 ? 2 : 4); }
+
+#define UR_ATTN_DISPATCH(HD_, CAUSAL_, NW_, FN, ...)                                      \
+  do {                                                                                    \
+    if ((HD_) == 64) {                                                                    \
+      if (CAUSAL_) { if ((NW_) == 1) return FN<64, true, 1>(__VA_ARGS__); if ((NW_) == 2) return FN<64, true, 2>(__VA_ARGS__); return FN<64, true, 4>(__VA_ARGS__); } \
+      else { if ((NW_) == 1) return FN<64, false, 1>(__VA_ARGS__); if ((NW_) == 2) return FN<64, false, 2>(__VA_ARGS__); return FN<64, false, 4>(__VA_ARGS__); }      \
+    } else {                                                                              \
+      if (CAUSAL_) { if ((NW_) == 1) return FN<128, true, 1>(__VA_ARGS__); if ((NW_) == 2) return FN<128, true, 2>(__VA_ARGS__); return FN<128, true, 4>(__VA_ARGS__); } \
+      else { if ((NW_) == 1) return FN<128, false, 1>(__VA_ARGS__); if ((NW_) == 2) return FN<128, false, 2>(__VA_ARGS__); return FN<128, false, 4>(__VA_ARGS__); }      \
+    }                                                                                     \
+  } while (0)
+
+int do_fwd(const AttnP& p, int hd, bool causal, hipStream_t st) { UR_ATTN_DISPATCH(hd, causal, pick_nw(p.Sq), launch_fwd, p, st); }
+int do_dq(const AttnP& p, int hd, bool causal, hipStream_t st) { UR_ATTN_DISPATCH(hd, causal, pick_nw(p.Sq), launch_dq, p, st); }
+int do_dkv(const AttnP& p, int hd, bool causal, hipStream_t st) { UR_ATTN_DISPATCH(hd, causal, pick_nw(p.Sk), launch_dkv, p, st); }
+
+}  // namespace
+
+extern "C" int ur_attn_fwd(const ur_attn_args* a, void* stream) {
+  AttnP p;
+  int rc = fill(p, a);
+  if (rc) return rc;
+  if (a->B == 0) return 0;
+  UR_REQUIRE(a->o && UR_ALIGNED16(a->o) && (a->ldo % 4) == 0 && a->ldo >= (int64_t)a->nq * a->head_dim, "ur_attn_fwd: bad output");
+  return do_fwd(p, a->head_dim, a->causal != 0, (hipStream_t)stream);
+}
+
+extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, void* stream) {
+  AttnP p;
+  int rc = fill(p, a);
+  if (rc) return rc;
+  if (a->B == 0) return 0;
+  UR_REQUIRE(g && g->dout && g->dq && g->dk && g->dv && g->delta && a->o, "ur_attn_bwd: null argument");
+  UR_REQUIRE(UR_ALIGNED16(g->dout) && UR_ALIGNED16(a->o) && (g->lddo % 8) == 0 && (a->ldo % 8) == 0, "ur_attn_bwd: dout/o need 16-byte aligned rows");
+  UR_REQUIRE((g->lddq % 4) == 0 && (g->lddk % 4) == 0 && (g->lddv % 4) == 0 && ((uintptr_t)g->dq & 7) == 0 && ((uintptr_t)g->dk & 7) == 0 &&
+             ((uintptr_t)g->dv & 7) == 0, "ur_attn_bwd: gradient outputs need 8-byte aligned rows");
+  p.dout = (const bf16_t*)g->dout; p.dq = (bf16_t*)g->dq; p.dk = (bf16_t*)g->dk; p.dv = (bf16_t*)g->dv; p.delta = g->delta;
+  p.lddo = g->lddo; p.lddq = g->lddq; p.lddk = g->lddk; p.lddv = g->lddv;
+  hipStream_t st = (hipStream_t)stream;
+  const long nrows = (long)p.B * p.Sq * p.nq;
+  if (a->head_dim == 64) {
+    hipLaunchKernelGGL((attn_delta_kernel<64>), dim3(ur_cdiv(nrows, 4 * 8)), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((attn_delta_kernel<128>), dim3(ur_cdiv(nrows, 4 * 4)), dim3(256), 0, st, p);
+  }
+  UR_CHECK_LAUNCH("ur_attn_bwd(delta)");
+  rc = do_dq(p, a->head_dim, a->causal != 0, st);
+  if (rc) return rc;
+  return do_dkv(p, a->head_dim, a->causal != 0, st);
+}

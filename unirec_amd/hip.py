@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import GemmArgs, check
+from ._lib import AttnArgs, AttnBwdArgs, GemmArgs, check
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -161,6 +161,63 @@ def rmsnorm_bwd(dout, x, w, rstd, add=None):
     check(lib.ur_rmsnorm_bwd(dout.data_ptr(), x.data_ptr(), w.data_ptr(), rstd.data_ptr(), _p(add), dx.data_ptr(), M, D, _stream()),
           "ur_rmsnorm_bwd")
     return dx
+
+
+class AttnCtx:
+    """What ur_attn_bwd needs from the forward (argument struct + the tensors it points into)."""
+    __slots__ = ("args", "keep", "o", "stats")
+
+
+def _tok_stride(t):
+    # [B,S,heads,hd] view (possibly a slice of a fused projection buffer): elements between tokens
+    if t.stride(3) != 1 or t.stride(2) != t.shape[3] or t.stride(0) != t.shape[1] * t.stride(1):
+        raise ValueError("attention operand must be [B,S,heads,hd] with dense heads and uniform token stride")
+    return t.stride(1)
+
+
+def attn_fwd(q, k, v, *, causal, key_mask=None, scale=None, dropout_p=0.0, seed=0, out=None):
+    """q [B,Sq,nq,hd], k/v [B,Sk,nkv,hd] bf16 (strided views allowed).  key_mask uint8 [B,Sk] or None.
+    Returns (o [B,Sq,nq,hd] contiguous, ctx)."""
+    lib = _lib.load()
+    B, Sq, nq, hd = q.shape
+    Sk, nkv = k.shape[1], k.shape[2]
+    if out is None:
+        out = torch.empty((B, Sq, nq, hd), dtype=BF16, device=q.device)
+    stats = torch.empty((B, nq, Sq, 2), dtype=F32, device=q.device)
+    if key_mask is not None and (key_mask.dtype != torch.uint8 or not key_mask.is_contiguous()):
+        raise TypeError("key_mask must be a contiguous uint8 [B,Sk] tensor")
+    a = AttnArgs()
+    a.q, a.k, a.v, a.o, a.stats = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), stats.data_ptr()
+    a.ldq, a.ldk, a.ldv, a.ldo = _tok_stride(q), _tok_stride(k), _tok_stride(v), _tok_stride(out)
+    a.key_mask = _p(key_mask)
+    a.B, a.Sq, a.Sk, a.nq, a.nkv, a.head_dim = B, Sq, Sk, nq, nkv, hd
+    a.causal = int(causal)
+    a.scale = float(scale if scale is not None else hd ** -0.5)
+    a.dropout_p, a.seed = float(dropout_p), int(seed)
+    check(lib.ur_attn_fwd(ctypes.byref(a), _stream()), "ur_attn_fwd")
+    ctx = AttnCtx()
+    ctx.args, ctx.keep, ctx.o, ctx.stats = a, (q, k, v, key_mask), out, stats
+    return out, ctx
+
+
+def attn_bwd(ctx, dout, dq=None, dk=None, dv=None):
+    """dout [B,Sq,nq,hd] -> (dq, dk, dv); outputs may be strided views into a fused gradient buffer."""
+    lib = _lib.load()
+    q, k, v, _ = ctx.keep
+    if dq is None:
+        dq = torch.empty(q.shape, dtype=BF16, device=q.device)
+    if dk is None:
+        dk = torch.empty(k.shape, dtype=BF16, device=q.device)
+    if dv is None:
+        dv = torch.empty(v.shape, dtype=BF16, device=q.device)
+    a = ctx.args
+    delta = torch.empty((a.B, a.nq, a.Sq), dtype=F32, device=q.device)
+    g = AttnBwdArgs()
+    g.dout, g.dq, g.dk, g.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    g.lddo, g.lddq, g.lddk, g.lddv = _tok_stride(dout), _tok_stride(dq), _tok_stride(dk), _tok_stride(dv)
+    g.delta = delta.data_ptr()
+    check(lib.ur_attn_bwd(ctypes.byref(a), ctypes.byref(g), _stream()), "ur_attn_bwd")
+    return dq, dk, dv
 
 
 def cast_f32_to_bf16(src, dst=None):
