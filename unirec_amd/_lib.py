@@ -61,9 +61,35 @@ SIGNATURES = {
     "ur_rmsnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ur_attn_fwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
     "ur_attn_bwd": (c_int, [ctypes.POINTER(AttnArgs), ctypes.POINTER(AttnBwdArgs), c_void_p]),
+    "ur_rope_table": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "ur_qknorm_rope_fwd": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
+                                   c_int, c_int, c_int, c_float, c_void_p]),
+    "ur_qknorm_rope_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
+                                   c_i64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ur_embed_inject_fwd": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ur_inject_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ur_mean_pool_workspace_bytes": (c_i64, [c_int, c_int]),
+    "ur_mean_pool_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
+    "ur_mean_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ur_cosine_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ur_infonce_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
+    "ur_infonce_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p,
+                                   c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
+    "ur_mrr_rank": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ur_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "ur_heads_workspace_bytes": (c_i64, [c_int, c_int]),
+    "ur_field_projection_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ur_field_projection_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_i64, c_void_p]),
+    "ur_recon_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_i64, c_void_p]),
+    "ur_recon_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_i64, c_int, c_void_p]),
+    "ur_triplet_margin": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                  c_i64, c_void_p]),
+    "ur_mse_loss": (c_int, [c_void_p, c_void_p, c_i64, c_float, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "ur_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_swiglu_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ur_swiglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ur_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_float, c_float, c_float, c_float, c_float,

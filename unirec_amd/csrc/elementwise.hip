@@ -86,6 +86,18 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t*
   }
 }
 
+__global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ u, bf16_t* __restrict__ dx, long n8) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    float a[8], b[8], o[8];
+    un8(*reinterpret_cast<const uint4*>(dy + i * 8), a);
+    un8(*reinterpret_cast<const uint4*>(u + i * 8), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = a[e] * gelu_erf_grad_f(b[e]);
+    *reinterpret_cast<uint4*>(dx + i * 8) = pk8(o);
+  }
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
                              float gscale) {
@@ -141,6 +153,15 @@ extern "C" int ur_add_bf16(const void* a, const void* b, void* out, int64_t n, v
   hipLaunchKernelGGL(add_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)b,
                      (bf16_t*)out, (long)(n / 8));
   UR_CHECK_LAUNCH("ur_add_bf16");
+  return 0;
+}
+extern "C" int ur_gelu_bwd(const void* dy, const void* u, void* dx, int64_t n, void* stream) {
+  UR_REQUIRE(n >= 0 && (n % 8) == 0, "ur_gelu_bwd: n must be a multiple of 8");
+  if (n == 0) return 0;
+  UR_REQUIRE(dy && u && dx && UR_ALIGNED16(dy) && UR_ALIGNED16(u) && UR_ALIGNED16(dx), "ur_gelu_bwd: null / misaligned");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)u,
+                     (bf16_t*)dx, (long)(n / 8));
+  UR_CHECK_LAUNCH("ur_gelu_bwd");
   return 0;
 }
 extern "C" int ur_swiglu_fwd(const void* gu, void* act, int32_t M, int32_t I, void* stream) {

@@ -275,7 +275,9 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
   UR_REQUIRE(a->M >= 0 && a->N >= 0 && a->K >= 0 && a->K2 >= 0, "ur_gemm: negative dimension");
   if (a->M == 0 || a->N == 0) return 0;
   UR_REQUIRE(a->R && a->S && a->C, "ur_gemm: null operand");
-  UR_REQUIRE((a->K % 8) == 0 && (a->K2 % 8) == 0, "ur_gemm: K (%d) and K2 (%d) must be multiples of 8", a->K, a->K2);
+  // a K-contiguous operand is staged in 16-byte chunks along K; K-strided operands put K on rows
+  UR_REQUIRE((!a->r_kcontig && !a->s_kcontig) || ((a->K % 8) == 0 && (a->K2 % 8) == 0),
+             "ur_gemm: K (%d) and K2 (%d) must be multiples of 8 for K-contiguous operands", a->K, a->K2);
   UR_REQUIRE((a->N % 4) == 0 && (a->ldc % 4) == 0, "ur_gemm: N (%d) and ldc (%ld) must be multiples of 4", a->N, (long)a->ldc);
   UR_REQUIRE((a->ldr % 8) == 0 && (a->lds % 8) == 0, "ur_gemm: ldr/lds must be multiples of 8 elements");
   UR_REQUIRE(a->r_kcontig || (a->M % 8) == 0, "ur_gemm: K-strided R needs M %% 8 == 0 (M=%d)", a->M);

@@ -1,0 +1,310 @@
+// Qwen3-side HBM-bound kernels: RoPE table, fused per-head q/k RMSNorm + RoPE (fwd/bwd), embedding
+// gather fused with Q-Former token injection (fwd/bwd), mean pooling (fwd/bwd).  gfx950 only.
+#include "common.cuh"
+#include "unirec_hip.h"
+
+namespace {
+
+__device__ __forceinline__ void un8(const uint4& u, float (&f)[8]) {
+  f[0] = bf_lo(u.x); f[1] = bf_hi(u.x); f[2] = bf_lo(u.y); f[3] = bf_hi(u.y);
+  f[4] = bf_lo(u.z); f[5] = bf_hi(u.z); f[6] = bf_lo(u.w); f[7] = bf_hi(u.w);
+}
+__device__ __forceinline__ uint4 pk8(const float (&f)[8]) {
+  return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+}
+__device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// cos/sin [S][hd/2] f32 : inv_freq_i = theta^(-2i/hd), angle = pos * inv_freq_i  (modeling_qwen3.py:107-137)
+__global__ void rope_table_kernel(float* __restrict__ cs, float* __restrict__ sn, int S, int half, float theta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * half) return;
+  const int pos = i / half, j = i - pos * half;
+  const float inv = 1.0f / powf(theta, (float)(2 * j) / (float)(2 * half));
+  const float ang = (float)pos * inv;
+  cs[i] = cosf(ang);
+  sn[i] = sinf(ang);
+}
+
+// One (token, head) row of hd elements per LPH = hd/8 lanes.  Heads 0..nq-1 are q, nq..nq+nkv-1 are k.
+template <int HD, bool BWD>
+__global__ __launch_bounds__(256) void qknorm_rope_kernel(const bf16_t* __restrict__ raw, long ldraw,
+                                                          const float* __restrict__ qw, const float* __restrict__ kw,
+                                                          const float* __restrict__ cs, const float* __restrict__ sn,
+                                                          bf16_t* __restrict__ qo, bf16_t* __restrict__ ko,   // fwd outputs / bwd: dq_out, dk_out inputs
+                                                          bf16_t* __restrict__ draw, long lddraw,             // bwd output (q,k sections)
+                                                          long M, int S, int nq, int nkv, float eps) {
+  constexpr int LPH = HD / 8, HALF = HD / 2;
+  const int lane = threadIdx.x & 63;
+  const int li = lane % LPH;
+  const long nrows = M * (nq + nkv);
+  const long rows_per_block = 256 / LPH;
+  // all LPH lanes of a group share `row`, so the group shuffles below never see a diverged partner
+  for (long row = (long)blockIdx.x * rows_per_block + threadIdx.x / LPH; row < nrows; row += (long)gridDim.x * rows_per_block) {
+    const bool ok = true;
+    const long m = row / (nq + nkv);
+    const int hh = (int)(row - m * (nq + nkv));
+    const bool isq = hh < nq;
+    const int pos = (int)(m % S);
+    const float* w = isq ? qw : kw;
+    float x[8], ww[8], c[8], s[8];
+    un8(*reinterpret_cast<const uint4*>(raw + m * ldraw + (long)hh * HD + li * 8), x);
+    ld8f(w + li * 8, ww);
+    ld8f(cs + (long)pos * HALF + (li % (LPH / 2)) * 8, c);
+    ld8f(sn + (long)pos * HALF + (li % (LPH / 2)) * 8, s);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+    ss = group_sum<LPH>(ss);
+    const float rs = rsqrtf(ss / (float)HD + eps);
+    const float sign = (li < LPH / 2) ? -1.f : 1.f;     // rotate_half: first half gets -x[d+half]
+    bf16_t* op = isq ? (qo + m * (long)nq * HD + (long)hh * HD) : (ko + m * (long)nkv * HD + (long)(hh - nq) * HD);
+    if (!BWD) {
+      float xn[8], o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xn[e] = x[e] * rs * ww[e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float partner = __shfl_xor(xn[e], LPH / 2, 64);
+        o[e] = xn[e] * c[e] + sign * partner * s[e];
+      }
+      if (ok) *reinterpret_cast<uint4*>(op + li * 8) = pk8(o);
+    } else {
+      float dy[8], g[8], xh[8];
+      un8(*reinterpret_cast<const uint4*>(op + li * 8), dy);
+      float t = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float partner = __shfl_xor(dy[e] * s[e], LPH / 2, 64);   // (dout*sin) of the paired element
+        const float dxn = dy[e] * c[e] - sign * partner;               // d<half: +partner, d>=half: -partner
+        g[e] = dxn * ww[e];
+        xh[e] = x[e] * rs;
+        t += g[e] * xh[e];
+      }
+      t = group_sum<LPH>(t) / (float)HD;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = rs * (g[e] - xh[e] * t);
+      if (ok) *reinterpret_cast<uint4*>(draw + m * lddraw + (long)hh * HD + li * 8) = pk8(o);
+    }
+  }
+}
+
+// out[b][s][:] = special(ids) ? tokens[b][ids - first][:] : embed[ids][:]
+__global__ __launch_bounds__(256) void embed_inject_kernel(const bf16_t* __restrict__ embed, const long* __restrict__ ids,
+                                                           const bf16_t* __restrict__ tokens, long first, int T,
+                                                           bf16_t* __restrict__ out, long rows, int S, int D, long vocab) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int D8 = D / 8;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const long id = ids[row];
+    const long rel = id - first;
+    const bf16_t* src;
+    if (tokens != nullptr && rel >= 0 && rel < T) src = tokens + ((row / S) * T + rel) * (long)D;
+    else src = embed + (id < 0 ? 0 : (id >= vocab ? vocab - 1 : id)) * (long)D;
+    for (int c = lane; c < D8; c += 64)
+      *reinterpret_cast<uint4*>(out + row * D + c * 8) = *reinterpret_cast<const uint4*>(src + c * 8);
+  }
+}
+
+// d_tokens[b][t][:] = sum over positions s with ids[b][s] == first + t of dx[b][s][:]   (0 if absent)
+__global__ __launch_bounds__(256) void inject_bwd_kernel(const bf16_t* __restrict__ dx, const long* __restrict__ ids, long first,
+                                                         int T, bf16_t* __restrict__ dtok, int S, int D) {
+  __shared__ unsigned char match[256];
+  const int b = blockIdx.x / T, t = blockIdx.x - b * T;
+  const int tid = threadIdx.x;
+  const long want = first + t;
+  const int D8 = D / 8;
+  float acc[2][8];   // up to D = 4096 with 256 threads
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[i][e] = 0.f;
+  for (int s0 = 0; s0 < S; s0 += 256) {
+    const int s = s0 + tid;
+    match[tid] = (s < S && ids[(long)b * S + s] == want) ? 1 : 0;
+    __syncthreads();
+    for (int j = 0; j < 256; ++j) {          // ascending position order: bitwise reproducible
+      if (!match[j]) continue;
+      const bf16_t* rowp = dx + ((long)b * S + s0 + j) * D;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = tid + i * 256;
+        if (c < D8) {
+          float f[8];
+          un8(*reinterpret_cast<const uint4*>(rowp + c * 8), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[i][e] += f[e];
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = tid + i * 256;
+    if (c < D8) *reinterpret_cast<uint4*>(dtok + ((long)b * T + t) * D + c * 8) = pk8(acc[i]);
+  }
+}
+
+// mean over the middle axis: x [B][S][D] bf16 -> out [B][D] (f32 and/or bf16)
+constexpr int POOL_SLICES = 16;
+__global__ void pool_stage1(const bf16_t* __restrict__ x, float* __restrict__ part, int S, int D8, int per) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D8) return;
+  const int sl = blockIdx.y, b = blockIdx.z;
+  const int s0 = sl * per, s1 = min(S, s0 + per);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = s0; s < s1; ++s) {
+    float f[8];
+    un8(*reinterpret_cast<const uint4*>(x + (((long)b * S + s) * D8 + c) * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += f[e];
+  }
+  float* o = part + (((long)b * POOL_SLICES + sl) * D8 + c) * 8;
+  *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+__global__ void pool_stage2(const float* __restrict__ part, float* __restrict__ out32, bf16_t* __restrict__ out16, long BD, int D,
+                            float inv) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= BD) return;
+  const long b = i / D; const int d = (int)(i - b * D);
+  float s = 0.f;
+  for (int k = 0; k < POOL_SLICES; ++k) s += part[(b * POOL_SLICES + k) * D + d];
+  s *= inv;
+  if (out32) out32[i] = s;
+  if (out16) out16[i] = f2bf(s);
+}
+// dx[b][s][:] = dout[b][:] * inv   (dout f32 or bf16)
+__global__ void pool_bwd_kernel(const float* __restrict__ d32, const bf16_t* __restrict__ d16, bf16_t* __restrict__ dx, long B,
+                                int S, int D8, float inv) {
+  const long total = B * S * D8, stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % D8); const long b = i / ((long)S * D8);
+    float f[8];
+    if (d32) ld8f(d32 + (b * D8 + c) * 8, f);
+    else un8(*reinterpret_cast<const uint4*>(d16 + (b * D8 + c) * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] *= inv;
+    *reinterpret_cast<uint4*>(dx + i * 8) = pk8(f);
+  }
+}
+
+inline int grid_cap(long n, int cap) { return (int)(n < 1 ? 1 : (n > cap ? cap : n)); }
+
+}  // namespace
+
+extern "C" int ur_rope_table(float* cos_out, float* sin_out, int32_t S, int32_t head_dim, float theta, void* stream) {
+  UR_REQUIRE(cos_out && sin_out && S > 0 && head_dim > 0 && (head_dim % 2) == 0, "ur_rope_table: bad argument");
+  const int n = S * (head_dim / 2);
+  hipLaunchKernelGGL(rope_table_kernel, dim3(ur_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, cos_out, sin_out, S, head_dim / 2, theta);
+  UR_CHECK_LAUNCH("ur_rope_table");
+  return 0;
+}
+
+static int qk_common_check(const void* raw, int64_t ldraw, const float* qw, const float* kw, const float* c, const float* s,
+                           int64_t M, int32_t S, int32_t nq, int32_t nkv, int32_t hd, const char* who) {
+  UR_REQUIRE(hd == 64 || hd == 128, "%s: head_dim must be 64 or 128", who);
+  UR_REQUIRE(raw && qw && kw && c && s && M >= 0 && S > 0 && nq > 0 && nkv > 0, "%s: null / bad argument", who);
+  UR_REQUIRE((ldraw % 8) == 0 && ldraw >= (int64_t)(nq + 2 * nkv) * hd && UR_ALIGNED16(raw) && UR_ALIGNED16(qw) && UR_ALIGNED16(kw) &&
+             UR_ALIGNED16(c) && UR_ALIGNED16(s), "%s: alignment / stride", who);
+  return 0;
+}
+
+extern "C" int ur_qknorm_rope_fwd(const void* qkv_raw, int64_t ldraw, const float* q_norm_w, const float* k_norm_w,
+                                  const float* cos_tab, const float* sin_tab, void* q_out, void* k_out, int64_t M, int32_t S,
+                                  int32_t nq, int32_t nkv, int32_t head_dim, float eps, void* stream) {
+  int rc = qk_common_check(qkv_raw, ldraw, q_norm_w, k_norm_w, cos_tab, sin_tab, M, S, nq, nkv, head_dim, "ur_qknorm_rope_fwd");
+  if (rc) return rc;
+  if (M == 0) return 0;
+  UR_REQUIRE(q_out && k_out && UR_ALIGNED16(q_out) && UR_ALIGNED16(k_out), "ur_qknorm_rope_fwd: bad outputs");
+  const long nrows = (long)M * (nq + nkv);
+  const int rpb = 256 / (head_dim / 8);
+  const int grid = grid_cap((nrows + rpb - 1) / rpb, 256 * 16);
+  if (head_dim == 128)
+    hipLaunchKernelGGL((qknorm_rope_kernel<128, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv_raw, (long)ldraw,
+                       q_norm_w, k_norm_w, cos_tab, sin_tab, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)nullptr, 0L, (long)M, S, nq, nkv, eps);
+  else
+    hipLaunchKernelGGL((qknorm_rope_kernel<64, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv_raw, (long)ldraw,
+                       q_norm_w, k_norm_w, cos_tab, sin_tab, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)nullptr, 0L, (long)M, S, nq, nkv, eps);
+  UR_CHECK_LAUNCH("ur_qknorm_rope_fwd");
+  return 0;
+}
+
+extern "C" int ur_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const void* qkv_raw, int64_t ldraw,
+                                  const float* q_norm_w, const float* k_norm_w, const float* cos_tab, const float* sin_tab,
+                                  void* dqkv_raw, int64_t lddraw, int64_t M, int32_t S, int32_t nq, int32_t nkv,
+                                  int32_t head_dim, float eps, void* stream) {
+  int rc = qk_common_check(qkv_raw, ldraw, q_norm_w, k_norm_w, cos_tab, sin_tab, M, S, nq, nkv, head_dim, "ur_qknorm_rope_bwd");
+  if (rc) return rc;
+  if (M == 0) return 0;
+  UR_REQUIRE(dq_out && dk_out && dqkv_raw && UR_ALIGNED16(dq_out) && UR_ALIGNED16(dk_out) && UR_ALIGNED16(dqkv_raw) && (lddraw % 8) == 0 &&
+             lddraw >= (int64_t)(nq + nkv) * head_dim, "ur_qknorm_rope_bwd: bad gradient buffers");
+  const long nrows = (long)M * (nq + nkv);
+  const int rpb = 256 / (head_dim / 8);
+  const int grid = grid_cap((nrows + rpb - 1) / rpb, 256 * 16);
+  if (head_dim == 128)
+    hipLaunchKernelGGL((qknorm_rope_kernel<128, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv_raw, (long)ldraw,
+                       q_norm_w, k_norm_w, cos_tab, sin_tab, (bf16_t*)dq_out, (bf16_t*)dk_out, (bf16_t*)dqkv_raw, (long)lddraw, (long)M, S, nq, nkv, eps);
+  else
+    hipLaunchKernelGGL((qknorm_rope_kernel<64, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv_raw, (long)ldraw,
+                       q_norm_w, k_norm_w, cos_tab, sin_tab, (bf16_t*)dq_out, (bf16_t*)dk_out, (bf16_t*)dqkv_raw, (long)lddraw, (long)M, S, nq, nkv, eps);
+  UR_CHECK_LAUNCH("ur_qknorm_rope_bwd");
+  return 0;
+}
+
+extern "C" int ur_embed_inject_fwd(const void* embed, int64_t vocab, const int64_t* input_ids, const void* item_tokens,
+                                   int64_t first_special_id, int32_t T, void* out, int32_t B, int32_t S, int32_t D, void* stream) {
+  UR_REQUIRE(embed && input_ids && out && vocab > 0 && B >= 0 && S > 0 && D > 0 && (D % 8) == 0 && T >= 0, "ur_embed_inject_fwd: bad argument");
+  UR_REQUIRE(UR_ALIGNED16(embed) && UR_ALIGNED16(out) && (!item_tokens || UR_ALIGNED16(item_tokens)), "ur_embed_inject_fwd: alignment");
+  if (B == 0) return 0;
+  const long rows = (long)B * S;
+  hipLaunchKernelGGL(embed_inject_kernel, dim3(grid_cap((rows + 3) / 4, 256 * 16)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)embed,
+                     (const long*)input_ids, (const bf16_t*)(T > 0 ? item_tokens : nullptr), (long)first_special_id, T, (bf16_t*)out, rows, S, D,
+                     (long)vocab);
+  UR_CHECK_LAUNCH("ur_embed_inject_fwd");
+  return 0;
+}
+
+extern "C" int ur_inject_bwd(const void* dx, const int64_t* input_ids, int64_t first_special_id, int32_t T, void* d_item_tokens,
+                             int32_t B, int32_t S, int32_t D, void* stream) {
+  UR_REQUIRE(dx && input_ids && d_item_tokens && B >= 0 && S > 0 && T >= 0 && D > 0 && (D % 8) == 0 && D <= 4096, "ur_inject_bwd: bad argument");
+  UR_REQUIRE(UR_ALIGNED16(dx) && UR_ALIGNED16(d_item_tokens), "ur_inject_bwd: alignment");
+  if (B == 0 || T == 0) return 0;
+  hipLaunchKernelGGL(inject_bwd_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dx, (const long*)input_ids,
+                     (long)first_special_id, T, (bf16_t*)d_item_tokens, S, D);
+  UR_CHECK_LAUNCH("ur_inject_bwd");
+  return 0;
+}
+
+extern "C" int64_t ur_mean_pool_workspace_bytes(int32_t B, int32_t D) { return (int64_t)B * POOL_SLICES * D * (int64_t)sizeof(float); }
+
+extern "C" int ur_mean_pool_fwd(const void* x, float* out_f32, void* out_bf16, int32_t B, int32_t S, int32_t D, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+  UR_REQUIRE(x && (out_f32 || out_bf16) && B >= 0 && S > 0 && D > 0 && (D % 8) == 0 && UR_ALIGNED16(x), "ur_mean_pool_fwd: bad argument");
+  UR_REQUIRE(workspace && UR_ALIGNED16(workspace) && workspace_bytes >= ur_mean_pool_workspace_bytes(B, D), "ur_mean_pool_fwd: workspace too small");
+  if (B == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int D8 = D / 8, per = ur_cdiv(S, POOL_SLICES);
+  hipLaunchKernelGGL(pool_stage1, dim3(ur_cdiv(D8, 64), POOL_SLICES, B), dim3(64), 0, st, (const bf16_t*)x, (float*)workspace, S, D8, per);
+  UR_CHECK_LAUNCH("ur_mean_pool_fwd(stage1)");
+  const long BD = (long)B * D;
+  hipLaunchKernelGGL(pool_stage2, dim3(ur_cdiv(BD, 256)), dim3(256), 0, st, (const float*)workspace, out_f32, (bf16_t*)out_bf16, BD, D,
+                     1.0f / (float)S);
+  UR_CHECK_LAUNCH("ur_mean_pool_fwd(stage2)");
+  return 0;
+}
+
+extern "C" int ur_mean_pool_bwd(const float* dout_f32, const void* dout_bf16, void* dx, int32_t B, int32_t S, int32_t D, void* stream) {
+  UR_REQUIRE((dout_f32 || dout_bf16) && dx && B >= 0 && S > 0 && D > 0 && (D % 8) == 0 && UR_ALIGNED16(dx), "ur_mean_pool_bwd: bad argument");
+  UR_REQUIRE((!dout_f32 || UR_ALIGNED16(dout_f32)) && (!dout_bf16 || UR_ALIGNED16(dout_bf16)), "ur_mean_pool_bwd: alignment");
+  if (B == 0) return 0;
+  const long total = (long)B * S * (D / 8);
+  hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_cap((total + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, dout_f32,
+                     (const bf16_t*)dout_bf16, (bf16_t*)dx, (long)B, S, D / 8, 1.0f / (float)S);
+  UR_CHECK_LAUNCH("ur_mean_pool_bwd");
+  return 0;
+}

@@ -266,3 +266,209 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_d
     lib = _lib.load()
     check(lib.ur_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), lr,
                             beta1, beta2, eps, weight_decay, step, grad_scale, _stream()), "ur_adamw_step")
+
+
+# ---- Qwen3-side ops ------------------------------------------------------------------------------
+def rope_table(S, head_dim, theta, device):
+    lib = _lib.load()
+    cos = torch.empty((S, head_dim // 2), dtype=F32, device=device)
+    sin = torch.empty((S, head_dim // 2), dtype=F32, device=device)
+    check(lib.ur_rope_table(cos.data_ptr(), sin.data_ptr(), S, head_dim, theta, _stream()), "ur_rope_table")
+    return cos, sin
+
+
+def qknorm_rope_fwd(qkv_raw, qw, kw, cos, sin, S, nq, nkv, hd, eps):
+    """qkv_raw [M,(nq+2nkv)*hd] -> (q_out [M,nq*hd], k_out [M,nkv*hd])."""
+    lib = _lib.load()
+    M = qkv_raw.shape[0]
+    q_out = torch.empty((M, nq * hd), dtype=BF16, device=qkv_raw.device)
+    k_out = torch.empty((M, nkv * hd), dtype=BF16, device=qkv_raw.device)
+    check(lib.ur_qknorm_rope_fwd(qkv_raw.data_ptr(), qkv_raw.stride(0), qw.data_ptr(), kw.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+                                 q_out.data_ptr(), k_out.data_ptr(), M, S, nq, nkv, hd, eps, _stream()), "ur_qknorm_rope_fwd")
+    return q_out, k_out
+
+
+def qknorm_rope_bwd(dq_out, dk_out, qkv_raw, qw, kw, cos, sin, dqkv_raw, S, nq, nkv, hd, eps):
+    lib = _lib.load()
+    M = qkv_raw.shape[0]
+    check(lib.ur_qknorm_rope_bwd(dq_out.data_ptr(), dk_out.data_ptr(), qkv_raw.data_ptr(), qkv_raw.stride(0), qw.data_ptr(), kw.data_ptr(),
+                                 cos.data_ptr(), sin.data_ptr(), dqkv_raw.data_ptr(), dqkv_raw.stride(0), M, S, nq, nkv, hd, eps,
+                                 _stream()), "ur_qknorm_rope_bwd")
+    return dqkv_raw
+
+
+def embed_inject_fwd(embed, input_ids, item_tokens, first_special_id):
+    """embed [V,D] bf16, input_ids int64 [B,S], item_tokens [B,T,D] bf16 or None -> [B,S,D] bf16."""
+    lib = _lib.load()
+    _need(embed, BF16, "embed")
+    _need(input_ids, torch.int64, "input_ids")
+    B, S = input_ids.shape
+    V, D = embed.shape
+    T = 0 if item_tokens is None else item_tokens.shape[1]
+    out = torch.empty((B, S, D), dtype=BF16, device=embed.device)
+    check(lib.ur_embed_inject_fwd(embed.data_ptr(), V, input_ids.data_ptr(), _p(item_tokens), first_special_id, T, out.data_ptr(),
+                                  B, S, D, _stream()), "ur_embed_inject_fwd")
+    return out
+
+
+def inject_bwd(dx, input_ids, first_special_id, T):
+    lib = _lib.load()
+    B, S, D = dx.shape
+    d_tok = torch.empty((B, T, D), dtype=BF16, device=dx.device)
+    check(lib.ur_inject_bwd(dx.data_ptr(), input_ids.data_ptr(), first_special_id, T, d_tok.data_ptr(), B, S, D, _stream()),
+          "ur_inject_bwd")
+    return d_tok
+
+
+def mean_pool_fwd(x, out_f32=True, out_bf16=False):
+    """x [B,S,D] bf16 -> (f32 [B,D] or None, bf16 [B,D] or None)."""
+    lib = _lib.load()
+    _need(x, BF16, "x")
+    B, S, D = x.shape
+    o32 = torch.empty((B, D), dtype=F32, device=x.device) if out_f32 else None
+    o16 = torch.empty((B, D), dtype=BF16, device=x.device) if out_bf16 else None
+    wsb = lib.ur_mean_pool_workspace_bytes(B, D)
+    ws = workspace(wsb, x.device, "pool")
+    check(lib.ur_mean_pool_fwd(x.data_ptr(), _p(o32), _p(o16), B, S, D, ws.data_ptr(), wsb, _stream()), "ur_mean_pool_fwd")
+    return o32, o16
+
+
+def mean_pool_bwd(dout, S):
+    """dout [B,D] (f32 or bf16) -> dx [B,S,D] bf16 = dout / S broadcast."""
+    lib = _lib.load()
+    B, D = dout.shape
+    dx = torch.empty((B, S, D), dtype=BF16, device=dout.device)
+    d32 = dout.data_ptr() if dout.dtype == F32 else 0
+    d16 = dout.data_ptr() if dout.dtype == BF16 else 0
+    check(lib.ur_mean_pool_bwd(d32, d16, dx.data_ptr(), B, S, D, _stream()), "ur_mean_pool_bwd")
+    return dx
+
+
+# ---- ranking head --------------------------------------------------------------------------------
+def cosine_scores(user, pos, neg):
+    """user [B,D], pos [B,D], neg [B,N,D] f32 -> (scores [B,1+N], cand_inv_norm [B,1+N])."""
+    lib = _lib.load()
+    for t, n in ((user, "user"), (pos, "pos"), (neg, "neg")):
+        _need(t, F32, n)
+    B, D = user.shape
+    N = neg.shape[1]
+    scores = torch.empty((B, N + 1), dtype=F32, device=user.device)
+    inv = torch.empty((B, N + 1), dtype=F32, device=user.device)
+    check(lib.ur_cosine_scores(user.data_ptr(), pos.data_ptr(), neg.data_ptr(), scores.data_ptr(), inv.data_ptr(), B, N, D, _stream()),
+          "ur_cosine_scores")
+    return scores, inv
+
+
+def infonce_fwd_bwd(user, pos, neg, neg_mask, scores, inv, temperature=0.07, grad_scale=1.0, need_grad=True):
+    """Returns (loss [1] f32, d_user [B,D] f32 or None)."""
+    lib = _lib.load()
+    B, D = user.shape
+    N = neg.shape[1]
+    loss = torch.empty((1,), dtype=F32, device=user.device)
+    du = torch.empty((B, D), dtype=F32, device=user.device) if need_grad else None
+    wsb = lib.ur_infonce_workspace_bytes(B, N, D)
+    ws = workspace(wsb, user.device, "infonce")
+    check(lib.ur_infonce_fwd_bwd(user.data_ptr(), pos.data_ptr(), neg.data_ptr(), _p(neg_mask), scores.data_ptr(), inv.data_ptr(),
+                                 temperature, grad_scale, loss.data_ptr(), _p(du), B, N, D, ws.data_ptr(), wsb, _stream()),
+          "ur_infonce_fwd_bwd")
+    return loss, du
+
+
+def mrr_rank(scores, neg_mask=None):
+    lib = _lib.load()
+    B, C = scores.shape
+    rank = torch.empty((B,), dtype=torch.int32, device=scores.device)
+    check(lib.ur_mrr_rank(scores.data_ptr(), _p(neg_mask), rank.data_ptr(), B, C - 1, _stream()), "ur_mrr_rank")
+    return rank
+
+
+def topk(scores, K):
+    lib = _lib.load()
+    _need(scores, F32, "scores")
+    B, C = scores.shape
+    idx = torch.empty((B, K), dtype=torch.int32, device=scores.device)
+    val = torch.empty((B, K), dtype=F32, device=scores.device)
+    ws = workspace(B * C, scores.device, "topk")
+    check(lib.ur_topk(scores.data_ptr(), B, C, K, idx.data_ptr(), val.data_ptr(), ws.data_ptr(), B * C, _stream()), "ur_topk")
+    return idx, val
+
+
+# ---- heads / losses ------------------------------------------------------------------------------
+def gelu_bwd(dy, u):
+    lib = _lib.load()
+    dx = torch.empty_like(u)
+    check(lib.ur_gelu_bwd(dy.data_ptr(), u.data_ptr(), dx.data_ptr(), u.numel(), _stream()), "ur_gelu_bwd")
+    return dx
+
+
+def _heads_ws(Q, F, device):
+    lib = _lib.load()
+    n = max(lib.ur_heads_workspace_bytes(Q, F), 4096 * 4)
+    return workspace(n, device, "heads"), n
+
+
+def field_projection_fwd(rec16, Wf, bf):
+    """rec16 [B,Q,E] bf16, Wf [F,Q] f32, bf [F] f32 -> [B,F,E] f32."""
+    lib = _lib.load()
+    B, Q, E = rec16.shape
+    F_ = Wf.shape[0]
+    out = torch.empty((B, F_, E), dtype=F32, device=rec16.device)
+    check(lib.ur_field_projection_fwd(rec16.data_ptr(), Wf.data_ptr(), bf.data_ptr(), out.data_ptr(), B, Q, F_, E, _stream()),
+          "ur_field_projection_fwd")
+    return out
+
+
+def field_projection_bwd(dout, rec16, Wf, dWf, dbf):
+    lib = _lib.load()
+    B, Q, E = rec16.shape
+    F_ = Wf.shape[0]
+    drec = torch.empty_like(rec16)
+    ws, n = _heads_ws(Q, F_, rec16.device)
+    check(lib.ur_field_projection_bwd(dout.data_ptr(), rec16.data_ptr(), Wf.data_ptr(), drec.data_ptr(), dWf.data_ptr(), dbf.data_ptr(),
+                                      B, Q, F_, E, ws.data_ptr(), n, _stream()), "ur_field_projection_bwd")
+    return drec
+
+
+def recon_stats(rec, x, mask):
+    """f32 [rows,E] x2 + f32 mask [rows] -> sums3 = (sum mask*se, sum mask, sum cos over valid rows)."""
+    lib = _lib.load()
+    E = rec.shape[-1]
+    rows = rec.numel() // E
+    sums = torch.empty((3,), dtype=F32, device=rec.device)
+    ws, n = _heads_ws(1, 1, rec.device)
+    check(lib.ur_recon_stats(rec.data_ptr(), x.data_ptr(), mask.data_ptr(), sums.data_ptr(), rows, E, ws.data_ptr(), n, _stream()),
+          "ur_recon_stats")
+    return sums
+
+
+def recon_grad(rec, x, mask, sums, coef):
+    lib = _lib.load()
+    E = rec.shape[-1]
+    rows = rec.numel() // E
+    d = torch.empty_like(rec)
+    check(lib.ur_recon_grad(rec.data_ptr(), x.data_ptr(), mask.data_ptr(), sums.data_ptr(), coef, d.data_ptr(), rows, E, _stream()),
+          "ur_recon_grad")
+    return d
+
+
+def triplet_margin(anchor, pos, neg, margin, coef, need_grad=True):
+    lib = _lib.load()
+    B, E = anchor.shape
+    loss = torch.empty((1,), dtype=F32, device=anchor.device)
+    da = torch.empty_like(anchor) if need_grad else None
+    ws, n = _heads_ws(1, 1, anchor.device)
+    if n < 4 * B:
+        ws, n = workspace(4 * B, anchor.device, "heads"), 4 * B
+    check(lib.ur_triplet_margin(anchor.data_ptr(), pos.data_ptr(), neg.data_ptr(), margin, coef, loss.data_ptr(), _p(da), B, E,
+                                ws.data_ptr(), n, _stream()), "ur_triplet_margin")
+    return loss, da
+
+
+def mse_loss(a, b, coef=1.0, need_grad=True):
+    lib = _lib.load()
+    loss = torch.empty((1,), dtype=F32, device=a.device)
+    da = torch.empty_like(a) if need_grad else None
+    ws, n = _heads_ws(1, 1, a.device)
+    check(lib.ur_mse_loss(a.data_ptr(), b.data_ptr(), a.numel(), coef, loss.data_ptr(), _p(da), ws.data_ptr(), n, _stream()),
+          "ur_mse_loss")
+    return loss, da

@@ -1,0 +1,450 @@
+"""MI355X-native drop-in for the reference's ``models/qformer.py`` (query-only Q-Former path).
+
+Public surface kept: ``BertConfig`` (re-export), ``BertModel(config,
+add_pooling_layer=False)`` with ``.forward(query_embeds=, encoder_hidden_states=,
+encoder_attention_mask=, attention_mask=, return_dict=True).last_hidden_state`` and the reference's
+exact ``state_dict`` keys (dead tensors included, models/qformer.py:56-61,396-397), so reference
+checkpoints load unchanged.
+
+Underneath, one autograd node runs the whole encoder forward and one runs the whole backward, each a
+sequence of libunirec_hip.so calls (bf16 MFMA GEMMs with fused epilogues, fused MFMA attention, fused
+dropout+residual+LayerNorm); torch only owns the memory.  There is no eager fallback.
+
+Reference lines restated here: embeddings models/qformer.py:78-108; masks :784-802 + HF
+invert_attention_mask; BertSelfAttention :169-275; BertSelfOutput :285-289; BertLayer (query branch)
+:402-484; BertEncoder loop :517-566; BertModel.forward :804-972.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .packing import ParamPack
+
+try:  # the reference re-exports transformers' BertConfig (models/qformer.py:46); checkpoints pickle it
+    from transformers.models.bert.configuration_bert import BertConfig
+except Exception:  # pragma: no cover - transformers is optional for the compute path
+    class BertConfig:  # minimal stand-in with the fields the path reads
+        def __init__(self, vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                     intermediate_size=3072, hidden_act="gelu", hidden_dropout_prob=0.1,
+                     attention_probs_dropout_prob=0.1, max_position_embeddings=512, initializer_range=0.02,
+                     layer_norm_eps=1e-12, pad_token_id=0, **kw):
+            self.__dict__.update(dict(vocab_size=vocab_size, hidden_size=hidden_size, num_hidden_layers=num_hidden_layers,
+                                      num_attention_heads=num_attention_heads, intermediate_size=intermediate_size,
+                                      hidden_act=hidden_act, hidden_dropout_prob=hidden_dropout_prob,
+                                      attention_probs_dropout_prob=attention_probs_dropout_prob,
+                                      max_position_embeddings=max_position_embeddings, initializer_range=initializer_range,
+                                      layer_norm_eps=layer_norm_eps, pad_token_id=pad_token_id))
+            self.__dict__.update(kw)
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# -------------------------------------------------------------------------------------------------
+# Parameter containers: plain nn modules used ONLY for their parameters / state_dict keys.
+# -------------------------------------------------------------------------------------------------
+class _SelfAttentionParams(nn.Module):
+    def __init__(self, config, is_cross):
+        super().__init__()
+        H = config.hidden_size
+        kin = config.encoder_width if is_cross else H
+        self.query = nn.Linear(H, H)
+        self.key = nn.Linear(kin, H)
+        self.value = nn.Linear(kin, H)
+
+
+class _SelfOutputParams(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class _AttentionParams(nn.Module):
+    def __init__(self, config, is_cross=False):
+        super().__init__()
+        self.self = _SelfAttentionParams(config, is_cross)
+        self.output = _SelfOutputParams(config)
+
+
+class _IntermediateParams(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+
+
+class _OutputParams(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+
+
+class _LayerParams(nn.Module):
+    def __init__(self, config, layer_num):
+        super().__init__()
+        self.attention = _AttentionParams(config)
+        # models/qformer.py:386-393
+        self.has_cross_attention = bool(config.add_cross_attention and layer_num % config.cross_attention_freq == 0)
+        if self.has_cross_attention:
+            self.crossattention = _AttentionParams(config, is_cross=True)
+        self.intermediate = _IntermediateParams(config)          # dead on the query-only path
+        self.output = _OutputParams(config)                      # dead
+        self.intermediate_query = _IntermediateParams(config)
+        self.output_query = _OutputParams(config)
+
+
+class _EmbeddingParams(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=config.pad_token_id)  # dead
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)                  # dead
+        self.LayerNorm = nn.LayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.register_buffer("position_ids", torch.arange(config.max_position_embeddings).expand((1, -1)))
+
+
+class _EncoderParams(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.layer = nn.ModuleList([_LayerParams(config, i) for i in range(config.num_hidden_layers)])
+
+
+def _dead(name):
+    return (".intermediate.dense." in name or ".output.dense." in name or ".output.LayerNorm." in name
+            or "word_embeddings" in name or "position_embeddings" in name)
+
+
+def _split_k_for(out_rows, out_cols, red):
+    """dW GEMMs have tiny output grids; split the token reduction so the launch fills 256 CUs."""
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    want = max(1, 512 // max(tiles, 1))
+    return int(max(1, min(want, red // 256, 64)))
+
+
+# -------------------------------------------------------------------------------------------------
+# The encoder as ONE autograd node.
+# -------------------------------------------------------------------------------------------------
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, query_embeds, enc, enc_mask_u8, B, qe_param_name):
+        out, saved = model._forward_impl(query_embeds, enc, enc_mask_u8, B)
+        ctx.model = model
+        ctx.saved = saved
+        ctx.enc_needs_grad = bool(enc.requires_grad)
+        ctx.qe_param_name = qe_param_name
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model = ctx.model
+        d_qe, d_enc = model._backward_impl(ctx.saved, dout, ctx.enc_needs_grad, ctx.qe_param_name)
+        ctx.saved = None
+        return None, d_qe, d_enc, None, None, None
+
+
+class BertModel(nn.Module):
+    """Query-only Q-Former backbone (``input_ids`` is not supported: the reference's hot path never
+    passes it)."""
+
+    def __init__(self, config, add_pooling_layer=False):
+        super().__init__()
+        if add_pooling_layer:
+            raise NotImplementedError("pooler is not on the UniRec hot path (models/qformer.py:592 unused)")
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (config.hidden_size, config.num_attention_heads))
+        if config.hidden_size // config.num_attention_heads != 64:
+            raise ValueError("the MI355X Q-Former attention kernel is built for head_dim 64 "
+                             "(every UniRec configuration: 256/4, 768/12, 1024/16)")
+        self.config = config
+        self.embeddings = _EmbeddingParams(config)
+        self.encoder = _EncoderParams(config)
+        self.pooler = None
+        self._init_weights_like_reference()
+        self._pack = None
+        object.__setattr__(self, "_pack_owner", None)   # wrapper owning a bigger pack (not a submodule: no cycle)
+        self._pack_prefix = ""
+        self._step = 0
+        self.seed = 0x5EED
+
+    # models/qformer.py:664-674
+    def _init_weights_like_reference(self):
+        std = getattr(self.config, "initializer_range", 0.02)
+        for m in self.modules():
+            if isinstance(m, (nn.Linear, nn.Embedding)):
+                m.weight.data.normal_(mean=0.0, std=std)
+            elif isinstance(m, nn.LayerNorm):
+                m.bias.data.zero_()
+                m.weight.data.fill_(1.0)
+            if isinstance(m, nn.Linear) and m.bias is not None:
+                m.bias.data.zero_()
+
+    # ---- live-parameter ordering (q|k|v and k|v adjacent so they fuse into one GEMM operand) ----
+    def live_named_parameters(self, prefix=""):
+        named = dict(self.named_parameters())
+        order = ["embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"]
+        for i, lyr in enumerate(self.encoder.layer):
+            lp = f"encoder.layer.{i}."
+            blocks = ["attention."] + (["crossattention."] if lyr.has_cross_attention else [])
+            for b in blocks:
+                order += [lp + b + f"self.{n}.weight" for n in ("query", "key", "value")]
+                order += [lp + b + f"self.{n}.bias" for n in ("query", "key", "value")]
+                order += [lp + b + "output.dense.weight", lp + b + "output.dense.bias",
+                          lp + b + "output.LayerNorm.weight", lp + b + "output.LayerNorm.bias"]
+            order += [lp + "intermediate_query.dense.weight", lp + "intermediate_query.dense.bias",
+                      lp + "output_query.dense.weight", lp + "output_query.dense.bias",
+                      lp + "output_query.LayerNorm.weight", lp + "output_query.LayerNorm.bias"]
+        return [(prefix + n, named[n]) for n in order]
+
+    def dead_parameters(self):
+        return [p for n, p in self.named_parameters() if _dead(n)]
+
+    def _ensure_pack(self, device, prefix=""):
+        if self._pack_owner is not None:
+            return self._pack_owner._ensure_pack(device)
+        if self._pack is None or not self._pack.is_current() or self._pack.device != torch.device(device):
+            for p in self.dead_parameters():
+                p.requires_grad_(False)
+            self._pack = ParamPack(self.live_named_parameters(), device)
+        return self._pack
+
+    def _set_pack_owner(self, owner, prefix):
+        object.__setattr__(self, "_pack_owner", owner)
+        self._pack_prefix = prefix
+
+    def _live_names(self):
+        if getattr(self, "_live_names_cache", None) is None or self._live_names_cache[0] != self._pack_prefix:
+            self._live_names_cache = (self._pack_prefix, [n for n, _ in self.live_named_parameters(self._pack_prefix)])
+        return self._live_names_cache[1]
+
+    def _names(self):
+        return self._pack_prefix
+
+    # ---- forward -------------------------------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, head_mask=None, query_embeds=None,
+                encoder_hidden_states=None, encoder_attention_mask=None, past_key_values=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, return_dict=None, is_decoder=False):
+        if input_ids is not None or past_key_values is not None or is_decoder or output_attentions or head_mask is not None:
+            raise NotImplementedError("only the query-only encoder path of models/qformer.py is on the UniRec hot path")
+        assert query_embeds is not None, "You have to specify query_embeds when input_ids is None"
+        hidden = self.encode(query_embeds, encoder_hidden_states, encoder_attention_mask, attention_mask)
+        out = hidden if getattr(self, "return_bf16", False) else _CastFn.apply(hidden)
+        if return_dict is False:
+            return (out, None)
+        return SimpleNamespace(last_hidden_state=out, pooler_output=None, past_key_values=None, hidden_states=None,
+                               attentions=None, cross_attentions=None)
+
+    def encode(self, query_embeds, encoder_hidden_states, encoder_attention_mask=None, attention_mask=None,
+               qe_param_name=None):
+        """bf16 [B,Q,H] hidden states (internal fast path used by the wrappers).  qe_param_name: the
+        pack entry that receives the query-table gradient directly (wrappers); None returns it through
+        autograd (free-standing BertModel use)."""
+        if not query_embeds.is_cuda:
+            raise hip._lib.UniRecHipError("BertModel runs on the MI355X only: move the model and inputs to 'cuda' "
+                                          "(there is no CPU fallback in the product path)")
+        B, Q, H = query_embeds.shape
+        if attention_mask is not None and not bool((attention_mask != 0).all()):
+            raise NotImplementedError("query attention_mask with zeros is not on the UniRec path "
+                                      "(models/qformer_utils.py:43 passes all ones)")
+        enc = encoder_hidden_states
+        assert enc is not None, "encoder_hidden_states must be given for cross-attention layers"
+        if enc.dim() != 3 or enc.shape[0] != B or enc.shape[2] != self.config.encoder_width:
+            raise ValueError(f"encoder_hidden_states must be [B,T,{self.config.encoder_width}], got {tuple(enc.shape)}")
+        mask_u8 = None
+        if encoder_attention_mask is not None:
+            if tuple(encoder_attention_mask.shape) != (B, enc.shape[1]):
+                raise ValueError("Wrong shape for encoder_attention_mask")
+            mask_u8 = (encoder_attention_mask != 0).to(torch.uint8).contiguous()
+        # the reference expands one [1,Q,H] parameter over the batch (models/qformer_utils.py:39):
+        # keep it un-expanded so the LayerNorm kernel broadcasts it and the gradient reduces over B.
+        qe = query_embeds
+        if qe.stride(0) == 0 or B == 1:
+            qe_src = qe[0:1] if qe.stride(0) == 0 else qe
+        else:
+            qe_src = qe
+        self._ensure_pack(query_embeds.device)
+        return _EncoderFn.apply(self, qe_src, enc, mask_u8, B, qe_param_name)
+
+    # ---- implementation (sequence of HIP calls) --------------------------------------------------
+    def _drop(self):
+        p = float(self.config.hidden_dropout_prob) if self.training else 0.0
+        pa = float(self.config.attention_probs_dropout_prob) if self.training else 0.0
+        return p, pa
+
+    def _seed(self, layer, site):
+        return (self.seed * 1000003 + self._step * 8191 + layer * 64 + site) & 0x7FFFFFFFFFFFFFFF
+
+    def _forward_impl(self, query_embeds, enc, mask_u8, B):
+        cfg = self.config
+        pack = self._ensure_pack(query_embeds.device)
+        pre = self._names()
+        pack.refresh_shadow()
+        H, nh, I, eps = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size, cfg.layer_norm_eps
+        dh = H // nh
+        Qn = query_embeds.shape[1]
+        T = enc.shape[1]
+        M, Me = B * Qn, B * T
+        p_h, p_a = self._drop()
+        if self.training:
+            self._step += 1
+        qe16 = hip.cast_f32_to_bf16(query_embeds.detach().contiguous().view(-1, H)) if query_embeds.dtype == F32 \
+            else query_embeds.detach().contiguous().view(-1, H)
+        enc16 = (hip.cast_f32_to_bf16(enc.detach().contiguous()) if enc.dtype == F32 else enc.detach().contiguous()).view(Me, -1)
+        S = {"B": B, "Q": Qn, "T": T, "p_h": p_h, "p_a": p_a, "layers": [], "enc16": enc16, "mask": mask_u8,
+             "qe_rows": qe16.shape[0], "step_seed": self._step}
+        w = lambda n: pack.w32(pre + n)
+        x, z0, mean0, rstd0 = hip.layernorm_fwd(qe16, w("embeddings.LayerNorm.weight"), w("embeddings.LayerNorm.bias"), eps,
+                                                M=M, p_post=p_h, seed_post=self._seed(1023, 0))
+        S["emb"] = (z0, mean0, rstd0, self._seed(1023, 0))
+        for i, lyr in enumerate(self.encoder.layer):
+            lp = pre + f"encoder.layer.{i}."
+            L = {}
+            # ---- self attention
+            a = lp + "attention."
+            Wqkv = pack.fused16([a + "self.query.weight", a + "self.key.weight", a + "self.value.weight"])
+            bqkv = pack.fused32([a + "self.query.bias", a + "self.key.bias", a + "self.value.bias"])
+            qkv = hip.gemm(x, Wqkv, bias=bqkv)
+            q5 = qkv.view(B, Qn, 3, nh, dh)
+            s_att = self._seed(i, 1)
+            ctx_o, actx = hip.attn_fwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=False, dropout_p=p_a, seed=s_att)
+            y = hip.gemm(ctx_o.view(M, H), pack.w16(a + "output.dense.weight"), bias=pack.w32(a + "output.dense.bias"))
+            s_h = self._seed(i, 2)
+            x1, z1, m1, r1 = hip.layernorm_fwd(y, pack.w32(a + "output.LayerNorm.weight"), pack.w32(a + "output.LayerNorm.bias"),
+                                               eps, residual=x, p_pre=p_h, seed_pre=s_h)
+            L["self"] = (x, qkv, actx, ctx_o, z1, m1, r1, s_h)
+            xc = x1
+            # ---- cross attention (models/qformer.py:432-447)
+            if lyr.has_cross_attention:
+                c = lp + "crossattention."
+                qc = hip.gemm(x1, pack.w16(c + "self.query.weight"), bias=pack.w32(c + "self.query.bias"))
+                Wkv = pack.fused16([c + "self.key.weight", c + "self.value.weight"])
+                bkv = pack.fused32([c + "self.key.bias", c + "self.value.bias"])
+                kv = hip.gemm(enc16, Wkv, bias=bkv)
+                kv5 = kv.view(B, T, 2, nh, dh)
+                s_att2 = self._seed(i, 3)
+                ctx2, actx2 = hip.attn_fwd(qc.view(B, Qn, nh, dh), kv5[:, :, 0], kv5[:, :, 1], causal=False, key_mask=mask_u8,
+                                           dropout_p=p_a, seed=s_att2)
+                y2 = hip.gemm(ctx2.view(M, H), pack.w16(c + "output.dense.weight"), bias=pack.w32(c + "output.dense.bias"))
+                s_h2 = self._seed(i, 4)
+                x2, z2, m2, r2 = hip.layernorm_fwd(y2, pack.w32(c + "output.LayerNorm.weight"),
+                                                   pack.w32(c + "output.LayerNorm.bias"), eps, residual=x1, p_pre=p_h, seed_pre=s_h2)
+                L["cross"] = (x1, qc, kv, actx2, ctx2, z2, m2, r2, s_h2)
+                xc = x2
+            # ---- query FFN (models/qformer.py:449-454, 481-484)
+            f1, f2 = lp + "intermediate_query.dense.", lp + "output_query."
+            hbuf = torch.empty((M, I), dtype=BF16, device=x.device)
+            u = hip.gemm(xc, pack.w16(f1 + "weight"), bias=pack.w32(f1 + "bias"), gelu_out=hbuf)
+            y3 = hip.gemm(hbuf, pack.w16(f2 + "dense.weight"), bias=pack.w32(f2 + "dense.bias"))
+            s_h3 = self._seed(i, 5)
+            x3, z3, m3, r3 = hip.layernorm_fwd(y3, pack.w32(f2 + "LayerNorm.weight"), pack.w32(f2 + "LayerNorm.bias"), eps,
+                                               residual=xc, p_pre=p_h, seed_pre=s_h3)
+            L["ffn"] = (xc, u, hbuf, z3, m3, r3, s_h3)
+            S["layers"].append(L)
+            x = x3
+        return x.view(B, Qn, H), S
+
+    def _backward_impl(self, S, dout, enc_needs_grad, qe_param_name=None):
+        cfg = self.config
+        pack = self._ensure_pack(dout.device)
+        pre = self._names()
+        H, nh, I = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size
+        dh = H // nh
+        B, Qn, T = S["B"], S["Q"], S["T"]
+        M, Me = B * Qn, B * T
+        p_h = S["p_h"]
+        enc16 = S["enc16"]
+        dx = dout.contiguous().view(M, H)
+        if dx.dtype != BF16:
+            dx = hip.cast_f32_to_bf16(dx)
+        d_enc = None
+        g = lambda n: pack.g32(pre + n)
+
+        def dW(dy, xin, names):
+            """grad of an [out,in] weight (or several adjacent ones): dY^T X, token reduction split over CUs."""
+            out = pack.fusedg(names) if len(names) > 1 else pack.g32(names[0])
+            hip.gemm(dy, xin, r_kcontig=False, s_kcontig=False, out=out, split_k=_split_k_for(out.shape[0], out.shape[1], dy.shape[0]))
+
+        for i in reversed(range(len(self.encoder.layer))):
+            lyr = self.encoder.layer[i]
+            L = S["layers"][i]
+            lp = pre + f"encoder.layer.{i}."
+            # ---- FFN
+            xc, u, hbuf, z3, m3, r3, s_h3 = L["ffn"]
+            f1, f2 = lp + "intermediate_query.dense.", lp + "output_query."
+            dz3, dy3 = hip.layernorm_bwd(dx, z3, m3, r3, pack.w32(f2 + "LayerNorm.weight"), pack.g32(f2 + "LayerNorm.weight"),
+                                         pack.g32(f2 + "LayerNorm.bias"), dbias=pack.g32(f2 + "dense.bias"), p_pre=p_h, seed_pre=s_h3)
+            dW(dy3, hbuf, [f2 + "dense.weight"])
+            du = hip.gemm(dy3, pack.w16(f2 + "dense.weight"), s_kcontig=False, gelu_grad_aux=u)
+            hip.colsum(du, out=pack.g32(f1 + "bias"))
+            dW(du, xc, [f1 + "weight"])
+            dx = hip.gemm(du, pack.w16(f1 + "weight"), s_kcontig=False, residual=dz3)
+            # ---- cross attention
+            if lyr.has_cross_attention:
+                c = lp + "crossattention."
+                x1, qc, kv, actx2, ctx2, z2, m2, r2, s_h2 = L["cross"]
+                dz2, dy2 = hip.layernorm_bwd(dx, z2, m2, r2, pack.w32(c + "output.LayerNorm.weight"),
+                                             pack.g32(c + "output.LayerNorm.weight"), pack.g32(c + "output.LayerNorm.bias"),
+                                             dbias=pack.g32(c + "output.dense.bias"), p_pre=p_h, seed_pre=s_h2)
+                dW(dy2, ctx2.view(M, H), [c + "output.dense.weight"])
+                dctx2 = hip.gemm(dy2, pack.w16(c + "output.dense.weight"), s_kcontig=False)
+                dkv = torch.empty_like(kv)
+                dkv5 = dkv.view(B, T, 2, nh, dh)
+                dqc = torch.empty_like(qc)
+                hip.attn_bwd(actx2, dctx2.view(B, Qn, nh, dh), dq=dqc.view(B, Qn, nh, dh), dk=dkv5[:, :, 0], dv=dkv5[:, :, 1])
+                dW(dqc, x1, [c + "self.query.weight"])
+                hip.colsum(dqc, out=pack.g32(c + "self.query.bias"))
+                dW(dkv, enc16, [c + "self.key.weight", c + "self.value.weight"])
+                hip.colsum(dkv, out=pack.fusedg([c + "self.key.bias", c + "self.value.bias"]))
+                if enc_needs_grad:
+                    Wkv = pack.fused16([c + "self.key.weight", c + "self.value.weight"])
+                    d_enc = hip.gemm(dkv, Wkv, s_kcontig=False, residual=d_enc)
+                dx = hip.gemm(dqc, pack.w16(c + "self.query.weight"), s_kcontig=False, residual=dz2)
+            # ---- self attention
+            a = lp + "attention."
+            x0, qkv, actx, ctx_o, z1, m1, r1, s_h = L["self"]
+            dz1, dy1 = hip.layernorm_bwd(dx, z1, m1, r1, pack.w32(a + "output.LayerNorm.weight"),
+                                         pack.g32(a + "output.LayerNorm.weight"), pack.g32(a + "output.LayerNorm.bias"),
+                                         dbias=pack.g32(a + "output.dense.bias"), p_pre=p_h, seed_pre=s_h)
+            dW(dy1, ctx_o.view(M, H), [a + "output.dense.weight"])
+            dctx = hip.gemm(dy1, pack.w16(a + "output.dense.weight"), s_kcontig=False)
+            dqkv = torch.empty_like(qkv)
+            d5 = dqkv.view(B, Qn, 3, nh, dh)
+            hip.attn_bwd(actx, dctx.view(B, Qn, nh, dh), dq=d5[:, :, 0], dk=d5[:, :, 1], dv=d5[:, :, 2])
+            names = [a + "self.query.weight", a + "self.key.weight", a + "self.value.weight"]
+            dW(dqkv, x0, names)
+            hip.colsum(dqkv, out=pack.fusedg([a + "self.query.bias", a + "self.key.bias", a + "self.value.bias"]))
+            dx = hip.gemm(dqkv, pack.fused16(names), s_kcontig=False, residual=dz1)
+            L.clear()
+        # ---- embeddings LayerNorm; gradient of the batch-broadcast query table reduces over B
+        z0, mean0, rstd0, s0 = S["emb"]
+        dz0, _ = hip.layernorm_bwd(dx, z0, mean0, rstd0, pack.w32(pre + "embeddings.LayerNorm.weight"),
+                                   g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), p_post=p_h, seed_post=s0,
+                                   need_dy=False)
+        rows = S["qe_rows"]
+        touched = list(self._live_names())
+        if qe_param_name is not None:      # wrapper-owned [1,Q,H] table: gradient goes straight into the pack
+            hip.batch_reduce(dz0, M // rows, rows, H, out=pack.g32(qe_param_name).view(rows, H))
+            touched.append(qe_param_name)
+            d_qe = None
+        elif rows == M:
+            d_qe = hip.cast_bf16_to_f32(dz0).view(B, Qn, H)
+        else:
+            d_qe = hip.batch_reduce(dz0, M // rows, rows, H).view(1, Qn, H)
+        if d_enc is not None:
+            d_enc = hip.cast_bf16_to_f32(d_enc).view(B, T, -1)
+        pack.publish_grads(touched)
+        return d_qe, d_enc
+
+
+class _CastFn(torch.autograd.Function):
+    """bf16 -> f32 view of the encoder output for callers that expect the reference's fp32 tensors."""
+
+    @staticmethod
+    def forward(ctx, x16):
+        return hip.cast_bf16_to_f32(x16)
+
+    @staticmethod
+    def backward(ctx, g):
+        return hip.cast_f32_to_bf16(g.contiguous())
