@@ -1,0 +1,166 @@
+"""GPU parity: Qwen3(+LoRA) decoder, token injection, mean-pool, InfoNCE and MRR on the HIP path vs
+golden vectors produced by the installed transformers Qwen3Model + the reference's joint module."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import qformer_ref as R  # noqa: E402
+from oracle import qwen3_ref as Q  # noqa: E402
+from oracle import weights as W  # noqa: E402
+from tests.golden import cases  # noqa: E402
+from tests.parity_utils import GRAD_REL, OUT_REL, assert_close, load_generated, load_golden  # noqa: E402
+
+DEV = "cuda"
+JOINT = [n for n, c in cases.ALL.items() if c["kind"] == "joint"]
+QWEN = [n for n, c in cases.ALL.items() if c["kind"] == "qwen"]
+
+
+def _qwen_cfg(qc, lora):
+    from unirec_amd.qwen3 import Qwen3Config
+    return Qwen3Config(vocab_size=qc.vocab_size, hidden_size=qc.hidden_size, intermediate_size=qc.intermediate_size,
+                       num_hidden_layers=qc.num_hidden_layers, num_attention_heads=qc.num_attention_heads,
+                       num_key_value_heads=qc.num_key_value_heads, head_dim=qc.head_dim, rms_norm_eps=qc.rms_norm_eps,
+                       rope_theta=qc.rope_theta, lora_r=qc.lora_r, lora_alpha=qc.lora_alpha)
+
+
+def _build_joint(case, use_lora, lora_seed=None):
+    from unirec_amd.joint import MultiModalQwenEmbedding
+    from unirec_amd.qformer_model import QFormerForItemRepresentation
+    c = case["cfg"]
+    qc = cases.qwen_cfg(case)
+    cfg = R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 2)
+    qf = QFormerForItemRepresentation(hidden_size=c["H"], num_hidden_layers=c["L"], num_attention_heads=c["nh"],
+                                      intermediate_size=c["I"], num_query_tokens=c["Q"], field_embedding_dim=c["E"],
+                                      num_fields=c["F"], dropout=0.0)
+    qf = load_generated(qf, R.item_qformer_shapes(cfg, c["F"]), case["seed"])
+    hc = _qwen_cfg(qc, use_lora)
+    hc.vocab_size = case["first_special_id"]        # specials are appended after the base vocabulary
+    m = MultiModalQwenEmbedding(qformer_model=qf, use_lora=use_lora, qwen_config=hc, num_history_items=case["hist"],
+                                num_query_tokens_per_item=c["Q"])
+    assert m.first_special_id == case["first_special_id"]
+    shapes = Q.qwen3_shapes(qc, lora=False)
+    sd = {k: torch.from_numpy(v) for k, v in W.fill_state_dict(shapes, case["seed"] + 1).items()}
+    missing, unexpected = m.base_model.load_state_dict(sd, strict=False)
+    assert not unexpected
+    if use_lora:
+        lsd = {k: torch.from_numpy(v) for k, v in W.fill_state_dict(
+            {k: s for k, s in Q.qwen3_shapes(qc, lora=True).items() if ".lora_" in k}, lora_seed).items()}
+        m.base_model.load_state_dict(lsd, strict=False)
+    return m.to(DEV).train(), qf
+
+
+@pytest.mark.parametrize("name", QWEN)
+def test_qwen3_decoder_matches_transformers(name):
+    from unirec_amd.qwen3 import Qwen3LoRAModel
+    case = cases.ALL[name]
+    g = load_golden(name)
+    qc = cases.qwen_cfg(case)
+    m = Qwen3LoRAModel(_qwen_cfg(qc, False), use_lora=False)
+    m = load_generated(m, Q.qwen3_shapes(qc, lora=False), case["seed"] + 1)
+    x, am = cases.qwen_inputs(case)
+    # feed inputs_embeds through the embedding table: vocabulary = the B*S input rows
+    B, S, D = x.shape
+    m.embed_tokens.weight = torch.nn.Parameter(torch.from_numpy(x.reshape(B * S, D)).to(DEV), requires_grad=False)
+    m.config.vocab_size = B * S
+    ids = torch.arange(B * S, device=DEV).view(B, S)
+    pooled = m.forward_pooled(ids, torch.from_numpy(am).to(DEV))
+    want = g["sdpa/last_hidden_state"].mean(axis=1)
+    print(name)
+    assert_close(pooled, want, OUT_REL, "mean-pooled last_hidden_state (sdpa semantics)")
+
+
+@pytest.mark.parametrize("name", JOINT)
+def test_joint_matches_reference(name):
+    from unirec_amd.joint import InfoNCELoss, mrr_ranks
+    case = cases.ALL[name]
+    c = case["cfg"]
+    g = {k[5:]: v for k, v in load_golden(name).items() if k.startswith("sdpa/")}
+    m, qf = _build_joint(case, use_lora=False)
+    ids, am, hfe, ham, pos, neg, nmask = cases.joint_inputs(case)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    user = m(t(ids), t(am), t(hfe), t(ham))
+    print(name)
+    assert_close(user, g["user_embeddings"], OUT_REL, "user_embeddings")
+    loss = InfoNCELoss()(user, t(pos), t(neg), t(nmask))
+    assert_close(loss, g["loss"], OUT_REL, "infonce loss")
+    scores, rank = mrr_ranks(user, t(pos), t(neg))
+    assert rank.cpu().tolist() == g["ranks"].tolist()
+    loss.backward()
+    named = dict(qf.named_parameters())
+    for k in cases.item_grad_keys(c, heads=False):
+        assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL * 1.5, "grad/" + k, floor=1e-6)
+    assert named["item_representation_head.weight"].grad is None      # unused heads stay untouched (as in the reference)
+
+
+@pytest.mark.parametrize("name", JOINT)
+def test_joint_with_lora_matches_oracle(name):
+    """LoRA has no importable reference here (peft absent: parity unpinned); check against the oracle's
+    restatement of the published formula, including dA / dB."""
+    from unirec_amd.joint import InfoNCELoss
+    case = cases.ALL[name]
+    c = case["cfg"]
+    qc = cases.qwen_cfg(case)
+    m, qf = _build_joint(case, use_lora=True, lora_seed=case["seed"] + 2)
+    ids, am, hfe, ham, pos, neg, nmask = cases.joint_inputs(case)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    user = m(t(ids), t(am), t(hfe), t(ham))
+    loss = InfoNCELoss()(user, t(pos), t(neg), t(nmask))
+    loss.backward()
+    # oracle
+    cfg = R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 2)
+    PQ = {k: torch.from_numpy(v).requires_grad_(True) for k, v in W.fill_state_dict(R.item_qformer_shapes(cfg, c["F"]), case["seed"]).items()}
+    PW = {k: torch.from_numpy(v) for k, v in W.fill_state_dict(Q.qwen3_shapes(qc, lora=False), case["seed"] + 1).items()}
+    lsh = {k: s for k, s in Q.qwen3_shapes(qc, lora=True).items() if ".lora_" in k}
+    PL = {k: torch.from_numpy(v).requires_grad_(True) for k, v in W.fill_state_dict(lsh, case["seed"] + 2).items()}
+    B, hist = case["B"], case["hist"]
+    out = R.item_qformer_forward(PQ, cfg, torch.from_numpy(hfe).view(B * hist, c["F"], c["E"]), torch.from_numpy(ham).view(B * hist, c["F"]))
+    toks = out["query_outputs"].view(B, hist, c["Q"], c["H"])
+    ou = Q.joint_forward({**PW, **PL}, qc, torch.from_numpy(ids), torch.from_numpy(am), toks, case["first_special_id"])
+    ol = Q.infonce_loss(ou, torch.from_numpy(pos), torch.from_numpy(neg), torch.from_numpy(nmask))
+    ol.backward()
+    print(name, "(LoRA)")
+    assert_close(user, ou.detach().numpy(), OUT_REL, "user_embeddings")
+    assert_close(loss, ol.detach().numpy(), OUT_REL, "loss")
+    named = dict(m.base_model.named_parameters())
+    for k in ("layers.0.self_attn.q_proj.lora_A.weight", "layers.0.self_attn.k_proj.lora_B.weight", "layers.0.self_attn.v_proj.lora_A.weight",
+              "layers.1.self_attn.o_proj.lora_B.weight", "layers.1.mlp.gate_proj.lora_A.weight", "layers.0.mlp.up_proj.lora_B.weight",
+              "layers.1.mlp.down_proj.lora_A.weight", "layers.1.mlp.down_proj.lora_B.weight"):
+        assert_close(named[k].grad, PL[k].grad.numpy(), GRAD_REL * 1.5, "grad/" + k)
+    assert_close(dict(qf.named_parameters())["query_embeddings"].grad, PQ["query_embeddings"].grad.numpy(), GRAD_REL * 1.5, "grad/query_embeddings")
+    assert named["layers.0.self_attn.q_proj.weight"].grad is None      # base weights are frozen
+
+
+def test_topk_and_ranks_are_exact():
+    from unirec_amd import hip
+    g = torch.Generator().manual_seed(0)
+    s = torch.randn(5, 1001, generator=g)
+    s[0, 7] = s[0, 3]                    # a tie: lowest index first
+    sd = s.to(DEV)
+    idx, val = hip.topk(sd, 10)
+    want = Q.topk_indices(s, 10)
+    assert idx.cpu().tolist() == want.tolist()
+    rank = hip.mrr_rank(sd)
+    assert rank.cpu().tolist() == (1 + (s[:, 1:] > s[:, :1]).sum(1)).tolist()
+
+
+def test_inject_handles_repeated_and_missing_tokens():
+    from unirec_amd import hip
+    B, S, D, T, first = 2, 300, 64, 3, 50
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, first, (B, S), generator=g)
+    ids[0, 5] = first; ids[0, 290] = first; ids[0, 17] = first + 2      # token 0 twice, token 1 missing
+    ids[1, 0] = first + 1
+    emb = torch.randn(first + T, D, generator=g).to(DEV).to(torch.bfloat16)
+    tok = torch.randn(B, T, D, generator=g).to(DEV).to(torch.bfloat16)
+    idsd = ids.to(DEV)
+    out = hip.embed_inject_fwd(emb, idsd, tok, first)
+    want = emb[idsd]
+    want[0, 5] = tok[0, 0]; want[0, 290] = tok[0, 0]; want[0, 17] = tok[0, 2]; want[1, 0] = tok[1, 1]
+    assert torch.equal(out, want)
+    dx = torch.randn(B, S, D, generator=g).to(DEV).to(torch.bfloat16)
+    dt = hip.inject_bwd(dx, idsd, first, T)
+    assert torch.equal(dt[0, 0], (dx[0, 5].float() + dx[0, 290].float()).to(torch.bfloat16))
+    assert torch.equal(dt[0, 2], dx[0, 17]) and torch.equal(dt[1, 1], dx[1, 0])
+    assert float(dt[0, 1].abs().max()) == 0 and float(dt[1, 0].abs().max()) == 0

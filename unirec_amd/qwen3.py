@@ -1,0 +1,389 @@
+"""Qwen3 decoder + LoRA on the MI355X: the third-party half of the joint path.
+
+The reference loads ``AutoModel.from_pretrained("Qwen/Qwen3-Embedding-0.6B")`` and wraps it with
+``peft.get_peft_model`` (training/train_item_individual_token_joint.py:98-132); neither package's
+source is part of the reference tree, so this module restates the published arithmetic
+(transformers ``modeling_qwen3.py``: RMSNorm :59-64, MLP :81-83, RoPE :107-170, attention :185-280,
+decoder layer :306-331, model :367-425) and the LoRA definition
+``y = W x + (alpha/r) B A x`` with HF-compatible parameter names:
+    embed_tokens.weight, layers.{i}.input_layernorm.weight, layers.{i}.self_attn.{q,k,v,o}_proj.weight,
+    layers.{i}.self_attn.{q,k}_norm.weight, layers.{i}.post_attention_layernorm.weight,
+    layers.{i}.mlp.{gate,up,down}_proj.weight, norm.weight
+LoRA tensors are ``<proj>.lora_A.weight [r,in]`` / ``<proj>.lora_B.weight [out,r]`` (the only trainable
+tensors, bias none: :123-129); ``peft_state_dict()`` exports them under peft's adapter key names.
+
+Execution: the whole stack (embed + Q-Former token injection, 28 decoder layers, final norm, mean
+pool over ALL positions :179-181) is ONE autograd node.  Base weights are frozen, so the backward is
+dX GEMMs on the frozen bf16 weights plus rank-r reductions for dA/dB; every LoRA B-product rides in
+the base GEMM's accumulators (second K-range of ur_gemm).  Activations are kept in HBM (288 GB:
+no gradient checkpointing), normed inputs and SwiGLU outputs are recomputed in the backward.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .packing import ParamPack
+
+BF16, F32 = torch.bfloat16, torch.float32
+LORA_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+
+
+class Qwen3Config:
+    """Shape of Qwen3-Embedding-0.6B by default (public model card)."""
+
+    def __init__(self, vocab_size=151669, hidden_size=1024, intermediate_size=3072, num_hidden_layers=28,
+                 num_attention_heads=16, num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-6, rope_theta=1e6,
+                 lora_r=16, lora_alpha=32.0, lora_dropout=0.0, initializer_range=0.02):
+        self.vocab_size, self.hidden_size, self.intermediate_size = vocab_size, hidden_size, intermediate_size
+        self.num_hidden_layers, self.num_attention_heads, self.num_key_value_heads = num_hidden_layers, num_attention_heads, num_key_value_heads
+        self.head_dim, self.rms_norm_eps, self.rope_theta = head_dim, rms_norm_eps, rope_theta
+        self.lora_r, self.lora_alpha, self.lora_dropout = lora_r, lora_alpha, lora_dropout
+        self.initializer_range = initializer_range
+
+
+class _Proj(nn.Module):
+    def __init__(self, fin, fout, r):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin), requires_grad=False)
+        if r > 0:
+            self.lora_A = nn.Linear(fin, r, bias=False)
+            self.lora_B = nn.Linear(r, fout, bias=False)
+
+
+class _Norm(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d), requires_grad=False)
+
+
+class _Attn(nn.Module):
+    def __init__(self, c, r):
+        super().__init__()
+        D, hd = c.hidden_size, c.head_dim
+        self.q_proj = _Proj(D, c.num_attention_heads * hd, r)
+        self.k_proj = _Proj(D, c.num_key_value_heads * hd, r)
+        self.v_proj = _Proj(D, c.num_key_value_heads * hd, r)
+        self.o_proj = _Proj(c.num_attention_heads * hd, D, r)
+        self.q_norm = _Norm(hd)
+        self.k_norm = _Norm(hd)
+
+
+class _MLP(nn.Module):
+    def __init__(self, c, r):
+        super().__init__()
+        self.gate_proj = _Proj(c.hidden_size, c.intermediate_size, r)
+        self.up_proj = _Proj(c.hidden_size, c.intermediate_size, r)
+        self.down_proj = _Proj(c.intermediate_size, c.hidden_size, r)
+
+
+class _Layer(nn.Module):
+    def __init__(self, c, r):
+        super().__init__()
+        self.self_attn = _Attn(c, r)
+        self.mlp = _MLP(c, r)
+        self.input_layernorm = _Norm(c.hidden_size)
+        self.post_attention_layernorm = _Norm(c.hidden_size)
+
+
+class _TokenTable(nn.Module):
+    def __init__(self, v, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(v, d), requires_grad=False)
+
+
+def _split_k(red, out_rows, out_cols):
+    tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
+    return int(max(1, min(1024 // max(tiles, 1), red // 512, 128)))
+
+
+class _JointFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, item_tokens16, input_ids, mask_u8, first_special_id, anchor):
+        pooled, saved = model._forward_impl(item_tokens16, input_ids, mask_u8, first_special_id)
+        ctx.model, ctx.saved = model, saved
+        return pooled
+
+    @staticmethod
+    def backward(ctx, d_pooled):
+        d_tok = ctx.model._backward_impl(ctx.saved, d_pooled)
+        ctx.saved = None
+        return None, d_tok, None, None, None, None
+
+
+class Qwen3LoRAModel(nn.Module):
+    """Frozen Qwen3 decoder with LoRA adapters on all 7 projections."""
+
+    def __init__(self, config: Qwen3Config, use_lora=True):
+        super().__init__()
+        self.config = config
+        r = config.lora_r if use_lora else 0
+        self.use_lora = r > 0
+        self.embed_tokens = _TokenTable(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList([_Layer(config, r) for _ in range(config.num_hidden_layers)])
+        self.norm = _Norm(config.hidden_size)
+        self._pack = None
+        self._frozen = None
+        self._rope = None
+        self.reset_parameters()
+
+    def reset_parameters(self, lora_b_std=0.0):
+        """Base N(0, initializer_range) (weights are random: no network for the checkpoint); LoRA A
+        kaiming-uniform(a=sqrt(5)), B zeros -- peft's default init.  lora_b_std > 0 draws B ~ N(0, std)
+        so the LoRA path is numerically exercised."""
+        std = self.config.initializer_range
+        for n, p in self.named_parameters():
+            if n.endswith("lora_A.weight"):
+                nn.init.kaiming_uniform_(p, a=math.sqrt(5))
+            elif n.endswith("lora_B.weight"):
+                if lora_b_std > 0:
+                    nn.init.normal_(p, std=lora_b_std)
+                else:
+                    nn.init.zeros_(p)
+            elif n.endswith("norm.weight") or n.endswith("layernorm.weight"):
+                nn.init.ones_(p)
+            else:
+                nn.init.normal_(p, std=std)
+
+    def resize_token_embeddings(self, new_size):
+        """train_item_individual_token_joint.py:112-119 (rows for the added special tokens)."""
+        old = self.embed_tokens.weight.data
+        if new_size == old.shape[0]:
+            return
+        new = torch.empty(new_size, old.shape[1], dtype=old.dtype, device=old.device).normal_(std=self.config.initializer_range)
+        n = min(new_size, old.shape[0])
+        new[:n] = old[:n]
+        self.embed_tokens.weight = nn.Parameter(new, requires_grad=False)
+        self.config.vocab_size = new_size
+        self._frozen = None
+
+    # ---- parameter plumbing ---------------------------------------------------------------------
+    def lora_named_parameters(self):
+        named = dict(self.named_parameters())
+        order = []
+        for i in range(self.config.num_hidden_layers):
+            lp = f"layers.{i}."
+            for grp in (("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), ("self_attn.o_proj",),
+                        ("mlp.gate_proj", "mlp.up_proj"), ("mlp.down_proj",)):
+                order += [lp + g + ".lora_A.weight" for g in grp]
+            for g in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj",
+                      "mlp.up_proj", "mlp.down_proj"):
+                order.append(lp + g + ".lora_B.weight")
+        return [(n, named[n]) for n in order]
+
+    def _ensure_pack(self, device):
+        if not self.use_lora:
+            return None
+        if self._pack is None or not self._pack.is_current() or self._pack.device != torch.device(device):
+            self._pack = ParamPack(self.lora_named_parameters(), device)
+        return self._pack
+
+    @property
+    def pack(self):
+        return self._pack
+
+    def _ensure_frozen(self, device):
+        """bf16 operands of the frozen base weights, fused per layer: [q|k|v], o, [gate|up], down."""
+        key = (str(device), self.embed_tokens.weight.data_ptr(), self.embed_tokens.weight._version)
+        if self._frozen is not None and self._frozen["key"] == key:
+            return self._frozen
+        fz = {"key": key, "layers": []}
+        dev = torch.device(device)
+
+        def c16(t):
+            return hip.cast_f32_to_bf16(t.detach().to(dev, F32).contiguous())
+        fz["embed"] = c16(self.embed_tokens.weight)
+        fz["norm"] = self.norm.weight.detach().to(dev, F32).contiguous()
+        for lyr in self.layers:
+            a, m = lyr.self_attn, lyr.mlp
+            fz["layers"].append({
+                "qkv": c16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)),
+                "o": c16(a.o_proj.weight),
+                "gu": c16(torch.cat([m.gate_proj.weight, m.up_proj.weight], 0)),
+                "d": c16(m.down_proj.weight),
+                "qn": a.q_norm.weight.detach().to(dev, F32).contiguous(), "kn": a.k_norm.weight.detach().to(dev, F32).contiguous(),
+                "ln1": lyr.input_layernorm.weight.detach().to(dev, F32).contiguous(),
+                "ln2": lyr.post_attention_layernorm.weight.detach().to(dev, F32).contiguous()})
+        self._frozen = fz
+        return fz
+
+    def _rope_tables(self, S, device):
+        if self._rope is None or self._rope[0] != (S, str(device)):
+            self._rope = ((S, str(device)), hip.rope_table(S, self.config.head_dim, float(self.config.rope_theta), device))
+        return self._rope[1]
+
+    def peft_state_dict(self):
+        """LoRA tensors under peft's adapter key names (save_pretrained compatibility, :183-200)."""
+        out = {}
+        for n, p in self.named_parameters():
+            if ".lora_A." in n or ".lora_B." in n:
+                out["base_model.model." + n] = p.detach().cpu()
+        return out
+
+    # ---- public forward ---------------------------------------------------------------------------
+    def forward_pooled(self, input_ids, attention_mask=None, item_tokens16=None, first_special_id=0):
+        """input_ids int64 [B,S]; attention_mask [B,S] or None; item_tokens16 [B,T,D] bf16 (Q-Former
+        query tokens to inject at ids first_special_id + t) or None -> mean-pooled f32 [B,D]."""
+        if not input_ids.is_cuda:
+            raise hip._lib.UniRecHipError("Qwen3LoRAModel runs on the MI355X only (no CPU fallback in the product path)")
+        B, S = input_ids.shape
+        mask_u8 = None if attention_mask is None else (attention_mask != 0).to(torch.uint8).contiguous()
+        if item_tokens16 is None:
+            item_tokens16 = torch.zeros((B, 0, self.config.hidden_size), dtype=BF16, device=input_ids.device)
+        # the LoRA gradients are side effects of this node's backward: an anchor input keeps the node
+        # alive even when the injected tokens do not require grad (frozen / absent Q-Former)
+        anchor = torch.zeros(1, device=input_ids.device, requires_grad=True) if (torch.is_grad_enabled() and self.use_lora) else None
+        return _JointFn.apply(self, item_tokens16, input_ids.contiguous(), mask_u8, int(first_special_id), anchor)
+
+    # ---- implementation ---------------------------------------------------------------------------
+    def _lora(self, pack, name):
+        return None if pack is None else pack.w16(name)
+
+    def _forward_impl(self, item_tokens16, input_ids, mask_u8, first_special_id):
+        c = self.config
+        dev = input_ids.device
+        fz = self._ensure_frozen(dev)
+        pack = self._ensure_pack(dev)
+        if pack is not None:
+            pack.refresh_shadow()
+        B, S = input_ids.shape
+        D, I, nq, nkv, hd, r = c.hidden_size, c.intermediate_size, c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.lora_r
+        NQ, NKV = nq * hd, nkv * hd
+        M = B * S
+        eps, sc = c.rms_norm_eps, (c.lora_alpha / c.lora_r if self.use_lora else 0.0)
+        cos, sin = self._rope_tables(S, dev)
+        T = item_tokens16.shape[1]
+        tok = item_tokens16.detach().contiguous() if T > 0 else None
+        x = hip.embed_inject_fwd(fz["embed"], input_ids, tok, first_special_id).view(M, D)
+        saved = {"B": B, "S": S, "T": T, "ids": input_ids, "first": first_special_id, "mask": mask_u8, "layers": []}
+        for i, fl in enumerate(fz["layers"]):
+            lp = f"layers.{i}."
+            L = {"x": x}
+            h, rstd1 = hip.rmsnorm_fwd(x, fl["ln1"], eps)
+            qkv = torch.empty((M, NQ + 2 * NKV), dtype=BF16, device=dev)
+            if pack is not None:
+                A_qkv = pack.fused16([lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"])
+                t_qkv = hip.gemm(h, A_qkv, alpha=sc)                                   # [M,3r] = s * h A^T
+                col = 0
+                for j, (p, n) in enumerate((("q", NQ), ("k", NKV), ("v", NKV))):
+                    hip.gemm(h, fl["qkv"][col:col + n], out=qkv[:, col:col + n], R2=t_qkv[:, j * r:(j + 1) * r],
+                             S2=pack.w16(lp + f"self_attn.{p}_proj.lora_B.weight"))
+                    col += n
+                L["t_qkv"] = t_qkv
+            else:
+                hip.gemm(h, fl["qkv"], out=qkv)
+            q_r, k_r = hip.qknorm_rope_fwd(qkv, fl["qn"], fl["kn"], cos, sin, S, nq, nkv, hd, eps)
+            v4 = qkv[:, NQ + NKV:].view(B, S, nkv, hd)
+            att, actx = hip.attn_fwd(q_r.view(B, S, nq, hd), k_r.view(B, S, nkv, hd), v4, causal=True, key_mask=mask_u8)
+            att2 = att.view(M, NQ)
+            if pack is not None:
+                t_o = hip.gemm(att2, pack.w16(lp + "self_attn.o_proj.lora_A.weight"), alpha=sc)
+                x2 = hip.gemm(att2, fl["o"], residual=x, R2=t_o, S2=pack.w16(lp + "self_attn.o_proj.lora_B.weight"))
+                L["t_o"] = t_o
+            else:
+                x2 = hip.gemm(att2, fl["o"], residual=x)
+            h2, rstd2 = hip.rmsnorm_fwd(x2, fl["ln2"], eps)
+            gu = torch.empty((M, 2 * I), dtype=BF16, device=dev)
+            if pack is not None:
+                A_gu = pack.fused16([lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"])
+                t_gu = hip.gemm(h2, A_gu, alpha=sc)
+                for j, p in enumerate(("gate", "up")):
+                    hip.gemm(h2, fl["gu"][j * I:(j + 1) * I], out=gu[:, j * I:(j + 1) * I], R2=t_gu[:, j * r:(j + 1) * r],
+                             S2=pack.w16(lp + f"mlp.{p}_proj.lora_B.weight"))
+                L["t_gu"] = t_gu
+            else:
+                hip.gemm(h2, fl["gu"], out=gu)
+            act = hip.swiglu_fwd(gu, I)
+            if pack is not None:
+                t_d = hip.gemm(act, pack.w16(lp + "mlp.down_proj.lora_A.weight"), alpha=sc)
+                x3 = hip.gemm(act, fl["d"], residual=x2, R2=t_d, S2=pack.w16(lp + "mlp.down_proj.lora_B.weight"))
+                L["t_d"] = t_d
+            else:
+                x3 = hip.gemm(act, fl["d"], residual=x2)
+            L.update(rstd1=rstd1, qkv=qkv, actx=actx, att=att2, x2=x2, rstd2=rstd2, gu=gu)
+            saved["layers"].append(L)
+            x = x3
+        last, rstd_f = hip.rmsnorm_fwd(x, fz["norm"], eps)
+        pooled, _ = hip.mean_pool_fwd(last.view(B, S, D))
+        saved["xf"], saved["rstd_f"] = x, rstd_f
+        return pooled, saved
+
+    def _backward_impl(self, saved, d_pooled):
+        c = self.config
+        fz = self._frozen
+        pack = self._pack if self.use_lora else None
+        B, S, T = saved["B"], saved["S"], saved["T"]
+        D, I, nq, nkv, hd, r = c.hidden_size, c.intermediate_size, c.num_attention_heads, c.num_key_value_heads, c.head_dim, c.lora_r
+        NQ, NKV = nq * hd, nkv * hd
+        M = B * S
+        eps, sc = c.rms_norm_eps, (c.lora_alpha / c.lora_r if self.use_lora else 0.0)
+        dev = d_pooled.device
+        cos, sin = self._rope_tables(S, dev)
+        dlast = hip.mean_pool_bwd(d_pooled.contiguous().to(F32), S).view(M, D)
+        dx = hip.rmsnorm_bwd(dlast, saved["xf"], fz["norm"], saved["rstd_f"])
+        touched = []
+
+        def lora_grads(dy, t, xin, a_names, b_specs):
+            """dB_p = dy_p^T t_p ; tb = s * dy B ; dA = tb^T x.  Returns tb [M, len(b)*r] (bf16)."""
+            nb = len(b_specs)
+            tb = torch.empty((M, nb * r), dtype=BF16, device=dev)
+            for j, (bname, c0, n) in enumerate(b_specs):
+                dyp = dy[:, c0:c0 + n]
+                hip.gemm(dyp, t[:, j * r:(j + 1) * r], r_kcontig=False, s_kcontig=False, out=pack.g32(bname), split_k=_split_k(M, n, r))
+                hip.gemm(dyp, pack.w16(bname), s_kcontig=False, out=tb[:, j * r:(j + 1) * r], alpha=sc)
+                touched.append(bname)
+            gA = pack.fusedg(a_names) if len(a_names) > 1 else pack.g32(a_names[0])
+            hip.gemm(tb, xin, r_kcontig=False, s_kcontig=False, out=gA, split_k=_split_k(M, nb * r, xin.shape[1]))
+            touched.extend(a_names)
+            return tb
+
+        for i in reversed(range(len(fz["layers"]))):
+            fl, L = fz["layers"][i], saved["layers"][i]
+            lp = f"layers.{i}."
+            x, x2, gu, qkv = L["x"], L["x2"], L["gu"], L["qkv"]
+            # ---- MLP: x3 = x2 + down(silu(gate) * up)
+            act = hip.swiglu_fwd(gu, I)                                   # recomputed
+            if pack is not None:
+                tb = lora_grads(dx, L["t_d"], act, [lp + "mlp.down_proj.lora_A.weight"], [(lp + "mlp.down_proj.lora_B.weight", 0, D)])
+                dact = hip.gemm(dx, fl["d"], s_kcontig=False, R2=tb, S2=pack.w16(lp + "mlp.down_proj.lora_A.weight"))
+            else:
+                dact = hip.gemm(dx, fl["d"], s_kcontig=False)
+            dgu = hip.swiglu_bwd(dact, gu, I)
+            h2, _ = hip.rmsnorm_fwd(x2, fl["ln2"], eps)                   # recomputed
+            if pack is not None:
+                a_names = [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"]
+                tb = lora_grads(dgu, L["t_gu"], h2, a_names, [(lp + "mlp.gate_proj.lora_B.weight", 0, I), (lp + "mlp.up_proj.lora_B.weight", I, I)])
+                dh2 = hip.gemm(dgu, fl["gu"], s_kcontig=False, R2=tb, S2=pack.fused16(a_names))
+            else:
+                dh2 = hip.gemm(dgu, fl["gu"], s_kcontig=False)
+            dx2 = hip.rmsnorm_bwd(dh2, x2, fl["ln2"], L["rstd2"], add=dx)
+            # ---- attention: x2 = x + o(attn)
+            att = L["att"]
+            if pack is not None:
+                tb = lora_grads(dx2, L["t_o"], att, [lp + "self_attn.o_proj.lora_A.weight"], [(lp + "self_attn.o_proj.lora_B.weight", 0, D)])
+                datt = hip.gemm(dx2, fl["o"], s_kcontig=False, R2=tb, S2=pack.w16(lp + "self_attn.o_proj.lora_A.weight"))
+            else:
+                datt = hip.gemm(dx2, fl["o"], s_kcontig=False)
+            dqkv = torch.empty_like(qkv)
+            dq_r = torch.empty((M, NQ), dtype=BF16, device=dev)
+            dk_r = torch.empty((M, NKV), dtype=BF16, device=dev)
+            hip.attn_bwd(L["actx"], datt.view(B, S, nq, hd), dq=dq_r.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd),
+                         dv=dqkv[:, NQ + NKV:].view(B, S, nkv, hd))
+            hip.qknorm_rope_bwd(dq_r, dk_r, qkv, fl["qn"], fl["kn"], cos, sin, dqkv, S, nq, nkv, hd, eps)
+            h, _ = hip.rmsnorm_fwd(x, fl["ln1"], eps)                     # recomputed
+            if pack is not None:
+                a_names = [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"]
+                specs = [(lp + "self_attn.q_proj.lora_B.weight", 0, NQ), (lp + "self_attn.k_proj.lora_B.weight", NQ, NKV),
+                         (lp + "self_attn.v_proj.lora_B.weight", NQ + NKV, NKV)]
+                tb = lora_grads(dqkv, L["t_qkv"], h, a_names, specs)
+                dh = hip.gemm(dqkv, fl["qkv"], s_kcontig=False, R2=tb, S2=pack.fused16(a_names))
+            else:
+                dh = hip.gemm(dqkv, fl["qkv"], s_kcontig=False)
+            dx = hip.rmsnorm_bwd(dh, x, fl["ln1"], L["rstd1"], add=dx2)
+            L.clear()
+        if pack is not None:
+            pack.publish_grads(touched)
+        if T > 0:
+            return hip.inject_bwd(dx.view(B, S, D), saved["ids"], saved["first"], T)
+        return None
