@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the UniRec MI355X hot path.
+
+Metric (BASELINE.json): user-sequences/sec of the JOINT training step (item Q-Former on the
+history -> token injection -> Qwen3-Embedding-0.6B-shaped decoder + LoRA r=16 -> mean pool -> InfoNCE
+over the candidate pool; forward + backward + gradient all-reduce + AdamW), hist=50, Q_item=2,
+S=2048, pool 1000, batch 64 per GPU (configs[3] = C4; weak scaling: per-GPU batch fixed).
+A "step" = one such pass over one batch of synthetic inputs that are already resident in HBM.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) carrying `roofline` (dominant kernel =
+the bf16 MFMA projection GEMM, timed live with HIP events on its launch stream) and `cpu_baseline`
+(the oracle's joint step timed on the host cores on a bounded sample; N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="user sequences per GPU (C4: 64)")
+    ap.add_argument("--hist", type=int, default=50)
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--pool", type=int, default=1000)
+    ap.add_argument("--layers", type=int, default=28, help="Qwen3 layers (28 = the named model; fewer is a debug run)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true")
+    return ap.parse_args()
+
+
+# ---- synthetic inputs ----------------------------------------------------------
+def make_batch(B, hist, S, pool, F, E, D, Qi, vocab, first_special, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(B, hist, F, E, generator=g)
+    x = x / x.norm(dim=-1, keepdim=True)
+    x[:, :, 1, E - 256:] = 0.0                                   # CLIP field: 768 dims zero-padded to 1024
+    hmask = (torch.rand(B, hist, F, generator=g) < 0.8).long()
+    hmask[..., 0] = 1
+    hlen = torch.randint(hist // 2, hist + 1, (B,), generator=g)
+    for b in range(B):
+        hmask[b, hlen[b]:] = 0                                   # padded history slots: fully masked zeros
+    x = x * hmask[..., None]
+    ids = torch.randint(0, vocab, (B, S), generator=g)
+    am = torch.ones(B, S, dtype=torch.long)
+    npad = (torch.rand(B, generator=g) * 0.2 * S).long()
+    stride = max(1, (S - int(npad.max()) - 8) // (hist * Qi))
+    for b in range(B):
+        am[b, :npad[b]] = 0                                      # left padding (~10 % of positions)
+        pos = npad[b] + 4 + torch.arange(hist * Qi) * stride
+        ids[b, pos] = first_special + torch.arange(hist * Qi)    # each special token exactly once
+    posv = torch.randn(B, D, generator=g)
+    posv = posv / posv.norm(dim=-1, keepdim=True)
+    neg = torch.randn(B, pool - 1, D, generator=g)
+    neg = neg / neg.norm(dim=-1, keepdim=True)
+    return dict(input_ids=ids.to(device), attention_mask=am.to(device), history_field_embeddings=x.to(device),
+                history_attention_mask=hmask.to(device), positive_item_embeddings=posv.to(device),
+                negative_item_embeddings=neg.to(device), negative_masks=None)
+
+
+def build(args, device):
+    from unirec_amd.joint import MultiModalQwenEmbedding
+    from unirec_amd.qformer_utils import QFormerForItemRepresentation
+    from unirec_amd.qwen3 import Qwen3Config
+    torch.manual_seed(1234)
+    Qi, F, E, D = 2, 14, 1024, 1024
+    p = 0.0 if args.no_dropout else 0.2
+    qf = QFormerForItemRepresentation(hidden_size=D, num_hidden_layers=12, num_attention_heads=16, intermediate_size=4096,
+                                      num_query_tokens=Qi, field_embedding_dim=E, num_fields=F, dropout=p)
+    cfg = Qwen3Config(num_hidden_layers=args.layers)
+    model = MultiModalQwenEmbedding(qformer_model=qf, use_lora=True, qwen_config=cfg, num_history_items=args.hist,
+                                    num_query_tokens_per_item=Qi)
+    model.base_model.reset_parameters(lora_b_std=0.01)           # exercise the LoRA path
+    model = model.to(device).train()
+    return model, qf, cfg, (Qi, F, E, D)
+
+
+def flops_per_step(args, B, cfg, dims):
+    """Algorithmic FLOPs of one joint step on one GPU (SURVEY.md §8(d) formulas)."""
+    Qi, F, E, D = dims
+    S, hist = args.seq, args.hist
+    H, I_q, L_q = 1024, 4096, 12
+    items = B * hist
+    per_layer = items * Qi * (8 * H * H + 4 * Qi * H + 4 * H * I_q)
+    cross = 4 * items * Qi * H * H + 4 * items * F * E * H + 4 * items * Qi * F * H
+    qf_fwd = L_q * per_layer + 6 * cross
+    nq, nkv, hd, I = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size
+    w = D * (nq + 2 * nkv) * hd + nq * hd * D + 3 * D * I
+    tok = B * S
+    gemm_fwd = cfg.num_hidden_layers * 2 * w * tok
+    attn_fwd = cfg.num_hidden_layers * (4 * B * nq * S * S * hd) / 2
+    lora_fwd = cfg.num_hidden_layers * 2 * tok * cfg.lora_r * (2 * D * 4 + (nq + 2 * nkv) * hd + nq * hd + 3 * I + I)
+    qwen = (gemm_fwd + lora_fwd) * 2 + attn_fwd * 3.5     # bwd: dX only for frozen weights (+LoRA dA/dB); attention bwd = 2.5x fwd
+    return qf_fwd * 3 + qwen
+
+
+def cpu_baseline(args, cfg, dims):
+    """Oracle joint step (fwd+bwd, fp32) on the host cores, B=1 sequence of the same workload."""
+    from oracle import qformer_ref as R, qwen3_ref as Q, weights as W
+    Qi, F, E, D = dims
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    qcfg = R.QFormerCfg(D, 12, 16, 4096, Qi, E, 2)
+    wc = Q.Qwen3Cfg(hidden_size=D, num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                    num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, intermediate_size=cfg.intermediate_size,
+                    vocab_size=4096 + args.hist * Qi, rope_theta=cfg.rope_theta, lora_r=cfg.lora_r, lora_alpha=cfg.lora_alpha)
+    g = torch.Generator().manual_seed(0)
+    PQ = {k: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for k, s in R.item_qformer_shapes(qcfg, F).items()}
+    PW = {}
+    for k, s in Q.qwen3_shapes(wc, lora=True).items():
+        t = torch.randn(s, generator=g) * 0.02
+        if "norm" in k:
+            t = torch.ones(s)
+        PW[k] = t.requires_grad_(".lora_" in k)
+    first = 4096
+    b = make_batch(1, args.hist, args.seq, args.pool, F, E, D, Qi, first, first, 7, "cpu")
+
+    def step():
+        out = R.item_qformer_forward(PQ, qcfg, b["history_field_embeddings"].view(args.hist, F, E), b["history_attention_mask"].view(args.hist, F))
+        toks = out["query_outputs"].view(1, args.hist, Qi, D)
+        u = Q.joint_forward(PW, wc, b["input_ids"], b["attention_mask"], toks, first)
+        loss = Q.infonce_loss(u, b["positive_item_embeddings"], b["negative_item_embeddings"])
+        loss.backward()
+    t0 = time.time()
+    step()
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "user-sequences/sec", "cores": threads, "kind": "port",
+            "sample": f"1 user-sequence (hist={args.hist}, S={args.seq}, pool={args.pool}, {cfg.num_hidden_layers} layers), oracle fp32 fwd+bwd, 1 run"}
+
+
+def main():
+    args = parse()
+    from unirec_amd import dp, hip
+    from unirec_amd.joint import InfoNCELoss
+    from unirec_amd.optim import FusedAdamW
+    rank, world, local = dp.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    model, qf, cfg, dims = build(args, device)
+    Qi, F, E, D = dims
+    B = args.batch
+    batch = make_batch(B, args.hist, args.seq, args.pool, F, E, D, Qi, cfg.vocab_size - args.hist * Qi, model.first_special_id,
+                       1234 + rank, device)
+    loss_fn = InfoNCELoss(0.07)
+    qw = model.base_model
+    qpack, lpack = qf._ensure_pack(device), qw._ensure_pack(device)
+    opt = FusedAdamW([qpack, lpack], lr=1e-4, weight_decay=0.01)
+
+    # ---- gradient buckets in backward-completion order (LoRA 27..0, Q-Former 11..0, query table) ----
+    lgrp, qgrp = 7, 3
+    lb = dp.layer_boundaries(lpack, [f"layers.{i}." for i in range(cfg.num_hidden_layers)], lgrp)
+    qb = dp.layer_boundaries(qpack, [f"qformer.encoder.layer.{i}." for i in range(12)], qgrp)
+    lbk, qbk = dp.GradBuckets(lpack.grad, lb), dp.GradBuckets(qpack.grad, qb)
+    l_first = {min(i for i in range(cfg.num_hidden_layers) if i // lgrp == k): k for k in range((cfg.num_hidden_layers + lgrp - 1) // lgrp)}
+    qw.grad_ready_hook = lambda i: lbk.ready(l_first[i]) if i in l_first else None
+    q_first = {k * qgrp: 1 + k for k in range(12 // qgrp)}       # bucket 0 = query table + embedding LN, last = heads (unused here)
+    qf.qformer.grad_ready_hook = lambda i: qbk.ready(0) if i == -1 else (qbk.ready(q_first[i]) if i in q_first else None)
+
+    def step():
+        user = model(batch["input_ids"], batch["attention_mask"], batch["history_field_embeddings"], batch["history_attention_mask"])
+        loss = loss_fn(user, batch["positive_item_embeddings"], batch["negative_item_embeddings"], batch["negative_masks"])
+        loss.backward()
+        lbk.wait(); qbk.wait()
+        opt.step(grad_scale=1.0 / world)
+        return loss
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    hip.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    prof, hip.PROFILE = hip.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    lossv = float(loss.item())
+    if not math.isfinite(lossv):
+        raise SystemExit("non-finite loss")
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: forward projection GEMM gemm_kernel<RK=1,SK=1,bf16> -----
+        tot_ms, tot_fl, n = 0.0, 0.0, 0
+        all_ms, all_fl = 0.0, 0.0
+        for (e0, e1, rk, sk, f32, M, N, K, split) in prof:
+            ms = e0.elapsed_time(e1)
+            all_ms += ms; all_fl += 2.0 * M * N * K
+            if rk and sk and not f32 and M >= 4096 and N >= 1024:
+                tot_ms += ms; tot_fl += 2.0 * M * N * K; n += 1
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
+                "traffic": None, "kernel": "gemm_kernel<RK=1,SK=1,bf16 out> (forward projections, M>=4096,N>=1024)",
+                "launches": n, "avg_launch_ms": round(tot_ms / max(n, 1), 4),
+                "all_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
+                "all_gemm_ms_per_step": round(all_ms / args.steps, 2)}
+        fl = flops_per_step(args, B, cfg, dims)
+        out = {"metric": "user-sequences/sec joint fwd+bwd (Qwen3-0.6B+LoRA, hist=50)", "value": round(world * B * args.steps / dt, 3),
+               "unit": "user-sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"C4 joint step: item Q-Former(L12,H1024,Q2,F14) on {B}x{args.hist} items -> inject -> "
+                                      f"Qwen3-0.6B-shaped({cfg.num_hidden_layers}L)+LoRA r16 -> mean-pool -> InfoNCE pool {args.pool}; "
+                                      f"fwd+bwd+allreduce+AdamW", "per_gpu_batch": B, "global_batch": B * world, "seq_len": args.seq,
+                          "hist": args.hist, "pool": args.pool, "dropout": 0.0 if args.no_dropout else 0.2, "lora_dropout": 0.0,
+                          "parallelism": f"dp{world}", "random_init": True},
+               "step_tflops_per_gpu": round(fl / (dt / args.steps) / 1e12, 1), "loss": round(lossv, 4),
+               "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, cfg, dims)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -34,6 +34,10 @@ def _need(t, dtype, name):
 
 _ws_cache = {}
 
+# Optional live kernel timing (bench.py roofline leg): when PROFILE is a list, every ur_gemm launch is
+# bracketed by HIP events recorded on the launching (current) stream and logged with its shape.
+PROFILE = None
+
 
 def workspace(nbytes, device, tag="default"):
     """Grow-only scratch buffer per (device, tag); owned by the caller side (torch allocator)."""
@@ -85,6 +89,13 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
     if split_k > 1:
         wsb = lib.ur_gemm_workspace_bytes(ctypes.byref(a))
         ws = workspace(wsb, R.device, "gemm").data_ptr()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ur_gemm(ctypes.byref(a), ws, wsb, _stream()), "ur_gemm")
+        e1.record()
+        PROFILE.append((e0, e1, int(r_kcontig), int(s_kcontig), int(out.dtype == F32), M, N, K + int(a.K2), int(split_k)))
+        return out
     check(lib.ur_gemm(ctypes.byref(a), ws, wsb, _stream()), "ur_gemm")
     return out
 

@@ -168,6 +168,7 @@ class BertModel(nn.Module):
         self._pack_prefix = ""
         self._step = 0
         self.seed = 0x5EED
+        self.grad_ready_hook = None
 
     # models/qformer.py:664-674
     def _init_weights_like_reference(self):
@@ -417,6 +418,8 @@ class BertModel(nn.Module):
             hip.colsum(dqkv, out=pack.fusedg([a + "self.query.bias", a + "self.key.bias", a + "self.value.bias"]))
             dx = hip.gemm(dqkv, pack.fused16(names), s_kcontig=False, residual=dz1)
             L.clear()
+            if self.grad_ready_hook is not None:      # dp.GradBuckets: layer i's gradients are final
+                self.grad_ready_hook(i)
         # ---- embeddings LayerNorm; gradient of the batch-broadcast query table reduces over B
         z0, mean0, rstd0, s0 = S["emb"]
         dz0, _ = hip.layernorm_bwd(dx, z0, mean0, rstd0, pack.w32(pre + "embeddings.LayerNorm.weight"),
@@ -435,6 +438,8 @@ class BertModel(nn.Module):
         if d_enc is not None:
             d_enc = hip.cast_bf16_to_f32(d_enc).view(B, T, -1)
         pack.publish_grads(touched)
+        if self.grad_ready_hook is not None:
+            self.grad_ready_hook(-1)                  # query table + embedding LayerNorm
         return d_qe, d_enc
 
 

@@ -126,6 +126,7 @@ class Qwen3LoRAModel(nn.Module):
         self._pack = None
         self._frozen = None
         self._rope = None
+        self.grad_ready_hook = None
         self.reset_parameters()
 
     def reset_parameters(self, lora_b_std=0.0):
@@ -382,6 +383,8 @@ class Qwen3LoRAModel(nn.Module):
                 dh = hip.gemm(dqkv, fl["qkv"], s_kcontig=False)
             dx = hip.rmsnorm_bwd(dh, x, fl["ln1"], L["rstd1"], add=dx2)
             L.clear()
+            if self.grad_ready_hook is not None:      # dp.GradBuckets: layer i's LoRA gradients are final
+                self.grad_ready_hook(i)
         if pack is not None:
             pack.publish_grads(touched)
         if T > 0:
