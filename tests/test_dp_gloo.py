@@ -1,0 +1,111 @@
+"""CPU: the N>1 data-parallel path with world_size 2 over gloo:
+sharding, bucket boundaries, bucketed async all-reduce of the flat gradient pack, and the algebra it
+relies on (sum of per-shard gradients of mean-reduced losses == world * full-batch gradient)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import qformer_ref as R
+from oracle import weights as W
+from unirec_amd import dp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakePack:
+    """Host-side stand-in with ParamPack's layout fields (no HIP needed for the bucket logic)."""
+
+    def __init__(self, named_shapes):
+        self.names, self.offsets, self.params = [], {}, {}
+        off = 0
+        for n, shp in named_shapes:
+            self.names.append(n)
+            self.offsets[n] = off
+            self.params[n] = torch.zeros(shp)
+            off += (self.params[n].numel() + 7) // 8 * 8
+        self.numel = off
+        self.grad = torch.zeros(off)
+
+
+def _pack():
+    shapes = [("query_embeddings", (1, 4, 16))]
+    for i in range(4):
+        shapes += [(f"qformer.encoder.layer.{i}.a.weight", (16, 16)), (f"qformer.encoder.layer.{i}.a.bias", (16,))]
+    shapes += [("head.weight", (8, 16))]
+    return _FakePack(shapes)
+
+
+def test_bucket_boundaries_cover_the_pack_in_layer_groups():
+    p = _pack()
+    b = dp.layer_boundaries(p, [f"qformer.encoder.layer.{i}." for i in range(4)], 2)
+    assert b[0] == 0 and b[-1] == p.numel and b == sorted(set(b))
+    assert p.offsets["qformer.encoder.layer.0.a.weight"] in b and p.offsets["qformer.encoder.layer.2.a.weight"] in b
+    assert p.offsets["qformer.encoder.layer.1.a.weight"] not in b
+    assert p.offsets["head.weight"] in b            # untouched heads sit in their own trailing bucket
+
+
+def test_shard_range_partitions_the_global_batch():
+    got = [dp.shard_range(64 * 8, r, 8) for r in range(8)]
+    assert got[0] == (0, 64) and got[-1] == (448, 512)
+    assert all(got[i][1] == got[i + 1][0] for i in range(7))
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.set_num_threads(1)
+    # a tiny item Q-Former on this rank's shard of a fixed global batch (oracle = host arithmetic)
+    cfg = R.QFormerCfg(64, 2, 1, 128, 4, 32, 2)
+    shapes = R.item_qformer_shapes(cfg, 5)
+    P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in W.fill_state_dict(shapes, 3).items()}
+    Bg = 8
+    x = torch.from_numpy(W.normal("x", (Bg, 5, 32), 1, std=1.0))
+    lo, hi = dp.shard_range(Bg, rank, world)
+    out = R.item_qformer_forward(P, cfg, x[lo:hi], None)
+    loss = out["query_outputs"].pow(2).mean()          # per-sample independent loss, mean over the local shard
+    loss.backward()
+    names = list(shapes.keys())
+    pack = _FakePack([(n, shapes[n]) for n in names])
+    for n in names:
+        o = pack.offsets[n]
+        if P[n].grad is not None:                       # heads are unused by this loss: stay zero
+            pack.grad[o:o + P[n].numel()] = P[n].grad.reshape(-1)
+    bounds = dp.layer_boundaries(pack, [f"qformer.encoder.layer.{i}." for i in range(2)], 1)
+    bk = dp.GradBuckets(pack.grad, bounds)
+    assert bk.enabled
+    for i in reversed(range(bk.n)):                      # backward-completion order
+        bk.ready(i)
+    bk.wait()
+    torch.save(pack.grad / world, os.path.join(tmp, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_matches_unsharded_gradient(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    assert torch.equal(g0, g1), "ranks must hold bitwise-identical reduced gradients"
+    # unsharded reference
+    cfg = R.QFormerCfg(64, 2, 1, 128, 4, 32, 2)
+    shapes = R.item_qformer_shapes(cfg, 5)
+    P = {k: torch.from_numpy(v).requires_grad_(True) for k, v in W.fill_state_dict(shapes, 3).items()}
+    x = torch.from_numpy(W.normal("x", (8, 5, 32), 1, std=1.0))
+    R.item_qformer_forward(P, cfg, x, None)["query_outputs"].pow(2).mean().backward()
+    pack = _FakePack([(n, shapes[n]) for n in shapes])
+    for n in shapes:
+        o = pack.offsets[n]
+        want = torch.zeros(P[n].numel()) if P[n].grad is None else P[n].grad.reshape(-1)
+        assert torch.allclose(g0[o:o + P[n].numel()], want, rtol=1e-4, atol=1e-7), n

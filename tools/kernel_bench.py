@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the individual hot kernels (attention fwd/bwd, projection GEMMs) at the C4
+shapes; used under rocprofv3 (--kernel-trace / --pmc) when tuning.  Usage:
+    python tools/kernel_bench.py attn|gemm [--B 8] [--iters 5]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from unirec_amd import hip
+
+
+def timeit(fn, iters):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def attn(args):
+    B, S, nq, nkv, hd = args.B, args.S, 16, 8, 128
+    g = torch.Generator().manual_seed(0)
+    qkv = (torch.randn(B, S, (nq + 2 * nkv) * hd, generator=g)).cuda().to(torch.bfloat16)
+    q = qkv[..., :nq * hd].view(B, S, nq, hd); k = qkv[..., nq * hd:(nq + nkv) * hd].view(B, S, nkv, hd); v = qkv[..., (nq + nkv) * hd:].view(B, S, nkv, hd)
+    dout = torch.randn(B, S, nq, hd, generator=g).cuda().to(torch.bfloat16)
+    fl = 4 * B * nq * S * S * hd / 2
+    o, ctx = hip.attn_fwd(q, k, v, causal=True)
+    t = timeit(lambda: hip.attn_fwd(q, k, v, causal=True), args.iters)
+    print(f"attn fwd  B={B} S={S}: {t:.3f} ms  {fl / t / 1e9:.1f} TFLOP/s")
+    t = timeit(lambda: hip.attn_bwd(ctx, dout), args.iters)
+    print(f"attn bwd  B={B} S={S}: {t:.3f} ms  {2.5 * fl / t / 1e9:.1f} TFLOP/s (2.5x fwd flops; 3.5x executed)")
+
+
+def gemm(args):
+    M = args.B * args.S
+    g = torch.Generator().manual_seed(0)
+    for (N, K, rk, sk, name) in [(2048, 1024, True, True, "q_proj fwd"), (3072, 1024, True, True, "gate fwd"), (1024, 3072, True, True, "down fwd"),
+                                 (1024, 4096, True, False, "dX qkv"), (3072, 1024, True, False, "dX down"), (1024, 6144, True, False, "dX gate|up")]:
+        R = torch.randn(M, K, generator=g).cuda().to(torch.bfloat16)
+        S_ = (torch.randn(N, K, generator=g) if sk else torch.randn(K, N, generator=g)).cuda().to(torch.bfloat16) * 0.05
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        t = timeit(lambda: hip.gemm(R, S_, r_kcontig=rk, s_kcontig=sk, out=out), args.iters)
+        print(f"gemm {name:12s} M={M} N={N} K={K}: {t:.3f} ms  {2 * M * N * K / t / 1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["attn", "gemm"])
+    ap.add_argument("--B", type=int, default=8)
+    ap.add_argument("--S", type=int, default=2048)
+    ap.add_argument("--iters", type=int, default=5)
+    a = ap.parse_args()
+    {"attn": attn, "gemm": gemm}[a.what](a)

@@ -11,8 +11,13 @@
 //   column, so the online-softmax row reductions are 16 in-register ops + one cross-half shuffle,
 //   and the P accumulators are directly the B operand of O^T += V^T P (no LDS round trip, no lane
 //   movement).  V^T (and K^T / Q^T / dO^T in the backward) fragments come from the plain row-major
-//   LDS tile through ds_read_b64_tr_b16.  K/V tiles are staged once per workgroup with coalesced
-//   16-byte loads; LDS rows are padded by 16 B so the ds_read_b128 row reads are conflict-free.
+//   LDS tile through ds_read_b64_tr_b16.
+//   Staging: 64-key tiles, double-buffered in LDS, next tile's global loads issued into registers
+//   before the current tile's MFMAs and written to LDS after them (one barrier per tile).
+//   head_dim 128 tiles use 256-B rows with a 16-B chunk XOR swizzle that is conflict-free for both the
+//   ds_read_b128 row reads and the transposed reads; head_dim 64 tiles use 16-B padded rows.
+//   Interior tiles (all keys valid, below the causal diagonal, no dropout) take a mask-free softmax:
+//   p = exp2(fma(s, scale*log2e, -m*log2e)); O is rescaled only when some row's max moved.
 // Backward = dQ kernel (same decomposition as forward) + dK/dV kernel (one 32-key block per wave,
 // looping over the query heads of its GQA group): no atomics, bitwise reproducible.
 #include "common.cuh"
@@ -22,14 +27,20 @@ namespace {
 
 constexpr float NEG_INF = -__builtin_huge_valf();
 constexpr float F32_MIN = -3.4028234663852886e38f;   // torch.finfo(torch.float32).min
+constexpr float LOG2E = 1.4426950408889634f;
 constexpr int KT = 64;                                // keys (or queries, in dK/dV) staged per LDS tile
 
 template <int HD> struct Cfg {
-  static constexpr int ROWB = HD * 2 + 16;            // padded LDS row (bytes)
+  static constexpr int ROWB = (HD == 128) ? 256 : 144;
   static constexpr int NS = HD / 16;                  // MFMA k-steps contracting over head_dim
-  static constexpr int NDT = HD / 32;                 // 32-wide head_dim tiles of an O^T/dQ^T/dK^T/dV^T accumulator
+  static constexpr int NDT = HD / 32;                 // 32-wide head_dim tiles of a transposed accumulator
   static constexpr int CH = HD / 8;                   // 16-byte chunks per row
   static constexpr int TILE = KT * ROWB;
+  // byte offset of 16-byte chunk `ch` of row `row`
+  static __device__ __forceinline__ int off(int row, int ch) {
+    if (HD == 128) return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    return 144 * row + 16 * ch;
+  }
 };
 
 struct AttnP {
@@ -51,24 +62,36 @@ __device__ __forceinline__ f32x16 zero16() {
 }
 // accumulator register r of lane-half h  <->  row index inside the 32-row tile
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// rows [row0, row0+KT) x HD of a [S][ld] bf16 matrix -> LDS tile (zero-filled past S)
+// rows [row0, row0+KT) x HD of a [S][ld] bf16 matrix: global -> registers -> LDS tile (zero past S)
 template <int HD, int NT>
-__device__ __forceinline__ void stage_tile(char* tile, const bf16_t* __restrict__ base, long ld, int row0, int S, int tid) {
-  constexpr int CH = Cfg<HD>::CH, ROWB = Cfg<HD>::ROWB;
-  for (int c = tid; c < KT * CH; c += NT) {
-    const int r = c / CH, cc = c - r * CH;
-    const int g = row0 + r;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (g < S) v = *reinterpret_cast<const uint4*>(base + (long)g * ld + cc * 8);
-    *reinterpret_cast<uint4*>(tile + r * ROWB + cc * 16) = v;
+struct Stager {
+  static constexpr int N = (KT * Cfg<HD>::CH) / NT;
+  uint4 r[N];
+  __device__ __forceinline__ void load(const bf16_t* __restrict__ base, long ld, int row0, int S, int tid) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + i * NT;
+      const int row = c / Cfg<HD>::CH, cc = c % Cfg<HD>::CH;
+      const int g = row0 + row;
+      r[i] = (g < S) ? *reinterpret_cast<const uint4*>(base + (long)g * ld + cc * 8) : make_uint4(0, 0, 0, 0);
+    }
   }
-}
+  __device__ __forceinline__ void store(char* tile, int tid) const {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int c = tid + i * NT;
+      const int row = c / Cfg<HD>::CH, cc = c % Cfg<HD>::CH;
+      *reinterpret_cast<uint4*>(tile + Cfg<HD>::off(row, cc)) = r[i];
+    }
+  }
+};
 
 // row fragment: X[r0 + (lane&31)][16*s + 8*(lane>>5) + 0..7]   (MFMA A or B operand, k = head_dim)
 template <int HD>
 __device__ __forceinline__ bf16x8 row_frag(const char* tile, int r0, int s, int lane) {
-  return *reinterpret_cast<const bf16x8*>(tile + (r0 + (lane & 31)) * Cfg<HD>::ROWB + (2 * s + (lane >> 5)) * 16);
+  return *reinterpret_cast<const bf16x8*>(tile + Cfg<HD>::off(r0 + (lane & 31), 2 * s + (lane >> 5)));
 }
 // transposed fragment: A[m = 32*dt + (lane&31)][k-element j] = X[r0 + 8*(j>>2) + 4*(lane>>5) + (j&3)][m]
 // (16 rows r0..r0+15 of X; k order matches an accumulator tile used as the B operand)
@@ -76,9 +99,11 @@ template <int HD>
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int r0, int dt, int lane) {
   typedef __attribute__((address_space(3))) bf16x4 lds_v4;
   const int h = lane >> 5, g16 = (lane >> 4) & 1, i = lane & 15;
-  const char* pa = tile + (r0 + 4 * h + (i >> 2)) * Cfg<HD>::ROWB + (32 * dt + 16 * g16 + 4 * (i & 3)) * 2;
+  const int row = r0 + 4 * h + (i >> 2), ch = 4 * dt + 2 * g16 + ((i & 3) >> 1), sub8 = 8 * (i & 1);
+  const char* pa = tile + Cfg<HD>::off(row, ch) + sub8;
+  const char* pb = tile + Cfg<HD>::off(row + 8, ch) + sub8;
   const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pa);
-  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(pa + 8 * Cfg<HD>::ROWB));
+  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pb);
   bf16x8 r;
   r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
   return r;
@@ -87,7 +112,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int r0, int dt, int 
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s2) {
   bf16x8 r;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(a[8 * s2 + j]);
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t w = pack_bf2(a[8 * s2 + 2 * j], a[8 * s2 + 2 * j + 1]);
+    r[2 * j] = (short)(w & 0xffffu);
+    r[2 * j + 1] = (short)(w >> 16);
+  }
   return r;
 }
 // global row fragment (same element map as row_frag), zero when !ok
@@ -96,7 +125,7 @@ __device__ __forceinline__ bf16x8 g_frag(const bf16_t* rowp, int s, int lane, bo
   if (!ok) return z;
   return *reinterpret_cast<const bf16x8*>(rowp + 16 * s + 8 * (lane >> 5));
 }
-// store an O^T-layout accumulator set (lane = row of the output matrix, regs = head_dim) as bf16
+// store a transposed accumulator set (lane = row of the output matrix, regs = head_dim) as bf16
 template <int HD>
 __device__ __forceinline__ void store_T(bf16_t* rowp, const f32x16 (&acc)[Cfg<HD>::NDT], float mul, int lane) {
   const int h = lane >> 5;
@@ -110,29 +139,30 @@ __device__ __forceinline__ void store_T(bf16_t* rowp, const f32x16 (&acc)[Cfg<HD
     }
 }
 
-// key-state byte staged beside each tile: 0 = beyond Sk, 1 = masked by key_mask, 2 = valid
-__device__ __forceinline__ void stage_kstate(uint8_t* ks, const uint8_t* km, int k0, int Sk, int tid) {
-  if (tid < KT) {
-    const int key = k0 + tid;
-    ks[tid] = (key >= Sk) ? 0 : ((km == nullptr || km[key]) ? 2 : 1);
-  }
+// Per-tile key state of the 64 keys k0..k0+63 as wave-uniform bit masks (bit i = key k0+i):
+// `valid` = inside Sk and allowed by key_mask, `inr` = inside Sk.
+struct KeyBits { unsigned long long valid, inr; };
+__device__ __forceinline__ KeyBits key_bits(const uint8_t* km, int k0, int Sk, int lane) {
+  const int key = k0 + lane;
+  const bool in = key < Sk;
+  const bool ok = in && (km == nullptr || km[key] != 0);
+  KeyBits kb; kb.valid = __ballot(ok); kb.inr = __ballot(in);
+  return kb;
 }
 
-// masked, scaled score.  CAUSAL: SDPA semantics (-inf); else the Q-Former's additive finfo.min.
+// masked, scaled score (natural-log domain).  CAUSAL: SDPA semantics (-inf); else the Q-Former's
+// additive finfo.min (the sum collapses to exactly finfo.min in f32).
 template <bool CAUSAL>
-__device__ __forceinline__ float mask_score(float raw, float scale, uint8_t st, int key, int qpos) {
-  if (CAUSAL) return (st == 2 && key <= qpos) ? raw * scale : NEG_INF;
-  return st == 0 ? NEG_INF : (st == 2 ? raw * scale : F32_MIN);
+__device__ __forceinline__ float mask_score(float raw, float scale, bool valid, bool inr, int key, int qpos) {
+  if (CAUSAL) return (valid && key <= qpos) ? raw * scale : NEG_INF;
+  return !inr ? NEG_INF : (valid ? raw * scale : F32_MIN);
 }
 
 // ================================================================================================
 template <int HD, bool CAUSAL, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   using C = Cfg<HD>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ktile = smem;
-  char* vtile = smem + C::TILE;
-  uint8_t* kst = reinterpret_cast<uint8_t*>(smem + 2 * C::TILE);
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int hq = blockIdx.y, b = blockIdx.z, kvh = hq / p.rep;
   const int qblk = blockIdx.x * (32 * NW) + wave * 32;
@@ -147,65 +177,102 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   f32x16 o[C::NDT];
 #pragma unroll
   for (int dt = 0; dt < C::NDT; ++dt) o[dt] = zero16();
-  float m = NEG_INF, l = 0.f;
+  float m = NEG_INF, l = 0.f;          // running max (natural-log domain, scaled scores) and row sum
+  const float c2 = p.scale * LOG2E;
 
   int kend = p.Sk;
   if (CAUSAL) kend = min(p.Sk, (int)(blockIdx.x + 1) * (32 * NW));
+  const int ntiles = (kend + KT - 1) / KT;
   const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * HD;
   const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * HD;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
   const uint64_t drow = ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
+  const bool dropping = (!CAUSAL) && p.drop_thr != 0;
 
-  for (int k0 = 0; k0 < kend; k0 += KT) {
-    __syncthreads();
-    stage_tile<HD, NW * 64>(ktile, kb, p.ldk, k0, p.Sk, tid);
-    stage_tile<HD, NW * 64>(vtile, vb, p.ldv, k0, p.Sk, tid);
-    stage_kstate(kst, km, k0, p.Sk, tid);
-    __syncthreads();
-    if (qblk >= p.Sq) continue;
+  Stager<HD, NW * 64> ks, vs;
+  ks.load(kb, p.ldk, 0, p.Sk, tid);
+  vs.load(vb, p.ldv, 0, p.Sk, tid);
+  ks.store(smem, tid);
+  vs.store(smem + C::TILE, tid);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int k0 = t * KT;
+    const char* ktile = smem + (t & 1) * 2 * C::TILE;
+    const char* vtile = ktile + C::TILE;
+    if (t + 1 < ntiles) {
+      ks.load(kb, p.ldk, k0 + KT, p.Sk, tid);
+      vs.load(vb, p.ldv, k0 + KT, p.Sk, tid);
+    }
+    const KeyBits kbits = key_bits(km, k0, p.Sk, lane);
+    if (qblk < p.Sq) {
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int kbase = k0 + 32 * sub;
-      if (kbase >= kend || (CAUSAL && kbase > qblk + 31)) break;
-      f32x16 s = zero16();
+      for (int sub = 0; sub < 2; ++sub) {
+        const int kbase = k0 + 32 * sub;
+        if (kbase >= kend || (CAUSAL && kbase > qblk + 31)) break;
+        f32x16 s = zero16();
 #pragma unroll
-      for (int st = 0; st < C::NS; ++st)
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ktile, 32 * sub, st, lane), qf[st], s, 0, 0, 0);
-      float mx = NEG_INF;
+        for (int st = 0; st < C::NS; ++st)
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ktile, 32 * sub, st, lane), qf[st], s, 0, 0, 0);
+        const uint32_t v32 = (uint32_t)(kbits.valid >> (32 * sub)), i32 = (uint32_t)(kbits.inr >> (32 * sub));
+        const bool fast = (v32 == 0xffffffffu) && (!CAUSAL || kbase + 31 <= qblk) && !dropping;
+        float mx = NEG_INF;
+        if (fast) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kr = 32 * sub + acc_row(r, h);
-        s[r] = mask_score<CAUSAL>(s[r], p.scale, kst[kr], k0 + kr, q);
-        mx = fmaxf(mx, s[r]);
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(m, mx);
-      const float muse = (mnew == NEG_INF) ? 0.f : mnew;
-      const float alpha = __expf(m - muse);
-      float rs = 0.f;
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+          mx *= p.scale;
+        } else {
+          const uint32_t vh = v32 >> (4 * h), ih = i32 >> (4 * h);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float pr = __expf(s[r] - muse);
-        rs += pr;
-        if (!CAUSAL && p.drop_thr)
-          pr *= ur_dropout_scale(p.seed, drow + (uint64_t)(k0 + 32 * sub + acc_row(r, h)), p.drop_thr, p.drop_inv);
-        s[r] = pr;
-      }
-      rs += __shfl_xor(rs, 32, 64);
-      l = l * alpha + rs;
-      m = mnew;
+          for (int r = 0; r < 16; ++r) {
+            const int bit = (r & 3) + 8 * (r >> 2);
+            s[r] = mask_score<CAUSAL>(s[r], p.scale, (vh >> bit) & 1u, (ih >> bit) & 1u, kbase + acc_row(r, h), q);
+            mx = fmaxf(mx, s[r]);
+          }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m, mx);
+        const float muse = (mnew == NEG_INF) ? 0.f : mnew;
+        if (__any(mnew != m)) {                       // some row's max moved: rescale O and l
+          const float alpha = fast_exp2((m - muse) * LOG2E);
+          l *= alpha;
 #pragma unroll
-      for (int dt = 0; dt < C::NDT; ++dt)
+          for (int dt = 0; dt < C::NDT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+          m = mnew;
+        }
+        const float mc = muse * LOG2E;
+        float rs = 0.f;
+        if (fast) {
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pf = acc_frag(s, s2);
+          for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], c2, -mc)); rs += s[r]; }
+        } else {
 #pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt)
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(vtile, 32 * sub + 16 * s2, dt, lane), pf, o[dt], 0, 0, 0);
+          for (int r = 0; r < 16; ++r) {
+            float pr = fast_exp2((s[r] - muse) * LOG2E);
+            rs += pr;
+            if (dropping) pr *= ur_dropout_scale(p.seed, drow + (uint64_t)(kbase + acc_row(r, h)), p.drop_thr, p.drop_inv);
+            s[r] = pr;
+          }
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        l += rs;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = acc_frag(s, s2);
+#pragma unroll
+          for (int dt = 0; dt < C::NDT; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(vtile, 32 * sub + 16 * s2, dt, lane), pf, o[dt], 0, 0, 0);
+        }
       }
     }
+    if (t + 1 < ntiles) {
+      char* nk = smem + ((t + 1) & 1) * 2 * C::TILE;
+      ks.store(nk, tid);
+      vs.store(nk + C::TILE, tid);
+    }
+    __syncthreads();
   }
   if (qok) {
     const float inv = l > 0.f ? 1.0f / l : 0.f;
@@ -246,9 +313,6 @@ template <int HD, bool CAUSAL, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
   using C = Cfg<HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ktile = smem;
-  char* vtile = smem + C::TILE;
-  uint8_t* kst = reinterpret_cast<uint8_t*>(smem + 2 * C::TILE);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int hq = blockIdx.y, b = blockIdx.z, kvh = hq / p.rep;
   const int qblk = blockIdx.x * (32 * NW) + wave * 32;
@@ -264,6 +328,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
   }
   const long srow = ((long)b * p.nq + hq) * p.Sq + (qok ? q : 0);
   const float m = p.stats[srow * 2], inv = qok ? p.stats[srow * 2 + 1] : 0.f, dlt = p.delta[srow];
+  const float c2 = p.scale * LOG2E, mc = m * LOG2E;
+  const float invs = inv * p.scale;    // fold the 1/sqrt(d) of dS into the normaliser
 
   f32x16 dq[C::NDT];
 #pragma unroll
@@ -271,45 +337,73 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
 
   int kend = p.Sk;
   if (CAUSAL) kend = min(p.Sk, (int)(blockIdx.x + 1) * (32 * NW));
+  const int ntiles = (kend + KT - 1) / KT;
   const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * HD;
   const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * HD;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
   const uint64_t drow = ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
+  const bool dropping = (!CAUSAL) && p.drop_thr != 0;
 
-  for (int k0 = 0; k0 < kend; k0 += KT) {
-    __syncthreads();
-    stage_tile<HD, NW * 64>(ktile, kb, p.ldk, k0, p.Sk, tid);
-    stage_tile<HD, NW * 64>(vtile, vb, p.ldv, k0, p.Sk, tid);
-    stage_kstate(kst, km, k0, p.Sk, tid);
-    __syncthreads();
-    if (qblk >= p.Sq) continue;
+  Stager<HD, NW * 64> ks, vs;
+  ks.load(kb, p.ldk, 0, p.Sk, tid);
+  vs.load(vb, p.ldv, 0, p.Sk, tid);
+  ks.store(smem, tid);
+  vs.store(smem + C::TILE, tid);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int k0 = t * KT;
+    const char* ktile = smem + (t & 1) * 2 * C::TILE;
+    const char* vtile = ktile + C::TILE;
+    if (t + 1 < ntiles) {
+      ks.load(kb, p.ldk, k0 + KT, p.Sk, tid);
+      vs.load(vb, p.ldv, k0 + KT, p.Sk, tid);
+    }
+    const KeyBits kbits = key_bits(km, k0, p.Sk, lane);
+    if (qblk < p.Sq) {
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int kbase = k0 + 32 * sub;
-      if (kbase >= kend || (CAUSAL && kbase > qblk + 31)) break;
-      f32x16 s = zero16(), dp = zero16();
+      for (int sub = 0; sub < 2; ++sub) {
+        const int kbase = k0 + 32 * sub;
+        if (kbase >= kend || (CAUSAL && kbase > qblk + 31)) break;
+        f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-      for (int st = 0; st < C::NS; ++st) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ktile, 32 * sub, st, lane), qf[st], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(vtile, 32 * sub, st, lane), dof[st], dp, 0, 0, 0);
-      }
+        for (int st = 0; st < C::NS; ++st) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ktile, 32 * sub, st, lane), qf[st], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(vtile, 32 * sub, st, lane), dof[st], dp, 0, 0, 0);
+        }
+        const uint32_t v32 = (uint32_t)(kbits.valid >> (32 * sub)), i32 = (uint32_t)(kbits.inr >> (32 * sub));
+        const bool fast = (v32 == 0xffffffffu) && (!CAUSAL || kbase + 31 <= qblk) && !dropping;
+        if (fast) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kr = 32 * sub + acc_row(r, h);
-        const float sc = mask_score<CAUSAL>(s[r], p.scale, kst[kr], k0 + kr, q);
-        const float pr = (sc == NEG_INF) ? 0.f : __expf(sc - m) * inv;
-        float g = dp[r];
-        if (!CAUSAL && p.drop_thr) g *= ur_dropout_scale(p.seed, drow + (uint64_t)(k0 + kr), p.drop_thr, p.drop_inv);
-        s[r] = pr * (g - dlt) * p.scale;
-      }
+          for (int r = 0; r < 16; ++r) s[r] = fast_exp2(fmaf(s[r], c2, -mc)) * invs * (dp[r] - dlt);
+        } else {
+          const uint32_t vh = v32 >> (4 * h), ih = i32 >> (4 * h);
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 df = acc_frag(s, s2);
+          for (int r = 0; r < 16; ++r) {
+            const int bit = (r & 3) + 8 * (r >> 2);
+            const int kr = kbase + acc_row(r, h);
+            const float sc = mask_score<CAUSAL>(s[r], p.scale, (vh >> bit) & 1u, (ih >> bit) & 1u, kr, q);
+            const float pr = (sc == NEG_INF) ? 0.f : fast_exp2((sc - m) * LOG2E) * invs;
+            float g = dp[r];
+            if (dropping) g *= ur_dropout_scale(p.seed, drow + (uint64_t)kr, p.drop_thr, p.drop_inv);
+            s[r] = pr * (g - dlt);
+          }
+        }
 #pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt)
-          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(ktile, 32 * sub + 16 * s2, dt, lane), df, dq[dt], 0, 0, 0);
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 df = acc_frag(s, s2);
+#pragma unroll
+          for (int dt = 0; dt < C::NDT; ++dt)
+            dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(ktile, 32 * sub + 16 * s2, dt, lane), df, dq[dt], 0, 0, 0);
+        }
       }
     }
+    if (t + 1 < ntiles) {
+      char* nk = smem + ((t + 1) & 1) * 2 * C::TILE;
+      ks.store(nk, tid);
+      vs.store(nk + C::TILE, tid);
+    }
+    __syncthreads();
   }
   if (qok) store_T<HD>(p.dq + ((long)b * p.Sq + q) * p.lddq + (long)hq * HD, dq, 1.0f, lane);
 }
@@ -318,13 +412,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
 // dK/dV: one 32-key block per wave (lane = key column).  Per 32-query sub-tile:
 //   S[q][key] = Q K^T, dP[q][key] = dO V^T (A = Q / dO rows from LDS, B = K / V fragments in registers)
 //   dV^T[d][key] += dO^T[d][q] * (P.drop)[q][key];   dK^T[d][key] += Q^T[d][q] * dS[q][key]
+// LDS per buffer: Q tile | dO tile | row stats (m [64], scale/l [64], delta [64]).
 template <int HD, bool CAUSAL, int NW>
 __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
   using C = Cfg<HD>;
+  constexpr int STG = 2 * C::TILE + 3 * KT * (int)sizeof(float);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* qtile = smem;
-  char* dotile = smem + C::TILE;
-  float* fst = reinterpret_cast<float*>(smem + 2 * C::TILE);   // [KT][4]: m, inv_l, delta, valid
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const int kvh = blockIdx.y, b = blockIdx.z;
   const int kblk = blockIdx.x * (32 * NW) + wave * 32;
@@ -338,33 +431,63 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
     kf[s] = g_frag(p.k + ktok * p.ldk + (long)kvh * HD, s, lane, kok);
     vf[s] = g_frag(p.v + ktok * p.ldv + (long)kvh * HD, s, lane, kok);
   }
-  uint8_t kstate = 0;
-  if (kok) kstate = (p.kmask == nullptr || p.kmask[(long)b * p.Sk + key]) ? 2 : 1;
+  const bool kvalid = kok && (p.kmask == nullptr || p.kmask[(long)b * p.Sk + key] != 0);
+  const bool all_valid = __all(kvalid);
+  const float c2 = p.scale * LOG2E;
+  const bool dropping = (!CAUSAL) && p.drop_thr != 0;
 
   f32x16 dk[C::NDT], dv[C::NDT];
 #pragma unroll
   for (int dt = 0; dt < C::NDT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
 
   const int qstart = CAUSAL ? ((int)(blockIdx.x * (32 * NW)) / KT) * KT : 0;
-  for (int hr = 0; hr < p.rep; ++hr) {
+  const int ntq = (p.Sq - qstart + KT - 1) / KT;
+  const int ntot = ntq * p.rep;                    // tiles over (query head of the group, query tile)
+
+  Stager<HD, NW * 64> qs, dos;
+  float st0 = 0.f, st1 = 0.f, st2 = 0.f;          // staged row stats of thread tid < KT
+  auto tile_ptrs = [&](int it, const bf16_t*& qb, const bf16_t*& dob, long& sbase, int& q0) {
+    const int hr = it / ntq, tq = it - hr * ntq;
     const int hq = kvh * p.rep + hr;
-    const bf16_t* qb = p.q + (long)b * p.Sq * p.ldq + (long)hq * HD;
-    const bf16_t* dob = p.dout + (long)b * p.Sq * p.lddo + (long)hq * HD;
-    const long sbase = ((long)b * p.nq + hq) * p.Sq;
-    for (int q0 = qstart; q0 < p.Sq; q0 += KT) {
-      __syncthreads();
-      stage_tile<HD, NW * 64>(qtile, qb, p.ldq, q0, p.Sq, tid);
-      stage_tile<HD, NW * 64>(dotile, dob, p.lddo, q0, p.Sq, tid);
-      if (tid < KT) {
-        const int qq = q0 + tid;
-        const bool ok = qq < p.Sq;
-        fst[tid * 4 + 0] = ok ? p.stats[(sbase + qq) * 2] : 0.f;
-        fst[tid * 4 + 1] = ok ? p.stats[(sbase + qq) * 2 + 1] : 0.f;
-        fst[tid * 4 + 2] = ok ? p.delta[sbase + qq] : 0.f;
-        fst[tid * 4 + 3] = ok ? 1.f : 0.f;
-      }
-      __syncthreads();
-      if (kblk >= p.Sk) continue;
+    qb = p.q + (long)b * p.Sq * p.ldq + (long)hq * HD;
+    dob = p.dout + (long)b * p.Sq * p.lddo + (long)hq * HD;
+    sbase = ((long)b * p.nq + hq) * p.Sq;
+    q0 = qstart + tq * KT;
+  };
+  auto load_tile = [&](int it) {
+    const bf16_t* qb; const bf16_t* dob; long sbase; int q0;
+    tile_ptrs(it, qb, dob, sbase, q0);
+    qs.load(qb, p.ldq, q0, p.Sq, tid);
+    dos.load(dob, p.lddo, q0, p.Sq, tid);
+    if (tid < KT) {
+      const int qq = q0 + tid;
+      const bool ok = qq < p.Sq;
+      st0 = ok ? p.stats[(sbase + qq) * 2] : 0.f;                    // row max, natural-log domain
+      st1 = ok ? p.stats[(sbase + qq) * 2 + 1] * p.scale : 0.f;     // 0 for rows past Sq -> p = 0
+      st2 = ok ? p.delta[sbase + qq] : 0.f;
+    }
+  };
+  auto store_tile = [&](char* buf) {
+    qs.store(buf, tid);
+    dos.store(buf + C::TILE, tid);
+    if (tid < KT) {
+      float* f = reinterpret_cast<float*>(buf + 2 * C::TILE);
+      f[tid] = st0; f[KT + tid] = st1; f[2 * KT + tid] = st2;
+    }
+  };
+
+  if (ntot > 0) { load_tile(0); store_tile(smem); }
+  __syncthreads();
+
+  for (int it = 0; it < ntot; ++it) {
+    const char* qtile = smem + (it & 1) * STG;
+    const char* dotile = qtile + C::TILE;
+    const float* fst = reinterpret_cast<const float*>(qtile + 2 * C::TILE);
+    if (it + 1 < ntot) load_tile(it + 1);
+    const bf16_t* qb_; const bf16_t* dob_; long sbase_; int q0;
+    tile_ptrs(it, qb_, dob_, sbase_, q0);
+    const int hq = kvh * p.rep + it / ntq;
+    if (kblk < p.Sk) {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         const int qbase = q0 + 32 * sub;
@@ -376,22 +499,43 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(qtile, 32 * sub, st, lane), kf[st], s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dotile, 32 * sub, st, lane), vf[st], dp, 0, 0, 0);
         }
+        const bool fast = all_valid && (!CAUSAL || qbase >= kblk + 31) && !dropping;
+        // row stats of this lane's 16 query rows: 4 consecutive rows per 16-byte read
+        float mcr[16], ivr[16], dlr[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int qr = 32 * sub + acc_row(r, h);
-          const float4 f = *reinterpret_cast<const float4*>(fst + qr * 4);     // m, inv, delta, valid
-          const int qpos = q0 + qr;
-          const float sc = mask_score<CAUSAL>(s[r], p.scale, kstate, key, qpos);
-          float pr = (sc == NEG_INF || f.w == 0.f) ? 0.f : __expf(sc - f.x) * f.y;
-          float g = dp[r], pd = pr;
-          if (!CAUSAL && p.drop_thr) {
-            const float dsc = ur_dropout_scale(p.seed, (((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)qpos) * (uint64_t)p.Sk) + (uint64_t)key,
-                                               p.drop_thr, p.drop_inv);
-            g *= dsc; pd *= dsc;
-          }
-          s[r] = pd;                                  // P (with dropout) -> dV
-          dp[r] = pr * (g - f.z) * p.scale;           // dS               -> dK
+        for (int rq = 0; rq < 4; ++rq) {
+          const int qr = 32 * sub + 8 * rq + 4 * h;
+          const float4 a = *reinterpret_cast<const float4*>(fst + qr);
+          const float4 bq = *reinterpret_cast<const float4*>(fst + KT + qr);
+          const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
+          mcr[4 * rq] = a.x; mcr[4 * rq + 1] = a.y; mcr[4 * rq + 2] = a.z; mcr[4 * rq + 3] = a.w;
+          ivr[4 * rq] = bq.x; ivr[4 * rq + 1] = bq.y; ivr[4 * rq + 2] = bq.z; ivr[4 * rq + 3] = bq.w;
+          dlr[4 * rq] = cq.x; dlr[4 * rq + 1] = cq.y; dlr[4 * rq + 2] = cq.z; dlr[4 * rq + 3] = cq.w;
         }
+        if (fast) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float ps = fast_exp2(fmaf(s[r], c2, -mcr[r] * LOG2E)) * ivr[r];      // p * scale
+            s[r] = ps;
+            dp[r] = ps * (dp[r] - dlr[r]);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qpos = qbase + acc_row(r, h);
+            const float sc = mask_score<CAUSAL>(s[r], p.scale, kvalid, kok, key, qpos);       // natural-log domain
+            const float ps = (sc == NEG_INF) ? 0.f : fast_exp2((sc - mcr[r]) * LOG2E) * ivr[r];
+            float g = dp[r], pd = ps;
+            if (dropping) {
+              const float dsc = ur_dropout_scale(p.seed, (((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)qpos) * (uint64_t)p.Sk) + (uint64_t)key,
+                                                 p.drop_thr, p.drop_inv);
+              g *= dsc; pd *= dsc;
+            }
+            s[r] = pd;
+            dp[r] = ps * (g - dlr[r]);
+          }
+        }
+        // s = P*scale (with dropout) -> dV needs P: undo the scale on the dV side with one multiply per output
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const bf16x8 pf = acc_frag(s, s2), df = acc_frag(dp, s2);
@@ -403,16 +547,18 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
         }
       }
     }
+    if (it + 1 < ntot) store_tile(smem + ((it + 1) & 1) * STG);
+    __syncthreads();
   }
   if (kok) {
     store_T<HD>(p.dk + ((long)b * p.Sk + key) * p.lddk + (long)kvh * HD, dk, 1.0f, lane);
-    store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 1.0f, lane);
+    store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 1.0f / p.scale, lane);
   }
 }
 
 // ================================================================================================
-template <int HD> constexpr int fwd_smem() { return 2 * Cfg<HD>::TILE + 64; }
-template <int HD> constexpr int dkv_smem() { return 2 * Cfg<HD>::TILE + KT * 4 * (int)sizeof(float); }
+template <int HD> constexpr int fwd_smem() { return 4 * Cfg<HD>::TILE; }
+template <int HD> constexpr int dkv_smem() { return 2 * (2 * Cfg<HD>::TILE + 3 * KT * (int)sizeof(float)); }
 
 template <typename K>
 int set_smem(K kern, int bytes, const char* name) {
@@ -431,6 +577,7 @@ int fill(AttnP& p, const ur_attn_args* a) {
              "ur_attn: token stride smaller than heads*head_dim");
   UR_REQUIRE(!a->causal || a->Sq == a->Sk, "ur_attn: causal mode needs Sq == Sk");
   UR_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f && (!a->causal || a->dropout_p == 0.f), "ur_attn: bad dropout");
+  UR_REQUIRE(a->scale > 0.f, "ur_attn: scale must be positive");
   memset(&p, 0, sizeof(p));
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.o = (bf16_t*)a->o; p.stats = a->stats;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.kmask = a->key_mask;
