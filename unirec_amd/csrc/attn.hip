@@ -63,27 +63,61 @@ __device__ __forceinline__ f32x16 zero16() {
 // accumulator register r of lane-half h  <->  row index inside the 32-row tile
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// Pin a value inside the branch that uses it: without this hipcc speculates the masked path's
+// per-element compare/select arithmetic (~110 VALU per sub-tile) into the mask-free interior path.
+__device__ __forceinline__ uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// Online-softmax rescale threshold (natural-log units): the running max is only advanced when some
+// row's new max exceeds it by more than this, so exp() arguments stay <= RESCALE_THR (e^8 ~ 3e3: exact
+// in f32 sums, relative precision unchanged in bf16 P).  The saved (m, 1/l) pair stays consistent.
+constexpr float RESCALE_THR = 8.0f;
 
-// rows [row0, row0+KT) x HD of a [S][ld] bf16 matrix: global -> registers -> LDS tile (zero past S)
+// Tile loader: rows [row0, row0+KT) x HD of a [S][ld] bf16 matrix -> LDS tile.
+//   head_dim 128: LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write.  One wave
+//     instruction writes 1 KiB linearly (4 rows of 256 B), so the XOR swizzle is applied to the SOURCE
+//     chunk (pos ^ swz(row)); rows past S are clamped to S-1 (finite data, masked by the key state).
+//     issue() starts the copy into the tile that will be read NEXT iteration; the __syncthreads() that
+//     ends the iteration drains it (vmcnt(0) + barrier).
+//   head_dim 64 (Q-Former): global -> registers at issue(), registers -> padded LDS rows at commit().
 template <int HD, int NT>
-struct Stager {
+struct Loader {
+  static constexpr bool DMA = (HD == 128);
   static constexpr int N = (KT * Cfg<HD>::CH) / NT;
-  uint4 r[N];
-  __device__ __forceinline__ void load(const bf16_t* __restrict__ base, long ld, int row0, int S, int tid) {
+  uint4 r[DMA ? 1 : N];
+  __device__ __forceinline__ void issue(char* tile, const bf16_t* __restrict__ base, long ld, int row0, int S, int tid) {
+    if (DMA) {
+      typedef __attribute__((address_space(3))) void lds_void;
+      typedef const __attribute__((address_space(1))) void gbl_void;
+      const int lane = tid & 63;
+      const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int c = tid + i * NT;
-      const int row = c / Cfg<HD>::CH, cc = c % Cfg<HD>::CH;
-      const int g = row0 + row;
-      r[i] = (g < S) ? *reinterpret_cast<const uint4*>(base + (long)g * ld + cc * 8) : make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < N; ++i) {
+        const int inst = i * (NT / 64) + wave;                 // wave-uniform: 1 KiB piece index
+        const int c = inst * 64 + lane;
+        const int row = c >> 4, pos = c & 15;
+        const int g = min(row0 + row, S - 1);
+        const int src_chunk = pos ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        const bf16_t* src = base + (long)g * ld + src_chunk * 8;
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + inst * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int c = tid + i * NT;
+        const int row = c / Cfg<HD>::CH, cc = c % Cfg<HD>::CH;
+        const int g = row0 + row;
+        r[i] = (g < S) ? *reinterpret_cast<const uint4*>(base + (long)g * ld + cc * 8) : make_uint4(0, 0, 0, 0);
+      }
     }
   }
-  __device__ __forceinline__ void store(char* tile, int tid) const {
+  __device__ __forceinline__ void commit(char* tile, int tid) const {
+    if (!DMA) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const int c = tid + i * NT;
-      const int row = c / Cfg<HD>::CH, cc = c % Cfg<HD>::CH;
-      *reinterpret_cast<uint4*>(tile + Cfg<HD>::off(row, cc)) = r[i];
+      for (int i = 0; i < N; ++i) {
+        const int c = tid + i * NT;
+        const int row = c / Cfg<HD>::CH, cc = c % Cfg<HD>::CH;
+        *reinterpret_cast<uint4*>(tile + Cfg<HD>::off(row, cc)) = r[i];
+      }
     }
   }
 };
@@ -189,20 +223,21 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   const uint64_t drow = ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
   const bool dropping = (!CAUSAL) && p.drop_thr != 0;
 
-  Stager<HD, NW * 64> ks, vs;
-  ks.load(kb, p.ldk, 0, p.Sk, tid);
-  vs.load(vb, p.ldv, 0, p.Sk, tid);
-  ks.store(smem, tid);
-  vs.store(smem + C::TILE, tid);
+  Loader<HD, NW * 64> ks, vs;
+  ks.issue(smem, kb, p.ldk, 0, p.Sk, tid);
+  vs.issue(smem + C::TILE, vb, p.ldv, 0, p.Sk, tid);
+  ks.commit(smem, tid);
+  vs.commit(smem + C::TILE, tid);
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * KT;
     const char* ktile = smem + (t & 1) * 2 * C::TILE;
     const char* vtile = ktile + C::TILE;
+    char* nk = smem + ((t + 1) & 1) * 2 * C::TILE;
     if (t + 1 < ntiles) {
-      ks.load(kb, p.ldk, k0 + KT, p.Sk, tid);
-      vs.load(vb, p.ldv, k0 + KT, p.Sk, tid);
+      ks.issue(nk, kb, p.ldk, k0 + KT, p.Sk, tid);
+      vs.issue(nk + C::TILE, vb, p.ldv, k0 + KT, p.Sk, tid);
     }
     const KeyBits kbits = key_bits(km, k0, p.Sk, lane);
     if (qblk < p.Sq) {
@@ -222,19 +257,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
           for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
           mx *= p.scale;
         } else {
-          const uint32_t vh = v32 >> (4 * h), ih = i32 >> (4 * h);
+          const uint32_t vh = opaque(v32 >> (4 * h)), ih = opaque(i32 >> (4 * h));
+          const int qq = opaque(q), kb0 = opaque(kbase + 4 * h);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int bit = (r & 3) + 8 * (r >> 2);
-            s[r] = mask_score<CAUSAL>(s[r], p.scale, (vh >> bit) & 1u, (ih >> bit) & 1u, kbase + acc_row(r, h), q);
+            s[r] = mask_score<CAUSAL>(s[r], p.scale, (vh >> bit) & 1u, (ih >> bit) & 1u, kb0 + bit, qq);
             mx = fmaxf(mx, s[r]);
           }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m, mx);
-        const float muse = (mnew == NEG_INF) ? 0.f : mnew;
-        if (__any(mnew != m)) {                       // some row's max moved: rescale O and l
-          const float alpha = fast_exp2((m - muse) * LOG2E);
+        // branch-free rescale (alpha == 1 exactly when the max did not move): keeps the O accumulators
+        // in place across the loop (a conditional rescale made hipcc copy all 64 registers per sub-tile)
+        {
+          const float mnew = fmaxf(m, mx);
+          const float mu = (mnew == NEG_INF) ? 0.f : mnew;
+          const float alpha = fast_exp2((m - mu) * LOG2E);
           l *= alpha;
 #pragma unroll
           for (int dt = 0; dt < C::NDT; ++dt)
@@ -242,6 +280,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
             for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
           m = mnew;
         }
+        const float muse = (m == NEG_INF) ? 0.f : m;
         const float mc = muse * LOG2E;
         float rs = 0.f;
         if (fast) {
@@ -268,9 +307,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
       }
     }
     if (t + 1 < ntiles) {
-      char* nk = smem + ((t + 1) & 1) * 2 * C::TILE;
-      ks.store(nk, tid);
-      vs.store(nk + C::TILE, tid);
+      ks.commit(nk, tid);
+      vs.commit(nk + C::TILE, tid);
     }
     __syncthreads();
   }
@@ -344,20 +382,21 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
   const uint64_t drow = ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
   const bool dropping = (!CAUSAL) && p.drop_thr != 0;
 
-  Stager<HD, NW * 64> ks, vs;
-  ks.load(kb, p.ldk, 0, p.Sk, tid);
-  vs.load(vb, p.ldv, 0, p.Sk, tid);
-  ks.store(smem, tid);
-  vs.store(smem + C::TILE, tid);
+  Loader<HD, NW * 64> ks, vs;
+  ks.issue(smem, kb, p.ldk, 0, p.Sk, tid);
+  vs.issue(smem + C::TILE, vb, p.ldv, 0, p.Sk, tid);
+  ks.commit(smem, tid);
+  vs.commit(smem + C::TILE, tid);
   __syncthreads();
 
   for (int t = 0; t < ntiles; ++t) {
     const int k0 = t * KT;
     const char* ktile = smem + (t & 1) * 2 * C::TILE;
     const char* vtile = ktile + C::TILE;
+    char* nk = smem + ((t + 1) & 1) * 2 * C::TILE;
     if (t + 1 < ntiles) {
-      ks.load(kb, p.ldk, k0 + KT, p.Sk, tid);
-      vs.load(vb, p.ldv, k0 + KT, p.Sk, tid);
+      ks.issue(nk, kb, p.ldk, k0 + KT, p.Sk, tid);
+      vs.issue(nk + C::TILE, vb, p.ldv, k0 + KT, p.Sk, tid);
     }
     const KeyBits kbits = key_bits(km, k0, p.Sk, lane);
     if (qblk < p.Sq) {
@@ -377,12 +416,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[r] = fast_exp2(fmaf(s[r], c2, -mc)) * invs * (dp[r] - dlt);
         } else {
-          const uint32_t vh = v32 >> (4 * h), ih = i32 >> (4 * h);
+          const uint32_t vh = opaque(v32 >> (4 * h)), ih = opaque(i32 >> (4 * h));
+          const int qq = opaque(q), kb0 = opaque(kbase + 4 * h);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int bit = (r & 3) + 8 * (r >> 2);
-            const int kr = kbase + acc_row(r, h);
-            const float sc = mask_score<CAUSAL>(s[r], p.scale, (vh >> bit) & 1u, (ih >> bit) & 1u, kr, q);
+            const int kr = kb0 + bit;
+            const float sc = mask_score<CAUSAL>(s[r], p.scale, (vh >> bit) & 1u, (ih >> bit) & 1u, kr, qq);
             const float pr = (sc == NEG_INF) ? 0.f : fast_exp2((sc - m) * LOG2E) * invs;
             float g = dp[r];
             if (dropping) g *= ur_dropout_scale(p.seed, drow + (uint64_t)kr, p.drop_thr, p.drop_inv);
@@ -399,9 +439,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
       }
     }
     if (t + 1 < ntiles) {
-      char* nk = smem + ((t + 1) & 1) * 2 * C::TILE;
-      ks.store(nk, tid);
-      vs.store(nk + C::TILE, tid);
+      ks.commit(nk, tid);
+      vs.commit(nk + C::TILE, tid);
     }
     __syncthreads();
   }
@@ -444,7 +483,7 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
   const int ntq = (p.Sq - qstart + KT - 1) / KT;
   const int ntot = ntq * p.rep;                    // tiles over (query head of the group, query tile)
 
-  Stager<HD, NW * 64> qs, dos;
+  Loader<HD, NW * 64> qs, dos;
   float st0 = 0.f, st1 = 0.f, st2 = 0.f;          // staged row stats of thread tid < KT
   auto tile_ptrs = [&](int it, const bf16_t*& qb, const bf16_t*& dob, long& sbase, int& q0) {
     const int hr = it / ntq, tq = it - hr * ntq;
@@ -454,11 +493,11 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
     sbase = ((long)b * p.nq + hq) * p.Sq;
     q0 = qstart + tq * KT;
   };
-  auto load_tile = [&](int it) {
+  auto load_tile = [&](int it, char* buf) {
     const bf16_t* qb; const bf16_t* dob; long sbase; int q0;
     tile_ptrs(it, qb, dob, sbase, q0);
-    qs.load(qb, p.ldq, q0, p.Sq, tid);
-    dos.load(dob, p.lddo, q0, p.Sq, tid);
+    qs.issue(buf, qb, p.ldq, q0, p.Sq, tid);
+    dos.issue(buf + C::TILE, dob, p.lddo, q0, p.Sq, tid);
     if (tid < KT) {
       const int qq = q0 + tid;
       const bool ok = qq < p.Sq;
@@ -468,22 +507,22 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
     }
   };
   auto store_tile = [&](char* buf) {
-    qs.store(buf, tid);
-    dos.store(buf + C::TILE, tid);
+    qs.commit(buf, tid);
+    dos.commit(buf + C::TILE, tid);
     if (tid < KT) {
       float* f = reinterpret_cast<float*>(buf + 2 * C::TILE);
       f[tid] = st0; f[KT + tid] = st1; f[2 * KT + tid] = st2;
     }
   };
 
-  if (ntot > 0) { load_tile(0); store_tile(smem); }
+  if (ntot > 0) { load_tile(0, smem); store_tile(smem); }
   __syncthreads();
 
   for (int it = 0; it < ntot; ++it) {
     const char* qtile = smem + (it & 1) * STG;
     const char* dotile = qtile + C::TILE;
     const float* fst = reinterpret_cast<const float*>(qtile + 2 * C::TILE);
-    if (it + 1 < ntot) load_tile(it + 1);
+    if (it + 1 < ntot) load_tile(it + 1, smem + ((it + 1) & 1) * STG);
     const bf16_t* qb_; const bf16_t* dob_; long sbase_; int q0;
     tile_ptrs(it, qb_, dob_, sbase_, q0);
     const int hq = kvh * p.rep + it / ntq;
@@ -520,10 +559,11 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
             dp[r] = ps * (dp[r] - dlr[r]);
           }
         } else {
+          const int qb0 = opaque(qbase + 4 * h), keyo = opaque(key);
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int qpos = qbase + acc_row(r, h);
-            const float sc = mask_score<CAUSAL>(s[r], p.scale, kvalid, kok, key, qpos);       // natural-log domain
+            const int qpos = qb0 + (r & 3) + 8 * (r >> 2);
+            const float sc = mask_score<CAUSAL>(s[r], p.scale, kvalid, kok, keyo, qpos);       // natural-log domain
             const float ps = (sc == NEG_INF) ? 0.f : fast_exp2((sc - mcr[r]) * LOG2E) * ivr[r];
             float g = dp[r], pd = ps;
             if (dropping) {

@@ -11,26 +11,33 @@
 // The second (R2,S2,K2) range is the LoRA low-rank term: R2 = x A^T (rank r), S2 = B, so the
 // B-product is accumulated in the same MFMA accumulators as the base GEMM (no extra pass over Y).
 //
-// Tiling: 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4
-// v_mfma_f32_16x16x32_bf16 tiles.  The weight-side operand S is the MFMA "A" (row) operand and the
+// Tiling: 256x256x64 block tile with 8 waves (2x4, each wave 128x64 = 8x4 v_mfma_f32_16x16x32_bf16
+// tiles) for the large projections, 128x128x64 with 4 waves (2x2) for small / edge shapes.  The weight-side operand S is the MFMA "A" (row) operand and the
 // token-side operand R the "B" (column) operand, so each lane ends up with 4 CONSECUTIVE n for one
 // m: packed 8-byte (bf16) / 16-byte (f32) stores into row-major C.
-// Staging: global -> registers -> LDS, double-buffered, next tile's global loads issued before the
-// current tile's MFMAs (issue-early / write-late).  K-contiguous tiles: 128-B rows with 16-B chunk
-// XOR swizzle (conflict-free ds_read_b128).  K-strided tiles: [k][128] rows padded to 288 B with the
-// k-row slot permutation rho(k) = k ^ ((k>>1)&4), read with ds_read_b64_tr_b16 (hardware
-// transpose) conflict-free.
+// Staging: LDS-DMA (global_load_lds_dwordx4) straight into a double-buffered, XOR-swizzled LDS image
+// (no staging VGPRs, no ds_write); the next tile's DMA is in flight under the current tile's MFMAs
+// and is drained by the barrier that ends the tile.  K-contiguous tiles are read with ds_read_b128,
+// K-strided tiles with ds_read_b64_tr_b16 (hardware transpose); both images are bank-conflict-free.
 #include "common.cuh"
 #include "unirec_hip.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 constexpr int KC_ROWB = 128;               // K-contiguous tile row bytes (64 bf16)
-constexpr int KC_BYTES = 128 * KC_ROWB;    // 16 KiB
-constexpr int KS_ROWB = 288;               // K-strided tile row bytes (128 bf16 + 32 B pad)
-constexpr int KS_BYTES = BK * KS_ROWB;     // 18 KiB
-
+// LDS image of one operand tile of T rows (T = 128 or 256), no padding (LDS-DMA writes linearly):
+//   K-contiguous  [T][64 k] : 128-B rows, 16-B chunk c of row r stored at chunk c ^ (r & 7)
+//                             -> conflict-free ds_read_b128 fragment reads
+//   K-strided     [64 k][T] : 2T-byte rows, 32-B segment s of k-row r stored at segment s ^ f(r),
+//                             f(r) = (r & 3) | (((r >> 3) & 1) << 2)
+//                             -> the 8 (k-row, 32-B) pieces one half-wave ds_read_b64_tr_b16 touches
+//                                land on 8 different 32-B bank groups: conflict-free transposed reads
+template <int T> struct Tile {
+  static constexpr int KC_BYTES = T * KC_ROWB;
+  static constexpr int KS_ROWB = T * 2;
+  static constexpr int KS_BYTES = BK * KS_ROWB;
+};
 struct GemmP {
   const bf16_t* R; const bf16_t* S; long ldr, lds; int K;
   const bf16_t* R2; const bf16_t* S2; long ldr2, lds2; int K2;
@@ -41,60 +48,75 @@ struct GemmP {
   int gm, gn;
 };
 
-__device__ __forceinline__ int rho(int k) { return k ^ ((k >> 1) & 4); }
+__device__ __forceinline__ int ks_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-// ---- global -> register staging of one 128 x 64 operand tile (4 x 16 B per thread) -----------
-template <bool KC>
-__device__ __forceinline__ void g2r(uint4 (&v)[4], const bf16_t* __restrict__ base, long ld, int rows_total,
-                                    int row0, int k0, int kend, int tid) {
+// ---- LDS-DMA staging of a FULL 64-deep tile: 1 KiB per wave instruction, swizzle on the source ---
+// rows/cols past the matrix edge are clamped (they only feed output rows/cols that are never stored)
+template <bool KC, int T, int NT>
+__device__ __forceinline__ void dma_tile(char* tile, const bf16_t* __restrict__ base, long ld, int rows_total, int row0,
+                                         int k0, int tid) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+  constexpr int PIECES = T / 8;                 // 1 KiB pieces per tile
+  constexpr int PER_WAVE = PIECES / (NT / 64);
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = tid + i * 256;
-    uint4 z = make_uint4(0, 0, 0, 0);
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int inst = i * (NT / 64) + wave;
+    const bf16_t* src;
     if (KC) {
-      int row = c >> 3, kc = c & 7;
-      int grow = row0 + row, gk = k0 + kc * 8;
-      if (grow < rows_total && gk < kend) z = *reinterpret_cast<const uint4*>(base + (long)grow * ld + gk);
+      const int row = inst * 8 + (lane >> 3), pos = lane & 7;
+      const int g = min(row0 + row, rows_total - 1);
+      src = base + (long)g * ld + k0 + ((pos ^ (lane >> 3)) << 3);
     } else {
-      int kr = c >> 4, cc = c & 15;
-      int gk = k0 + kr, gcol = row0 + cc * 8;
-      if (gk < kend && gcol < rows_total) z = *reinterpret_cast<const uint4*>(base + (long)gk * ld + gcol);
+      const int c = inst * 64 + lane;
+      const int kr = c / (T / 8), ch = c % (T / 8);
+      const int col = min(row0 + ((ch ^ (ks_f(kr) << 1)) << 3), rows_total - 8);
+      src = base + (long)(k0 + kr) * ld + col;
     }
-    v[i] = z;
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + inst * 1024), 16, 0, 0);
   }
 }
 
-template <bool KC>
-__device__ __forceinline__ void r2s(const uint4 (&v)[4], char* tile, int tid) {
+// ---- register staging (partial K tiles only: zero-fill past kend) ------------------------------
+template <bool KC, int T, int NT>
+__device__ __forceinline__ void reg_tile(char* tile, const bf16_t* __restrict__ base, long ld, int rows_total, int row0,
+                                         int k0, int kend, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int c = tid + i * 256;
+  for (int i = 0; i < T * 8 / NT; ++i) {
+    const int c = tid + i * NT;
+    uint4 z = make_uint4(0, 0, 0, 0);
     int off;
     if (KC) {
-      int row = c >> 3, kc = c & 7;
+      const int row = c >> 3, kc = c & 7;
+      const int grow = min(row0 + row, rows_total - 1), gk = k0 + kc * 8;
+      if (gk < kend) z = *reinterpret_cast<const uint4*>(base + (long)grow * ld + gk);
       off = row * KC_ROWB + ((kc ^ (row & 7)) << 4);
     } else {
-      int kr = c >> 4, cc = c & 15;
-      off = rho(kr) * KS_ROWB + cc * 16;
+      const int kr = c / (T / 8), ch = c % (T / 8);
+      const int gk = k0 + kr, gcol = min(row0 + ch * 8, rows_total - 8);
+      if (gk < kend) z = *reinterpret_cast<const uint4*>(base + (long)gk * ld + gcol);
+      off = kr * Tile<T>::KS_ROWB + ((ch ^ (ks_f(kr) << 1)) << 4);
     }
-    *reinterpret_cast<uint4*>(tile + off) = v[i];
+    *reinterpret_cast<uint4*>(tile + off) = z;
   }
 }
 
 // ---- LDS -> MFMA fragment: lane holds [idx = base16 + (lane&15)][k = 32*kk + 8*(lane>>4) + 0..7]
-template <bool KC>
+template <bool KC, int T>
 __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int idx0, int kk, int lane) {
   if (KC) {
     int idx = idx0 + (lane & 15);
     int chunk = kk * 4 + (lane >> 4);
     return *reinterpret_cast<const bf16x8*>(tile + idx * KC_ROWB + ((chunk ^ (idx & 7)) << 4));
   } else {
-    int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    int ka = kk * 32 + 8 * g + q;
-    int col = idx0 + 4 * pp;
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+    const int ka = kk * 32 + 8 * g + q;                 // k-rows ka (elements 0..3) and ka+4 (elements 4..7)
+    const int seg = idx0 >> 4;                          // 32-byte segment of this 16-column block
     typedef __attribute__((address_space(3))) bf16x4 lds_v4;
-    const char* pa = tile + rho(ka) * KS_ROWB + col * 2;
-    const char* pb = tile + rho(ka + 4) * KS_ROWB + col * 2;
+    const char* pa = tile + ka * Tile<T>::KS_ROWB + ((seg ^ ks_f(ka)) << 5) + pp * 8;
+    const char* pb = tile + (ka + 4) * Tile<T>::KS_ROWB + ((seg ^ ks_f(ka + 4)) << 5) + pp * 8;
     bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pa);
     bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pb);
     bf16x8 r;
@@ -104,15 +126,19 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int idx0, int kk, i
   }
 }
 
-template <bool RK, bool SK, bool OUTF32>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
+// BM x BN block tile, NWM x NWN waves; each wave owns (BM/NWM) rows x (BN/NWN) columns of C.
+template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN>
+__global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int S_BYTES = SK ? KC_BYTES : KS_BYTES;
-  constexpr int R_BYTES = RK ? KC_BYTES : KS_BYTES;
+  constexpr int NT = NWM * NWN * 64;
+  constexpr int S_BYTES = SK ? Tile<BN>::KC_BYTES : Tile<BN>::KS_BYTES;
+  constexpr int R_BYTES = RK ? Tile<BM>::KC_BYTES : Tile<BM>::KS_BYTES;
   constexpr int STAGE = S_BYTES + R_BYTES;
+  constexpr int WM = BM / NWM, WN = BN / NWN;       // wave tile
+  constexpr int MI = WM / 16, NI = WN / 16;         // 16x16 MFMA tiles per wave
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / NWN, wc = wave % NWN;
 
   // XCD-aware tile order: blocks sharing (id % 8) sit on one XCD (speed only); give each XCD a
   // contiguous run of tiles, column-tile fastest, so an R panel is re-read from that XCD's L2.
@@ -132,62 +158,54 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
   const int nt2 = (p.K2 > 0) ? (p.K2 + BK - 1) / BK : 0;
   const int nt = nt1 + nt2;
 
-  f32x4 acc[4][4];
+  f32x4 acc[NI][MI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 sreg[4], rreg[4];
-  auto load_tile = [&](int t) {
-    if (t < nt1) {
-      int k0 = kbeg + t * BK;
-      g2r<SK>(sreg, p.S, p.lds, p.N, n0, k0, kend, tid);
-      g2r<RK>(rreg, p.R, p.ldr, p.M, m0, k0, kend, tid);
+  // stage tile t into `buf`: LDS-DMA for full 64-deep tiles, register path (zero-fill) for K tails
+  auto stage = [&](int t, char* buf) {
+    const bf16_t* S; const bf16_t* R; long lds_, ldr_; int k0, ke;
+    if (t < nt1) { S = p.S; R = p.R; lds_ = p.lds; ldr_ = p.ldr; k0 = kbeg + t * BK; ke = kend; }
+    else { S = p.S2; R = p.R2; lds_ = p.lds2; ldr_ = p.ldr2; k0 = (t - nt1) * BK; ke = p.K2; }
+    if (k0 + BK <= ke) {
+      dma_tile<SK, BN, NT>(buf, S, lds_, p.N, n0, k0, tid);
+      dma_tile<RK, BM, NT>(buf + S_BYTES, R, ldr_, p.M, m0, k0, tid);
     } else {
-      int k0 = (t - nt1) * BK;
-      g2r<SK>(sreg, p.S2, p.lds2, p.N, n0, k0, p.K2, tid);
-      g2r<RK>(rreg, p.R2, p.ldr2, p.M, m0, k0, p.K2, tid);
+      reg_tile<SK, BN, NT>(buf, S, lds_, p.N, n0, k0, ke, tid);
+      reg_tile<RK, BM, NT>(buf + S_BYTES, R, ldr_, p.M, m0, k0, ke, tid);
     }
   };
 
-  if (nt > 0) {
-    load_tile(0);
-    r2s<SK>(sreg, smem, tid);
-    r2s<RK>(rreg, smem + S_BYTES, tid);
-  }
-  __syncthreads();
+  if (nt > 0) stage(0, smem);
+  __syncthreads();            // drains the LDS-DMA (vmcnt(0)) and publishes the tile
 
   for (int t = 0; t < nt; ++t) {
     const char* sb = smem + (t & 1) * STAGE;
     const char* rb = sb + S_BYTES;
-    if (t + 1 < nt) load_tile(t + 1);
+    if (t + 1 < nt) stage(t + 1, smem + ((t + 1) & 1) * STAGE);   // in flight under this tile's MFMAs
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 sf[4], rf[4];
+      bf16x8 sf[NI], rf[MI];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sf[i] = lds_frag<SK>(sb, wc * 64 + i * 16, kk, lane);
+      for (int i = 0; i < NI; ++i) sf[i] = lds_frag<SK, BN>(sb, wc * WN + i * 16, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) rf[j] = lds_frag<RK>(rb, wr * 64 + j * 16, kk, lane);
+      for (int j = 0; j < MI; ++j) rf[j] = lds_frag<RK, BM>(rb, wr * WM + j * 16, kk, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < MI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[i], rf[j], acc[i][j], 0, 0, 0);
-    }
-    if (t + 1 < nt) {
-      char* nb = smem + ((t + 1) & 1) * STAGE;
-      r2s<SK>(sreg, nb, tid);
-      r2s<RK>(rreg, nb + S_BYTES, tid);
     }
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds n = n0 + wc*64 + i*16 + (lane>>4)*4 + 0..3, m = m0 + wr*64 + j*16 + (lane&15)
+  // ---- epilogue: lane holds n = n0 + wc*WN + i*16 + (lane>>4)*4 + 0..3, m = m0 + wr*WM + j*16 + (lane&15)
   const int nq = (lane >> 4) * 4, ml = lane & 15;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int n = n0 + wc * 64 + i * 16 + nq;
+  for (int i = 0; i < NI; ++i) {
+    const int n = n0 + wc * WN + i * 16 + nq;
     if (n >= p.N) continue;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -195,8 +213,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmP p) {
       b4[0] = bb.x; b4[1] = bb.y; b4[2] = bb.z; b4[3] = bb.w;
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int m = m0 + wr * 64 + j * 16 + ml;
+    for (int j = 0; j < MI; ++j) {
+      const int m = m0 + wr * WM + j * 16 + ml;
       if (m >= p.M) continue;
       float v[4];
 #pragma unroll
@@ -245,22 +263,32 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
   }
 }
 
-template <bool RK, bool SK, bool OUTF32>
-int launch(const GemmP& p, int splits, hipStream_t st) {
-  constexpr int S_BYTES = SK ? KC_BYTES : KS_BYTES;
-  constexpr int R_BYTES = RK ? KC_BYTES : KS_BYTES;
+template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN>
+int launch_cfg(GemmP p, int splits, hipStream_t st) {
+  constexpr int S_BYTES = SK ? Tile<BN>::KC_BYTES : Tile<BN>::KS_BYTES;
+  constexpr int R_BYTES = RK ? Tile<BM>::KC_BYTES : Tile<BM>::KS_BYTES;
   constexpr int SMEM = 2 * (S_BYTES + R_BYTES);
   static bool attr_set = false;   // idempotent; a race only repeats the call
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RK, SK, OUTF32>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) UR_FAIL((int)e, "ur_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     attr_set = true;
   }
+  p.gm = ur_cdiv(p.M, BM); p.gn = ur_cdiv(p.N, BN);
   dim3 grid(p.gm * p.gn, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<RK, SK, OUTF32>), grid, dim3(256), SMEM, st, p);
+  hipLaunchKernelGGL((gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN>), grid, dim3(NWM * NWN * 64), SMEM, st, p);
   UR_CHECK_LAUNCH("ur_gemm");
   return 0;
+}
+
+// Tile choice: 256x256 (8 waves, 130 FLOP per byte of L2 traffic) once the grid still fills the
+// chip (>= 256 workgroups); otherwise the 128x128 tile (4 waves, 2 workgroups per CU).
+template <bool RK, bool SK, bool OUTF32>
+int launch(const GemmP& p, int splits, hipStream_t st) {
+  const long big_wgs = (long)ur_cdiv(p.M, 256) * ur_cdiv(p.N, 256) * splits;
+  if (p.M >= 256 && p.N >= 256 && big_wgs >= 256) return launch_cfg<RK, SK, OUTF32, 256, 256, 2, 4>(p, splits, st);
+  return launch_cfg<RK, SK, OUTF32, 128, 128, 2, 2>(p, splits, st);
 }
 
 }  // namespace
@@ -314,7 +342,7 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
   p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.alpha = a->alpha;
   p.bias = a->bias; p.res = (const bf16_t*)a->residual; p.ldres = a->ldres;
   p.gelu_out = (bf16_t*)a->gelu_out; p.ldg = a->ldg; p.aux = (const bf16_t*)a->gelu_grad_aux; p.ldaux = a->ldaux;
-  p.gm = ur_cdiv(a->M, BM); p.gn = ur_cdiv(a->N, BN);
+  p.gm = 0; p.gn = 0;   // set by launch_cfg for the chosen tile
   p.slab_stride = 0;
   if (splits > 1) {
     int tiles = ur_cdiv(a->K, BK);
