@@ -67,10 +67,6 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // per-element compare/select arithmetic (~110 VALU per sub-tile) into the mask-free interior path.
 __device__ __forceinline__ uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
-// Online-softmax rescale threshold (natural-log units): the running max is only advanced when some
-// row's new max exceeds it by more than this, so exp() arguments stay <= RESCALE_THR (e^8 ~ 3e3: exact
-// in f32 sums, relative precision unchanged in bf16 P).  The saved (m, 1/l) pair stays consistent.
-constexpr float RESCALE_THR = 8.0f;
 
 // Tile loader: rows [row0, row0+KT) x HD of a [S][ld] bf16 matrix -> LDS tile.
 //   head_dim 128: LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write.  One wave
@@ -453,7 +449,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
 //   dV^T[d][key] += dO^T[d][q] * (P.drop)[q][key];   dK^T[d][key] += Q^T[d][q] * dS[q][key]
 // LDS per buffer: Q tile | dO tile | row stats (m [64], scale/l [64], delta [64]).
 template <int HD, bool CAUSAL, int NW>
-__global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv_kernel(AttnP p) {
   using C = Cfg<HD>;
   constexpr int STG = 2 * C::TILE + 3 * KT * (int)sizeof(float);
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -526,6 +522,82 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
     const bf16_t* qb_; const bf16_t* dob_; long sbase_; int q0;
     tile_ptrs(it, qb_, dob_, sbase_, q0);
     const int hq = kvh * p.rep + it / ntq;
+    // Interior tile (all keys valid, both 32-query sub-tiles in range and past the causal diagonal, no
+    // dropout): software-pipelined -- sub-tile 1's S/dP MFMAs are independent of sub-tile 0's softmax
+    // VALU and sub-tile 0's dV/dK MFMAs of sub-tile 1's softmax, so one wave keeps both pipes busy.
+    const bool tile_fast = all_valid && !dropping && (q0 + KT <= p.Sq) && (!CAUSAL || q0 >= kblk + 31);
+    if (kblk < p.Sk && tile_fast) {
+      f32x16 s0 = zero16(), dp0 = zero16(), s1 = zero16(), dp1 = zero16();
+      // phase 1: every row fragment of both sub-tiles goes in flight before the first MFMA (one wave per
+      // SIMD: nobody else hides the LDS latency, so a read-wait-MFMA chain would stall the matrix pipe)
+      bf16x8 qa0[C::NS], da0[C::NS], qa1[C::NS], da1[C::NS];
+#pragma unroll
+      for (int st = 0; st < C::NS; ++st) { qa0[st] = row_frag<HD>(qtile, 0, st, lane); da0[st] = row_frag<HD>(dotile, 0, st, lane); }
+#pragma unroll
+      for (int st = 0; st < C::NS; ++st) { qa1[st] = row_frag<HD>(qtile, 32, st, lane); da1[st] = row_frag<HD>(dotile, 32, st, lane); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int st = 0; st < C::NS; ++st) {
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa0[st], kf[st], s0, 0, 0, 0);
+        dp0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da0[st], vf[st], dp0, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // transposed fragments for sub-tile 0's dV/dK products: in flight under sub-tile 1's S/dP MFMAs
+      bf16x8 tdo0[2][C::NDT], tq0[2][C::NDT];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) { tdo0[s2][dt] = tr_frag<HD>(dotile, 16 * s2, dt, lane); tq0[s2][dt] = tr_frag<HD>(qtile, 16 * s2, dt, lane); }
+#pragma unroll
+      for (int st = 0; st < C::NS; ++st) {
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1[st], kf[st], s1, 0, 0, 0);
+        dp1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da1[st], vf[st], dp1, 0, 0, 0);
+      }
+      auto soft = [&](f32x16& sv, f32x16& dpv, int sub) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int qr = 32 * sub + 8 * rq + 4 * h;
+          const float4 a = *reinterpret_cast<const float4*>(fst + qr);
+          const float4 bq = *reinterpret_cast<const float4*>(fst + KT + qr);
+          const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
+          const float ma[4] = {a.x, a.y, a.z, a.w}, iv[4] = {bq.x, bq.y, bq.z, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
+            const float ps = fast_exp2(fmaf(sv[r], c2, -ma[e] * LOG2E)) * iv[e];
+            sv[r] = ps;
+            dpv[r] = ps * (dpv[r] - dl[e]);
+          }
+        }
+      };
+      soft(s0, dp0, 0);                 // VALU, independent of the s1/dp1 MFMAs above
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8 tdo1[2][C::NDT], tq1[2][C::NDT];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) { tdo1[s2][dt] = tr_frag<HD>(dotile, 32 + 16 * s2, dt, lane); tq1[s2][dt] = tr_frag<HD>(qtile, 32 + 16 * s2, dt, lane); }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(s0, s2), df = acc_frag(dp0, s2);
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tdo0[s2][dt], pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq0[s2][dt], df, dk[dt], 0, 0, 0);
+        }
+      }
+      soft(s1, dp1, 1);                 // VALU under sub-tile 0's dV/dK MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(s1, s2), df = acc_frag(dp1, s2);
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tdo1[s2][dt], pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq1[s2][dt], df, dk[dt], 0, 0, 0);
+        }
+      }
+    } else
     if (kblk < p.Sk) {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
@@ -539,40 +611,48 @@ __global__ __launch_bounds__(NW * 64, 1) void attn_bwd_dkv_kernel(AttnP p) {
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dotile, 32 * sub, st, lane), vf[st], dp, 0, 0, 0);
         }
         const bool fast = all_valid && (!CAUSAL || qbase >= kblk + 31) && !dropping;
-        // row stats of this lane's 16 query rows: 4 consecutive rows per 16-byte read
-        float mcr[16], ivr[16], dlr[16];
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const int qr = 32 * sub + 8 * rq + 4 * h;
-          const float4 a = *reinterpret_cast<const float4*>(fst + qr);
-          const float4 bq = *reinterpret_cast<const float4*>(fst + KT + qr);
-          const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
-          mcr[4 * rq] = a.x; mcr[4 * rq + 1] = a.y; mcr[4 * rq + 2] = a.z; mcr[4 * rq + 3] = a.w;
-          ivr[4 * rq] = bq.x; ivr[4 * rq + 1] = bq.y; ivr[4 * rq + 2] = bq.z; ivr[4 * rq + 3] = bq.w;
-          dlr[4 * rq] = cq.x; dlr[4 * rq + 1] = cq.y; dlr[4 * rq + 2] = cq.z; dlr[4 * rq + 3] = cq.w;
-        }
+        // row stats (m, scale/l, delta) of this lane's query rows: 4 consecutive rows per 16-byte LDS read,
+        // consumed group by group so only 12 of them are live at a time
         if (fast) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float ps = fast_exp2(fmaf(s[r], c2, -mcr[r] * LOG2E)) * ivr[r];      // p * scale
-            s[r] = ps;
-            dp[r] = ps * (dp[r] - dlr[r]);
+          for (int rq = 0; rq < 4; ++rq) {
+            const int qr = 32 * sub + 8 * rq + 4 * h;
+            const float4 a = *reinterpret_cast<const float4*>(fst + qr);
+            const float4 bq = *reinterpret_cast<const float4*>(fst + KT + qr);
+            const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
+            const float ma[4] = {a.x, a.y, a.z, a.w}, iv[4] = {bq.x, bq.y, bq.z, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * rq + e;
+              const float ps = fast_exp2(fmaf(s[r], c2, -ma[e] * LOG2E)) * iv[e];      // p * scale
+              s[r] = ps;
+              dp[r] = ps * (dp[r] - dl[e]);
+            }
           }
         } else {
           const int qb0 = opaque(qbase + 4 * h), keyo = opaque(key);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int qpos = qb0 + (r & 3) + 8 * (r >> 2);
-            const float sc = mask_score<CAUSAL>(s[r], p.scale, kvalid, kok, keyo, qpos);       // natural-log domain
-            const float ps = (sc == NEG_INF) ? 0.f : fast_exp2((sc - mcr[r]) * LOG2E) * ivr[r];
-            float g = dp[r], pd = ps;
-            if (dropping) {
-              const float dsc = ur_dropout_scale(p.seed, (((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)qpos) * (uint64_t)p.Sk) + (uint64_t)key,
-                                                 p.drop_thr, p.drop_inv);
-              g *= dsc; pd *= dsc;
+          for (int rq = 0; rq < 4; ++rq) {
+            const int qr = 32 * sub + 8 * rq + 4 * h;
+            const float4 a = *reinterpret_cast<const float4*>(fst + qr);
+            const float4 bq = *reinterpret_cast<const float4*>(fst + KT + qr);
+            const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
+            const float ma[4] = {a.x, a.y, a.z, a.w}, iv[4] = {bq.x, bq.y, bq.z, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * rq + e;
+              const int qpos = qb0 + e + 8 * rq;
+              const float sc = mask_score<CAUSAL>(s[r], p.scale, kvalid, kok, keyo, qpos);       // natural-log domain
+              const float ps = (sc == NEG_INF) ? 0.f : fast_exp2((sc - ma[e]) * LOG2E) * iv[e];
+              float g = dp[r], pd = ps;
+              if (dropping) {
+                const float dsc = ur_dropout_scale(p.seed, (((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)qpos) * (uint64_t)p.Sk) + (uint64_t)keyo,
+                                                   p.drop_thr, p.drop_inv);
+                g *= dsc; pd *= dsc;
+              }
+              s[r] = pd;
+              dp[r] = ps * (g - dl[e]);
             }
-            s[r] = pd;
-            dp[r] = ps * (g - dlr[r]);
           }
         }
         // s = P*scale (with dropout) -> dV needs P: undo the scale on the dV side with one multiply per output

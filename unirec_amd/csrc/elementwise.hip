@@ -98,6 +98,22 @@ __global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __r
   }
 }
 
+// dst[c][r] = src[r][c]  (bf16, 32x32 tiles through LDS; small matrices: LoRA A^T per step)
+__global__ void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows, int cols) {
+  __shared__ bf16_t t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 32 x 8
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    t[i][tx] = (r < rows && c < cols) ? src[(long)r * cols + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) dst[(long)c * rows + r] = t[tx][i];
+  }
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
                              float gscale) {
@@ -162,6 +178,13 @@ extern "C" int ur_gelu_bwd(const void* dy, const void* u, void* dx, int64_t n, v
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)u,
                      (bf16_t*)dx, (long)(n / 8));
   UR_CHECK_LAUNCH("ur_gelu_bwd");
+  return 0;
+}
+extern "C" int ur_transpose_bf16(const void* src, void* dst, int32_t rows, int32_t cols, void* stream) {
+  UR_REQUIRE(src && dst && rows > 0 && cols > 0, "ur_transpose_bf16: bad argument");
+  hipLaunchKernelGGL(transpose_kernel, dim3(ur_cdiv(cols, 32), ur_cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                     (bf16_t*)dst, rows, cols);
+  UR_CHECK_LAUNCH("ur_transpose_bf16");
   return 0;
 }
 extern "C" int ur_swiglu_fwd(const void* gu, void* act, int32_t M, int32_t I, void* stream) {

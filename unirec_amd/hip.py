@@ -249,6 +249,16 @@ def cast_bf16_to_f32(src, dst=None):
     return dst
 
 
+def transpose_bf16(src, dst=None):
+    lib = _lib.load()
+    _need(src, BF16, "src")
+    rows, cols = src.shape
+    if dst is None:
+        dst = torch.empty((cols, rows), dtype=BF16, device=src.device)
+    check(lib.ur_transpose_bf16(src.data_ptr(), dst.data_ptr(), rows, cols, _stream()), "ur_transpose_bf16")
+    return dst
+
+
 def add_bf16(a, b, out=None):
     lib = _lib.load()
     if out is None:

@@ -16,7 +16,7 @@ Execution: the whole stack (embed + Q-Former token injection, 28 decoder layers,
 pool over ALL positions :179-181) is ONE autograd node.  Base weights are frozen, so the backward is
 dX GEMMs on the frozen bf16 weights plus rank-r reductions for dA/dB; every LoRA B-product rides in
 the base GEMM's accumulators (second K-range of ur_gemm).  Activations are kept in HBM (288 GB:
-no gradient checkpointing), normed inputs and SwiGLU outputs are recomputed in the backward.
+no gradient checkpointing); only the RMSNorm outputs are recomputed in the backward.
 """
 import math
 
@@ -198,11 +198,12 @@ class Qwen3LoRAModel(nn.Module):
         fz["norm"] = self.norm.weight.detach().to(dev, F32).contiguous()
         for lyr in self.layers:
             a, m = lyr.self_attn, lyr.mlp
+            wqkv = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)
+            wgu = torch.cat([m.gate_proj.weight, m.up_proj.weight], 0)
             fz["layers"].append({
-                "qkv": c16(torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)),
-                "o": c16(a.o_proj.weight),
-                "gu": c16(torch.cat([m.gate_proj.weight, m.up_proj.weight], 0)),
-                "d": c16(m.down_proj.weight),
+                "qkv": c16(wqkv), "o": c16(a.o_proj.weight), "gu": c16(wgu), "d": c16(m.down_proj.weight),
+                # frozen => one-time transposed copies, so every dX GEMM is K-contiguous on both operands
+                "qkvT": c16(wqkv.t()), "oT": c16(a.o_proj.weight.t()), "guT": c16(wgu.t()), "dT": c16(m.down_proj.weight.t()),
                 "qn": a.q_norm.weight.detach().to(dev, F32).contiguous(), "kn": a.k_norm.weight.detach().to(dev, F32).contiguous(),
                 "ln1": lyr.input_layernorm.weight.detach().to(dev, F32).contiguous(),
                 "ln2": lyr.post_attention_layernorm.weight.detach().to(dev, F32).contiguous()})
@@ -302,7 +303,7 @@ class Qwen3LoRAModel(nn.Module):
                 L["t_d"] = t_d
             else:
                 x3 = hip.gemm(act, fl["d"], residual=x2)
-            L.update(rstd1=rstd1, qkv=qkv, actx=actx, att=att2, x2=x2, rstd2=rstd2, gu=gu)
+            L.update(rstd1=rstd1, qkv=qkv, actx=actx, att=att2, x2=x2, rstd2=rstd2, gu=gu, act=act)
             saved["layers"].append(L)
             x = x3
         last, rstd_f = hip.rmsnorm_fwd(x, fz["norm"], eps)
@@ -344,28 +345,28 @@ class Qwen3LoRAModel(nn.Module):
             lp = f"layers.{i}."
             x, x2, gu, qkv = L["x"], L["x2"], L["gu"], L["qkv"]
             # ---- MLP: x3 = x2 + down(silu(gate) * up)
-            act = hip.swiglu_fwd(gu, I)                                   # recomputed
+            act = L["act"]
             if pack is not None:
                 tb = lora_grads(dx, L["t_d"], act, [lp + "mlp.down_proj.lora_A.weight"], [(lp + "mlp.down_proj.lora_B.weight", 0, D)])
-                dact = hip.gemm(dx, fl["d"], s_kcontig=False, R2=tb, S2=pack.w16(lp + "mlp.down_proj.lora_A.weight"))
+                dact = hip.gemm(dx, fl["dT"], R2=tb, S2=hip.transpose_bf16(pack.w16(lp + "mlp.down_proj.lora_A.weight")))
             else:
-                dact = hip.gemm(dx, fl["d"], s_kcontig=False)
+                dact = hip.gemm(dx, fl["dT"])
             dgu = hip.swiglu_bwd(dact, gu, I)
             h2, _ = hip.rmsnorm_fwd(x2, fl["ln2"], eps)                   # recomputed
             if pack is not None:
                 a_names = [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"]
                 tb = lora_grads(dgu, L["t_gu"], h2, a_names, [(lp + "mlp.gate_proj.lora_B.weight", 0, I), (lp + "mlp.up_proj.lora_B.weight", I, I)])
-                dh2 = hip.gemm(dgu, fl["gu"], s_kcontig=False, R2=tb, S2=pack.fused16(a_names))
+                dh2 = hip.gemm(dgu, fl["guT"], R2=tb, S2=hip.transpose_bf16(pack.fused16(a_names)))
             else:
-                dh2 = hip.gemm(dgu, fl["gu"], s_kcontig=False)
+                dh2 = hip.gemm(dgu, fl["guT"])
             dx2 = hip.rmsnorm_bwd(dh2, x2, fl["ln2"], L["rstd2"], add=dx)
             # ---- attention: x2 = x + o(attn)
             att = L["att"]
             if pack is not None:
                 tb = lora_grads(dx2, L["t_o"], att, [lp + "self_attn.o_proj.lora_A.weight"], [(lp + "self_attn.o_proj.lora_B.weight", 0, D)])
-                datt = hip.gemm(dx2, fl["o"], s_kcontig=False, R2=tb, S2=pack.w16(lp + "self_attn.o_proj.lora_A.weight"))
+                datt = hip.gemm(dx2, fl["oT"], R2=tb, S2=hip.transpose_bf16(pack.w16(lp + "self_attn.o_proj.lora_A.weight")))
             else:
-                datt = hip.gemm(dx2, fl["o"], s_kcontig=False)
+                datt = hip.gemm(dx2, fl["oT"])
             dqkv = torch.empty_like(qkv)
             dq_r = torch.empty((M, NQ), dtype=BF16, device=dev)
             dk_r = torch.empty((M, NKV), dtype=BF16, device=dev)
@@ -378,9 +379,9 @@ class Qwen3LoRAModel(nn.Module):
                 specs = [(lp + "self_attn.q_proj.lora_B.weight", 0, NQ), (lp + "self_attn.k_proj.lora_B.weight", NQ, NKV),
                          (lp + "self_attn.v_proj.lora_B.weight", NQ + NKV, NKV)]
                 tb = lora_grads(dqkv, L["t_qkv"], h, a_names, specs)
-                dh = hip.gemm(dqkv, fl["qkv"], s_kcontig=False, R2=tb, S2=pack.fused16(a_names))
+                dh = hip.gemm(dqkv, fl["qkvT"], R2=tb, S2=hip.transpose_bf16(pack.fused16(a_names)))
             else:
-                dh = hip.gemm(dqkv, fl["qkv"], s_kcontig=False)
+                dh = hip.gemm(dqkv, fl["qkvT"])
             dx = hip.rmsnorm_bwd(dh, x, fl["ln1"], L["rstd1"], add=dx2)
             L.clear()
             if self.grad_ready_hook is not None:      # dp.GradBuckets: layer i's LoRA gradients are final
