@@ -123,20 +123,22 @@ template <int HD>
 __device__ __forceinline__ bf16x8 row_frag(const char* tile, int r0, int s, int lane) {
   return *reinterpret_cast<const bf16x8*>(tile + Cfg<HD>::off(r0 + (lane & 31), 2 * s + (lane >> 5)));
 }
-// transposed fragment: A[m = 32*dt + (lane&31)][k-element j] = X[r0 + 8*(j>>2) + 4*(lane>>5) + (j&3)][m]
-// (16 rows r0..r0+15 of X; k order matches an accumulator tile used as the B operand)
+// transposed fragments: A[m = 32*dt + (lane&31)][k-element j] = X[r0 + 8*(j>>2) + 4*(lane>>5) + (j&3)][m]
+// for dt = 0..NDT-1 (16 rows r0..r0+15 of X; k order matches an accumulator tile used as the B operand).
+// Inline-asm ds_read_b64_tr_b16 batches (common.cuh: the builtin would drain the LDS-DMA prefetch).
 template <int HD>
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int r0, int dt, int lane) {
-  typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+__device__ __forceinline__ void tr_frags(bf16x8 (&f)[Cfg<HD>::NDT], const char* tile, int r0, int lane) {
   const int h = lane >> 5, g16 = (lane >> 4) & 1, i = lane & 15;
-  const int row = r0 + 4 * h + (i >> 2), ch = 4 * dt + 2 * g16 + ((i & 3) >> 1), sub8 = 8 * (i & 1);
-  const char* pa = tile + Cfg<HD>::off(row, ch) + sub8;
-  const char* pb = tile + Cfg<HD>::off(row + 8, ch) + sub8;
-  const bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pa);
-  const bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pb);
-  bf16x8 r;
-  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-  return r;
+  const int row = r0 + 4 * h + (i >> 2), sub8 = 8 * (i & 1);
+  const uint32_t base = lds_off(tile) + sub8;
+  uint32_t a[Cfg<HD>::NDT], b[Cfg<HD>::NDT];
+#pragma unroll
+  for (int dt = 0; dt < Cfg<HD>::NDT; ++dt) {
+    const int ch = 4 * dt + 2 * g16 + ((i & 3) >> 1);
+    a[dt] = base + Cfg<HD>::off(row, ch);
+    b[dt] = base + Cfg<HD>::off(row + 8, ch);
+  }
+  tr_read(f, a, b);
 }
 // accumulator registers 8*s2 .. 8*s2+7 -> bf16 B-operand fragment of k-step s2
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s2) {
@@ -179,6 +181,16 @@ __device__ __forceinline__ KeyBits key_bits(const uint8_t* km, int k0, int Sk, i
   KeyBits kb; kb.valid = __ballot(ok); kb.inr = __ballot(in);
   return kb;
 }
+// All tiles' key-state words are computed ONCE per workgroup into LDS before the first LDS-DMA is
+// issued: an ordinary global load inside the DMA loop would make hipcc drain the prefetch (vmcnt(0)).
+constexpr int MAX_KTILES = 128;                      // Sk <= 8192
+__device__ __forceinline__ void fill_key_words(unsigned long long* kw, const uint8_t* km, int ntiles, int Sk, int tid, int nthreads) {
+  const int lane = tid & 63, wave = tid >> 6, nw = nthreads >> 6;
+  for (int t = wave; t < ntiles; t += nw) {
+    const KeyBits kb = key_bits(km, t * KT, Sk, lane);
+    if (lane == 0) { kw[2 * t] = kb.valid; kw[2 * t + 1] = kb.inr; }
+  }
+}
 
 // masked, scaled score (natural-log domain).  CAUSAL: SDPA semantics (-inf); else the Q-Former's
 // additive finfo.min (the sum collapses to exactly finfo.min in f32).
@@ -219,6 +231,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   const uint64_t drow = ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
   const bool dropping = (!CAUSAL) && p.drop_thr != 0;
 
+  unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + 4 * C::TILE);
+  fill_key_words(kwords, km, ntiles, p.Sk, tid, NW * 64);
   Loader<HD, NW * 64> ks, vs;
   ks.issue(smem, kb, p.ldk, 0, p.Sk, tid);
   vs.issue(smem + C::TILE, vb, p.ldv, 0, p.Sk, tid);
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
       ks.issue(nk, kb, p.ldk, k0 + KT, p.Sk, tid);
       vs.issue(nk + C::TILE, vb, p.ldv, k0 + KT, p.Sk, tid);
     }
-    const KeyBits kbits = key_bits(km, k0, p.Sk, lane);
+    KeyBits kbits; kbits.valid = kwords[2 * t]; kbits.inr = kwords[2 * t + 1];
     if (qblk < p.Sq) {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
@@ -296,9 +310,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const bf16x8 pf = acc_frag(s, s2);
+          bf16x8 vt[C::NDT];
+          tr_frags<HD>(vt, vtile, 32 * sub + 16 * s2, lane);
 #pragma unroll
-          for (int dt = 0; dt < C::NDT; ++dt)
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(vtile, 32 * sub + 16 * s2, dt, lane), pf, o[dt], 0, 0, 0);
+          for (int dt = 0; dt < C::NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[dt], pf, o[dt], 0, 0, 0);
         }
       }
     }
@@ -378,6 +393,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
   const uint64_t drow = ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
   const bool dropping = (!CAUSAL) && p.drop_thr != 0;
 
+  unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + 4 * C::TILE);
+  fill_key_words(kwords, km, ntiles, p.Sk, tid, NW * 64);
   Loader<HD, NW * 64> ks, vs;
   ks.issue(smem, kb, p.ldk, 0, p.Sk, tid);
   vs.issue(smem + C::TILE, vb, p.ldv, 0, p.Sk, tid);
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
       ks.issue(nk, kb, p.ldk, k0 + KT, p.Sk, tid);
       vs.issue(nk + C::TILE, vb, p.ldv, k0 + KT, p.Sk, tid);
     }
-    const KeyBits kbits = key_bits(km, k0, p.Sk, lane);
+    KeyBits kbits; kbits.valid = kwords[2 * t]; kbits.inr = kwords[2 * t + 1];
     if (qblk < p.Sq) {
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
@@ -428,9 +445,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const bf16x8 df = acc_frag(s, s2);
+          bf16x8 kt[C::NDT];
+          tr_frags<HD>(kt, ktile, 32 * sub + 16 * s2, lane);
 #pragma unroll
-          for (int dt = 0; dt < C::NDT; ++dt)
-            dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(ktile, 32 * sub + 16 * s2, dt, lane), df, dq[dt], 0, 0, 0);
+          for (int dt = 0; dt < C::NDT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt[dt], df, dq[dt], 0, 0, 0);
         }
       }
     }
@@ -447,7 +465,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
 // dK/dV: one 32-key block per wave (lane = key column).  Per 32-query sub-tile:
 //   S[q][key] = Q K^T, dP[q][key] = dO V^T (A = Q / dO rows from LDS, B = K / V fragments in registers)
 //   dV^T[d][key] += dO^T[d][q] * (P.drop)[q][key];   dK^T[d][key] += Q^T[d][q] * dS[q][key]
-// LDS per buffer: Q tile | dO tile | row stats (m [64], scale/l [64], delta [64]).
+// LDS per buffer: Q tile | dO tile | row stats ((m, 1/l) pairs [64][2], delta [64]).
 template <int HD, bool CAUSAL, int NW>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv_kernel(AttnP p) {
   using C = Cfg<HD>;
@@ -480,7 +498,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const int ntot = ntq * p.rep;                    // tiles over (query head of the group, query tile)
 
   Loader<HD, NW * 64> qs, dos;
-  float st0 = 0.f, st1 = 0.f, st2 = 0.f;          // staged row stats of thread tid < KT
   auto tile_ptrs = [&](int it, const bf16_t*& qb, const bf16_t*& dob, long& sbase, int& q0) {
     const int hr = it / ntq, tq = it - hr * ntq;
     const int hq = kvh * p.rep + hr;
@@ -489,26 +506,26 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     sbase = ((long)b * p.nq + hq) * p.Sq;
     q0 = qstart + tq * KT;
   };
+  // row stats travel by LDS-DMA too (dword per lane): [128 floats (m, 1/l) pairs][64 floats delta];
+  // rows past Sq are clamped copies and are masked by position in the general path
   auto load_tile = [&](int it, char* buf) {
     const bf16_t* qb; const bf16_t* dob; long sbase; int q0;
     tile_ptrs(it, qb, dob, sbase, q0);
     qs.issue(buf, qb, p.ldq, q0, p.Sq, tid);
     dos.issue(buf + C::TILE, dob, p.lddo, q0, p.Sq, tid);
-    if (tid < KT) {
-      const int qq = q0 + tid;
-      const bool ok = qq < p.Sq;
-      st0 = ok ? p.stats[(sbase + qq) * 2] : 0.f;                    // row max, natural-log domain
-      st1 = ok ? p.stats[(sbase + qq) * 2 + 1] * p.scale : 0.f;     // 0 for rows past Sq -> p = 0
-      st2 = ok ? p.delta[sbase + qq] : 0.f;
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+      typedef __attribute__((address_space(3))) void lds_void;
+      typedef const __attribute__((address_space(1))) void gbl_void;
+      char* fb = buf + 2 * C::TILE;
+      const int r0 = min(q0 + (lane >> 1), p.Sq - 1), r1 = min(q0 + 32 + (lane >> 1), p.Sq - 1), rd = min(q0 + lane, p.Sq - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(p.stats + (sbase + r0) * 2 + (lane & 1)), (lds_void*)fb, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(p.stats + (sbase + r1) * 2 + (lane & 1)), (lds_void*)(fb + 256), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(p.delta + sbase + rd), (lds_void*)(fb + 512), 4, 0, 0);
     }
   };
   auto store_tile = [&](char* buf) {
     qs.commit(buf, tid);
     dos.commit(buf + C::TILE, tid);
-    if (tid < KT) {
-      float* f = reinterpret_cast<float*>(buf + 2 * C::TILE);
-      f[tid] = st0; f[KT + tid] = st1; f[2 * KT + tid] = st2;
-    }
   };
 
   if (ntot > 0) { load_tile(0, smem); store_tile(smem); }
@@ -545,9 +562,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       // transposed fragments for sub-tile 0's dV/dK products: in flight under sub-tile 1's S/dP MFMAs
       bf16x8 tdo0[2][C::NDT], tq0[2][C::NDT];
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt) { tdo0[s2][dt] = tr_frag<HD>(dotile, 16 * s2, dt, lane); tq0[s2][dt] = tr_frag<HD>(qtile, 16 * s2, dt, lane); }
+      for (int s2 = 0; s2 < 2; ++s2) { tr_frags<HD>(tdo0[s2], dotile, 16 * s2, lane); tr_frags<HD>(tq0[s2], qtile, 16 * s2, lane); }
 #pragma unroll
       for (int st = 0; st < C::NS; ++st) {
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa1[st], kf[st], s1, 0, 0, 0);
@@ -557,14 +572,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
           const int qr = 32 * sub + 8 * rq + 4 * h;
-          const float4 a = *reinterpret_cast<const float4*>(fst + qr);
-          const float4 bq = *reinterpret_cast<const float4*>(fst + KT + qr);
-          const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
-          const float ma[4] = {a.x, a.y, a.z, a.w}, iv[4] = {bq.x, bq.y, bq.z, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
+          const float4 a = *reinterpret_cast<const float4*>(fst + 2 * qr);          // (m, 1/l) of rows qr, qr+1
+          const float4 bq = *reinterpret_cast<const float4*>(fst + 2 * qr + 4);     // rows qr+2, qr+3
+          const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);    // delta of rows qr..qr+3
+          const float ma[4] = {a.x, a.z, bq.x, bq.z}, iv[4] = {a.y, a.w, bq.y, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * rq + e;
-            const float ps = fast_exp2(fmaf(sv[r], c2, -ma[e] * LOG2E)) * iv[e];
+            const float ps = fast_exp2(fmaf(sv[r], c2, -ma[e] * LOG2E)) * iv[e];      // p (dS scale applied at the store)
             sv[r] = ps;
             dpv[r] = ps * (dpv[r] - dl[e]);
           }
@@ -574,9 +589,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       __builtin_amdgcn_sched_barrier(0);
       bf16x8 tdo1[2][C::NDT], tq1[2][C::NDT];
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt) { tdo1[s2][dt] = tr_frag<HD>(dotile, 32 + 16 * s2, dt, lane); tq1[s2][dt] = tr_frag<HD>(qtile, 32 + 16 * s2, dt, lane); }
+      for (int s2 = 0; s2 < 2; ++s2) { tr_frags<HD>(tdo1[s2], dotile, 32 + 16 * s2, lane); tr_frags<HD>(tq1[s2], qtile, 32 + 16 * s2, lane); }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pf = acc_frag(s0, s2), df = acc_frag(dp0, s2);
@@ -610,17 +623,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(qtile, 32 * sub, st, lane), kf[st], s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dotile, 32 * sub, st, lane), vf[st], dp, 0, 0, 0);
         }
-        const bool fast = all_valid && (!CAUSAL || qbase >= kblk + 31) && !dropping;
+        const bool fast = all_valid && (!CAUSAL || qbase >= kblk + 31) && !dropping && (qbase + 32 <= p.Sq);   // rows past Sq are clamped copies
         // row stats (m, scale/l, delta) of this lane's query rows: 4 consecutive rows per 16-byte LDS read,
         // consumed group by group so only 12 of them are live at a time
         if (fast) {
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
             const int qr = 32 * sub + 8 * rq + 4 * h;
-            const float4 a = *reinterpret_cast<const float4*>(fst + qr);
-            const float4 bq = *reinterpret_cast<const float4*>(fst + KT + qr);
+            const float4 a = *reinterpret_cast<const float4*>(fst + 2 * qr);
+            const float4 bq = *reinterpret_cast<const float4*>(fst + 2 * qr + 4);
             const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
-            const float ma[4] = {a.x, a.y, a.z, a.w}, iv[4] = {bq.x, bq.y, bq.z, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
+            const float ma[4] = {a.x, a.z, bq.x, bq.z}, iv[4] = {a.y, a.w, bq.y, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * rq + e;
@@ -634,16 +647,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
           for (int rq = 0; rq < 4; ++rq) {
             const int qr = 32 * sub + 8 * rq + 4 * h;
-            const float4 a = *reinterpret_cast<const float4*>(fst + qr);
-            const float4 bq = *reinterpret_cast<const float4*>(fst + KT + qr);
+            const float4 a = *reinterpret_cast<const float4*>(fst + 2 * qr);
+            const float4 bq = *reinterpret_cast<const float4*>(fst + 2 * qr + 4);
             const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
-            const float ma[4] = {a.x, a.y, a.z, a.w}, iv[4] = {bq.x, bq.y, bq.z, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
+            const float ma[4] = {a.x, a.z, bq.x, bq.z}, iv[4] = {a.y, a.w, bq.y, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * rq + e;
               const int qpos = qb0 + e + 8 * rq;
               const float sc = mask_score<CAUSAL>(s[r], p.scale, kvalid, kok, keyo, qpos);       // natural-log domain
-              const float ps = (sc == NEG_INF) ? 0.f : fast_exp2((sc - ma[e]) * LOG2E) * iv[e];
+              const float ps = (sc == NEG_INF || qpos >= p.Sq) ? 0.f : fast_exp2((sc - ma[e]) * LOG2E) * iv[e];
               float g = dp[r], pd = ps;
               if (dropping) {
                 const float dsc = ur_dropout_scale(p.seed, (((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)qpos) * (uint64_t)p.Sk) + (uint64_t)keyo,
@@ -659,10 +672,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const bf16x8 pf = acc_frag(s, s2), df = acc_frag(dp, s2);
+          bf16x8 tdo[C::NDT], tq[C::NDT];
+          tr_frags<HD>(tdo, dotile, 32 * sub + 16 * s2, lane);
+          tr_frags<HD>(tq, qtile, 32 * sub + 16 * s2, lane);
 #pragma unroll
           for (int dt = 0; dt < C::NDT; ++dt) {
-            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(dotile, 32 * sub + 16 * s2, dt, lane), pf, dv[dt], 0, 0, 0);
-            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag<HD>(qtile, 32 * sub + 16 * s2, dt, lane), df, dk[dt], 0, 0, 0);
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tdo[dt], pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[dt], df, dk[dt], 0, 0, 0);
           }
         }
       }
@@ -671,13 +687,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     __syncthreads();
   }
   if (kok) {
-    store_T<HD>(p.dk + ((long)b * p.Sk + key) * p.lddk + (long)kvh * HD, dk, 1.0f, lane);
-    store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 1.0f / p.scale, lane);
+    store_T<HD>(p.dk + ((long)b * p.Sk + key) * p.lddk + (long)kvh * HD, dk, p.scale, lane);     // dS was kept unscaled
+    store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 1.0f, lane);
   }
 }
 
 // ================================================================================================
-template <int HD> constexpr int fwd_smem() { return 4 * Cfg<HD>::TILE; }
+template <int HD> constexpr int fwd_smem() { return 4 * Cfg<HD>::TILE + MAX_KTILES * 16; }
 template <int HD> constexpr int dkv_smem() { return 2 * (2 * Cfg<HD>::TILE + 3 * KT * (int)sizeof(float)); }
 
 template <typename K>
@@ -698,6 +714,7 @@ int fill(AttnP& p, const ur_attn_args* a) {
   UR_REQUIRE(!a->causal || a->Sq == a->Sk, "ur_attn: causal mode needs Sq == Sk");
   UR_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f && (!a->causal || a->dropout_p == 0.f), "ur_attn: bad dropout");
   UR_REQUIRE(a->scale > 0.f, "ur_attn: scale must be positive");
+  UR_REQUIRE(a->Sk <= MAX_KTILES * KT, "ur_attn: Sk (%d) exceeds %d", a->Sk, MAX_KTILES * KT);
   memset(&p, 0, sizeof(p));
   p.q = (const bf16_t*)a->q; p.k = (const bf16_t*)a->k; p.v = (const bf16_t*)a->v; p.o = (bf16_t*)a->o; p.stats = a->stats;
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.kmask = a->key_mask;

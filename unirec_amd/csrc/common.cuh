@@ -49,6 +49,43 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
+// ---- transposed LDS reads (ds_read_b64_tr_b16) as inline asm -----------------------------------
+// hipcc (ROCm 7.2) drains every in-flight LDS-DMA (s_waitcnt vmcnt(0)) in front of the
+// __builtin_amdgcn_ds_read_tr16_b64 builtin, which kills the prefetch ring.  The asm form is invisible
+// to that pass.  Each statement issues all its reads, then waits lgkmcnt(0) itself, so its outputs are
+// valid when the statement ends (cdna_hip_programming.md §5.7 form (i)).  EXEC must be all ones.
+__device__ __forceinline__ uint32_t lds_off(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
+  bf16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3]; r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+// N fragments (N = 1, 2 or 4), each = two 4-row transposed reads at LDS byte offsets a[i], b[i]
+__device__ __forceinline__ void tr_read(bf16x8 (&f)[4], const uint32_t (&a)[4], const uint32_t (&b)[4]) {
+  bf16x4 l0, h0, l1, h1, l2, h2, l3, h3;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\t"
+      "ds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
+      "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\t"
+      "ds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1), "=&v"(l2), "=&v"(h2), "=&v"(l3), "=&v"(h3)
+      : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]));
+  f[0] = cat4(l0, h0); f[1] = cat4(l1, h1); f[2] = cat4(l2, h2); f[3] = cat4(l3, h3);
+}
+__device__ __forceinline__ void tr_read(bf16x8 (&f)[2], const uint32_t (&a)[2], const uint32_t (&b)[2]) {
+  bf16x4 l0, h0, l1, h1;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\t"
+      "ds_read_b64_tr_b16 %2, %6\n\tds_read_b64_tr_b16 %3, %7\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(l0), "=&v"(h0), "=&v"(l1), "=&v"(h1)
+      : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]));
+  f[0] = cat4(l0, h0); f[1] = cat4(l1, h1);
+}
+
 // ---- wave / block reductions -----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -15,21 +15,22 @@
 // tiles) for the large projections, 128x128x64 with 4 waves (2x2) for small / edge shapes.  The weight-side operand S is the MFMA "A" (row) operand and the
 // token-side operand R the "B" (column) operand, so each lane ends up with 4 CONSECUTIVE n for one
 // m: packed 8-byte (bf16) / 16-byte (f32) stores into row-major C.
-// Staging: LDS-DMA (global_load_lds_dwordx4) straight into a double-buffered, XOR-swizzled LDS image
-// (no staging VGPRs, no ds_write); the next tile's DMA is in flight under the current tile's MFMAs
-// and is drained by the barrier that ends the tile.  K-contiguous tiles are read with ds_read_b128,
+// Staging: LDS-DMA (global_load_lds_dwordx4) straight into a 4-stage ring of XOR-swizzled LDS images
+// (no staging VGPRs, no ds_write); three 32-deep tiles stay in flight under the current tile's MFMAs
+// (counted s_waitcnt vmcnt + raw s_barrier, one barrier per tile).  K-contiguous tiles are read with ds_read_b128,
 // K-strided tiles with ds_read_b64_tr_b16 (hardware transpose); both images are bank-conflict-free.
 #include "common.cuh"
 #include "unirec_hip.h"
 
 namespace {
 
-constexpr int BK = 64;
-constexpr int KC_ROWB = 128;               // K-contiguous tile row bytes (64 bf16)
+constexpr int BK = 32;                     // K depth of one ring stage = one v_mfma_f32_16x16x32_bf16 k-step
+constexpr int NSTAGE = 4;                  // LDS ring: 3 tiles of LDS-DMA in flight under the current tile's MFMAs
+constexpr int KC_ROWB = BK * 2;            // K-contiguous tile row bytes
 // LDS image of one operand tile of T rows (T = 128 or 256), no padding (LDS-DMA writes linearly):
-//   K-contiguous  [T][64 k] : 128-B rows, 16-B chunk c of row r stored at chunk c ^ (r & 7)
-//                             -> conflict-free ds_read_b128 fragment reads
-//   K-strided     [64 k][T] : 2T-byte rows, 32-B segment s of k-row r stored at segment s ^ f(r),
+//   K-contiguous  [T][32 k] : 64-B rows, 16-B chunk c of row r stored at chunk c ^ g(r),
+//                             g(r) = (-(r >> 2)) & 3  -> conflict-free ds_read_b128 fragment reads
+//   K-strided     [32 k][T] : 2T-byte rows, 32-B segment s of k-row r stored at segment s ^ f(r),
 //                             f(r) = (r & 3) | (((r >> 3) & 1) << 2)
 //                             -> the 8 (k-row, 32-B) pieces one half-wave ds_read_b64_tr_b16 touches
 //                                land on 8 different 32-B bank groups: conflict-free transposed reads
@@ -49,16 +50,18 @@ struct GemmP {
 };
 
 __device__ __forceinline__ int ks_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+__device__ __forceinline__ int kc_g(int r) { return (-(r >> 2)) & 3; }
 
-// ---- LDS-DMA staging of a FULL 64-deep tile: 1 KiB per wave instruction, swizzle on the source ---
+// ---- LDS-DMA staging of a FULL 32-deep tile: 1 KiB per wave instruction, swizzle on the source ---
 // rows/cols past the matrix edge are clamped (they only feed output rows/cols that are never stored)
 template <bool KC, int T, int NT>
 __device__ __forceinline__ void dma_tile(char* tile, const bf16_t* __restrict__ base, long ld, int rows_total, int row0,
                                          int k0, int tid) {
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void gbl_void;
-  constexpr int PIECES = T / 8;                 // 1 KiB pieces per tile
+  constexpr int PIECES = T * BK * 2 / 1024;     // 1 KiB pieces per tile
   constexpr int PER_WAVE = PIECES / (NT / 64);
+  static_assert(PER_WAVE >= 1, "tile too small for the workgroup");
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
@@ -66,9 +69,9 @@ __device__ __forceinline__ void dma_tile(char* tile, const bf16_t* __restrict__ 
     const int inst = i * (NT / 64) + wave;
     const bf16_t* src;
     if (KC) {
-      const int row = inst * 8 + (lane >> 3), pos = lane & 7;
+      const int row = inst * 16 + (lane >> 2), pos = lane & 3;
       const int g = min(row0 + row, rows_total - 1);
-      src = base + (long)g * ld + k0 + ((pos ^ (lane >> 3)) << 3);
+      src = base + (long)g * ld + k0 + ((pos ^ kc_g(row)) << 3);
     } else {
       const int c = inst * 64 + lane;
       const int kr = c / (T / 8), ch = c % (T / 8);
@@ -83,16 +86,18 @@ __device__ __forceinline__ void dma_tile(char* tile, const bf16_t* __restrict__ 
 template <bool KC, int T, int NT>
 __device__ __forceinline__ void reg_tile(char* tile, const bf16_t* __restrict__ base, long ld, int rows_total, int row0,
                                          int k0, int kend, int tid) {
+  constexpr int CHUNKS = T * BK / 8;
 #pragma unroll
-  for (int i = 0; i < T * 8 / NT; ++i) {
+  for (int i = 0; i < (CHUNKS + NT - 1) / NT; ++i) {
     const int c = tid + i * NT;
+    if (c >= CHUNKS) break;
     uint4 z = make_uint4(0, 0, 0, 0);
     int off;
     if (KC) {
-      const int row = c >> 3, kc = c & 7;
+      const int row = c >> 2, kc = c & 3;
       const int grow = min(row0 + row, rows_total - 1), gk = k0 + kc * 8;
       if (gk < kend) z = *reinterpret_cast<const uint4*>(base + (long)grow * ld + gk);
-      off = row * KC_ROWB + ((kc ^ (row & 7)) << 4);
+      off = row * KC_ROWB + ((kc ^ kc_g(row)) << 4);
     } else {
       const int kr = c / (T / 8), ch = c % (T / 8);
       const int gk = k0 + kr, gcol = min(row0 + ch * 8, rows_total - 8);
@@ -103,26 +108,34 @@ __device__ __forceinline__ void reg_tile(char* tile, const bf16_t* __restrict__ 
   }
 }
 
-// ---- LDS -> MFMA fragment: lane holds [idx = base16 + (lane&15)][k = 32*kk + 8*(lane>>4) + 0..7]
-template <bool KC, int T>
-__device__ __forceinline__ bf16x8 lds_frag(const char* tile, int idx0, int kk, int lane) {
+// ---- LDS -> MFMA fragments: lane holds [idx = idx0 + 16*i + (lane&15)][k = 8*(lane>>4) + 0..7] ---
+template <bool KC, int T, int N>
+__device__ __forceinline__ void lds_frags(bf16x8 (&f)[N], const char* tile, int idx0, int lane) {
   if (KC) {
-    int idx = idx0 + (lane & 15);
-    int chunk = kk * 4 + (lane >> 4);
-    return *reinterpret_cast<const bf16x8*>(tile + idx * KC_ROWB + ((chunk ^ (idx & 7)) << 4));
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const int idx = idx0 + 16 * i + (lane & 15);
+      f[i] = *reinterpret_cast<const bf16x8*>(tile + idx * KC_ROWB + (((lane >> 4) ^ kc_g(idx)) << 4));
+    }
   } else {
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int ka = kk * 32 + 8 * g + q;                 // k-rows ka (elements 0..3) and ka+4 (elements 4..7)
-    const int seg = idx0 >> 4;                          // 32-byte segment of this 16-column block
-    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
-    const char* pa = tile + ka * Tile<T>::KS_ROWB + ((seg ^ ks_f(ka)) << 5) + pp * 8;
-    const char* pb = tile + (ka + 4) * Tile<T>::KS_ROWB + ((seg ^ ks_f(ka + 4)) << 5) + pp * 8;
-    bf16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pa);
-    bf16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)pb);
-    bf16x8 r;
-    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
-    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
-    return r;
+    const int ka = 8 * g + q;                           // k-rows ka (elements 0..3) and ka+4 (elements 4..7)
+    const uint32_t ra = lds_off(tile) + ka * Tile<T>::KS_ROWB + pp * 8, rb = ra + 4 * Tile<T>::KS_ROWB;
+    const int fa = ks_f(ka), fb = ks_f(ka + 4);
+#pragma unroll
+    for (int i0 = 0; i0 < N; i0 += 4) {
+      uint32_t a[4], b[4];
+      bf16x8 t4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int seg = (idx0 >> 4) + i0 + i;           // 32-byte segment of this 16-column block
+        a[i] = ra + ((seg ^ fa) << 5);
+        b[i] = rb + ((seg ^ fb) << 5);
+      }
+      tr_read(t4, a, b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[i0 + i] = t4[i];
+    }
   }
 }
 
@@ -164,7 +177,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // stage tile t into `buf`: LDS-DMA for full 64-deep tiles, register path (zero-fill) for K tails
+  // stage tile t into ring slot `buf`: LDS-DMA for full tiles, register path (zero-fill) for K tails
   auto stage = [&](int t, char* buf) {
     const bf16_t* S; const bf16_t* R; long lds_, ldr_; int k0, ke;
     if (t < nt1) { S = p.S; R = p.R; lds_ = p.lds; ldr_ = p.ldr; k0 = kbeg + t * BK; ke = kend; }
@@ -177,28 +190,37 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
       reg_tile<RK, BM, NT>(buf + S_BYTES, R, ldr_, p.M, m0, k0, ke, tid);
     }
   };
+  // LDS-DMA instructions one wave issues per full tile (both operands): the unit of the counted waits
+  constexpr int DMA_PER_TILE = (BN * BK * 2 / 1024) / (NT / 64) + (BM * BK * 2 / 1024) / (NT / 64);
 
-  if (nt > 0) stage(0, smem);
-  __syncthreads();            // drains the LDS-DMA (vmcnt(0)) and publishes the tile
+  // prologue: NSTAGE-1 tiles in flight
+#pragma unroll
+  for (int t = 0; t < NSTAGE - 1; ++t)
+    if (t < nt) stage(t, smem + t * STAGE);
 
   for (int t = 0; t < nt; ++t) {
-    const char* sb = smem + (t & 1) * STAGE;
+    // (1) this wave's pieces of tile t have landed: at most the DMAs of the younger in-flight tiles
+    //     (t+1, t+2) may still be outstanding.  Near the end of the K loop fewer tiles are in flight.
+    const int younger = min(NSTAGE - 2, nt - 1 - t);
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_TILE) : "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // register-path ds_writes (K tails) and our own reads
+    // (2) every wave's pieces landed, and every wave has finished reading tile t-1's slot
+    __builtin_amdgcn_s_barrier();
+    // (3) refill the slot tile t-1 occupied with tile t+NSTAGE-1
+    if (t + NSTAGE - 1 < nt) stage(t + NSTAGE - 1, smem + ((t + NSTAGE - 1) % NSTAGE) * STAGE);
+    // (4) MFMAs of tile t
+    const char* sb = smem + (t % NSTAGE) * STAGE;
     const char* rb = sb + S_BYTES;
-    if (t + 1 < nt) stage(t + 1, smem + ((t + 1) & 1) * STAGE);   // in flight under this tile's MFMAs
+    bf16x8 sf[NI], rf[MI];
+    lds_frags<SK, BN, NI>(sf, sb, wc * WN, lane);
+    lds_frags<RK, BM, MI>(rf, rb, wr * WM, lane);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 sf[NI], rf[MI];
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int i = 0; i < NI; ++i) sf[i] = lds_frag<SK, BN>(sb, wc * WN + i * 16, kk, lane);
-#pragma unroll
-      for (int j = 0; j < MI; ++j) rf[j] = lds_frag<RK, BM>(rb, wr * WM + j * 16, kk, lane);
-#pragma unroll
-      for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[i], rf[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
+      for (int j = 0; j < MI; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[i], rf[j], acc[i][j], 0, 0, 0);
   }
 
   // ---- epilogue: lane holds n = n0 + wc*WN + i*16 + (lane>>4)*4 + 0..3, m = m0 + wr*WM + j*16 + (lane&15)
@@ -267,7 +289,7 @@ template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN>
 int launch_cfg(GemmP p, int splits, hipStream_t st) {
   constexpr int S_BYTES = SK ? Tile<BN>::KC_BYTES : Tile<BN>::KS_BYTES;
   constexpr int R_BYTES = RK ? Tile<BM>::KC_BYTES : Tile<BM>::KS_BYTES;
-  constexpr int SMEM = 2 * (S_BYTES + R_BYTES);
+  constexpr int SMEM = NSTAGE * (S_BYTES + R_BYTES);
   static bool attr_set = false;   // idempotent; a race only repeats the call
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN>),
