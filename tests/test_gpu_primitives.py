@@ -114,6 +114,25 @@ def test_gemm_splitk_tn(split):
     assert torch.equal(out, out2), "split-K reduction must be deterministic"
 
 
+@pytest.mark.parametrize("rk,sk", [(True, True), (True, False), (False, False)])
+def test_gemm_ring_stress_exact(rk, sk):
+    """The LDS-DMA ring is ordered only by counted vmcnt waits + barriers: a scheduling bug shows up as
+    rare wrong tiles under load.  Long K (128 ring tiles), many workgroups, repeated, two streams, exact."""
+    M, N, K = 4096, 1024, 4096
+    Rm, Sm = _ints((M, K), lo=-2, hi=3, seed=11), _ints((N, K), lo=-2, hi=3, seed=12)
+    R = _bf(Rm if rk else Rm.t())
+    S = _bf(Sm if sk else Sm.t())
+    ref = (Rm.to(DEV).double() @ Sm.to(DEV).double().t()).float()
+    big = torch.randn(64 * 1024 * 1024, device=DEV)          # memory traffic beside the GEMMs
+    s2 = torch.cuda.Stream()
+    for it in range(6):
+        with torch.cuda.stream(s2):
+            big.mul_(1.0001)
+        out = hip.gemm(R, S, r_kcontig=rk, s_kcontig=sk, out_f32=True)
+        assert torch.equal(out, ref), f"iteration {it}: {(out - ref).abs().max().item()}"
+    torch.cuda.synchronize()
+
+
 def test_gemm_rejects_bad_arguments():
     from unirec_amd._lib import UniRecHipError
     R, S = _bf(_randn((16, 12))), _bf(_randn((8, 12)))

@@ -193,75 +193,128 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   // LDS-DMA instructions one wave issues per full tile (both operands): the unit of the counted waits
   constexpr int DMA_PER_TILE = (BN * BK * 2 / 1024) / (NT / 64) + (BM * BK * 2 / 1024) / (NT / 64);
 
-  // prologue: NSTAGE-1 tiles in flight
-#pragma unroll
-  for (int t = 0; t < NSTAGE - 1; ++t)
-    if (t < nt) stage(t, smem + t * STAGE);
-
-  for (int t = 0; t < nt; ++t) {
-    // (1) this wave's pieces of tile t have landed: at most the DMAs of the younger in-flight tiles
-    //     (t+1, t+2) may still be outstanding.  Near the end of the K loop fewer tiles are in flight.
-    const int younger = min(NSTAGE - 2, nt - 1 - t);
-    if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_TILE) : "memory");
-    else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE) : "memory");
+  // Software pipeline (one barrier per 32-deep tile).  Invariant at the top of step(t): tile t's
+  // fragments are in registers, tiles t+1 .. t+NSTAGE-1 have been ISSUED (tile t+1 must have landed,
+  // the others may be in flight).  step(t):
+  //   wait(tile t+1 landed) -> barrier -> refill the ring slot of tile t (its fragments are in registers
+  //   of every wave) with tile t+NSTAGE -> issue the LDS fragment reads of tile t+1 -> MFMAs of tile t.
+  // The fragment reads of the next tile and NSTAGE-2 tiles of LDS-DMA run under the MFMAs.
+  // vmcnt is in-order: "at most n*DMA_PER_TILE outstanding" == "all but the n youngest tiles landed".
+  // A K-tail tile staged through registers issues no DMA, but its own (compiler-waited) global loads
+  // are younger than every DMA before it, so it only makes these waits more conservative.
+  auto wait_all_but = [&](int n_tiles) {
+    if (n_tiles >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * DMA_PER_TILE) : "memory");
+    else if (n_tiles == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_TILE) : "memory");
+    else if (n_tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // register-path ds_writes (K tails) and our own reads
-    // (2) every wave's pieces landed, and every wave has finished reading tile t-1's slot
-    __builtin_amdgcn_s_barrier();
-    // (3) refill the slot tile t-1 occupied with tile t+NSTAGE-1
-    if (t + NSTAGE - 1 < nt) stage(t + NSTAGE - 1, smem + ((t + NSTAGE - 1) % NSTAGE) * STAGE);
-    // (4) MFMAs of tile t
+  };
+  auto read_frags = [&](bf16x8 (&sf)[NI], bf16x8 (&rf)[MI], int t) {
     const char* sb = smem + (t % NSTAGE) * STAGE;
-    const char* rb = sb + S_BYTES;
-    bf16x8 sf[NI], rf[MI];
     lds_frags<SK, BN, NI>(sf, sb, wc * WN, lane);
-    lds_frags<RK, BM, MI>(rf, rb, wr * WM, lane);
+    lds_frags<RK, BM, MI>(rf, sb + S_BYTES, wr * WM, lane);
+  };
+  auto mfmas = [&](const bf16x8 (&sf)[NI], const bf16x8 (&rf)[MI]) {
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[i], rf[j], acc[i][j], 0, 0, 0);
+  };
+  // one pipeline step: `cur` holds tile t's fragments, `nxt` receives tile t+1's
+  auto step = [&](int t, const bf16x8 (&csf)[NI], const bf16x8 (&crf)[MI], bf16x8 (&nsf)[NI], bf16x8 (&nrf)[MI]) {
+    // issued so far: tiles <= min(nt-1, t+NSTAGE-1); tile t+1 must land, younger issued tiles may fly
+    if (t + 1 < nt) wait_all_but(min(nt - 1, t + NSTAGE - 1) - (t + 1));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // tile t's fragment reads (and K-tail ds_writes) are done
+    __builtin_amdgcn_s_barrier();                           // => slot of tile t is free, tile t+1 is complete
+    if (t + NSTAGE < nt) stage(t + NSTAGE, smem + (t % NSTAGE) * STAGE);
+    if (t + 1 < nt) read_frags(nsf, nrf, t + 1);
+    mfmas(csf, crf);
+  };
+
+  // prologue: NSTAGE tiles issued, tile 0 landed and in registers
+#pragma unroll
+  for (int t = 0; t < NSTAGE; ++t)
+    if (t < nt) stage(t, smem + t * STAGE);
+  bf16x8 sfA[NI], rfA[MI], sfB[NI], rfB[MI];
+  if (nt > 0) {
+    wait_all_but(min(nt - 1, NSTAGE - 1));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(sfA, rfA, 0);
+  }
+  for (int t = 0; t < nt; t += 2) {
+    step(t, sfA, rfA, sfB, rfB);
+    if (t + 1 < nt) step(t + 1, sfB, rfB, sfA, rfA);
   }
 
   // ---- epilogue: lane holds n = n0 + wc*WN + i*16 + (lane>>4)*4 + 0..3, m = m0 + wr*WM + j*16 + (lane&15)
+  // bf16 output: the finished tile goes through LDS (the ring is free now) and leaves as whole rows,
+  // 16 B per lane = 512 contiguous bytes per row of a 256-wide tile; direct 8-byte stores from the MFMA
+  // layout (16 rows x 4 pieces per instruction) ran at ~1.8 TB/s and cost ~30 % of a K=1024 GEMM.
+  constexpr int CROWB = BN * 2 + 16;              // padded LDS row of the C tile
   const int nq = (lane >> 4) * 4, ml = lane & 15;
+  if (!OUTF32) __syncthreads();                   // every wave is done with the ring
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int n = n0 + wc * WN + i * 16 + nq;
-    if (n >= p.N) continue;
+    const int nl = wc * WN + i * 16 + nq;
+    const int n = n0 + nl;
+    const bool nok = n < p.N;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    if (p.bias && nok) {
       const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
       b4[0] = bb.x; b4[1] = bb.y; b4[2] = bb.z; b4[3] = bb.w;
     }
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const int m = m0 + wr * WM + j * 16 + ml;
-      if (m >= p.M) continue;
+      const int mloc = wr * WM + j * 16 + ml;
+      const int m = m0 + mloc;
+      const bool ok = nok && m < p.M;
       float v[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha + b4[e];
       if (OUTF32) {
-        float* c = reinterpret_cast<float*>(p.C) + (long)z * p.slab_stride + (long)m * p.ldc + n;
-        *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        if (ok) {
+          float* c = reinterpret_cast<float*>(p.C) + (long)z * p.slab_stride + (long)m * p.ldc + n;
+          *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+        }
       } else {
-        if (p.res) {
+        if (ok && p.res) {
           const uint2 r = *reinterpret_cast<const uint2*>(p.res + (long)m * p.ldres + n);
           v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
         }
-        if (p.aux) {
+        if (ok && p.aux) {
           const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
           v[0] *= gelu_erf_grad_f(bf_lo(a.x)); v[1] *= gelu_erf_grad_f(bf_hi(a.x));
           v[2] *= gelu_erf_grad_f(bf_lo(a.y)); v[3] *= gelu_erf_grad_f(bf_hi(a.y));
         }
-        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
-        *reinterpret_cast<uint2*>(c) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-        if (p.gelu_out) {
+        *reinterpret_cast<uint2*>(smem + mloc * CROWB + nl * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+        if (ok && p.gelu_out) {
           // GELU of the bf16-ROUNDED pre-activation, so backward's gelu'(u) sees the same u
           float u0 = bf2f(f2bf(v[0])), u1 = bf2f(f2bf(v[1])), u2 = bf2f(f2bf(v[2])), u3 = bf2f(f2bf(v[3]));
           bf16_t* g = p.gelu_out + (long)m * p.ldg + n;
           *reinterpret_cast<uint2*>(g) = make_uint2(pack_bf2(gelu_erf_f(u0), gelu_erf_f(u1)),
                                                      pack_bf2(gelu_erf_f(u2), gelu_erf_f(u3)));
+        }
+      }
+    }
+  }
+  if (!OUTF32) {
+    __syncthreads();
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
+    const bool wide = ((p.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+    constexpr int CPR = BN / 8;                   // 16-byte chunks per tile row
+#pragma unroll 4
+    for (int c = tid; c < BM * CPR; c += NT) {
+      const int row = c / CPR, ch = c % CPR;
+      const int m = m0 + row, n = n0 + ch * 8;
+      if (m < p.M && n < p.N) {
+        const uint4 val = *reinterpret_cast<const uint4*>(smem + row * CROWB + ch * 16);
+        bf16_t* dst = Cb + (long)m * p.ldc + n;
+        if (wide && n + 8 <= p.N) {
+          *reinterpret_cast<uint4*>(dst) = val;
+        } else {
+          *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);                       // N % 4 == 0: first half always fits
+          if (n + 8 <= p.N) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(val.z, val.w);
         }
       }
     }
@@ -289,7 +342,8 @@ template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN>
 int launch_cfg(GemmP p, int splits, hipStream_t st) {
   constexpr int S_BYTES = SK ? Tile<BN>::KC_BYTES : Tile<BN>::KS_BYTES;
   constexpr int R_BYTES = RK ? Tile<BM>::KC_BYTES : Tile<BM>::KS_BYTES;
-  constexpr int SMEM = NSTAGE * (S_BYTES + R_BYTES);
+  constexpr int RING = NSTAGE * (S_BYTES + R_BYTES), CTILE = BM * (BN * 2 + 16);
+  constexpr int SMEM = OUTF32 ? RING : (RING > CTILE ? RING : CTILE);
   static bool attr_set = false;   // idempotent; a race only repeats the call
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN>),
