@@ -164,3 +164,81 @@ def test_inject_handles_repeated_and_missing_tokens():
     assert torch.equal(dt[0, 0], (dx[0, 5].float() + dx[0, 290].float()).to(torch.bfloat16))
     assert torch.equal(dt[0, 2], dx[0, 17]) and torch.equal(dt[1, 1], dx[1, 0])
     assert float(dt[0, 1].abs().max()) == 0 and float(dt[1, 0].abs().max()) == 0
+
+
+def test_user_tokens_into_qwen3_matches_oracle_composition():
+    """U4 (no reference code): UserQFormer query tokens injected after the history tokens; checked against
+    the oracle's composition of its pinned pieces (user Q-Former, injection, Qwen3, pool, InfoNCE)."""
+    from unirec_amd.joint import InfoNCELoss, MultiModalQwenEmbedding
+    from unirec_amd.qformer_model import QFormerForItemRepresentation
+    from unirec_amd.user_qformer import UserQFormer
+    case = cases.ALL["joint_right"]
+    c = case["cfg"]
+    qc = cases.qwen_cfg(case)
+    D, hist, Qi, B, S = qc.hidden_size, case["hist"], c["Q"], case["B"], case["S"]
+    NU, T, Eu = 8, 24, 192
+    cfg = R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 2)
+    ucfg = R.QFormerCfg(D, 2, D // 64, 512, NU, Eu, 1)
+    qf = load_generated(QFormerForItemRepresentation(hidden_size=c["H"], num_hidden_layers=c["L"], num_attention_heads=c["nh"],
+                                                     intermediate_size=c["I"], num_query_tokens=c["Q"], field_embedding_dim=c["E"],
+                                                     num_fields=c["F"], dropout=0.0), R.item_qformer_shapes(cfg, c["F"]), 5)
+    uq = load_generated(UserQFormer(hidden_size=D, num_hidden_layers=2, num_attention_heads=D // 64, intermediate_size=512,
+                                    num_query_tokens=NU, input_embedding_dim=Eu, num_item_tokens_to_predict=2, dropout=0.0),
+                        R.user_qformer_shapes(ucfg, 2), 6)
+    hc = _qwen_cfg(qc, False)
+    hc.vocab_size = case["first_special_id"]
+    m = MultiModalQwenEmbedding(qformer_model=qf, use_lora=False, qwen_config=hc, num_history_items=hist, num_query_tokens_per_item=Qi,
+                                user_qformer=uq)
+    sdw = {k: torch.from_numpy(v) for k, v in W.fill_state_dict(Q.qwen3_shapes(qc, lora=False), 7).items()}
+    emb = torch.from_numpy(W.normal("emb", (case["first_special_id"] + hist * Qi + NU, D), 7, std=0.02))
+    sdw["embed_tokens.weight"] = emb
+    m.base_model.load_state_dict(sdw, strict=False)
+    m = m.to(DEV).train()
+    ids, am, hfe, ham, pos, neg, nmask = cases.joint_inputs(case)
+    first_u = case["first_special_id"] + hist * Qi
+    for b in range(B):                                    # put each user special once into the real region
+        real = [p for p in np.nonzero(am[b])[0] if ids[b, p] < case["first_special_id"]][:NU]
+        for k, p in enumerate(real):
+            ids[b, p] = first_u + k
+    ut = W.normal("ut", (B, T, Eu), 8, std=0.8)
+    um = np.ones((B, T), dtype=np.float32); um[1, 15:] = 0; ut[1, 15:] = 0
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    user = m(t(ids), t(am), t(hfe), t(ham), user_sequence_tokens=t(ut), user_attention_mask=t(um))
+    loss = InfoNCELoss()(user, t(pos), t(neg), t(nmask))
+    loss.backward()
+    # oracle composition
+    PQ = {k: torch.from_numpy(v).requires_grad_(True) for k, v in W.fill_state_dict(R.item_qformer_shapes(cfg, c["F"]), 5).items()}
+    PU = {k: torch.from_numpy(v).requires_grad_(True) for k, v in W.fill_state_dict(R.user_qformer_shapes(ucfg, 2), 6).items()}
+    PW = {k: v for k, v in sdw.items()}
+    it = R.item_qformer_forward(PQ, cfg, torch.from_numpy(hfe).view(B * hist, c["F"], c["E"]), torch.from_numpy(ham).view(B * hist, c["F"]))
+    _, uqo = R.user_qformer_forward(PU, ucfg, torch.from_numpy(ut), torch.from_numpy(um), 2)
+    toks = torch.cat([it["query_outputs"].view(B, hist * Qi, D), uqo], dim=1).view(B, 1, hist * Qi + NU, D)
+    ou = Q.joint_forward(PW, qc, torch.from_numpy(ids), torch.from_numpy(am), toks, case["first_special_id"])
+    ol = Q.infonce_loss(ou, torch.from_numpy(pos), torch.from_numpy(neg), torch.from_numpy(nmask))
+    ol.backward()
+    print("U4")
+    assert_close(user, ou.detach().numpy(), OUT_REL, "user_embeddings")
+    assert_close(loss, ol.detach().numpy(), OUT_REL, "loss")
+    assert_close(uq.query_embeddings.grad, PU["query_embeddings"].grad.numpy(), GRAD_REL * 1.5, "grad/user query_embeddings")
+    assert_close(qf.query_embeddings.grad, PQ["query_embeddings"].grad.numpy(), GRAD_REL * 1.5, "grad/item query_embeddings")
+
+
+def test_user_sequence_assembly_matches_oracle():
+    """U0: tokens + context + sinusoidal PE over the flat index + right padding / mask in one kernel."""
+    from unirec_amd.user_sequence_encoder import UserSequenceAssembler
+    B, L, Qi, H = 3, 7, 4, 128
+    tok = W.normal("tok", (B, L, Qi, H), 1, std=0.8)
+    ctx = W.normal("ctx", (B, L, H), 2, std=0.3)
+    lens = np.array([7, 3, 1], dtype=np.int64)
+    asm = UserSequenceAssembler(embedding_dim=H, num_query_tokens=Qi)
+    out, mask = asm.encode_user_sequences(torch.from_numpy(tok).to(DEV), torch.from_numpy(ctx).to(DEV), torch.from_numpy(lens).to(DEV))
+    assert out.shape == (B, L * Qi, H) and mask.shape == (B, L * Qi)
+    for b in range(B):
+        n = int(lens[b])
+        tb = torch.from_numpy(tok[b, :n]).to(torch.bfloat16).float()
+        cb = torch.from_numpy(ctx[b, :n]).to(torch.bfloat16).float()
+        want = R.assemble_user_sequence(tb, cb)
+        got = out[b, :n * Qi].float().cpu()
+        assert torch.allclose(got, want, rtol=1e-2, atol=2e-2), (b, (got - want).abs().max())
+        assert float(out[b, n * Qi:].abs().max()) == 0.0 if n < L else True
+        assert mask[b].cpu().tolist() == [1.0] * (n * Qi) + [0.0] * ((L - n) * Qi)

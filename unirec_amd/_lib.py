@@ -68,6 +68,8 @@ SIGNATURES = {
                                    c_i64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ur_embed_inject_fwd": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ur_inject_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ur_user_sequence_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u64,
+                                          c_void_p]),
     "ur_mean_pool_workspace_bytes": (c_i64, [c_int, c_int]),
     "ur_mean_pool_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "ur_mean_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

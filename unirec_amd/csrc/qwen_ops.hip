@@ -193,6 +193,50 @@ __global__ void pool_bwd_kernel(const float* __restrict__ d32, const bf16_t* __r
   }
 }
 
+// U0 -- user-sequence assembly (models/user_sequence_encoder.py:128-142 + the collate's padding,
+// training/user_qformer_training.py:153-161), one pass:
+//   out[b][l*Qi + j][:] = tokens[b][l][j][:] + ctx[b][l][:] + PE[l*Qi + j][:]   for l < len[b]
+//                         0                                                    for l >= len[b] (padding)
+//   mask[b][l*Qi + j]   = l < len[b]
+// PE = sinusoidal table over the FLAT index (PositionalEncoding :20-25): even d -> sin(pos * w_d),
+// odd d -> cos(pos * w_{d-1}), w_d = exp(-d * ln(1e4) / H).  Dropout (p=0.1, the reference leaves the
+// module in train mode) is the same counter-based hash as everywhere else.
+__global__ __launch_bounds__(256) void user_seq_kernel(const bf16_t* __restrict__ tok, const bf16_t* __restrict__ ctx,
+                                                       const int* __restrict__ lens, bf16_t* __restrict__ out, float* __restrict__ mask,
+                                                       int B, int L, int Qi, int H, uint32_t thr, float inv_keep, uint64_t seed) {
+  const int H8 = H / 8;
+  const long rows = (long)B * L * Qi;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float wstep = -9.210340371976184f / (float)H;          // -ln(10000)/H
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const int b = (int)(row / ((long)L * Qi));
+    const int pos = (int)(row - (long)b * L * Qi);              // flat position l*Qi + j
+    const int l = pos / Qi;
+    const bool valid = l < lens[b];
+    if (lane == 0) mask[row] = valid ? 1.0f : 0.0f;
+    for (int c = lane; c < H8; c += 64) {
+      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        float t[8], cx[8];
+        un8(*reinterpret_cast<const uint4*>(tok + row * H + c * 8), t);
+        un8(*reinterpret_cast<const uint4*>(ctx + ((long)b * L + l) * H + c * 8), cx);
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const int d = c * 8 + e;                               // even index of the (sin, cos) pair
+          const float ang = (float)pos * __expf((float)d * wstep);
+          o[e] = t[e] + cx[e] + sinf(ang);
+          o[e + 1] = t[e + 1] + cx[e + 1] + cosf(ang);
+        }
+        if (thr) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] *= ur_dropout_scale(seed, (uint64_t)(row * H + c * 8 + e), thr, inv_keep);
+        }
+      }
+      *reinterpret_cast<uint4*>(out + row * H + c * 8) = pk8(o);
+    }
+  }
+}
+
 inline int grid_cap(long n, int cap) { return (int)(n < 1 ? 1 : (n > cap ? cap : n)); }
 
 }  // namespace
@@ -306,5 +350,20 @@ extern "C" int ur_mean_pool_bwd(const float* dout_f32, const void* dout_bf16, vo
   hipLaunchKernelGGL(pool_bwd_kernel, dim3(grid_cap((total + 255) / 256, 2048)), dim3(256), 0, (hipStream_t)stream, dout_f32,
                      (const bf16_t*)dout_bf16, (bf16_t*)dx, (long)B, S, D / 8, 1.0f / (float)S);
   UR_CHECK_LAUNCH("ur_mean_pool_bwd");
+  return 0;
+}
+
+extern "C" int ur_user_sequence_assemble(const void* item_tokens, const void* context, const int32_t* lengths, void* out, float* mask,
+                                         int32_t B, int32_t L, int32_t Qi, int32_t H, float dropout_p, uint64_t seed, void* stream) {
+  UR_REQUIRE(item_tokens && context && lengths && out && mask && B >= 0 && L > 0 && Qi > 0 && H > 0 && (H % 8) == 0,
+             "ur_user_sequence_assemble: bad argument");
+  UR_REQUIRE(UR_ALIGNED16(item_tokens) && UR_ALIGNED16(context) && UR_ALIGNED16(out), "ur_user_sequence_assemble: alignment");
+  UR_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "ur_user_sequence_assemble: dropout p out of range");
+  if (B == 0) return 0;
+  const long rows = (long)B * L * Qi;
+  hipLaunchKernelGGL(user_seq_kernel, dim3(grid_cap((rows + 3) / 4, 256 * 16)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)item_tokens,
+                     (const bf16_t*)context, (const int*)lengths, (bf16_t*)out, mask, B, L, Qi, H,
+                     dropout_p > 0.f ? ur_drop_threshold(dropout_p) : 0u, dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f, seed);
+  UR_CHECK_LAUNCH("ur_user_sequence_assemble");
   return 0;
 }

@@ -493,3 +493,17 @@ def mse_loss(a, b, coef=1.0, need_grad=True):
     check(lib.ur_mse_loss(a.data_ptr(), b.data_ptr(), a.numel(), coef, loss.data_ptr(), _p(da), ws.data_ptr(), n, _stream()),
           "ur_mse_loss")
     return loss, da
+
+
+def user_sequence_assemble(item_tokens, context, lengths, dropout_p=0.0, seed=0):
+    """item_tokens [B,L,Qi,H] bf16, context [B,L,H] bf16, lengths int32 [B] -> (out [B,L*Qi,H] bf16, mask [B,L*Qi] f32)."""
+    lib = _lib.load()
+    _need(item_tokens, BF16, "item_tokens")
+    _need(context, BF16, "context")
+    _need(lengths, torch.int32, "lengths")
+    B, L, Qi, H = item_tokens.shape
+    out = torch.empty((B, L * Qi, H), dtype=BF16, device=item_tokens.device)
+    mask = torch.empty((B, L * Qi), dtype=F32, device=item_tokens.device)
+    check(lib.ur_user_sequence_assemble(item_tokens.data_ptr(), context.data_ptr(), lengths.data_ptr(), out.data_ptr(), mask.data_ptr(),
+                                        B, L, Qi, H, dropout_p, seed, _stream()), "ur_user_sequence_assemble")
+    return out, mask

@@ -46,8 +46,12 @@ class HistoryTokenTable:
 class MultiModalQwenEmbedding(nn.Module):
     def __init__(self, base_model_name: str = "Qwen/Qwen3-Embedding-0.6B", qformer_model: nn.Module = None, use_lora: bool = True,
                  lora_config=None, qwen_config: Qwen3Config = None, num_history_items: int = 10,
-                 num_query_tokens_per_item: int = 2, tokenizer=None):
+                 num_query_tokens_per_item: int = 2, tokenizer=None, user_qformer: nn.Module = None):
         super().__init__()
+        # U4 (README.md:44-47 / figure (c), no reference code): the User Q-Former's query
+        # tokens are injected at <|user_query_k|> specials that follow the history specials.
+        self.user_qformer = user_qformer
+        self.num_user_query_tokens = 0 if user_qformer is None else int(user_qformer.num_query_tokens)
         self.use_lora = use_lora
         self.num_history_items = num_history_items
         self.num_query_tokens_per_item = num_query_tokens_per_item
@@ -66,9 +70,14 @@ class MultiModalQwenEmbedding(nn.Module):
                                for j in range(num_query_tokens_per_item)]
         # ids of the added special tokens are consecutive (tokenizer.add_special_tokens order, :106-119)
         self.first_special_id = int(self.tokenizer.convert_tokens_to_ids(self.history_tokens[0]))
-        self.base_model.resize_token_embeddings(max(base_vocab, self.first_special_id + len(self.history_tokens)))
+        self.user_tokens = [f"<|user_query_{k}|>" for k in range(self.num_user_query_tokens)]
+        self.first_user_special_id = self.first_special_id + len(self.history_tokens)
+        self.base_model.resize_token_embeddings(max(base_vocab, self.first_user_special_id + len(self.user_tokens)))
+        if user_qformer is not None and user_qformer.config.hidden_size != self.hidden_size:
+            raise ValueError("No projector: User Q-Former hidden size must equal the LLM hidden size")
 
-    def forward(self, input_ids, attention_mask=None, history_field_embeddings=None, history_attention_mask=None):
+    def forward(self, input_ids, attention_mask=None, history_field_embeddings=None, history_attention_mask=None,
+                user_sequence_tokens=None, user_attention_mask=None):
         dev = self.base_model.embed_tokens.weight.device
         input_ids = input_ids.to(dev)
         if attention_mask is not None:
@@ -82,6 +91,11 @@ class MultiModalQwenEmbedding(nn.Module):
             if h16.shape[1] != self.num_query_tokens_per_item or num_hist != self.num_history_items:
                 raise ValueError("history layout does not match num_history_items x num_query_tokens_per_item")
             item_tokens = h16.reshape(bh, num_hist * self.num_query_tokens_per_item, self.hidden_size)
+        if self.user_qformer is not None and user_sequence_tokens is not None:
+            u16 = self.user_qformer.encode_bf16(user_sequence_tokens.to(dev), user_attention_mask.to(dev))     # [B,64,D]
+            if item_tokens is None:
+                item_tokens = torch.zeros((u16.shape[0], len(self.history_tokens), self.hidden_size), dtype=BF16, device=dev)
+            item_tokens = torch.cat([item_tokens, u16], dim=1)      # special ids are consecutive: history block, then user block
         return self.base_model.forward_pooled(input_ids, attention_mask, item_tokens, self.first_special_id)
 
     def save_pretrained(self, save_directory):
