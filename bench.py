@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--pool", type=int, default=1000)
     ap.add_argument("--layers", type=int, default=28, help="Qwen3 layers (28 = the named model; fewer is a debug run)")
+    ap.add_argument("--workload", choices=["joint", "item", "user"], default="joint",
+                    help="joint = C4 headline (default); item = C2 item Q-Former step; user = C3 user Q-Former step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU oracle leg and print its JSON")
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -165,8 +167,79 @@ def cpu_baseline_subprocess(args):
                 "sample": f"oracle leg did not finish within 240 s ({type(e).__name__})"}
 
 
+# ---- per-stage workloads (BASELINE configs[1], configs[2]); reported with their own metric names ----
+def run_stage(args):
+    from unirec_amd import dp
+    from unirec_amd.losses import QFormerLoss, mse_loss
+    from unirec_amd.optim import FusedAdamW
+    rank, world, local = dp.init_from_env()
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    torch.manual_seed(1234)
+    g = torch.Generator().manual_seed(1234 + rank)
+    p = 0.0 if args.no_dropout else None
+    if args.workload == "item":
+        from unirec_amd.qformer_utils import QFormerForItemRepresentation
+        B = args.batch if args.batch != 64 else 256
+        m = QFormerForItemRepresentation(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                                         num_query_tokens=32, field_embedding_dim=1024, num_fields=14,
+                                         dropout=0.2 if p is None else p).to(device).train()
+        def fields():
+            x = torch.randn(B, 14, 1024, generator=g); x = x / x.norm(dim=-1, keepdim=True)
+            mk = (torch.rand(B, 14, generator=g) < 0.8).long(); mk[:, 0] = 1
+            return (x * mk[..., None]).to(device), mk.to(device)
+        (xa, ma), (xp, mp), (xn, mn) = fields(), fields(), fields()
+        loss_fn = QFormerLoss()
+        pack = m._ensure_pack(device)
+        opt = FusedAdamW([pack], lr=1e-4)
+        def step():          # training/item_qformer_training.py:117-131: anchor with grad, pos/neg without
+            out = m(xa, ma)
+            with torch.no_grad():
+                pr = m(xp, mp)["item_representation"]; nr = m(xn, mn)["item_representation"]
+            loss, _, _ = loss_fn(out, {"field_embeddings": xa}, pr, nr, ma)
+            loss.backward(); opt.step(grad_scale=1.0 / world)
+            return loss
+        unit, metric = "items/sec", "items/sec item Q-Former triplet step (C2: L12 Q32 H768 F14, 3 fwd + 1 bwd + AdamW)"
+        flops = 2 * 8.0e12 / 256 * B / 2          # 8.0 TFLOP per 256-item triplet step
+    else:
+        from unirec_amd.user_qformer import UserQFormer
+        B = args.batch if args.batch != 64 else 512
+        T = args.hist * 32
+        m = UserQFormer(dropout=0.1 if p is None else p).to(device).train()
+        x = (torch.randn(B, T, 1024, generator=g) * 0.8).to(device).to(torch.bfloat16)
+        lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+        mask = (torch.arange(T)[None, :] < lens[:, None]).float().to(device)
+        x = x * mask[..., None].to(torch.bfloat16)
+        tgt = (torch.randn(B, 32, 1024, generator=g) * 0.8).to(device)
+        pack = m._ensure_pack(device)
+        opt = FusedAdamW([pack], lr=1e-4)
+        def step():          # training/user_qformer_training.py:203-214
+            loss = mse_loss(m(x, mask), tgt)
+            loss.backward(); opt.step(grad_scale=1.0 / world)
+            return loss
+        unit, metric = "user-sequences/sec", f"user-sequences/sec user Q-Former step (C3: L4 Q64 H1024, T={T}, fwd+bwd+AdamW)"
+        flops = 55.6e12 / 512 * B * (T / 1600.0)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": metric, "value": round(world * B * args.steps / dt, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": args.workload, "per_gpu_batch": B, "dropout": "off" if args.no_dropout else "on"},
+                          "step_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1), "loss": round(float(loss), 5),
+                          "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload != "joint":
+        return run_stage(args)
     if args.cpu_baseline_only:
         from unirec_amd.qwen3 import Qwen3Config
         print(json.dumps(cpu_baseline(args, Qwen3Config(num_hidden_layers=args.layers), (2, 14, 1024, 1024))), flush=True)
