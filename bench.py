@@ -310,11 +310,23 @@ def main():
         for (e0, e1, rk, sk, f32, M, N, K, split) in prof:
             ms = e0.elapsed_time(e1)
             all_ms += ms; all_fl += 2.0 * M * N * K
-            if rk and sk and not f32 and M >= 4096 and N >= 1024:
+            # exactly the launches ur_gemm dispatches to gemm_kernel<RK=1,SK=1,bf16,256,256,2,4> (gemm.hip: launch())
+            if rk and sk and not f32 and M >= 256 and N >= 256 and (-(-M // 256)) * (-(-N // 256)) * max(split, 1) >= 256:
                 tot_ms += ms; tot_fl += 2.0 * M * N * K; n += 1
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        # HBM bytes of one launch from the separate rocprofv3 --pmc passes (profiles/r1_gemm_pmc.json); bench.py itself
+        # cannot collect PMC counters.  Reported for the gate_proj-shaped launch (M=131072,N=3072,K=1024).
+        traffic, tnote = None, "no PMC summary found"
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_gemm_pmc.json")))["launches"]["gate_proj fwd"]
+            if B * args.seq == pm["M"]:
+                traffic = pm["hbm_bytes"]
+                tnote = f"gate_proj launch: PMC HBM bytes {pm['hbm_bytes']} vs algorithmic {pm['algorithmic_bytes']} (x{pm['ratio']}); profiles/r1_gemm_pmc.json"
+        except Exception:
+            pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-                "traffic": None, "kernel": "gemm_kernel<RK=1,SK=1,bf16 out> (forward projections, M>=4096,N>=1024)",
+                "traffic": traffic, "kernel": "gemm_kernel<true,true,false,256,256,2,4> (K-contiguous projection GEMM: forward + frozen-weight dX)",
+                "traffic_note": tnote,
                 "launches": n, "avg_launch_ms": round(tot_ms / max(n, 1), 4),
                 "all_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
                 "all_gemm_ms_per_step": round(all_ms / args.steps, 2)}
