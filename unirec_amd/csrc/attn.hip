@@ -192,6 +192,26 @@ __device__ __forceinline__ void fill_key_words(unsigned long long* kw, const uin
   }
 }
 
+// Workgroup -> (x block, head, batch).  The grid is 1-D.  Consecutive workgroup ids are dealt round-robin to
+// the 8 XCDs, each with its own L2, so the ids are re-read as (xcd = id % 8, slot = id / 8): every (batch,
+// kv head) group -- whose blocks stream the same K/V (forward, dQ) or the same Q/dO (dK/dV) -- gets all its
+// blocks on ONE XCD, adjacent in time, and under the causal mask the heaviest block of the group first.
+struct BlockMap { int x, head, b; };
+template <bool HEAVY_LAST>     // HEAVY_LAST: work grows with x (forward, dQ); else it shrinks (dK/dV)
+__device__ __forceinline__ BlockMap block_map(int nx, int heads_per_group, int ngroups_per_batch, int B) {
+  const int id = blockIdx.x;
+  const int gsz = nx * heads_per_group, ngroups = ngroups_per_batch * B;
+  int grp, j;
+  if ((ngroups & 7) == 0) { const int slot = id >> 3; grp = (slot / gsz) * 8 + (id & 7); j = slot % gsz; }
+  else { grp = id / gsz; j = id % gsz; }
+  BlockMap m;
+  const int xi = j / heads_per_group;
+  m.x = HEAVY_LAST ? nx - 1 - xi : xi;
+  m.head = (grp % ngroups_per_batch) * heads_per_group + j % heads_per_group;
+  m.b = grp / ngroups_per_batch;
+  return m;
+}
+
 // masked, scaled score (natural-log domain).  CAUSAL: SDPA semantics (-inf); else the Q-Former's
 // additive finfo.min (the sum collapses to exactly finfo.min in f32).
 template <bool CAUSAL>
@@ -206,8 +226,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   using C = Cfg<HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int hq = blockIdx.y, b = blockIdx.z, kvh = hq / p.rep;
-  const int qblk = blockIdx.x * (32 * NW) + wave * 32;
+  const BlockMap bm = block_map<true>((p.Sq + 32 * NW - 1) / (32 * NW), p.rep, p.nkv, p.B);
+  const int hq = bm.head, b = bm.b, kvh = hq / p.rep;
+  const int qblk = bm.x * (32 * NW) + wave * 32;
   const int q = qblk + (lane & 31);
   const bool qok = q < p.Sq;
 
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   const float c2 = p.scale * LOG2E;
 
   int kend = p.Sk;
-  if (CAUSAL) kend = min(p.Sk, (int)(blockIdx.x + 1) * (32 * NW));
+  if (CAUSAL) kend = min(p.Sk, (bm.x + 1) * (32 * NW));
   const int ntiles = (kend + KT - 1) / KT;
   const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * HD;
   const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * HD;
@@ -363,8 +384,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
   using C = Cfg<HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int hq = blockIdx.y, b = blockIdx.z, kvh = hq / p.rep;
-  const int qblk = blockIdx.x * (32 * NW) + wave * 32;
+  const BlockMap bm = block_map<true>((p.Sq + 32 * NW - 1) / (32 * NW), p.rep, p.nkv, p.B);
+  const int hq = bm.head, b = bm.b, kvh = hq / p.rep;
+  const int qblk = bm.x * (32 * NW) + wave * 32;
   const int q = qblk + (lane & 31);
   const bool qok = q < p.Sq;
   const long qtok = (long)b * p.Sq + (qok ? q : 0);
@@ -385,7 +407,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
   for (int dt = 0; dt < C::NDT; ++dt) dq[dt] = zero16();
 
   int kend = p.Sk;
-  if (CAUSAL) kend = min(p.Sk, (int)(blockIdx.x + 1) * (32 * NW));
+  if (CAUSAL) kend = min(p.Sk, (bm.x + 1) * (32 * NW));
   const int ntiles = (kend + KT - 1) / KT;
   const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * HD;
   const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * HD;
@@ -472,8 +494,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   constexpr int STG = 2 * C::TILE + 3 * KT * (int)sizeof(float);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
-  const int kvh = blockIdx.y, b = blockIdx.z;
-  const int kblk = blockIdx.x * (32 * NW) + wave * 32;
+  const BlockMap bm = block_map<false>((p.Sk + 32 * NW - 1) / (32 * NW), 1, p.nkv, p.B);
+  const int kvh = bm.head, b = bm.b;
+  const int kblk = bm.x * (32 * NW) + wave * 32;
   const int key = kblk + (lane & 31);
   const bool kok = key < p.Sk;
   const long ktok = (long)b * p.Sk + (kok ? key : 0);
@@ -493,7 +516,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 #pragma unroll
   for (int dt = 0; dt < C::NDT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
 
-  const int qstart = CAUSAL ? ((int)(blockIdx.x * (32 * NW)) / KT) * KT : 0;
+  const int qstart = CAUSAL ? ((bm.x * (32 * NW)) / KT) * KT : 0;
   const int ntq = (p.Sq - qstart + KT - 1) / KT;
   const int ntot = ntq * p.rep;                    // tiles over (query head of the group, query tile)
 
@@ -729,7 +752,7 @@ template <int HD, bool CAUSAL, int NW>
 int launch_fwd(const AttnP& p, hipStream_t st) {
   static bool once = false;
   if (!once) { int rc = set_smem(&attn_fwd_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_fwd"); if (rc) return rc; once = true; }
-  dim3 grid(ur_cdiv(p.Sq, 32 * NW), p.nq, p.B);
+  dim3 grid(ur_cdiv(p.Sq, 32 * NW) * p.nq * p.B);
   hipLaunchKernelGGL((attn_fwd_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), fwd_smem<HD>(), st, p);
   UR_CHECK_LAUNCH("ur_attn_fwd");
   return 0;
@@ -738,7 +761,7 @@ template <int HD, bool CAUSAL, int NW>
 int launch_dq(const AttnP& p, hipStream_t st) {
   static bool once = false;
   if (!once) { int rc = set_smem(&attn_bwd_dq_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_bwd(dq)"); if (rc) return rc; once = true; }
-  dim3 grid(ur_cdiv(p.Sq, 32 * NW), p.nq, p.B);
+  dim3 grid(ur_cdiv(p.Sq, 32 * NW) * p.nq * p.B);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), fwd_smem<HD>(), st, p);
   UR_CHECK_LAUNCH("ur_attn_bwd(dq)");
   return 0;
@@ -747,7 +770,7 @@ template <int HD, bool CAUSAL, int NW>
 int launch_dkv(const AttnP& p, hipStream_t st) {
   static bool once = false;
   if (!once) { int rc = set_smem(&attn_bwd_dkv_kernel<HD, CAUSAL, NW>, dkv_smem<HD>(), "ur_attn_bwd(dkv)"); if (rc) return rc; once = true; }
-  dim3 grid(ur_cdiv(p.Sk, 32 * NW), p.nkv, p.B);
+  dim3 grid(ur_cdiv(p.Sk, 32 * NW) * p.nkv * p.B);
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), dkv_smem<HD>(), st, p);
   UR_CHECK_LAUNCH("ur_attn_bwd(dkv)");
   return 0;
