@@ -79,13 +79,33 @@ template <int HD, int NT>
 struct Loader {
   static constexpr bool DMA = (HD == 128);
   static constexpr int N = (KT * Cfg<HD>::CH) / NT;
+  // 256-thread workgroups: piece i of a tile covers rows 16i + 4*wave + (lane>>4), and the swizzled source
+  // chunk does not depend on i, so the lane's source offset is loop invariant (voff) and a tile costs
+  // no vector arithmetic: uniform row base (scalar) + voff.
+  static constexpr bool HOIST = DMA && NT == 256;
   uint4 r[DMA ? 1 : N];
+  uint32_t voff;
+  __device__ __forceinline__ void init(long ld, int tid) {
+    if (HOIST) {
+      const int lane = tid & 63, wave = tid >> 6;
+      const int row = 4 * wave + (lane >> 4), pos = lane & 15;
+      voff = (uint32_t)(row * ld + (pos ^ (((row & 3) << 2) | ((row >> 2) & 3))) * 8) * 2u;
+    }
+  }
   __device__ __forceinline__ void issue(char* tile, const bf16_t* __restrict__ base, long ld, int row0, int S, int tid) {
     if (DMA) {
       typedef __attribute__((address_space(3))) void lds_void;
       typedef const __attribute__((address_space(1))) void gbl_void;
       const int lane = tid & 63;
       const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+      if (HOIST && row0 + KT <= S) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const char* ub = reinterpret_cast<const char*>(base + (long)(row0 + 16 * i) * ld);     // wave-uniform
+          __builtin_amdgcn_global_load_lds((gbl_void*)(ub + voff), (lds_void*)(tile + (i * 4 + wave) * 1024), 16, 0, 0);
+        }
+        return;
+      }
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const int inst = i * (NT / 64) + wave;                 // wave-uniform: 1 KiB piece index
@@ -255,6 +275,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + 4 * C::TILE);
   fill_key_words(kwords, km, ntiles, p.Sk, tid, NW * 64);
   Loader<HD, NW * 64> ks, vs;
+  ks.init(p.ldk, tid); vs.init(p.ldv, tid);
   ks.issue(smem, kb, p.ldk, 0, p.Sk, tid);
   vs.issue(smem + C::TILE, vb, p.ldv, 0, p.Sk, tid);
   ks.commit(smem, tid);
@@ -418,6 +439,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
   unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + 4 * C::TILE);
   fill_key_words(kwords, km, ntiles, p.Sk, tid, NW * 64);
   Loader<HD, NW * 64> ks, vs;
+  ks.init(p.ldk, tid); vs.init(p.ldv, tid);
   ks.issue(smem, kb, p.ldk, 0, p.Sk, tid);
   vs.issue(smem + C::TILE, vb, p.ldv, 0, p.Sk, tid);
   ks.commit(smem, tid);
@@ -521,6 +543,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   const int ntot = ntq * p.rep;                    // tiles over (query head of the group, query tile)
 
   Loader<HD, NW * 64> qs, dos;
+  qs.init(p.ldq, tid); dos.init(p.lddo, tid);
   auto tile_ptrs = [&](int it, const bf16_t*& qb, const bf16_t*& dob, long& sbase, int& q0) {
     const int hr = it / ntq, tq = it - hr * ntq;
     const int hq = kvh * p.rep + hr;

@@ -82,6 +82,40 @@ __device__ __forceinline__ void dma_tile(char* tile, const bf16_t* __restrict__ 
   }
 }
 
+// Steady-state LDS-DMA: the lane's source offset inside the block's operand panel does not change from
+// tile to tile (only the uniform K position does), so it is computed once (dma_offsets) and a full tile
+// costs no vector arithmetic: every piece is  uniform base (SGPRs) + 32-bit lane offset.
+template <bool KC, int T, int NT>
+__device__ __forceinline__ void dma_offsets(uint32_t (&voff)[(T * BK * 2 / 1024) / (NT / 64)], long ld, int rows_total, int row0, int tid) {
+  constexpr int PER_WAVE = (T * BK * 2 / 1024) / (NT / 64);
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i) {
+    const int inst = i * (NT / 64) + wave;
+    long e;                                     // element offset from base + (KC ? row0 * ld : row0)
+    if (KC) {
+      const int row = inst * 16 + (lane >> 2), pos = lane & 3;
+      const int g = min(row0 + row, rows_total - 1) - row0;
+      e = (long)g * ld + ((pos ^ kc_g(row)) << 3);
+    } else {
+      const int c = inst * 64 + lane;
+      const int kr = c / (T / 8), ch = c % (T / 8);
+      const int col = min(row0 + ((ch ^ (ks_f(kr) << 1)) << 3), rows_total - 8) - row0;
+      e = (long)kr * ld + col;
+    }
+    voff[i] = (uint32_t)(e * 2);
+  }
+}
+template <int T, int NT>
+__device__ __forceinline__ void dma_tile_fast(char* tile, const char* ubase, const uint32_t (&voff)[(T * BK * 2 / 1024) / (NT / 64)], int wave) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+  constexpr int PER_WAVE = (T * BK * 2 / 1024) / (NT / 64);
+#pragma unroll
+  for (int i = 0; i < PER_WAVE; ++i)
+    __builtin_amdgcn_global_load_lds((gbl_void*)(ubase + voff[i]), (lds_void*)(tile + (i * (NT / 64) + wave) * 1024), 16, 0, 0);
+}
+
 // ---- register staging (partial K tiles only: zero-fill past kend) ------------------------------
 template <bool KC, int T, int NT>
 __device__ __forceinline__ void reg_tile(char* tile, const bf16_t* __restrict__ base, long ld, int rows_total, int row0,
@@ -231,6 +265,57 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     mfmas(csf, crf);
   };
 
+  // Steady state (tile t+NSTAGE is a full tile of the first K range, so every tile in flight is a DMA
+  // tile and the counted wait is exact): ONE basic block per step -- the 4 LDS-DMA pieces of the tile
+  // NSTAGE ahead and the 12 fragment reads of tile t+1 are spread between the 32 MFMAs of tile t, so
+  // their issue cost (60-180 cycles per DMA piece) hides under the matrix pipe instead of preceding it.
+  constexpr int SPW = (BN * BK * 2 / 1024) / (NT / 64), RPW = (BM * BK * 2 / 1024) / (NT / 64);
+  uint32_t svoff[SPW], rvoff[RPW];
+  dma_offsets<SK, BN, NT>(svoff, p.lds, p.N, n0, tid);
+  dma_offsets<RK, BM, NT>(rvoff, p.ldr, p.M, m0, tid);
+  const char* const sbase = reinterpret_cast<const char*>(p.S + (SK ? (long)n0 * p.lds : (long)n0));
+  const char* const rbase = reinterpret_cast<const char*>(p.R + (RK ? (long)m0 * p.ldr : (long)m0));
+  const long skstep = (SK ? 1 : p.lds) * 2, rkstep = (RK ? 1 : p.ldr) * 2;      // bytes per unit of k
+  const int uwave = __builtin_amdgcn_readfirstlane(wave);
+  const int nfull1 = (kend > kbeg) ? (kend - kbeg) / BK : 0;
+  auto fast_step = [&](int t, const bf16x8 (&csf)[NI], const bf16x8 (&crf)[MI], bf16x8 (&nsf)[NI], bf16x8 (&nrf)[MI]) {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * DMA_PER_TILE) : "memory");   // tile t+1 landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    char* buf = smem + (t % NSTAGE) * STAGE;
+    const long k0 = kbeg + (long)(t + NSTAGE) * BK;
+    const char* sb = smem + ((t + 1) % NSTAGE) * STAGE;
+    if (SK && RK && NI == 4 && (MI % 4) == 0 && SPW == 2 && RPW == 2) {
+      // four hard-fenced groups: 8 MFMAs + one 1-KiB DMA piece + a quarter of tile t+1's fragment reads
+      typedef __attribute__((address_space(3))) void lds_void;
+      typedef const __attribute__((address_space(1))) void gbl_void;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const char* ub = (g < 2) ? sbase + k0 * skstep : rbase + k0 * rkstep;
+        const uint32_t vo = (g < 2) ? svoff[g & 1] : rvoff[g & 1];
+        char* dst = buf + (g < 2 ? 0 : S_BYTES) + ((g & 1) * (NT / 64) + uwave) * 1024;
+        __builtin_amdgcn_global_load_lds((gbl_void*)(ub + vo), (lds_void*)dst, 16, 0, 0);
+        {
+          bf16x8 one[1];
+          lds_frags<true, BN, 1>(one, sb, wc * WN + 16 * g, lane); nsf[g] = one[0];
+#pragma unroll
+          for (int j = 0; j < MI / 4; ++j) {
+            lds_frags<true, BM, 1>(one, sb + S_BYTES, wr * WM + 16 * (g * (MI / 4) + j), lane);
+            nrf[g * (MI / 4) + j] = one[0];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < MI; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(csf[g], crf[j], acc[g][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      dma_tile_fast<BN, NT>(buf, sbase + k0 * skstep, svoff, uwave);
+      dma_tile_fast<BM, NT>(buf + S_BYTES, rbase + k0 * rkstep, rvoff, uwave);
+      read_frags(nsf, nrf, t + 1);
+      mfmas(csf, crf);
+    }
+  };
+
   // prologue: NSTAGE tiles issued, tile 0 landed and in registers
 #pragma unroll
   for (int t = 0; t < NSTAGE; ++t)
@@ -242,7 +327,12 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     read_frags(sfA, rfA, 0);
   }
-  for (int t = 0; t < nt; t += 2) {
+  int t = 0;
+  for (; t + 1 + NSTAGE < nfull1; t += 2) {
+    fast_step(t, sfA, rfA, sfB, rfB);
+    fast_step(t + 1, sfB, rfB, sfA, rfA);
+  }
+  for (; t < nt; t += 2) {
     step(t, sfA, rfA, sfB, rfB);
     if (t + 1 < nt) step(t + 1, sfB, rfB, sfA, rfA);
   }
