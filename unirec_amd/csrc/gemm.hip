@@ -15,22 +15,29 @@
 // tiles) for the large projections, 128x128x64 with 4 waves (2x2) for small / edge shapes.  The weight-side operand S is the MFMA "A" (row) operand and the
 // token-side operand R the "B" (column) operand, so each lane ends up with 4 CONSECUTIVE n for one
 // m: packed 8-byte (bf16) / 16-byte (f32) stores into row-major C.
-// Staging: LDS-DMA (global_load_lds_dwordx4) straight into a 4-stage ring of XOR-swizzled LDS images
-// (no staging VGPRs, no ds_write); three 32-deep tiles stay in flight under the current tile's MFMAs
-// (counted s_waitcnt vmcnt + raw s_barrier, one barrier per tile).  K-contiguous tiles are read with ds_read_b128,
-// K-strided tiles with ds_read_b64_tr_b16 (hardware transpose); both images are bank-conflict-free.
+// Staging: LDS-DMA (global_load_lds_dwordx4) straight into a 2-slot ring of XOR-swizzled 64-deep LDS images
+// (no staging VGPRs, no ds_write): every wave instruction moves 8 full 128-byte lines; tile t+1 lands and
+// tile t+2 is issued under tile t's 64 MFMAs per wave (one barrier per tile, between its two k-halves).
+// K-contiguous tiles are read with ds_read_b128, K-strided tiles with ds_read_b64_tr_b16 (hardware
+// transpose); both images are bank-conflict-free.
+#include <type_traits>
 #include "common.cuh"
 #include "unirec_hip.h"
 
 namespace {
 
-constexpr int BK = 32;                     // K depth of one ring stage = one v_mfma_f32_16x16x32_bf16 k-step
-constexpr int NSTAGE = 4;                  // LDS ring: 3 tiles of LDS-DMA in flight under the current tile's MFMAs
-constexpr int KC_ROWB = BK * 2;            // K-contiguous tile row bytes
+#ifndef UR_GEMM_ABLATE
+#define UR_GEMM_ABLATE 0          // lab builds only (tools/lab): 1 = no LDS-DMA in the steady state, 2 = no MFMAs, 3 = no barrier
+#endif
+constexpr int BK = 64;                     // K depth of one LDS stage = two v_mfma_f32_16x16x32_bf16 k-steps ("halves")
+constexpr int NSTAGE = 2;                  // LDS ring: tile t is consumed while tile t+1 lands and tile t+2 is issued
+constexpr int KC_ROWB = BK * 2;            // K-contiguous tile row bytes: one full 128-byte cache line per row
 // LDS image of one operand tile of T rows (T = 128 or 256), no padding (LDS-DMA writes linearly):
-//   K-contiguous  [T][32 k] : 64-B rows, 16-B chunk c of row r stored at chunk c ^ g(r),
-//                             g(r) = (-(r >> 2)) & 3  -> conflict-free ds_read_b128 fragment reads
-//   K-strided     [32 k][T] : 2T-byte rows, 32-B segment s of k-row r stored at segment s ^ f(r),
+//   K-contiguous  [T][64 k] : 128-B rows, 16-B chunk c of row r stored at chunk c ^ g(r), g(r) = (r >> 1) & 7
+//                             -> conflict-free ds_read_b128 fragment reads (16 rows x 4 chunks per read), and one
+//                                LDS-DMA wave instruction moves 8 rows x 128 B = 8 FULL cache lines (a 32-deep
+//                                tile moves 16 half lines per instruction: 36 vs 49 B/clk/CU from L2, tools/lab)
+//   K-strided     [64 k][T] : 2T-byte rows, 32-B segment s of k-row r stored at segment s ^ f(r),
 //                             f(r) = (r & 3) | (((r >> 3) & 1) << 2)
 //                             -> the 8 (k-row, 32-B) pieces one half-wave ds_read_b64_tr_b16 touches
 //                                land on 8 different 32-B bank groups: conflict-free transposed reads
@@ -49,10 +56,17 @@ struct GemmP {
   int gm, gn;
 };
 
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));     // opaque SGPR pair: keeps loop strength reduction from turning
+                                             // (uniform base + lane offset) into per-lane 64-bit pointers
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ int ks_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
-__device__ __forceinline__ int kc_g(int r) { return (-(r >> 2)) & 3; }
+__device__ __forceinline__ int kc_g(int r) { return (r >> 1) & 7; }
 
-// ---- LDS-DMA staging of a FULL 32-deep tile: 1 KiB per wave instruction, swizzle on the source ---
+// ---- LDS-DMA staging of a FULL 64-deep tile: 1 KiB per wave instruction, swizzle on the source ---
 // rows/cols past the matrix edge are clamped (they only feed output rows/cols that are never stored)
 template <bool KC, int T, int NT>
 __device__ __forceinline__ void dma_tile(char* tile, const bf16_t* __restrict__ base, long ld, int rows_total, int row0,
@@ -69,7 +83,7 @@ __device__ __forceinline__ void dma_tile(char* tile, const bf16_t* __restrict__ 
     const int inst = i * (NT / 64) + wave;
     const bf16_t* src;
     if (KC) {
-      const int row = inst * 16 + (lane >> 2), pos = lane & 3;
+      const int row = inst * 8 + (lane >> 3), pos = lane & 7;
       const int g = min(row0 + row, rows_total - 1);
       src = base + (long)g * ld + k0 + ((pos ^ kc_g(row)) << 3);
     } else {
@@ -84,7 +98,7 @@ __device__ __forceinline__ void dma_tile(char* tile, const bf16_t* __restrict__ 
 
 // Steady-state LDS-DMA: the lane's source offset inside the block's operand panel does not change from
 // tile to tile (only the uniform K position does), so it is computed once (dma_offsets) and a full tile
-// costs no vector arithmetic: every piece is  uniform base (SGPRs) + 32-bit lane offset.
+// costs no vector arithmetic: every piece is  uniform base + 32-bit lane offset.
 template <bool KC, int T, int NT>
 __device__ __forceinline__ void dma_offsets(uint32_t (&voff)[(T * BK * 2 / 1024) / (NT / 64)], long ld, int rows_total, int row0, int tid) {
   constexpr int PER_WAVE = (T * BK * 2 / 1024) / (NT / 64);
@@ -94,7 +108,7 @@ __device__ __forceinline__ void dma_offsets(uint32_t (&voff)[(T * BK * 2 / 1024)
     const int inst = i * (NT / 64) + wave;
     long e;                                     // element offset from base + (KC ? row0 * ld : row0)
     if (KC) {
-      const int row = inst * 16 + (lane >> 2), pos = lane & 3;
+      const int row = inst * 8 + (lane >> 3), pos = lane & 7;
       const int g = min(row0 + row, rows_total - 1) - row0;
       e = (long)g * ld + ((pos ^ kc_g(row)) << 3);
     } else {
@@ -105,15 +119,6 @@ __device__ __forceinline__ void dma_offsets(uint32_t (&voff)[(T * BK * 2 / 1024)
     }
     voff[i] = (uint32_t)(e * 2);
   }
-}
-template <int T, int NT>
-__device__ __forceinline__ void dma_tile_fast(char* tile, const char* ubase, const uint32_t (&voff)[(T * BK * 2 / 1024) / (NT / 64)], int wave) {
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void gbl_void;
-  constexpr int PER_WAVE = (T * BK * 2 / 1024) / (NT / 64);
-#pragma unroll
-  for (int i = 0; i < PER_WAVE; ++i)
-    __builtin_amdgcn_global_load_lds((gbl_void*)(ubase + voff[i]), (lds_void*)(tile + (i * (NT / 64) + wave) * 1024), 16, 0, 0);
 }
 
 // ---- register staging (partial K tiles only: zero-fill past kend) ------------------------------
@@ -128,7 +133,7 @@ __device__ __forceinline__ void reg_tile(char* tile, const bf16_t* __restrict__ 
     uint4 z = make_uint4(0, 0, 0, 0);
     int off;
     if (KC) {
-      const int row = c >> 2, kc = c & 3;
+      const int row = c >> 3, kc = c & 7;
       const int grow = min(row0 + row, rows_total - 1), gk = k0 + kc * 8;
       if (gk < kend) z = *reinterpret_cast<const uint4*>(base + (long)grow * ld + gk);
       off = row * KC_ROWB + ((kc ^ kc_g(row)) << 4);
@@ -142,33 +147,36 @@ __device__ __forceinline__ void reg_tile(char* tile, const bf16_t* __restrict__ 
   }
 }
 
-// ---- LDS -> MFMA fragments: lane holds [idx = idx0 + 16*i + (lane&15)][k = 8*(lane>>4) + 0..7] ---
+// ---- LDS -> MFMA fragments of k-half h (k = 32h .. 32h+31 of the stage):
+//      lane holds [idx = idx0 + 16*i + (lane&15)][k = 32h + 8*(lane>>4) + 0..7] ---------------------------------
 template <bool KC, int T, int N>
-__device__ __forceinline__ void lds_frags(bf16x8 (&f)[N], const char* tile, int idx0, int lane) {
+__device__ __forceinline__ void lds_frags(bf16x8 (&f)[N], const char* tile, int idx0, int h, int lane) {
   if (KC) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       const int idx = idx0 + 16 * i + (lane & 15);
-      f[i] = *reinterpret_cast<const bf16x8*>(tile + idx * KC_ROWB + (((lane >> 4) ^ kc_g(idx)) << 4));
+      f[i] = *reinterpret_cast<const bf16x8*>(tile + idx * KC_ROWB + (((4 * h + (lane >> 4)) ^ kc_g(idx)) << 4));
     }
   } else {
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-    const int ka = 8 * g + q;                           // k-rows ka (elements 0..3) and ka+4 (elements 4..7)
+    const int ka = 32 * h + 8 * g + q;                  // k-rows ka (elements 0..3) and ka+4 (elements 4..7)
     const uint32_t ra = lds_off(tile) + ka * Tile<T>::KS_ROWB + pp * 8, rb = ra + 4 * Tile<T>::KS_ROWB;
     const int fa = ks_f(ka), fb = ks_f(ka + 4);
+    if (N >= 4) {
 #pragma unroll
-    for (int i0 = 0; i0 < N; i0 += 4) {
-      uint32_t a[4], b[4];
-      bf16x8 t4[4];
+      for (int i0 = 0; i0 < N; i0 += 4) {
+        uint32_t a[4], b[4];
+        bf16x8 t4[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int seg = (idx0 >> 4) + i0 + i;           // 32-byte segment of this 16-column block
-        a[i] = ra + ((seg ^ fa) << 5);
-        b[i] = rb + ((seg ^ fb) << 5);
+        for (int i = 0; i < 4; ++i) {
+          const int seg = (idx0 >> 4) + i0 + i;           // 32-byte segment of this 16-column block
+          a[i] = ra + ((seg ^ fa) << 5);
+          b[i] = rb + ((seg ^ fb) << 5);
+        }
+        tr_read(t4, a, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i0 + i] = t4[i];
       }
-      tr_read(t4, a, b);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) f[i0 + i] = t4[i];
     }
   }
 }
@@ -183,6 +191,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   constexpr int STAGE = S_BYTES + R_BYTES;
   constexpr int WM = BM / NWM, WN = BN / NWN;       // wave tile
   constexpr int MI = WM / 16, NI = WN / 16;         // 16x16 MFMA tiles per wave
+  static_assert((MI % 4) == 0 && (NI % 4) == 0, "fragment reads go in groups of 4");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / NWN, wc = wave % NWN;
@@ -204,6 +213,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   const int nt1 = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
   const int nt2 = (p.K2 > 0) ? (p.K2 + BK - 1) / BK : 0;
   const int nt = nt1 + nt2;
+  const int nfull1 = (kend > kbeg) ? (kend - kbeg) / BK : 0;      // leading full tiles of the first K range
 
   f32x4 acc[NI][MI];
 #pragma unroll
@@ -211,11 +221,15 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // k extent of tile t (how many of its two 32-deep halves carry data)
+  auto tile_k = [&](int t, int& k0, int& ke) {
+    if (t < nt1) { k0 = kbeg + t * BK; ke = kend; } else { k0 = (t - nt1) * BK; ke = p.K2; }
+  };
   // stage tile t into ring slot `buf`: LDS-DMA for full tiles, register path (zero-fill) for K tails
   auto stage = [&](int t, char* buf) {
     const bf16_t* S; const bf16_t* R; long lds_, ldr_; int k0, ke;
-    if (t < nt1) { S = p.S; R = p.R; lds_ = p.lds; ldr_ = p.ldr; k0 = kbeg + t * BK; ke = kend; }
-    else { S = p.S2; R = p.R2; lds_ = p.lds2; ldr_ = p.ldr2; k0 = (t - nt1) * BK; ke = p.K2; }
+    tile_k(t, k0, ke);
+    if (t < nt1) { S = p.S; R = p.R; lds_ = p.lds; ldr_ = p.ldr; } else { S = p.S2; R = p.R2; lds_ = p.lds2; ldr_ = p.ldr2; }
     if (k0 + BK <= ke) {
       dma_tile<SK, BN, NT>(buf, S, lds_, p.N, n0, k0, tid);
       dma_tile<RK, BM, NT>(buf + S_BYTES, R, ldr_, p.M, m0, k0, tid);
@@ -224,28 +238,10 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
       reg_tile<RK, BM, NT>(buf + S_BYTES, R, ldr_, p.M, m0, k0, ke, tid);
     }
   };
-  // LDS-DMA instructions one wave issues per full tile (both operands): the unit of the counted waits
-  constexpr int DMA_PER_TILE = (BN * BK * 2 / 1024) / (NT / 64) + (BM * BK * 2 / 1024) / (NT / 64);
-
-  // Software pipeline (one barrier per 32-deep tile).  Invariant at the top of step(t): tile t's
-  // fragments are in registers, tiles t+1 .. t+NSTAGE-1 have been ISSUED (tile t+1 must have landed,
-  // the others may be in flight).  step(t):
-  //   wait(tile t+1 landed) -> barrier -> refill the ring slot of tile t (its fragments are in registers
-  //   of every wave) with tile t+NSTAGE -> issue the LDS fragment reads of tile t+1 -> MFMAs of tile t.
-  // The fragment reads of the next tile and NSTAGE-2 tiles of LDS-DMA run under the MFMAs.
-  // vmcnt is in-order: "at most n*DMA_PER_TILE outstanding" == "all but the n youngest tiles landed".
-  // A K-tail tile staged through registers issues no DMA, but its own (compiler-waited) global loads
-  // are younger than every DMA before it, so it only makes these waits more conservative.
-  auto wait_all_but = [&](int n_tiles) {
-    if (n_tiles >= 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * DMA_PER_TILE) : "memory");
-    else if (n_tiles == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * DMA_PER_TILE) : "memory");
-    else if (n_tiles == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DMA_PER_TILE) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  auto read_frags = [&](bf16x8 (&sf)[NI], bf16x8 (&rf)[MI], int t) {
-    const char* sb = smem + (t % NSTAGE) * STAGE;
-    lds_frags<SK, BN, NI>(sf, sb, wc * WN, lane);
-    lds_frags<RK, BM, MI>(rf, sb + S_BYTES, wr * WM, lane);
+  auto read_frags = [&](bf16x8 (&sf)[NI], bf16x8 (&rf)[MI], int t, int h) {
+    const char* sb = smem + (t & 1) * STAGE;
+    lds_frags<SK, BN, NI>(sf, sb, wc * WN, h, lane);
+    lds_frags<RK, BM, MI>(rf, sb + S_BYTES, wr * WM, h, lane);
   };
   auto mfmas = [&](const bf16x8 (&sf)[NI], const bf16x8 (&rf)[MI]) {
 #pragma unroll
@@ -254,87 +250,135 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
       for (int j = 0; j < MI; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[i], rf[j], acc[i][j], 0, 0, 0);
   };
-  // one pipeline step: `cur` holds tile t's fragments, `nxt` receives tile t+1's
-  auto step = [&](int t, const bf16x8 (&csf)[NI], const bf16x8 (&crf)[MI], bf16x8 (&nsf)[NI], bf16x8 (&nrf)[MI]) {
-    // issued so far: tiles <= min(nt-1, t+NSTAGE-1); tile t+1 must land, younger issued tiles may fly
-    if (t + 1 < nt) wait_all_but(min(nt - 1, t + NSTAGE - 1) - (t + 1));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // tile t's fragment reads (and K-tail ds_writes) are done
-    __builtin_amdgcn_s_barrier();                           // => slot of tile t is free, tile t+1 is complete
-    if (t + NSTAGE < nt) stage(t + NSTAGE, smem + (t % NSTAGE) * STAGE);
-    if (t + 1 < nt) read_frags(nsf, nrf, t + 1);
-    mfmas(csf, crf);
-  };
 
-  // Steady state (tile t+NSTAGE is a full tile of the first K range, so every tile in flight is a DMA
-  // tile and the counted wait is exact): ONE basic block per step -- the 4 LDS-DMA pieces of the tile
-  // NSTAGE ahead and the 12 fragment reads of tile t+1 are spread between the 32 MFMAs of tile t, so
-  // their issue cost (60-180 cycles per DMA piece) hides under the matrix pipe instead of preceding it.
+  // Software pipeline, ONE barrier per 64-deep tile, placed between its two halves.  Fragment register
+  // sets: A = half 0, B = half 1.  Tile t lives in ring slot t & 1.
+  //   P0(t):  MFMAs(t, half 0) from A   ||  fragment reads (t, half 1) -> B
+  //   mid(t): lgkmcnt(0) (every read of slot t&1 by this wave is done), vmcnt(0) (this wave's pieces of
+  //           tile t+1, issued one tile ago, have landed), barrier  => slot t&1 is free, tile t+1 is complete
+  //   P1(t):  LDS-DMA of tile t+2 -> slot t&1  ||  MFMAs(t, half 1) from B  ||  fragment reads (t+1, half 0) -> A
+  // In the steady state (tile t+2 is a full tile of the first K range) P0 and P1 are four hard-fenced groups
+  // each: 8 (4) MFMAs + a quarter of the fragment reads (+ two DMA pieces in P1), so the issue cost of the
+  // DMA pieces and LDS reads hides under the matrix pipe instead of preceding it.
   constexpr int SPW = (BN * BK * 2 / 1024) / (NT / 64), RPW = (BM * BK * 2 / 1024) / (NT / 64);
-  uint32_t svoff[SPW], rvoff[RPW];
-  dma_offsets<SK, BN, NT>(svoff, p.lds, p.N, n0, tid);
-  dma_offsets<RK, BM, NT>(rvoff, p.ldr, p.M, m0, tid);
+  constexpr bool GROUPED = SK && RK && NI <= MI && ((SPW + RPW) % MI) == 0;
+  // Interior blocks (no edge clamping): piece i of an operand is piece 0 shifted by a uniform number of rows
+  // (K-contiguous: 8 * NT/64 rows; the swizzle term does not depend on i), so ONE lane offset per operand
+  // serves all pieces and the per-piece shift goes into the scalar base.
+  uint32_t svoff0, rvoff0;
+  {
+    uint32_t sv[SPW], rv[RPW];
+    dma_offsets<SK, BN, NT>(sv, p.lds, p.N, n0, tid);
+    dma_offsets<RK, BM, NT>(rv, p.ldr, p.M, m0, tid);
+    svoff0 = sv[0]; rvoff0 = rv[0];
+  }
+  const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  const long spiece = (SK ? (long)(8 * (NT / 64)) * p.lds : (long)((NT / 64) * 512 / (BN / 8)) * p.lds) * 2;   // bytes between pieces
+  const long rpiece = (RK ? (long)(8 * (NT / 64)) * p.ldr : (long)((NT / 64) * 512 / (BM / 8)) * p.ldr) * 2;
   const char* const sbase = reinterpret_cast<const char*>(p.S + (SK ? (long)n0 * p.lds : (long)n0));
   const char* const rbase = reinterpret_cast<const char*>(p.R + (RK ? (long)m0 * p.ldr : (long)m0));
   const long skstep = (SK ? 1 : p.lds) * 2, rkstep = (RK ? 1 : p.ldr) * 2;      // bytes per unit of k
   const int uwave = __builtin_amdgcn_readfirstlane(wave);
-  const int nfull1 = (kend > kbeg) ? (kend - kbeg) / BK : 0;
-  auto fast_step = [&](int t, const bf16x8 (&csf)[NI], const bf16x8 (&crf)[MI], bf16x8 (&nsf)[NI], bf16x8 (&nrf)[MI]) {
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * DMA_PER_TILE) : "memory");   // tile t+1 landed
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    char* buf = smem + (t % NSTAGE) * STAGE;
-    const long k0 = kbeg + (long)(t + NSTAGE) * BK;
-    const char* sb = smem + ((t + 1) % NSTAGE) * STAGE;
-    if (SK && RK && NI == 4 && (MI % 4) == 0 && SPW == 2 && RPW == 2) {
-      // four hard-fenced groups: 8 MFMAs + one 1-KiB DMA piece + a quarter of tile t+1's fragment reads
-      typedef __attribute__((address_space(3))) void lds_void;
-      typedef const __attribute__((address_space(1))) void gbl_void;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const char* ub = (g < 2) ? sbase + k0 * skstep : rbase + k0 * rkstep;
-        const uint32_t vo = (g < 2) ? svoff[g & 1] : rvoff[g & 1];
-        char* dst = buf + (g < 2 ? 0 : S_BYTES) + ((g & 1) * (NT / 64) + uwave) * 1024;
-        __builtin_amdgcn_global_load_lds((gbl_void*)(ub + vo), (lds_void*)dst, 16, 0, 0);
-        {
-          bf16x8 one[1];
-          lds_frags<true, BN, 1>(one, sb, wc * WN + 16 * g, lane); nsf[g] = one[0];
-#pragma unroll
-          for (int j = 0; j < MI / 4; ++j) {
-            lds_frags<true, BM, 1>(one, sb + S_BYTES, wr * WM + 16 * (g * (MI / 4) + j), lane);
-            nrf[g * (MI / 4) + j] = one[0];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(csf[g], crf[j], acc[g][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      dma_tile_fast<BN, NT>(buf, sbase + k0 * skstep, svoff, uwave);
-      dma_tile_fast<BM, NT>(buf + S_BYTES, rbase + k0 * rkstep, rvoff, uwave);
-      read_frags(nsf, nrf, t + 1);
-      mfmas(csf, crf);
-    }
-  };
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
 
-  // prologue: NSTAGE tiles issued, tile 0 landed and in registers
-#pragma unroll
-  for (int t = 0; t < NSTAGE; ++t)
-    if (t < nt) stage(t, smem + t * STAGE);
-  bf16x8 sfA[NI], rfA[MI], sfB[NI], rfB[MI];
-  if (nt > 0) {
-    wait_all_but(min(nt - 1, NSTAGE - 1));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  auto mid = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0), as a builtin so the compiler's wait tracking sees it
+#if UR_GEMM_ABLATE != 3
     __builtin_amdgcn_s_barrier();
-    read_frags(sfA, rfA, 0);
+#endif
+  };
+  // One half-step (32 deep) of the steady state = MI groups, group j = the NI MFMAs of row block j.
+  // The R fragment of the NEXT half-step for block j-1 is read right after block j-1's last use, so it can
+  // take over that register (the next set costs 16 registers for S instead of 48 for S and R), the S
+  // fragments of the next half are spread over the first NI groups, and `extra(j)` issues the group's
+  // share of the LDS-DMA pieces.  Hard fences keep loads and MFMAs of a group in the chosen order.
+  auto half_step = [&](auto loads_first, const bf16x8 (&csf)[NI], bf16x8 (&crf)[MI], bf16x8 (&nsf)[NI],
+                       const char* nb, int nh, auto extra) {
+    constexpr bool LF = decltype(loads_first)::value;
+    auto loads = [&](int j) {
+      bf16x8 one[1];
+      if (j >= 1) { lds_frags<true, BM, 1>(one, nb + S_BYTES, wr * WM + 16 * (j - 1), nh, lane); crf[j - 1] = one[0]; }
+      if (j < NI) { lds_frags<true, BN, 1>(one, nb, wc * WN + 16 * j, nh, lane); nsf[j] = one[0]; }
+      extra(j);
+    };
+#pragma unroll
+    for (int j = 0; j < MI; ++j) {
+      if (LF) { loads(j); __builtin_amdgcn_sched_barrier(0); }
+      bf16x8 rj = crf[j];
+#pragma unroll
+#if UR_GEMM_ABLATE == 2
+      for (int i = 0; i < NI; ++i) acc[i][j][0] += (float)(csf[i][0] ^ rj[0]);       // lab build: no MFMAs
+#else
+      for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(csf[i], rj, acc[i][j], 0, 0, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      if (!LF) { loads(j); __builtin_amdgcn_sched_barrier(0); }
+    }
+    { bf16x8 one[1]; lds_frags<true, BM, 1>(one, nb + S_BYTES, wr * WM + 16 * (MI - 1), nh, lane); crf[MI - 1] = one[0]; }
+  };
+  bf16x8 sfA[NI], rfA[MI], sfB[NI], rfB[MI];
+
+  // prologue: tiles 0 and 1 issued, tile 0 landed, its half-0 fragments in A
+  if (nt > 0) stage(0, smem);
+  if (nt > 1) stage(1, smem + STAGE);
+  if (nt > 0) {
+    // a K-tail tile staged through registers issues no DMA; its own (compiler-waited) loads are older
+    if (nt > 1 && nfull1 >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SPW + RPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    read_frags(sfA, rfA, 0, 0);
   }
   int t = 0;
-  for (; t + 1 + NSTAGE < nfull1; t += 2) {
-    fast_step(t, sfA, rfA, sfB, rfB);
-    fast_step(t + 1, sfB, rfB, sfA, rfA);
+  if (GROUPED && interior) {
+    // ---- steady state: tiles t, t+1 and t+2 are full tiles of the first K range ----
+    auto steady = [&](auto order) {
+      for (; t + 2 < nfull1; ++t) {
+        const char* cur = smem + (t & 1) * STAGE;
+        char* slot = smem + (t & 1) * STAGE;
+        const char* nxt = smem + ((t + 1) & 1) * STAGE;
+        // P0: half 0 from (sfA, rf); the next half's fragments come from the same tile
+        half_step(order, sfA, rfA, sfB, cur, 1, [](int) {});
+        mid();
+        const long kn = kbeg + (long)(t + 2) * BK;
+        // uniform tile bases pinned to SGPRs (scalar per-piece shifts, one lane offset per operand)
+        const char* const ubs = uniform_ptr(sbase + kn * skstep);
+        const char* const ubr = uniform_ptr(rbase + kn * rkstep);
+        auto dma = [&](int j) {
+          constexpr int PPG = (SPW + RPW) / MI;             // pieces per group
+#pragma unroll
+          for (int d = 0; d < PPG; ++d) {
+            const int pi = j * PPG + d;                     // piece index: S pieces first, then R pieces
+            const bool is_s = pi < SPW;
+            const int li = is_s ? pi : pi - SPW;
+            const char* ub = is_s ? ubs + li * spiece : ubr + li * rpiece;      // scalar
+            const uint32_t vo = is_s ? svoff0 : rvoff0;
+            char* dst = slot + (is_s ? 0 : S_BYTES) + (li * (NT / 64) + uwave) * 1024;
+#if UR_GEMM_ABLATE != 1
+            __builtin_amdgcn_global_load_lds((gbl_void*)(ub + vo), (lds_void*)dst, 16, 0, 0);
+#endif
+          }
+        };
+        // P1: half 1 from (sfB, rf); the next half's fragments come from tile t+1
+        half_step(order, sfB, rfA, sfA, nxt, 0, dma);
+      }
+    };
+    steady(std::false_type{});       // MFMAs, then the group's loads (loads-first is the same stream shifted by one group)
   }
-  for (; t < nt; t += 2) {
-    step(t, sfA, rfA, sfB, rfB);
-    if (t + 1 < nt) step(t + 1, sfB, rfB, sfA, rfA);
+  // ---- generic tiles: K tails, the second (LoRA) K range, the last two tiles, K-strided operands ----
+  for (; t < nt; ++t) {
+    char* slot = smem + (t & 1) * STAGE;
+    int k0, ke;
+    tile_k(t, k0, ke);
+    const bool two = ke - k0 > 32;                      // the tile's second half carries data
+    if (two) read_frags(sfB, rfB, t, 1);
+    mfmas(sfA, rfA);
+    mid();
+    if (t + 2 < nt) stage(t + 2, slot);
+    if (t + 1 < nt) read_frags(sfA, rfA, t + 1, 0);
+    if (two) mfmas(sfB, rfB);
   }
 
   // ---- epilogue: lane holds n = n0 + wc*WN + i*16 + (lane>>4)*4 + 0..3, m = m0 + wr*WM + j*16 + (lane&15)
