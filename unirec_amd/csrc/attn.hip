@@ -376,7 +376,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   }
 }
 
-// delta[b][h][q] = sum_d dO[q][d] * O[q][d]
+// Row constants of the backward, two planes of n = B*nq*Sq floats in the caller's scratch:
+//   plane 0: nd[row] = -sum_d dO[q][d] * O[q][d]                      (dS = P * (dP + nd))
+//   plane 1: ns[row] = -(m + ln l) / scale = -LSE / scale             (P = exp2(scale*log2e * (S_raw + ns)))
+// The dK/dV kernel loads both as the INITIAL MFMA accumulators of S and dP, so an interior tile's softmax
+// is one multiply and one exp2 per element with no row maximum, no subtraction and no normaliser.
+// A row without any allowed key (l = 0, SDPA semantics) gets ns = -inf: P = 0.
 template <int HD>
 __global__ void attn_delta_kernel(AttnP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -395,7 +400,13 @@ __global__ void attn_delta_kernel(AttnP p) {
           bf_lo(a.z) * bf_lo(o.z) + bf_hi(a.z) * bf_hi(o.z) + bf_lo(a.w) * bf_lo(o.w) + bf_hi(a.w) * bf_hi(o.w);
   }
   acc = group_sum<LPR>(acc);
-  if (row < nrows && (lane % LPR) == 0) const_cast<float*>(p.delta)[(b * p.nq + hq) * p.Sq + q] = acc;
+  if (row < nrows && (lane % LPR) == 0) {
+    const long r = (b * p.nq + hq) * p.Sq + q;
+    float* ws = const_cast<float*>(p.delta);
+    ws[r] = -acc;
+    const float m = p.stats[2 * r], inv = p.stats[2 * r + 1];
+    ws[nrows + r] = (inv > 0.f) ? -(m - __logf(inv)) / p.scale : NEG_INF;
+  }
 }
 
 // ================================================================================================
@@ -419,7 +430,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
     dof[s] = g_frag(p.dout + qtok * p.lddo + (long)hq * HD, s, lane, qok);
   }
   const long srow = ((long)b * p.nq + hq) * p.Sq + (qok ? q : 0);
-  const float m = p.stats[srow * 2], inv = qok ? p.stats[srow * 2 + 1] : 0.f, dlt = p.delta[srow];
+  const float m = p.stats[srow * 2], inv = qok ? p.stats[srow * 2 + 1] : 0.f, dlt = -p.delta[srow];
   const float c2 = p.scale * LOG2E, mc = m * LOG2E;
   const float invs = inv * p.scale;    // fold the 1/sqrt(d) of dS into the normaliser
 
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             const int r = 4 * rq + e;
             const float ps = fast_exp2(fmaf(sv[r], c2, -ma[e] * LOG2E)) * iv[e];      // p (dS scale applied at the store)
             sv[r] = ps;
-            dpv[r] = ps * (dpv[r] - dl[e]);
+            dpv[r] = ps * (dpv[r] + dl[e]);        // dl = -delta
           }
         }
       };
@@ -685,7 +696,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
               const int r = 4 * rq + e;
               const float ps = fast_exp2(fmaf(s[r], c2, -ma[e] * LOG2E)) * iv[e];      // p * scale
               s[r] = ps;
-              dp[r] = ps * (dp[r] - dl[e]);
+              dp[r] = ps * (dp[r] + dl[e]);          // dl = -delta
             }
           }
         } else {
@@ -710,7 +721,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
                 g *= dsc; pd *= dsc;
               }
               s[r] = pd;
-              dp[r] = ps * (g - dl[e]);
+              dp[r] = ps * (g + dl[e]);
             }
           }
         }
@@ -730,6 +741,270 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       }
     }
     if (it + 1 < ntot) store_tile(smem + ((it + 1) & 1) * STG);
+    __syncthreads();
+  }
+  if (kok) {
+    store_T<HD>(p.dk + ((long)b * p.Sk + key) * p.lddk + (long)kvh * HD, dk, p.scale, lane);     // dS was kept unscaled
+    store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 1.0f, lane);
+  }
+}
+
+// ================================================================================================
+// dK/dV for head_dim 128, 4 waves (the Qwen3 shape): same decomposition as attn_bwd_dkv_kernel, one wave per
+// SIMD with the whole register file, but built for instruction ISSUE, which bounded the first version
+// (10 vector instructions per MFMA, 175 accumulator moves per tile):
+//   * interior tiles load -LSE/scale and -delta (attn_delta_kernel) as the INITIAL accumulators of the S and
+//     dP chains: P = exp2(c * S'), dS = P * dP' -- three vector instructions per element, no row constants
+//     held in registers;
+//   * lane-constant LDS offsets (row fragments, transposed fragments) are computed once per workgroup;
+//   * four hard-fenced phases per 64-query tile: [S,dP](a) | [S,dP](b) + softmax(a) | [dV,dK](a) + softmax(b)
+//     | [dV,dK](b): every phase pairs 16 MFMAs with independent vector work of the other half.
+// LDS per buffer: Q tile | dO tile | ns[64] | nd[64] | (m, 1/l)[64] (general path only).
+// Split transposed reads for the one-wave-per-SIMD dK/dV kernel: tr_issue4 starts the 8 reads of one batch
+// (4 fragments), tr_landed<N> waits until at most N younger LDS reads are outstanding and ties the batch's
+// registers to that wait.  Between the two the registers hold no data yet: this is only sound while the
+// allocator leaves them alone (it parked them in AGPRs at 426 registers; at <= 380 it does not -- the
+// build check in tests/test_cabi.py greps the ISA for exactly that).
+__device__ __forceinline__ void tr_issue4(bf16x4 (&lo)[4], bf16x4 (&hi)[4], const uint32_t (&a)[4], const uint32_t (&b)[4]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\t"
+      "ds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
+      "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\t"
+      "ds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15"
+      : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
+      : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]));
+}
+template <int N>
+__device__ __forceinline__ void tr_landed(bf16x4 (&lo)[4], bf16x4 (&hi)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3])
+               : "n"(N));
+}
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv2_kernel(AttnP p) {
+  constexpr int HD = 128, NW = 4;
+  using C = Cfg<HD>;
+  constexpr int STG = 2 * C::TILE + 4 * KT * (int)sizeof(float);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const BlockMap bm = block_map<false>((p.Sk + 32 * NW - 1) / (32 * NW), 1, p.nkv, p.B);
+  const int kvh = bm.head, b = bm.b;
+  const int kblk = bm.x * (32 * NW) + wave * 32;
+  const int key = kblk + (lane & 31);
+  const bool kok = key < p.Sk;
+  const long ktok = (long)b * p.Sk + (kok ? key : 0);
+
+  bf16x8 kf[C::NS], vf[C::NS];
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) {
+    kf[s] = g_frag(p.k + ktok * p.ldk + (long)kvh * HD, s, lane, kok);
+    vf[s] = g_frag(p.v + ktok * p.ldv + (long)kvh * HD, s, lane, kok);
+  }
+  const bool kvalid = kok && (p.kmask == nullptr || p.kmask[(long)b * p.Sk + key] != 0);
+  const bool all_valid = __all(kvalid);
+  const float c2 = p.scale * LOG2E;
+  const long nrows = (long)p.B * p.nq * p.Sq;
+
+  f32x16 dk[C::NDT], dv[C::NDT];
+#pragma unroll
+  for (int dt = 0; dt < C::NDT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
+
+  const int qstart = CAUSAL ? ((bm.x * (32 * NW)) / KT) * KT : 0;
+  const int ntq = (p.Sq - qstart + KT - 1) / KT;
+  const int ntot = ntq * p.rep;                    // tiles over (query head of the group, query tile)
+
+  Loader<HD, NW * 64> qs, dos;
+  qs.init(p.ldq, tid); dos.init(p.lddo, tid);
+  auto tile_ptrs = [&](int it, const bf16_t*& qb, const bf16_t*& dob, long& sbase, int& q0) {
+    const int hr = it / ntq, tq = it - hr * ntq;
+    const int hq = kvh * p.rep + hr;
+    qb = p.q + (long)b * p.Sq * p.ldq + (long)hq * HD;
+    dob = p.dout + (long)b * p.Sq * p.lddo + (long)hq * HD;
+    sbase = ((long)b * p.nq + hq) * p.Sq;
+    q0 = qstart + tq * KT;
+  };
+  // row constants travel by LDS-DMA too (one dword per lane): ns[64] | nd[64] | (m, 1/l)[64]; rows past Sq are
+  // clamped copies (masked by position in the general path; an interior tile has none)
+  auto load_tile = [&](int it, char* buf) {
+    const bf16_t* qb; const bf16_t* dob; long sbase; int q0;
+    tile_ptrs(it, qb, dob, sbase, q0);
+    qs.issue(buf, qb, p.ldq, q0, p.Sq, tid);
+    dos.issue(buf + C::TILE, dob, p.lddo, q0, p.Sq, tid);
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+      typedef __attribute__((address_space(3))) void lds_void;
+      typedef const __attribute__((address_space(1))) void gbl_void;
+      char* fb = buf + 2 * C::TILE;
+      const int rd = min(q0 + lane, p.Sq - 1);
+      const int r0 = min(q0 + (lane >> 1), p.Sq - 1), r1 = min(q0 + 32 + (lane >> 1), p.Sq - 1);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(p.delta + nrows + sbase + rd), (lds_void*)fb, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(p.delta + sbase + rd), (lds_void*)(fb + 256), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(p.stats + (sbase + r0) * 2 + (lane & 1)), (lds_void*)(fb + 512), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(p.stats + (sbase + r1) * 2 + (lane & 1)), (lds_void*)(fb + 768), 4, 0, 0);
+    }
+  };
+
+  // lane-constant LDS byte offsets (relative to a tile): row fragments of rows (lane&31) for the 8 k-steps, and the
+  // transposed-read offsets of the 4 head_dim blocks; 32-row / 16-row steps are immediates (the swizzle repeats)
+  uint32_t rfo[C::NS], tao[C::NDT], tbo[C::NDT];
+#pragma unroll
+  for (int st = 0; st < C::NS; ++st) rfo[st] = C::off(lane & 31, 2 * st + h);
+  {
+    const int g16 = (lane >> 4) & 1, i = lane & 15;
+    const int row = 4 * h + (i >> 2), sub8 = 8 * (i & 1);
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) {
+      const int ch = 4 * dt + 2 * g16 + ((i & 3) >> 1);
+      tao[dt] = C::off(row, ch) + sub8;
+      tbo[dt] = C::off(row + 8, ch) + sub8;
+    }
+  }
+
+  if (ntot > 0) load_tile(0, smem);
+  __syncthreads();
+
+  for (int it = 0; it < ntot; ++it) {
+    const char* qtile = smem + (it & 1) * STG;
+    const char* dotile = qtile + C::TILE;
+    const float* fst = reinterpret_cast<const float*>(qtile + 2 * C::TILE);
+    // The next tile's LDS-DMA is issued only AFTER the last compiler-visible LDS load of this tile (the row
+    // fragments and row constants of phases 1-2): hipcc puts s_waitcnt vmcnt(0) in front of the first plain LDS
+    // load that follows an LDS-DMA (it cannot tell the two buffers apart), which would expose the whole DMA
+    // latency on every tile.  Phases 3-4 only read LDS through the inline-asm transposed reads.
+    const bf16_t* qb_; const bf16_t* dob_; long sbase_; int q0;
+    tile_ptrs(it, qb_, dob_, sbase_, q0);
+    const bool tile_fast = all_valid && (q0 + KT <= p.Sq) && (!CAUSAL || q0 >= kblk + 31);
+    if (kblk < p.Sk && tile_fast) {
+      const uint32_t qbase = lds_off(qtile), dobase = lds_off(dotile);
+      // initial accumulators: rows 8g + 4h + 0..3 of the 32-row half -> registers 4g .. 4g+3
+      auto init16 = [&](f32x16& a, const float* src) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = *reinterpret_cast<const float4*>(src + 8 * g + 4 * h);
+          a[4 * g] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
+        }
+      };
+      // S' and dP' of one 32-query half: row fragments are read two k-steps ahead of the MFMAs that use them
+      // (one wave per SIMD: nobody else hides the LDS latency), fenced per k-step so the order stays as written
+      auto s_dp = [&](f32x16& sv, f32x16& dpv, int half) {
+        init16(sv, fst + 32 * half);
+        init16(dpv, fst + 64 + 32 * half);
+        bf16x8 qa[3], da[3];
+        auto rd = [&](int st) {
+          qa[st % 3] = *reinterpret_cast<const bf16x8*>(qtile + rfo[st] + 32 * 256 * half);
+          da[st % 3] = *reinterpret_cast<const bf16x8*>(dotile + rfo[st] + 32 * 256 * half);
+        };
+        rd(0); rd(1);
+#pragma unroll
+        for (int st = 0; st < C::NS; ++st) {
+          if (st + 2 < C::NS) rd(st + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          sv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[st % 3], kf[st], sv, 0, 0, 0);
+          dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[st % 3], vf[st], dpv, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      auto soft = [&](f32x16& sv, f32x16& dpv) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pr = fast_exp2(sv[r] * c2);
+          sv[r] = pr;
+          dpv[r] = pr * dpv[r];
+        }
+      };
+      f32x16 sa, dpa, sb, dpb;
+      // dV^T += dO^T P, dK^T += Q^T dS of one 32-query half: four batches of transposed fragments (dO^T and Q^T of
+      // the two 16-query steps), each issued one batch ahead of the 4 MFMAs that consume the previous one
+      auto dvdk_half = [&](const f32x16& pv, const f32x16& dsv, int row0) {
+        const bf16x8 p0 = acc_frag(pv, 0), d0 = acc_frag(dsv, 0), p1 = acc_frag(pv, 1), d1 = acc_frag(dsv, 1);
+        bf16x4 l0[4], h0[4], l1[4], h1[4];
+        auto issue = [&](bf16x4 (&lo)[4], bf16x4 (&hi)[4], uint32_t base, int r0) {
+          uint32_t a[4], bb[4];
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) { a[dt] = base + tao[dt] + 256 * r0; bb[dt] = base + tbo[dt] + 256 * r0; }
+          tr_issue4(lo, hi, a, bb);
+        };
+        issue(l0, h0, dobase, row0);            // batch 0: dO^T, queries row0 .. row0+15
+        issue(l1, h1, qbase, row0);             // batch 1: Q^T
+        tr_landed<8>(l0, h0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat4(l0[dt], h0[dt]), p0, dv[dt], 0, 0, 0);
+        issue(l0, h0, dobase, row0 + 16);       // batch 2: dO^T, queries row0+16 .. row0+31
+        tr_landed<8>(l1, h1);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat4(l1[dt], h1[dt]), d0, dk[dt], 0, 0, 0);
+        issue(l1, h1, qbase, row0 + 16);        // batch 3: Q^T
+        tr_landed<8>(l0, h0);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat4(l0[dt], h0[dt]), p1, dv[dt], 0, 0, 0);
+        tr_landed<0>(l1, h1);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat4(l1[dt], h1[dt]), d1, dk[dt], 0, 0, 0);
+      };
+      // phase 1: S', dP' of half a
+      s_dp(sa, dpa, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // phase 2: S', dP' of half b; softmax of half a
+      s_dp(sb, dpb, 1);
+      soft(sa, dpa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (it + 1 < ntot) load_tile(it + 1, smem + ((it + 1) & 1) * STG);
+      __builtin_amdgcn_sched_barrier(0);
+      // phase 3: dV, dK of half a; softmax of half b
+      dvdk_half(sa, dpa, 0);
+      soft(sb, dpb);
+      __builtin_amdgcn_sched_barrier(0);
+      // phase 4: dV, dK of half b
+      dvdk_half(sb, dpb, 32);
+    } else if (kblk < p.Sk) {
+      const int hq = kvh * p.rep + it / ntq;
+      (void)hq;
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub) {
+        const int qbase = q0 + 32 * sub;
+        if (qbase >= p.Sq) break;
+        if (CAUSAL && qbase + 31 < kblk) continue;        // every query of this sub-tile precedes every key
+        f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+        for (int st = 0; st < C::NS; ++st) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(qtile, 32 * sub, st, lane), kf[st], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dotile, 32 * sub, st, lane), vf[st], dp, 0, 0, 0);
+        }
+        const int qb0 = opaque(qbase + 4 * h), keyo = opaque(key);
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int qr = 32 * sub + 8 * rq + 4 * h;
+          const float4 a = *reinterpret_cast<const float4*>(fst + 128 + 2 * qr);          // (m, 1/l) of rows qr, qr+1
+          const float4 bq = *reinterpret_cast<const float4*>(fst + 128 + 2 * qr + 4);     // rows qr+2, qr+3
+          const float4 cq = *reinterpret_cast<const float4*>(fst + 64 + qr);              // -delta of rows qr..qr+3
+          const float ma[4] = {a.x, a.z, bq.x, bq.z}, iv[4] = {a.y, a.w, bq.y, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
+            const int qpos = qb0 + e + 8 * rq;
+            const float sc = mask_score<CAUSAL>(s[r], p.scale, kvalid, kok, keyo, qpos);       // natural-log domain
+            const float ps = (sc == NEG_INF || qpos >= p.Sq) ? 0.f : fast_exp2((sc - ma[e]) * LOG2E) * iv[e];
+            s[r] = ps;
+            dp[r] = ps * (dp[r] + dl[e]);
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pf = acc_frag(s, s2), df = acc_frag(dp, s2);
+          bf16x8 tdo[C::NDT], tq[C::NDT];
+          tr_frags<HD>(tdo, dotile, 32 * sub + 16 * s2, lane);
+          tr_frags<HD>(tq, qtile, 32 * sub + 16 * s2, lane);
+#pragma unroll
+          for (int dt = 0; dt < C::NDT; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tdo[dt], pf, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[dt], df, dk[dt], 0, 0, 0);
+          }
+        }
+      }
+      if (it + 1 < ntot) load_tile(it + 1, smem + ((it + 1) & 1) * STG);
+    } else {
+      if (it + 1 < ntot) load_tile(it + 1, smem + ((it + 1) & 1) * STG);     // waves past Sk still take part in the staging
+    }
     __syncthreads();
   }
   if (kok) {
@@ -791,9 +1066,17 @@ int launch_dq(const AttnP& p, hipStream_t st) {
 }
 template <int HD, bool CAUSAL, int NW>
 int launch_dkv(const AttnP& p, hipStream_t st) {
+  dim3 grid(ur_cdiv(p.Sk, 32 * NW) * p.nkv * p.B);
+  if (HD == 128 && NW == 4 && p.drop_thr == 0) {
+    constexpr int SM2 = 2 * (2 * Cfg<128>::TILE + 4 * KT * (int)sizeof(float));
+    static bool once2 = false;
+    if (!once2) { int rc = set_smem(&attn_bwd_dkv2_kernel<CAUSAL>, SM2, "ur_attn_bwd(dkv2)"); if (rc) return rc; once2 = true; }
+    hipLaunchKernelGGL((attn_bwd_dkv2_kernel<CAUSAL>), grid, dim3(256), SM2, st, p);
+    UR_CHECK_LAUNCH("ur_attn_bwd(dkv2)");
+    return 0;
+  }
   static bool once = false;
   if (!once) { int rc = set_smem(&attn_bwd_dkv_kernel<HD, CAUSAL, NW>, dkv_smem<HD>(), "ur_attn_bwd(dkv)"); if (rc) return rc; once = true; }
-  dim3 grid(ur_cdiv(p.Sk, 32 * NW) * p.nkv * p.B);
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), dkv_smem<HD>(), st, p);
   UR_CHECK_LAUNCH("ur_attn_bwd(dkv)");
   return 0;

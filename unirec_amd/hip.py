@@ -222,7 +222,7 @@ def attn_bwd(ctx, dout, dq=None, dk=None, dv=None):
     if dv is None:
         dv = torch.empty(v.shape, dtype=BF16, device=q.device)
     a = ctx.args
-    delta = torch.empty((a.B, a.nq, a.Sq), dtype=F32, device=q.device)
+    delta = torch.empty((2, a.B, a.nq, a.Sq), dtype=F32, device=q.device)   # row constants: -rowsum(dO*O), -LSE/scale
     g = AttnBwdArgs()
     g.dout, g.dq, g.dk, g.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     g.lddo, g.lddq, g.lddk, g.lddv = _tok_stride(dout), _tok_stride(dq), _tok_stride(dk), _tok_stride(dv)
