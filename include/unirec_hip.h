@@ -59,7 +59,23 @@ typedef struct {
   void* gelu_out; int64_t ldg;
   const void* gelu_grad_aux; int64_t ldaux;
   int32_t split_k;
+  /* LoRA dropout -- peft LoraLayer: result = base(x) + lora_B(lora_A(dropout(x))) * scaling, one nn.Dropout per
+   * adapter (training/train_item_individual_token_joint.py:121-131: lora_dropout=0.1).  The keep mask of adapter
+   * slot s (0..3; adapters that share an input use different slots) at element (row, col) of its [rows, drop_ld]
+   * input is a pure function of (drop_seed, row*drop_ld + col): bits [16s, 16s+16) of a 64-bit hash >= p*65536
+   * (ur_dropout_mask16 exports it).  The 1/(1-p) scale is the caller's (fold it into alpha), except in mode 3.
+   *   drop_mode 0: off.
+   *   drop_mode 1: operand R is the adapter input x (K-contiguous: x[m][k]; K-strided: x[k][m]); dropped elements
+   *                are zeroed while the tile is staged (forward: t = s * dropout(x) A^T).
+   *   drop_mode 2: the same for operand S (backward: dA = tb^T dropout(x)).
+   *   drop_mode 3: the second pair holds K2/drop_rank adapters that share the input: instead of joining the main
+   *                reduction, C(m,n) += sum_j keep_{slot+j}(m,n)/(1-p) * R2[m, j*r:(j+1)*r] . S2[n, j*r:(j+1)*r]
+   *                (backward: dx = dy W + sum_j mask_j * (tb_j A_j)); C is the adapter input gradient [M, drop_ld = N]. */
+  int32_t drop_mode; int32_t drop_slot; int32_t drop_rank;
+  float drop_p; uint64_t drop_seed; int64_t drop_ld;
 } ur_gemm_args;
+/* keep mask of ur_gemm's LoRA dropout for n consecutive elements starting at element index `first`: out[i] = 1/0 */
+int ur_dropout_mask16(uint64_t seed, int32_t slot, float p, int64_t first, int64_t n, uint8_t* out, void* stream);
 int64_t ur_gemm_workspace_bytes(const ur_gemm_args* a);
 int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, void* stream);
 

@@ -28,6 +28,7 @@ class Qwen3Cfg:
     rms_norm_eps: float = 1e-6
     lora_r: int = 16
     lora_alpha: float = 32.0
+    lora_dropout: float = 0.0        # reference call site :121-131 trains with 0.1; masks are an explicit input here
 
     @property
     def lora_scale(self):
@@ -57,12 +58,18 @@ def rotate_half(x):
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
 
 
-def lora_linear(P, name, x, cfg: Qwen3Cfg):
-    """Base Linear (bias-free) + LoRA delta if adapter tensors are present."""
+def lora_linear(P, name, x, cfg: Qwen3Cfg, masks=None):
+    """Base Linear (bias-free) + LoRA delta if adapter tensors are present.
+    peft LoraLayer (training mode): result = base(x) + lora_B(lora_A(dropout(x))) * scaling, one nn.Dropout per
+    adapter.  The Bernoulli keep mask is an explicit input (masks[name], 0/1, shape of x): nn.Dropout's RNG
+    stream is not part of the algorithm; dropout(x) = x * mask / (1 - p)."""
     y = linear(x, P[name + ".weight"])
     a = P.get(name + ".lora_A.weight")
     if a is not None:
-        y = y + cfg.lora_scale * linear(linear(x, a), P[name + ".lora_B.weight"])
+        xd = x
+        if masks is not None and name in masks:
+            xd = x * masks[name].to(x.dtype).reshape(x.shape) / (1.0 - cfg.lora_dropout)
+        y = y + cfg.lora_scale * linear(linear(xd, a), P[name + ".lora_B.weight"])
     return y
 
 
@@ -89,15 +96,15 @@ def masked_softmax(scores, ok, fully_masked):
     return torch.where(ok.any(dim=-1, keepdim=True), w, torch.zeros_like(w))
 
 
-def decoder_layer(P, pre, x, cos, sin, ok, cfg: Qwen3Cfg, fully_masked="zero"):
+def decoder_layer(P, pre, x, cos, sin, ok, cfg: Qwen3Cfg, fully_masked="zero", masks=None):
     """Qwen3DecoderLayer.forward modeling_qwen3.py:306-331 with Qwen3Attention :244-280,
     eager_attention_forward :185-208, Qwen3MLP :81-83."""
     B, S, _ = x.shape
     nq, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     h = rms_norm(x, P[pre + "input_layernorm.weight"], cfg.rms_norm_eps)
-    q = lora_linear(P, pre + "self_attn.q_proj", h, cfg).view(B, S, nq, hd)
-    k = lora_linear(P, pre + "self_attn.k_proj", h, cfg).view(B, S, nkv, hd)
-    v = lora_linear(P, pre + "self_attn.v_proj", h, cfg).view(B, S, nkv, hd)
+    q = lora_linear(P, pre + "self_attn.q_proj", h, cfg, masks).view(B, S, nq, hd)
+    k = lora_linear(P, pre + "self_attn.k_proj", h, cfg, masks).view(B, S, nkv, hd)
+    v = lora_linear(P, pre + "self_attn.v_proj", h, cfg, masks).view(B, S, nkv, hd)
     q = rms_norm(q, P[pre + "self_attn.q_norm.weight"], cfg.rms_norm_eps).transpose(1, 2)
     k = rms_norm(k, P[pre + "self_attn.k_norm.weight"], cfg.rms_norm_eps).transpose(1, 2)
     v = v.transpose(1, 2)
@@ -109,15 +116,15 @@ def decoder_layer(P, pre, x, cos, sin, ok, cfg: Qwen3Cfg, fully_masked="zero"):
     v = v[:, :, None].expand(B, nkv, rep, S, hd).reshape(B, nq, S, hd)
     w = masked_softmax(q @ k.transpose(2, 3) * (hd ** -0.5), ok, fully_masked)
     a = (w @ v).transpose(1, 2).reshape(B, S, nq * hd)
-    x = x + lora_linear(P, pre + "self_attn.o_proj", a, cfg)
+    x = x + lora_linear(P, pre + "self_attn.o_proj", a, cfg, masks)
     h = rms_norm(x, P[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
-    g = lora_linear(P, pre + "mlp.gate_proj", h, cfg)
-    u = lora_linear(P, pre + "mlp.up_proj", h, cfg)
-    x = x + lora_linear(P, pre + "mlp.down_proj", torch.nn.functional.silu(g) * u, cfg)
+    g = lora_linear(P, pre + "mlp.gate_proj", h, cfg, masks)
+    u = lora_linear(P, pre + "mlp.up_proj", h, cfg, masks)
+    x = x + lora_linear(P, pre + "mlp.down_proj", torch.nn.functional.silu(g) * u, cfg, masks)
     return x
 
 
-def qwen3_forward(P, cfg: Qwen3Cfg, inputs_embeds, attention_mask=None, prefix="", fully_masked="zero"):
+def qwen3_forward(P, cfg: Qwen3Cfg, inputs_embeds, attention_mask=None, prefix="", fully_masked="zero", lora_masks=None):
     """Qwen3Model.forward on inputs_embeds, modeling_qwen3.py:367-425 -> last_hidden_state
     (== hidden_states[-1], i.e. AFTER the final norm; SURVEY §3.3 [probe])."""
     B, S, _ = inputs_embeds.shape
@@ -125,7 +132,7 @@ def qwen3_forward(P, cfg: Qwen3Cfg, inputs_embeds, attention_mask=None, prefix="
     ok = attention_allowed(attention_mask, S)
     x = inputs_embeds
     for i in range(cfg.num_hidden_layers):
-        x = decoder_layer(P, f"{prefix}layers.{i}.", x, cos, sin, ok, cfg, fully_masked)
+        x = decoder_layer(P, f"{prefix}layers.{i}.", x, cos, sin, ok, cfg, fully_masked, lora_masks)
     return rms_norm(x, P[prefix + "norm.weight"], cfg.rms_norm_eps)
 
 
@@ -142,13 +149,13 @@ def inject_tokens(text_embeds, input_ids, item_tokens, first_special_id):
 
 
 def joint_forward(P, cfg: Qwen3Cfg, input_ids, attention_mask, item_tokens, first_special_id, prefix="",
-                  fully_masked="zero"):
+                  fully_masked="zero", lora_masks=None):
     """MultiModalQwenEmbedding.forward after the Q-Former call (:143,160-181):
     embed -> inject -> Qwen3(+LoRA) -> mean over ALL S positions."""
     text = P[prefix + "embed_tokens.weight"][input_ids]
     if item_tokens is not None:
         text = inject_tokens(text, input_ids, item_tokens, first_special_id)
-    h = qwen3_forward(P, cfg, text, attention_mask, prefix, fully_masked)
+    h = qwen3_forward(P, cfg, text, attention_mask, prefix, fully_masked, lora_masks)
     return h.mean(dim=1)
 
 

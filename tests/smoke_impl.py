@@ -23,7 +23,7 @@ def run_smoke():
     qf = load_generated(qf, R.item_qformer_shapes(cfg, c["F"]), case["seed"], dev)
     hc = Qwen3Config(vocab_size=case["first_special_id"], hidden_size=qc.hidden_size, intermediate_size=qc.intermediate_size,
                      num_hidden_layers=qc.num_hidden_layers, num_attention_heads=qc.num_attention_heads,
-                     num_key_value_heads=qc.num_key_value_heads, head_dim=qc.head_dim, lora_r=qc.lora_r, lora_alpha=qc.lora_alpha)
+                     num_key_value_heads=qc.num_key_value_heads, head_dim=qc.head_dim, lora_r=qc.lora_r, lora_alpha=qc.lora_alpha, lora_dropout=0.0)
     m = MultiModalQwenEmbedding(qformer_model=qf, use_lora=True, qwen_config=hc, num_history_items=case["hist"], num_query_tokens_per_item=c["Q"])
     base = {k: torch.from_numpy(v) for k, v in W.fill_state_dict(Q.qwen3_shapes(qc, lora=False), case["seed"] + 1).items()}
     lsh = {k: s for k, s in Q.qwen3_shapes(qc, lora=True).items() if ".lora_" in k}

@@ -22,7 +22,7 @@ def _qwen_cfg(qc, lora):
     return Qwen3Config(vocab_size=qc.vocab_size, hidden_size=qc.hidden_size, intermediate_size=qc.intermediate_size,
                        num_hidden_layers=qc.num_hidden_layers, num_attention_heads=qc.num_attention_heads,
                        num_key_value_heads=qc.num_key_value_heads, head_dim=qc.head_dim, rms_norm_eps=qc.rms_norm_eps,
-                       rope_theta=qc.rope_theta, lora_r=qc.lora_r, lora_alpha=qc.lora_alpha)
+                       rope_theta=qc.rope_theta, lora_r=qc.lora_r, lora_alpha=qc.lora_alpha, lora_dropout=0.0)
 
 
 def _build_joint(case, use_lora, lora_seed=None):
@@ -130,6 +130,77 @@ def test_joint_with_lora_matches_oracle(name):
         assert_close(named[k].grad, PL[k].grad.numpy(), GRAD_REL * 1.5, "grad/" + k)
     assert_close(dict(qf.named_parameters())["query_embeddings"].grad, PQ["query_embeddings"].grad.numpy(), GRAD_REL * 1.5, "grad/query_embeddings")
     assert named["layers.0.self_attn.q_proj.weight"].grad is None      # base weights are frozen
+
+
+@pytest.mark.parametrize("name", JOINT[:1])
+def test_joint_with_lora_dropout_matches_oracle(name):
+    """LoRA dropout (reference :121-131, lora_dropout=0.1; peft: one nn.Dropout per adapter on the adapter's
+    input).  The HIP path draws its masks from a counter-based hash; the test exports exactly those masks
+    (hip.dropout_mask16) and feeds them to the oracle, so the arithmetic -- forward, dA with the masked input,
+    dB, and the masked gradient into the adapter input -- is checked element for element; the mask statistics
+    are checked separately."""
+    from unirec_amd import hip
+    from unirec_amd.joint import InfoNCELoss
+    case = cases.ALL[name]
+    c = case["cfg"]
+    qc = cases.qwen_cfg(case)
+    pdrop = 0.25
+    m, qf = _build_joint(case, use_lora=True, lora_seed=case["seed"] + 2)
+    bm = m.base_model
+    bm.config.lora_dropout = pdrop
+    bm.lora_seed, bm._lora_step = 77, 5
+    ids, am, hfe, ham, pos, neg, nmask = cases.joint_inputs(case)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    user = m(t(ids), t(am), t(hfe), t(ham))
+    loss = InfoNCELoss()(user, t(pos), t(neg), t(nmask))
+    loss.backward()
+    assert bm._lora_step == 6
+    # the masks the kernels used
+    B, S = ids.shape
+    M, D, I, NQ = B * S, qc.hidden_size, qc.intermediate_size, qc.num_attention_heads * qc.head_dim
+    groups = {0: (("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), D), 1: (("self_attn.o_proj",), NQ),
+              2: (("mlp.gate_proj", "mlp.up_proj"), D), 3: (("mlp.down_proj",), I)}
+    masks, kept = {}, []
+    for i in range(qc.num_hidden_layers):
+        for g, (names, width) in groups.items():
+            seed = bm.lora_dropout_seed(5, i, g)
+            for slot, nm in enumerate(names):
+                mk = hip.dropout_mask16(seed, slot, pdrop, M * width, DEV).cpu().view(B, S, width)
+                masks[f"layers.{i}.{nm}"] = mk
+                kept.append(mk.float().mean().item())
+    assert abs(sum(kept) / len(kept) - (1 - pdrop)) < 0.01, kept
+    assert not torch.equal(masks["layers.0.self_attn.q_proj"], masks["layers.0.self_attn.k_proj"])      # one mask per adapter
+    # oracle with the same masks
+    qc.lora_dropout = pdrop
+    cfg = R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 2)
+    PQ = {k: torch.from_numpy(v).requires_grad_(True) for k, v in W.fill_state_dict(R.item_qformer_shapes(cfg, c["F"]), case["seed"]).items()}
+    PW = {k: torch.from_numpy(v) for k, v in W.fill_state_dict(Q.qwen3_shapes(qc, lora=False), case["seed"] + 1).items()}
+    lsh = {k: s_ for k, s_ in Q.qwen3_shapes(qc, lora=True).items() if ".lora_" in k}
+    PL = {k: torch.from_numpy(v).requires_grad_(True) for k, v in W.fill_state_dict(lsh, case["seed"] + 2).items()}
+    hist = case["hist"]
+    out = R.item_qformer_forward(PQ, cfg, torch.from_numpy(hfe).view(B * hist, c["F"], c["E"]), torch.from_numpy(ham).view(B * hist, c["F"]))
+    toks = out["query_outputs"].view(B, hist, c["Q"], c["H"])
+    ou = Q.joint_forward({**PW, **PL}, qc, torch.from_numpy(ids), torch.from_numpy(am), toks, case["first_special_id"], lora_masks=masks)
+    ol = Q.infonce_loss(ou, torch.from_numpy(pos), torch.from_numpy(neg), torch.from_numpy(nmask))
+    ol.backward()
+    print(name, "(LoRA dropout)")
+    assert_close(user, ou.detach().numpy(), OUT_REL, "user_embeddings")
+    assert_close(loss, ol.detach().numpy(), OUT_REL, "loss")
+    named = dict(bm.named_parameters())
+    for k in ("layers.0.self_attn.q_proj.lora_A.weight", "layers.0.self_attn.k_proj.lora_A.weight", "layers.0.self_attn.v_proj.lora_B.weight",
+              "layers.1.self_attn.o_proj.lora_A.weight", "layers.1.mlp.gate_proj.lora_A.weight", "layers.0.mlp.up_proj.lora_A.weight",
+              "layers.1.mlp.down_proj.lora_A.weight", "layers.0.mlp.down_proj.lora_B.weight"):
+        assert_close(named[k].grad, PL[k].grad.numpy(), GRAD_REL * 1.5, "grad/" + k)
+    # the gradient that reaches the Q-Former went through every masked adapter-input gradient (drop_mode 3)
+    assert_close(dict(qf.named_parameters())["query_embeddings"].grad, PQ["query_embeddings"].grad.numpy(), GRAD_REL * 1.5, "grad/query_embeddings")
+    # eval mode: no dropout, and the step counter does not move
+    m.eval()
+    with torch.no_grad():
+        u0 = m(t(ids), t(am), t(hfe), t(ham))
+    qc.lora_dropout = 0.0
+    ou0 = Q.joint_forward({**PW, **PL}, qc, torch.from_numpy(ids), torch.from_numpy(am), toks.detach(), case["first_special_id"])
+    assert_close(u0, ou0.detach().numpy(), OUT_REL, "user_embeddings(eval)")
+    assert bm._lora_step == 6
 
 
 def test_topk_and_ranks_are_exact():

@@ -243,3 +243,39 @@ def test_elementwise_and_adamw():
         opt.step()
         hip.adamw_step(p, g * 4.0, m, v, 1e-2, 0.9, 0.999, 1e-8, 0.01, i + 1, grad_scale=0.25)
     assert torch.allclose(p, pt.detach(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(300, 128, 16), (520, 200, 16)])
+def test_gemm_lora_dropout_modes(M, K, N):
+    """ur_gemm LoRA dropout: mode 1 (masked R, forward), mode 2 (masked K-strided S, dA) and mode 3 (masked rank-r
+    epilogue, dx) against torch with the exported mask."""
+    from unirec_amd import hip
+    g = torch.Generator().manual_seed(3)
+    p, seed, r = 0.3, 1234, 16
+    x = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    A = (torch.randn(N, K, generator=g) * 0.2).to(DEV).to(torch.bfloat16)
+    for slot in (0, 2):
+        keep = hip.dropout_mask16(seed, slot, p, M * K, DEV).view(M, K).float()
+        assert abs(keep.mean().item() - (1 - p)) < 0.02
+        # mode 1: t = dropout(x) A^T
+        got = hip.gemm(x, A, alpha=1.0 / (1 - p), drop=(1, seed, slot, p, K)).float()
+        want = (x.float() * keep / (1 - p)) @ A.float().t()
+        assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
+        # mode 2: dA = tb^T dropout(x)   (both operands K-strided, f32 out)
+        tb = torch.randn(M, r, generator=g).to(DEV).to(torch.bfloat16)
+        got = hip.gemm(tb, x, r_kcontig=False, s_kcontig=False, out_f32=True, alpha=1.0 / (1 - p), drop=(2, seed, slot, p, K))
+        want = tb.float().t() @ (x.float() * keep / (1 - p))
+        assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
+    # mode 3: dx = dy W + sum_j mask_j * (tb_j A_j), two adapters sharing the input (slots 0, 1)
+    Nout = 136
+    dy = torch.randn(M, Nout, generator=g).to(DEV).to(torch.bfloat16)
+    WT = (torch.randn(K, Nout, generator=g) * 0.1).to(DEV).to(torch.bfloat16)          # [in, out] = transposed weight
+    tb2 = torch.randn(M, 2 * r, generator=g).to(DEV).to(torch.bfloat16)
+    A2 = (torch.randn(2 * r, K, generator=g) * 0.2).to(DEV).to(torch.bfloat16)
+    got = hip.gemm(dy, WT, R2=tb2, S2=hip.transpose_bf16(A2), drop=(3, seed, 0, p, K, r)).float()
+    want = dy.float() @ WT.float().t()
+    for j in range(2):
+        keep = hip.dropout_mask16(seed, j, p, M * K, DEV).view(M, K).float()
+        want = want + keep / (1 - p) * (tb2[:, j * r:(j + 1) * r].float() @ A2[j * r:(j + 1) * r].float())
+    assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 2e-2

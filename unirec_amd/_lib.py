@@ -26,7 +26,9 @@ class GemmArgs(ctypes.Structure):
                 ("residual", c_void_p), ("ldres", c_i64),
                 ("gelu_out", c_void_p), ("ldg", c_i64),
                 ("gelu_grad_aux", c_void_p), ("ldaux", c_i64),
-                ("split_k", c_int)]
+                ("split_k", c_int),
+                ("drop_mode", c_int), ("drop_slot", c_int), ("drop_rank", c_int),
+                ("drop_p", c_float), ("drop_seed", c_u64), ("drop_ld", c_i64)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -51,6 +53,7 @@ SIGNATURES = {
     "ur_last_error": (ctypes.c_char_p, []),
     "ur_gemm_workspace_bytes": (c_i64, [ctypes.POINTER(GemmArgs)]),
     "ur_gemm": (c_int, [ctypes.POINTER(GemmArgs), c_void_p, c_i64, c_void_p]),
+    "ur_dropout_mask16": (c_int, [c_u64, c_int, c_float, c_i64, c_i64, c_void_p, c_void_p]),
     "ur_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_float, c_float, c_u64, c_float, c_u64, c_void_p]),
     "ur_layernorm_bwd_workspace_bytes": (c_i64, [c_int]),

@@ -120,6 +120,24 @@ __device__ __forceinline__ uint32_t ur_hash2(uint64_t seed, uint64_t idx) {
   z ^= z >> 31;
   return (uint32_t)(z >> 32);
 }
+// Full 64-bit mix of the same generator: four independent 16-bit fields per element (LoRA dropout:
+// one field per adapter that shares an input; keep iff field >= p * 65536).
+__device__ __forceinline__ uint64_t ur_hash64(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return z;
+}
+__device__ __forceinline__ bool ur_keep16(uint64_t seed, uint64_t idx, int slot, uint32_t thr16) {
+  return (uint32_t)((ur_hash64(seed, idx) >> (16 * slot)) & 0xffffu) >= thr16;
+}
+static inline uint32_t ur_drop_threshold16(float p) {
+  double t = (double)p * 65536.0 + 0.5;
+  if (t < 0) t = 0;
+  if (t > 65535.0) t = 65535.0;
+  return (uint32_t)t;
+}
 // keep-probability test: returns scale (1/(1-p)) if kept, 0 if dropped.  thr = p * 2^32.
 __device__ __forceinline__ float ur_dropout_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
   return (ur_hash2(seed, idx) >= thr) ? inv_keep : 0.0f;

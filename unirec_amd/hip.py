@@ -51,8 +51,9 @@ def workspace(nbytes, device, tag="default"):
 
 # ------------------------------------------------------------------------------------------------
 def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=None, out_f32=False, alpha=1.0,
-         bias=None, residual=None, gelu_out=None, gelu_grad_aux=None, R2=None, S2=None, split_k=1):
-    """C[M,N] = alpha*(R(m,k) S(n,k) + R2 S2) + epilogue.  R/S are 2-D bf16 (row stride = stride(0))."""
+         bias=None, residual=None, gelu_out=None, gelu_grad_aux=None, R2=None, S2=None, split_k=1, drop=None):
+    """C[M,N] = alpha*(R(m,k) S(n,k) + R2 S2) + epilogue.  R/S are 2-D bf16 (row stride = stride(0)).
+    drop = (mode, seed, slot, p, ld[, rank]): LoRA dropout, see ur_gemm_args in include/unirec_hip.h."""
     lib = _lib.load()
     for t, n in ((R, "R"), (S, "S")):
         if t.dtype != BF16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
@@ -85,6 +86,9 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
     if gelu_grad_aux is not None:
         a.gelu_grad_aux, a.ldaux = gelu_grad_aux.data_ptr(), gelu_grad_aux.stride(0)
     a.split_k = int(split_k)
+    if drop is not None and drop[3] > 0.0:
+        a.drop_mode, a.drop_seed, a.drop_slot, a.drop_p, a.drop_ld = int(drop[0]), int(drop[1]), int(drop[2]), float(drop[3]), int(drop[4])
+        a.drop_rank = int(drop[5]) if len(drop) > 5 else 0
     ws, wsb = 0, 0
     if split_k > 1:
         wsb = lib.ur_gemm_workspace_bytes(ctypes.byref(a))
@@ -97,6 +101,14 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
         PROFILE.append((e0, e1, int(r_kcontig), int(s_kcontig), int(out.dtype == F32), M, N, K + int(a.K2), int(split_k)))
         return out
     check(lib.ur_gemm(ctypes.byref(a), ws, wsb, _stream()), "ur_gemm")
+    return out
+
+
+def dropout_mask16(seed, slot, p, n, device, first=0):
+    """The LoRA-dropout keep mask (uint8 0/1) of elements first .. first+n-1 -- test / inspection helper."""
+    lib = _lib.load()
+    out = torch.empty((n,), dtype=torch.uint8, device=device)
+    check(lib.ur_dropout_mask16(int(seed), int(slot), float(p), int(first), int(n), out.data_ptr(), _stream()), "ur_dropout_mask16")
     return out
 
 

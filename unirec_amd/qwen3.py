@@ -35,7 +35,7 @@ class Qwen3Config:
 
     def __init__(self, vocab_size=151669, hidden_size=1024, intermediate_size=3072, num_hidden_layers=28,
                  num_attention_heads=16, num_key_value_heads=8, head_dim=128, rms_norm_eps=1e-6, rope_theta=1e6,
-                 lora_r=16, lora_alpha=32.0, lora_dropout=0.0, initializer_range=0.02):
+                 lora_r=16, lora_alpha=32.0, lora_dropout=0.1, initializer_range=0.02):
         self.vocab_size, self.hidden_size, self.intermediate_size = vocab_size, hidden_size, intermediate_size
         self.num_hidden_layers, self.num_attention_heads, self.num_key_value_heads = num_hidden_layers, num_attention_heads, num_key_value_heads
         self.head_dim, self.rms_norm_eps, self.rope_theta = head_dim, rms_norm_eps, rope_theta
@@ -127,6 +127,8 @@ class Qwen3LoRAModel(nn.Module):
         self._frozen = None
         self._rope = None
         self.grad_ready_hook = None
+        self.lora_seed = 0x5EED        # base seed of the LoRA dropout masks (set per rank / per run by the trainer)
+        self._lora_step = 0            # forward calls with dropout so far: every step draws new masks
         self.reset_parameters()
 
     def reset_parameters(self, lora_b_std=0.0):
@@ -242,6 +244,27 @@ class Qwen3LoRAModel(nn.Module):
     def _lora(self, pack, name):
         return None if pack is None else pack.w16(name)
 
+    def _drop_p(self):
+        """peft applies lora_dropout only in training mode (nn.Dropout inside every LoraLayer)."""
+        return float(self.config.lora_dropout) if (self.training and self.use_lora) else 0.0
+
+    def lora_dropout_seed(self, step, layer, group):
+        """Seed of the dropout masks of one adapter group (the adapters that share an input: 0 = q|k|v, 1 = o,
+        2 = gate|up, 3 = down) -- a pure function of (base seed, step, layer, group), so the backward regenerates
+        the masks instead of storing them and tests can export them (hip.dropout_mask16)."""
+        return (int(self.lora_seed) * 0x9E3779B1 + int(step) * 1000003 + layer * 8 + group) & 0x7FFFFFFFFFFFFFFF
+
+    def _lora_down(self, xin, a_names, pack, sc, seed, p):
+        """t[M, nb*r] = s * dropout_j(x) A_j^T for the nb adapters that share the input x (one mask per adapter)."""
+        r = self.config.lora_r
+        if p <= 0.0:
+            A = pack.fused16(a_names) if len(a_names) > 1 else pack.w16(a_names[0])
+            return hip.gemm(xin, A, alpha=sc)
+        t = torch.empty((xin.shape[0], len(a_names) * r), dtype=BF16, device=xin.device)
+        for j, an in enumerate(a_names):
+            hip.gemm(xin, pack.w16(an), out=t[:, j * r:(j + 1) * r], alpha=sc / (1.0 - p), drop=(1, seed, j, p, xin.shape[1]))
+        return t
+
     def _forward_impl(self, item_tokens16, input_ids, mask_u8, first_special_id):
         c = self.config
         dev = input_ids.device
@@ -258,15 +281,20 @@ class Qwen3LoRAModel(nn.Module):
         T = item_tokens16.shape[1]
         tok = item_tokens16.detach().contiguous() if T > 0 else None
         x = hip.embed_inject_fwd(fz["embed"], input_ids, tok, first_special_id).view(M, D)
-        saved = {"B": B, "S": S, "T": T, "ids": input_ids, "first": first_special_id, "mask": mask_u8, "layers": []}
+        pdrop = self._drop_p()
+        step = self._lora_step
+        if pdrop > 0.0:
+            self._lora_step += 1
+        saved = {"B": B, "S": S, "T": T, "ids": input_ids, "first": first_special_id, "mask": mask_u8, "layers": [],
+                 "pdrop": pdrop, "step": step}
         for i, fl in enumerate(fz["layers"]):
             lp = f"layers.{i}."
             L = {"x": x}
             h, rstd1 = hip.rmsnorm_fwd(x, fl["ln1"], eps)
             qkv = torch.empty((M, NQ + 2 * NKV), dtype=BF16, device=dev)
             if pack is not None:
-                A_qkv = pack.fused16([lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"])
-                t_qkv = hip.gemm(h, A_qkv, alpha=sc)                                   # [M,3r] = s * h A^T
+                t_qkv = self._lora_down(h, [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"], pack, sc,
+                                        self.lora_dropout_seed(step, i, 0), pdrop)     # [M,3r] = s * dropout(h) A^T
                 col = 0
                 for j, (p, n) in enumerate((("q", NQ), ("k", NKV), ("v", NKV))):
                     hip.gemm(h, fl["qkv"][col:col + n], out=qkv[:, col:col + n], R2=t_qkv[:, j * r:(j + 1) * r],
@@ -280,7 +308,7 @@ class Qwen3LoRAModel(nn.Module):
             att, actx = hip.attn_fwd(q_r.view(B, S, nq, hd), k_r.view(B, S, nkv, hd), v4, causal=True, key_mask=mask_u8)
             att2 = att.view(M, NQ)
             if pack is not None:
-                t_o = hip.gemm(att2, pack.w16(lp + "self_attn.o_proj.lora_A.weight"), alpha=sc)
+                t_o = self._lora_down(att2, [lp + "self_attn.o_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 1), pdrop)
                 x2 = hip.gemm(att2, fl["o"], residual=x, R2=t_o, S2=pack.w16(lp + "self_attn.o_proj.lora_B.weight"))
                 L["t_o"] = t_o
             else:
@@ -288,8 +316,8 @@ class Qwen3LoRAModel(nn.Module):
             h2, rstd2 = hip.rmsnorm_fwd(x2, fl["ln2"], eps)
             gu = torch.empty((M, 2 * I), dtype=BF16, device=dev)
             if pack is not None:
-                A_gu = pack.fused16([lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"])
-                t_gu = hip.gemm(h2, A_gu, alpha=sc)
+                t_gu = self._lora_down(h2, [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"], pack, sc,
+                                       self.lora_dropout_seed(step, i, 2), pdrop)
                 for j, p in enumerate(("gate", "up")):
                     hip.gemm(h2, fl["gu"][j * I:(j + 1) * I], out=gu[:, j * I:(j + 1) * I], R2=t_gu[:, j * r:(j + 1) * r],
                              S2=pack.w16(lp + f"mlp.{p}_proj.lora_B.weight"))
@@ -298,7 +326,7 @@ class Qwen3LoRAModel(nn.Module):
                 hip.gemm(h2, fl["gu"], out=gu)
             act = hip.swiglu_fwd(gu, I)
             if pack is not None:
-                t_d = hip.gemm(act, pack.w16(lp + "mlp.down_proj.lora_A.weight"), alpha=sc)
+                t_d = self._lora_down(act, [lp + "mlp.down_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 3), pdrop)
                 x3 = hip.gemm(act, fl["d"], residual=x2, R2=t_d, S2=pack.w16(lp + "mlp.down_proj.lora_B.weight"))
                 L["t_d"] = t_d
             else:
@@ -326,8 +354,10 @@ class Qwen3LoRAModel(nn.Module):
         dx = hip.rmsnorm_bwd(dlast, saved["xf"], fz["norm"], saved["rstd_f"])
         touched = []
 
-        def lora_grads(dy, t, xin, a_names, b_specs):
-            """dB_p = dy_p^T t_p ; tb = s * dy B ; dA = tb^T x.  Returns tb [M, len(b)*r] (bf16)."""
+        pdrop, step = saved["pdrop"], saved["step"]
+
+        def lora_grads(dy, t, xin, a_names, b_specs, seed):
+            """dB_p = dy_p^T t_p ; tb = s * dy B ; dA_p = tb_p^T dropout_p(x).  Returns tb [M, len(b)*r] (bf16)."""
             nb = len(b_specs)
             tb = torch.empty((M, nb * r), dtype=BF16, device=dev)
             for j, (bname, c0, n) in enumerate(b_specs):
@@ -335,10 +365,22 @@ class Qwen3LoRAModel(nn.Module):
                 hip.gemm(dyp, t[:, j * r:(j + 1) * r], r_kcontig=False, s_kcontig=False, out=pack.g32(bname), split_k=_split_k(M, n, r))
                 hip.gemm(dyp, pack.w16(bname), s_kcontig=False, out=tb[:, j * r:(j + 1) * r], alpha=sc)
                 touched.append(bname)
-            gA = pack.fusedg(a_names) if len(a_names) > 1 else pack.g32(a_names[0])
-            hip.gemm(tb, xin, r_kcontig=False, s_kcontig=False, out=gA, split_k=_split_k(M, nb * r, xin.shape[1]))
+            if pdrop > 0.0:
+                for j, an in enumerate(a_names):      # one mask per adapter: the token reduction runs per adapter
+                    hip.gemm(tb[:, j * r:(j + 1) * r], xin, r_kcontig=False, s_kcontig=False, out=pack.g32(an),
+                             split_k=_split_k(M, r, xin.shape[1]), alpha=1.0 / (1.0 - pdrop), drop=(2, seed, j, pdrop, xin.shape[1]))
+            else:
+                gA = pack.fusedg(a_names) if len(a_names) > 1 else pack.g32(a_names[0])
+                hip.gemm(tb, xin, r_kcontig=False, s_kcontig=False, out=gA, split_k=_split_k(M, nb * r, xin.shape[1]))
             touched.extend(a_names)
             return tb
+
+        def dx_gemm(dy, wT, tb, a_names, seed, n_in):
+            """dx = dy W + sum_j mask_j * (tb_j A_j): the adapters' part joins the main reduction when there is no
+            dropout, and is a masked rank-r epilogue (ur_gemm drop_mode 3) when there is."""
+            A = pack.fused16(a_names) if len(a_names) > 1 else pack.w16(a_names[0])
+            drop = (3, seed, 0, pdrop, n_in, r) if pdrop > 0.0 else None
+            return hip.gemm(dy, wT, R2=tb, S2=hip.transpose_bf16(A), drop=drop)
 
         for i in reversed(range(len(fz["layers"]))):
             fl, L = fz["layers"][i], saved["layers"][i]
@@ -347,24 +389,27 @@ class Qwen3LoRAModel(nn.Module):
             # ---- MLP: x3 = x2 + down(silu(gate) * up)
             act = L["act"]
             if pack is not None:
-                tb = lora_grads(dx, L["t_d"], act, [lp + "mlp.down_proj.lora_A.weight"], [(lp + "mlp.down_proj.lora_B.weight", 0, D)])
-                dact = hip.gemm(dx, fl["dT"], R2=tb, S2=hip.transpose_bf16(pack.w16(lp + "mlp.down_proj.lora_A.weight")))
+                sd = self.lora_dropout_seed(step, i, 3)
+                tb = lora_grads(dx, L["t_d"], act, [lp + "mlp.down_proj.lora_A.weight"], [(lp + "mlp.down_proj.lora_B.weight", 0, D)], sd)
+                dact = dx_gemm(dx, fl["dT"], tb, [lp + "mlp.down_proj.lora_A.weight"], sd, I)
             else:
                 dact = hip.gemm(dx, fl["dT"])
             dgu = hip.swiglu_bwd(dact, gu, I)
             h2, _ = hip.rmsnorm_fwd(x2, fl["ln2"], eps)                   # recomputed
             if pack is not None:
                 a_names = [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"]
-                tb = lora_grads(dgu, L["t_gu"], h2, a_names, [(lp + "mlp.gate_proj.lora_B.weight", 0, I), (lp + "mlp.up_proj.lora_B.weight", I, I)])
-                dh2 = hip.gemm(dgu, fl["guT"], R2=tb, S2=hip.transpose_bf16(pack.fused16(a_names)))
+                sd = self.lora_dropout_seed(step, i, 2)
+                tb = lora_grads(dgu, L["t_gu"], h2, a_names, [(lp + "mlp.gate_proj.lora_B.weight", 0, I), (lp + "mlp.up_proj.lora_B.weight", I, I)], sd)
+                dh2 = dx_gemm(dgu, fl["guT"], tb, a_names, sd, D)
             else:
                 dh2 = hip.gemm(dgu, fl["guT"])
             dx2 = hip.rmsnorm_bwd(dh2, x2, fl["ln2"], L["rstd2"], add=dx)
             # ---- attention: x2 = x + o(attn)
             att = L["att"]
             if pack is not None:
-                tb = lora_grads(dx2, L["t_o"], att, [lp + "self_attn.o_proj.lora_A.weight"], [(lp + "self_attn.o_proj.lora_B.weight", 0, D)])
-                datt = hip.gemm(dx2, fl["oT"], R2=tb, S2=hip.transpose_bf16(pack.w16(lp + "self_attn.o_proj.lora_A.weight")))
+                sd = self.lora_dropout_seed(step, i, 1)
+                tb = lora_grads(dx2, L["t_o"], att, [lp + "self_attn.o_proj.lora_A.weight"], [(lp + "self_attn.o_proj.lora_B.weight", 0, D)], sd)
+                datt = dx_gemm(dx2, fl["oT"], tb, [lp + "self_attn.o_proj.lora_A.weight"], sd, NQ)
             else:
                 datt = hip.gemm(dx2, fl["oT"])
             dqkv = torch.empty_like(qkv)
@@ -378,8 +423,9 @@ class Qwen3LoRAModel(nn.Module):
                 a_names = [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"]
                 specs = [(lp + "self_attn.q_proj.lora_B.weight", 0, NQ), (lp + "self_attn.k_proj.lora_B.weight", NQ, NKV),
                          (lp + "self_attn.v_proj.lora_B.weight", NQ + NKV, NKV)]
-                tb = lora_grads(dqkv, L["t_qkv"], h, a_names, specs)
-                dh = hip.gemm(dqkv, fl["qkvT"], R2=tb, S2=hip.transpose_bf16(pack.fused16(a_names)))
+                sd = self.lora_dropout_seed(step, i, 0)
+                tb = lora_grads(dqkv, L["t_qkv"], h, a_names, specs, sd)
+                dh = dx_gemm(dqkv, fl["qkvT"], tb, a_names, sd, D)
             else:
                 dh = hip.gemm(dqkv, fl["qkvT"])
             dx = hip.rmsnorm_bwd(dh, x, fl["ln1"], L["rstd1"], add=dx2)
