@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU oracle leg and print its JSON")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--lora-dropout", type=float, default=0.1, help="LoRA adapter dropout (reference lora_dropout=0.1)")
     return ap.parse_args()
 
 
@@ -86,7 +87,7 @@ def build(args, device):
     p = 0.0 if args.no_dropout else 0.2
     qf = QFormerForItemRepresentation(hidden_size=D, num_hidden_layers=12, num_attention_heads=16, intermediate_size=4096,
                                       num_query_tokens=Qi, field_embedding_dim=E, num_fields=F, dropout=p)
-    cfg = Qwen3Config(num_hidden_layers=args.layers, lora_dropout=0.0 if args.no_dropout else 0.1)    # reference: :121-131
+    cfg = Qwen3Config(num_hidden_layers=args.layers, lora_dropout=0.0 if args.no_dropout else args.lora_dropout)    # reference: :121-131
     model = MultiModalQwenEmbedding(qformer_model=qf, use_lora=True, qwen_config=cfg, num_history_items=args.hist,
                                     num_query_tokens_per_item=Qi)
     model.base_model.reset_parameters(lora_b_std=0.01)           # exercise the LoRA path
@@ -338,7 +339,7 @@ def main():
                "config": {"workload": f"C4 joint step: item Q-Former(L12,H1024,Q2,F14) on {B}x{args.hist} items -> inject -> "
                                       f"Qwen3-0.6B-shaped({cfg.num_hidden_layers}L)+LoRA r16 -> mean-pool -> InfoNCE pool {args.pool}; "
                                       f"fwd+bwd+allreduce+AdamW", "per_gpu_batch": B, "global_batch": B * world, "seq_len": args.seq,
-                          "hist": args.hist, "pool": args.pool, "dropout": 0.0 if args.no_dropout else 0.2, "lora_dropout": 0.0 if args.no_dropout else 0.1,
+                          "hist": args.hist, "pool": args.pool, "dropout": 0.0 if args.no_dropout else 0.2, "lora_dropout": 0.0 if args.no_dropout else args.lora_dropout,
                           "parallelism": f"dp{world}", "random_init": True},
                "step_tflops_per_gpu": round(fl / (dt / args.steps) / 1e12, 1), "loss": round(lossv, 4),
                "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof}

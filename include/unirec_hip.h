@@ -59,25 +59,51 @@ typedef struct {
   void* gelu_out; int64_t ldg;
   const void* gelu_grad_aux; int64_t ldaux;
   int32_t split_k;
-  /* LoRA dropout -- peft LoraLayer: result = base(x) + lora_B(lora_A(dropout(x))) * scaling, one nn.Dropout per
-   * adapter (training/train_item_individual_token_joint.py:121-131: lora_dropout=0.1).  The keep mask of adapter
-   * slot s (0..3; adapters that share an input use different slots) at element (row, col) of its [rows, drop_ld]
-   * input is a pure function of (drop_seed, row*drop_ld + col): bits [16s, 16s+16) of a 64-bit hash >= p*65536
-   * (ur_dropout_mask16 exports it).  The 1/(1-p) scale is the caller's (fold it into alpha), except in mode 3.
-   *   drop_mode 0: off.
-   *   drop_mode 1: operand R is the adapter input x (K-contiguous: x[m][k]; K-strided: x[k][m]); dropped elements
-   *                are zeroed while the tile is staged (forward: t = s * dropout(x) A^T).
-   *   drop_mode 2: the same for operand S (backward: dA = tb^T dropout(x)).
-   *   drop_mode 3: the second pair holds K2/drop_rank adapters that share the input: instead of joining the main
-   *                reduction, C(m,n) += sum_j keep_{slot+j}(m,n)/(1-p) * R2[m, j*r:(j+1)*r] . S2[n, j*r:(j+1)*r]
-   *                (backward: dx = dy W + sum_j mask_j * (tb_j A_j)); C is the adapter input gradient [M, drop_ld = N]. */
-  int32_t drop_mode; int32_t drop_slot; int32_t drop_rank;
-  float drop_p; uint64_t drop_seed; int64_t drop_ld;
+  /* LoRA dropout in the backward to the adapter input -- peft LoraLayer: result = base(x) + lora_B(lora_A(dropout(x)))
+   * * scaling, one nn.Dropout per adapter (training/train_item_individual_token_joint.py:121-131: lora_dropout=0.1).
+   * drop_bits != NULL: the second pair holds K2/drop_rank adapters that share the input x [M, N]; instead of joining
+   * the main reduction,  C(m,n) += sum_a keep_a(m,n)/(1-drop_p) * R2[m, a*r:(a+1)*r] . S2[n, a*r:(a+1)*r]
+   * (dx = dy W + sum_a mask_a * (tb_a A_a)); keep_a comes from bit plane a of ur_lora_dropout_bits (row stride
+   * drop_bits_ld = ur_lora_bits_ld(N) bytes, plane stride drop_bits_stride bytes). */
+  const void* drop_bits; int64_t drop_bits_ld; int64_t drop_bits_stride;
+  int32_t drop_rank; float drop_p;
 } ur_gemm_args;
-/* keep mask of ur_gemm's LoRA dropout for n consecutive elements starting at element index `first`: out[i] = 1/0 */
-int ur_dropout_mask16(uint64_t seed, int32_t slot, float p, int64_t first, int64_t n, uint8_t* out, void* stream);
 int64_t ur_gemm_workspace_bytes(const ur_gemm_args* a);
 int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LoRA adapter products, rank 16 (peft LoraLayer; call site training/train_item_individual_token_joint.py:121-131,
+ * r=16, lora_alpha=32, lora_dropout=0.1).  HBM-bound streams over one [M, W] activation X:
+ *   ur_lora_project:  P[m, 16a + j] = alpha * sum_w keep_a(m,w) X[m, col0_a + w] U_a[j, w]
+ *       forward  t  = s * dropout_a(x) A_a^T   (shared = 1: the nad adapters read the same columns, one bit plane each)
+ *       backward tb = s * dy_a B_a             (shared = 0: adapter a owns columns [col0[a], col0[a]+width[a]) of dy;
+ *                                               U_a = B_a^T stored [16, width[a]])
+ *   ur_lora_reduce:   G_a[j, w] = alpha * sum_m V[m, 16a + j] keep_a(m,w) X[m, col0_a + w]
+ *       dA_a = tb_a^T dropout_a(x)  (shared = 1, g_transposed = 0: G = [16 nad, W] f32, dense)
+ *       dB_a = dy_a^T t_a           (shared = 0, g_transposed = 1: G = [sum width, 16] f32, dense, adapter ranges in order)
+ *       Token reduction split deterministically over blocks; partial slabs live in the caller's workspace.
+ *   ur_lora_dropout_bits: dropped flags of nad adapters over an [M, W] input: plane a at bits + a*bits_stride, row m at
+ *       + m*bits_ld (bits_ld = ur_lora_bits_ld(W) = 16 * ceil(W/128) bytes); the byte at column c/8 (c % 8 == 0) holds
+ *       bit i (i<4) = element c+2i dropped, bit 4+i = element c+2i+1 dropped.  A pure function of (seed, p, m, c, a).
+ * drop_bits == NULL: no dropout.  The 1/(1-p) scale is the caller's (alpha).
+ * Constraints: rank == 16; column ranges and ldx multiples of 8; X, U, V, G 16-byte aligned; P 8-byte aligned. */
+typedef struct {
+  const void* X; int64_t ldx; int32_t M;
+  int32_t nad; int32_t rank; int32_t shared;
+  int32_t col0[4]; int32_t width[4];
+  const void* drop_bits; int64_t bits_ld; int64_t bits_stride;
+  float alpha;
+  const void* U[4]; int64_t ldu[4];       /* project: U_a bf16 [16, width_a] */
+  void* P; int64_t ldp;                   /* project: bf16 [M, >= 16 nad] */
+  const void* V; int64_t ldv;             /* reduce: bf16 [M, >= 16 nad] */
+  void* G; int32_t g_transposed;          /* reduce: f32, dense */
+} ur_lora_args;
+int64_t ur_lora_bits_ld(int32_t W);
+int ur_lora_dropout_bits(uint64_t seed, float p, int32_t M, int32_t W, int32_t nad, uint8_t* bits, int64_t bits_ld,
+                         int64_t bits_stride, void* stream);
+int ur_lora_project(const ur_lora_args* a, void* stream);
+int64_t ur_lora_reduce_workspace_bytes(const ur_lora_args* a);
+int ur_lora_reduce(const ur_lora_args* a, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (+ fused dropout / residual) -- models/qformer.py:64,106-107 (embeddings: LN then

@@ -135,8 +135,8 @@ def test_joint_with_lora_matches_oracle(name):
 @pytest.mark.parametrize("name", JOINT[:1])
 def test_joint_with_lora_dropout_matches_oracle(name):
     """LoRA dropout (reference :121-131, lora_dropout=0.1; peft: one nn.Dropout per adapter on the adapter's
-    input).  The HIP path draws its masks from a counter-based hash; the test exports exactly those masks
-    (hip.dropout_mask16) and feeds them to the oracle, so the arithmetic -- forward, dA with the masked input,
+    input).  The HIP path draws its masks from a counter-based generator (ur_lora_dropout_bits); the test regenerates
+    exactly those bit planes from the layer's seed and feeds the unpacked masks to the oracle, so the arithmetic -- forward, dA with the masked input,
     dB, and the masked gradient into the adapter input -- is checked element for element; the mask statistics
     are checked separately."""
     from unirec_amd import hip
@@ -164,8 +164,9 @@ def test_joint_with_lora_dropout_matches_oracle(name):
     for i in range(qc.num_hidden_layers):
         for g, (names, width) in groups.items():
             seed = bm.lora_dropout_seed(5, i, g)
+            keep = hip.lora_bits_to_keep(hip.lora_dropout_bits(seed, pdrop, M, width, len(names), DEV), width).cpu()
             for slot, nm in enumerate(names):
-                mk = hip.dropout_mask16(seed, slot, pdrop, M * width, DEV).cpu().view(B, S, width)
+                mk = keep[slot].view(B, S, width)
                 masks[f"layers.{i}.{nm}"] = mk
                 kept.append(mk.float().mean().item())
     assert abs(sum(kept) / len(kept) - (1 - pdrop)) < 0.01, kept
@@ -191,7 +192,7 @@ def test_joint_with_lora_dropout_matches_oracle(name):
               "layers.1.self_attn.o_proj.lora_A.weight", "layers.1.mlp.gate_proj.lora_A.weight", "layers.0.mlp.up_proj.lora_A.weight",
               "layers.1.mlp.down_proj.lora_A.weight", "layers.0.mlp.down_proj.lora_B.weight"):
         assert_close(named[k].grad, PL[k].grad.numpy(), GRAD_REL * 1.5, "grad/" + k)
-    # the gradient that reaches the Q-Former went through every masked adapter-input gradient (drop_mode 3)
+    # the gradient that reaches the Q-Former went through every masked adapter-input gradient (ur_gemm drop_bits)
     assert_close(dict(qf.named_parameters())["query_embeddings"].grad, PQ["query_embeddings"].grad.numpy(), GRAD_REL * 1.5, "grad/query_embeddings")
     # eval mode: no dropout, and the step counter does not move
     m.eval()

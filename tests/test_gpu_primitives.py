@@ -246,36 +246,75 @@ def test_elementwise_and_adamw():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,K,N", [(300, 128, 16), (520, 200, 16)])
-def test_gemm_lora_dropout_modes(M, K, N):
-    """ur_gemm LoRA dropout: mode 1 (masked R, forward), mode 2 (masked K-strided S, dA) and mode 3 (masked rank-r
-    epilogue, dx) against torch with the exported mask."""
+@pytest.mark.parametrize("M,K", [(300, 128), (520, 200), (1111, 1024)])
+def test_lora_kernels_with_dropout_bits(M, K):
+    """The dedicated rank-16 LoRA kernels against torch, with the dropout bit planes the library generated:
+    ur_lora_project (t = dropout_a(x) A_a^T, shared input), ur_lora_reduce (dA_a = tb_a^T dropout_a(x)) and
+    ur_gemm's masked rank-r epilogue (dx = dy W + sum_a mask_a * (tb_a A_a))."""
     from unirec_amd import hip
     g = torch.Generator().manual_seed(3)
     p, seed, r = 0.3, 1234, 16
     x = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
-    A = (torch.randn(N, K, generator=g) * 0.2).to(DEV).to(torch.bfloat16)
-    for slot in (0, 2):
-        keep = hip.dropout_mask16(seed, slot, p, M * K, DEV).view(M, K).float()
+    for nad in (1, 3):
+        A = (torch.randn(nad * r, K, generator=g) * 0.2).to(DEV).to(torch.bfloat16)
+        bits = hip.lora_dropout_bits(seed + nad, p, M, K, nad, DEV)
+        keep = hip.lora_bits_to_keep(bits, K).float()                       # [nad, M, K]
         assert abs(keep.mean().item() - (1 - p)) < 0.02
-        # mode 1: t = dropout(x) A^T
-        got = hip.gemm(x, A, alpha=1.0 / (1 - p), drop=(1, seed, slot, p, K)).float()
-        want = (x.float() * keep / (1 - p)) @ A.float().t()
+        if nad > 1:
+            assert not torch.equal(keep[0], keep[1])                        # one mask per adapter
+        again = hip.lora_dropout_bits(seed + nad, p, M, K, nad, DEV)
+        assert torch.equal(bits, again)                                     # a pure function of (seed, p, shape)
+        got = hip.lora_project(x, [A[a * r:(a + 1) * r] for a in range(nad)], alpha=1.0 / (1 - p), bits=bits).float()
+        want = torch.cat([(x.float() * keep[a] / (1 - p)) @ A[a * r:(a + 1) * r].float().t() for a in range(nad)], 1)
         assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
-        # mode 2: dA = tb^T dropout(x)   (both operands K-strided, f32 out)
-        tb = torch.randn(M, r, generator=g).to(DEV).to(torch.bfloat16)
-        got = hip.gemm(tb, x, r_kcontig=False, s_kcontig=False, out_f32=True, alpha=1.0 / (1 - p), drop=(2, seed, slot, p, K))
-        want = tb.float().t() @ (x.float() * keep / (1 - p))
-        assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
-    # mode 3: dx = dy W + sum_j mask_j * (tb_j A_j), two adapters sharing the input (slots 0, 1)
-    Nout = 136
-    dy = torch.randn(M, Nout, generator=g).to(DEV).to(torch.bfloat16)
-    WT = (torch.randn(K, Nout, generator=g) * 0.1).to(DEV).to(torch.bfloat16)          # [in, out] = transposed weight
-    tb2 = torch.randn(M, 2 * r, generator=g).to(DEV).to(torch.bfloat16)
-    A2 = (torch.randn(2 * r, K, generator=g) * 0.2).to(DEV).to(torch.bfloat16)
-    got = hip.gemm(dy, WT, R2=tb2, S2=hip.transpose_bf16(A2), drop=(3, seed, 0, p, K, r)).float()
-    want = dy.float() @ WT.float().t()
-    for j in range(2):
-        keep = hip.dropout_mask16(seed, j, p, M * K, DEV).view(M, K).float()
-        want = want + keep / (1 - p) * (tb2[:, j * r:(j + 1) * r].float() @ A2[j * r:(j + 1) * r].float())
-    assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 2e-2
+        tb = torch.randn(M, nad * r, generator=g).to(DEV).to(torch.bfloat16)
+        gA = torch.empty(nad * r, K, device=DEV)
+        hip.lora_reduce(x, tb, gA, nad=nad, alpha=1.0 / (1 - p), bits=bits)
+        want = torch.cat([tb[:, a * r:(a + 1) * r].float().t() @ (x.float() * keep[a] / (1 - p)) for a in range(nad)], 0)
+        assert (gA - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
+        # masked epilogue of the dx GEMM
+        Nout = 136
+        dy = torch.randn(M, Nout, generator=g).to(DEV).to(torch.bfloat16)
+        WT = (torch.randn(K, Nout, generator=g) * 0.1).to(DEV).to(torch.bfloat16)          # [in, out] = transposed weight
+        got = hip.gemm(dy, WT, R2=tb, S2=hip.transpose_bf16(A), drop=(bits, p, r)).float()
+        want = dy.float() @ WT.float().t()
+        for a in range(nad):
+            want = want + keep[a] / (1 - p) * (tb[:, a * r:(a + 1) * r].float() @ A[a * r:(a + 1) * r].float())
+        assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 2e-2
+    # p = 0: nothing is dropped
+    assert hip.lora_bits_to_keep(hip.lora_dropout_bits(1, 0.0, 64, K, 2, DEV), K).min().item() == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [200, 4100])
+def test_lora_kernels_on_column_ranges(M):
+    """Adapters that own column ranges of one activation (backward): tb_a = s * dy_a B_a (ur_lora_project, no
+    dropout) and dB_a = dy_a^T t_a (ur_lora_reduce, transposed dense output), plus the no-dropout shared forms."""
+    from unirec_amd import hip
+    g = torch.Generator().manual_seed(5)
+    r = 16
+    cols = [(0, 256), (256, 128), (384, 72)]
+    Wt = 456
+    dy = torch.randn(M, Wt + 8, generator=g).to(DEV).to(torch.bfloat16)[:, :Wt]             # ld != width
+    B = [(torch.randn(n, r, generator=g) * 0.2).to(DEV).to(torch.bfloat16) for _, n in cols]
+    t = torch.randn(M, 3 * r, generator=g).to(DEV).to(torch.bfloat16)
+    tb = hip.lora_project(dy, [hip.transpose_bf16(b) for b in B], cols=cols, alpha=2.0).float()
+    want = torch.cat([2.0 * dy[:, c0:c0 + n].float() @ B[a].float() for a, (c0, n) in enumerate(cols)], 1)
+    assert (tb - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
+    gB = torch.empty(Wt, r, device=DEV)
+    hip.lora_reduce(dy, t, gB, cols=cols, transposed=True)
+    want = torch.cat([dy[:, c0:c0 + n].float().t() @ t[:, a * r:(a + 1) * r].float() for a, (c0, n) in enumerate(cols)], 0)
+    assert (gB - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
+    again = torch.empty_like(gB)
+    hip.lora_reduce(dy, t, again, cols=cols, transposed=True)
+    assert torch.equal(gB, again)                                                          # deterministic token split
+    # shared input, no dropout
+    x = dy[:, :200]
+    A = (torch.randn(2 * r, 200, generator=g) * 0.2).to(DEV).to(torch.bfloat16)
+    got = hip.lora_project(x, [A[:r], A[r:]]).float()
+    want = x.float() @ A.float().t()
+    assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
+    gA = torch.empty(2 * r, 200, device=DEV)
+    hip.lora_reduce(x, t[:, :2 * r], gA, nad=2)
+    want = t[:, :2 * r].float().t() @ x.float()
+    assert (gA - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2

@@ -27,8 +27,21 @@ class GemmArgs(ctypes.Structure):
                 ("gelu_out", c_void_p), ("ldg", c_i64),
                 ("gelu_grad_aux", c_void_p), ("ldaux", c_i64),
                 ("split_k", c_int),
-                ("drop_mode", c_int), ("drop_slot", c_int), ("drop_rank", c_int),
-                ("drop_p", c_float), ("drop_seed", c_u64), ("drop_ld", c_i64)]
+                ("drop_bits", c_void_p), ("drop_bits_ld", c_i64), ("drop_bits_stride", c_i64),
+                ("drop_rank", c_int), ("drop_p", c_float)]
+
+
+class LoraArgs(ctypes.Structure):
+    """Mirror of ur_lora_args."""
+    _fields_ = [("X", c_void_p), ("ldx", c_i64), ("M", c_int),
+                ("nad", c_int), ("rank", c_int), ("shared", c_int),
+                ("col0", c_int * 4), ("width", c_int * 4),
+                ("drop_bits", c_void_p), ("bits_ld", c_i64), ("bits_stride", c_i64),
+                ("alpha", c_float),
+                ("U", c_void_p * 4), ("ldu", c_i64 * 4),
+                ("P", c_void_p), ("ldp", c_i64),
+                ("V", c_void_p), ("ldv", c_i64),
+                ("G", c_void_p), ("g_transposed", c_int)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -53,7 +66,11 @@ SIGNATURES = {
     "ur_last_error": (ctypes.c_char_p, []),
     "ur_gemm_workspace_bytes": (c_i64, [ctypes.POINTER(GemmArgs)]),
     "ur_gemm": (c_int, [ctypes.POINTER(GemmArgs), c_void_p, c_i64, c_void_p]),
-    "ur_dropout_mask16": (c_int, [c_u64, c_int, c_float, c_i64, c_i64, c_void_p, c_void_p]),
+    "ur_lora_bits_ld": (c_i64, [c_int]),
+    "ur_lora_dropout_bits": (c_int, [c_u64, c_float, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_void_p]),
+    "ur_lora_project": (c_int, [ctypes.POINTER(LoraArgs), c_void_p]),
+    "ur_lora_reduce_workspace_bytes": (c_i64, [ctypes.POINTER(LoraArgs)]),
+    "ur_lora_reduce": (c_int, [ctypes.POINTER(LoraArgs), c_void_p, c_i64, c_void_p]),
     "ur_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_float, c_float, c_u64, c_float, c_u64, c_void_p]),
     "ur_layernorm_bwd_workspace_bytes": (c_i64, [c_int]),

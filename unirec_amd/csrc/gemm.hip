@@ -54,8 +54,8 @@ struct GemmP {
   bf16_t* gelu_out; long ldg; const bf16_t* aux; long ldaux;
   int ksplit_len; long slab_stride;
   int gm, gn;
-  // LoRA dropout (ur_gemm_args.drop_*): mode 1/2 mask operand R/S while staging, mode 3 masked LoRA epilogue
-  int drop_mode, drop_slot, drop_rank; uint32_t drop_thr16; float drop_inv_keep; uint64_t drop_seed; long drop_ld;
+  // LoRA dropout (ur_gemm_args.drop_*): masked rank-r LoRA epilogue driven by the adapters' dropped-flag bit planes
+  const uint8_t* drop_bits; long drop_bits_ld, drop_bits_stride; int drop_rank; float drop_inv_keep;
 };
 
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
@@ -123,22 +123,10 @@ __device__ __forceinline__ void dma_offsets(uint32_t (&voff)[(T * BK * 2 / 1024)
   }
 }
 
-// ---- register staging: partial K tiles (zero-fill past kend) and LoRA-dropout operands --------
-struct DropMask { bool on; uint64_t seed; int slot; uint32_t thr16; long ld; };
-// zero the dropped elements of 8 consecutive x elements starting at element index idx0
-__device__ __forceinline__ uint4 drop8(uint4 z, const DropMask& d, uint64_t idx0) {
-  uint32_t w[4] = {z.x, z.y, z.z, z.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t lo = ur_keep16(d.seed, idx0 + 2 * i, d.slot, d.thr16) ? 0xffffu : 0u;
-    const uint32_t hi = ur_keep16(d.seed, idx0 + 2 * i + 1, d.slot, d.thr16) ? 0xffff0000u : 0u;
-    w[i] &= (lo | hi);
-  }
-  return make_uint4(w[0], w[1], w[2], w[3]);
-}
+// ---- register staging: partial K tiles (zero-fill past kend) ------------------------------------
 template <bool KC, int T, int NT>
 __device__ __forceinline__ void reg_tile(char* tile, const bf16_t* __restrict__ base, long ld, int rows_total, int row0,
-                                         int k0, int kend, int tid, const DropMask& dm) {
+                                         int k0, int kend, int tid) {
   constexpr int CHUNKS = T * BK / 8;
 #pragma unroll
   for (int i = 0; i < (CHUNKS + NT - 1) / NT; ++i) {
@@ -149,18 +137,12 @@ __device__ __forceinline__ void reg_tile(char* tile, const bf16_t* __restrict__ 
     if (KC) {
       const int row = c >> 3, kc = c & 7;
       const int grow = min(row0 + row, rows_total - 1), gk = k0 + kc * 8;
-      if (gk < kend) {
-        z = *reinterpret_cast<const uint4*>(base + (long)grow * ld + gk);
-        if (dm.on) z = drop8(z, dm, (uint64_t)grow * (uint64_t)dm.ld + (uint64_t)gk);           // x[row][k]
-      }
+      if (gk < kend) z = *reinterpret_cast<const uint4*>(base + (long)grow * ld + gk);
       off = row * KC_ROWB + ((kc ^ kc_g(row)) << 4);
     } else {
       const int kr = c / (T / 8), ch = c % (T / 8);
       const int gk = k0 + kr, gcol = min(row0 + ch * 8, rows_total - 8);
-      if (gk < kend) {
-        z = *reinterpret_cast<const uint4*>(base + (long)gk * ld + gcol);
-        if (dm.on) z = drop8(z, dm, (uint64_t)gk * (uint64_t)dm.ld + (uint64_t)gcol);           // x[k][col]
-      }
+      if (gk < kend) z = *reinterpret_cast<const uint4*>(base + (long)gk * ld + gcol);
       off = kr * Tile<T>::KS_ROWB + ((ch ^ (ks_f(kr) << 1)) << 4);
     }
     *reinterpret_cast<uint4*>(tile + off) = z;
@@ -231,7 +213,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   int kbeg = z * p.ksplit_len;
   int kend = min(p.K, kbeg + p.ksplit_len);
   const int nt1 = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-  const int nt2 = (p.K2 > 0 && p.drop_mode != 3) ? (p.K2 + BK - 1) / BK : 0;
+  const int nt2 = (p.K2 > 0 && !p.drop_bits) ? (p.K2 + BK - 1) / BK : 0;
   const int nt = nt1 + nt2;
   const int nfull1 = (kend > kbeg) ? (kend - kbeg) / BK : 0;      // leading full tiles of the first K range
 
@@ -241,8 +223,6 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const DropMask dmR{p.drop_mode == 1, p.drop_seed, p.drop_slot, p.drop_thr16, p.drop_ld};
-  const DropMask dmS{p.drop_mode == 2, p.drop_seed, p.drop_slot, p.drop_thr16, p.drop_ld};
   // k extent of tile t (how many of its two 32-deep halves carry data)
   auto tile_k = [&](int t, int& k0, int& ke) {
     if (t < nt1) { k0 = kbeg + t * BK; ke = kend; } else { k0 = (t - nt1) * BK; ke = p.K2; }
@@ -253,11 +233,10 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     tile_k(t, k0, ke);
     if (t < nt1) { S = p.S; R = p.R; lds_ = p.lds; ldr_ = p.ldr; } else { S = p.S2; R = p.R2; lds_ = p.lds2; ldr_ = p.ldr2; }
     const bool full = k0 + BK <= ke;
-    // a LoRA-dropout operand always goes through registers (the mask is applied between the load and the LDS write)
-    if (full && !dmS.on) dma_tile<SK, BN, NT>(buf, S, lds_, p.N, n0, k0, tid);
-    else reg_tile<SK, BN, NT>(buf, S, lds_, p.N, n0, k0, ke, tid, dmS);
-    if (full && !dmR.on) dma_tile<RK, BM, NT>(buf + S_BYTES, R, ldr_, p.M, m0, k0, tid);
-    else reg_tile<RK, BM, NT>(buf + S_BYTES, R, ldr_, p.M, m0, k0, ke, tid, dmR);
+    if (full) dma_tile<SK, BN, NT>(buf, S, lds_, p.N, n0, k0, tid);
+    else reg_tile<SK, BN, NT>(buf, S, lds_, p.N, n0, k0, ke, tid);
+    if (full) dma_tile<RK, BM, NT>(buf + S_BYTES, R, ldr_, p.M, m0, k0, tid);
+    else reg_tile<RK, BM, NT>(buf + S_BYTES, R, ldr_, p.M, m0, k0, ke, tid);
   };
   auto read_frags = [&](bf16x8 (&sf)[NI], bf16x8 (&rf)[MI], int t, int h) {
     const char* sb = smem + (t & 1) * STAGE;
@@ -346,14 +325,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   if (nt > 1) stage(1, smem + STAGE);
   if (nt > 0) {
     // a K-tail tile staged through registers issues no DMA; its own (compiler-waited) loads are older
-    if (nt > 1 && nfull1 >= 2 && !dmR.on && !dmS.on) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SPW + RPW) : "memory");
+    if (nt > 1 && nfull1 >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SPW + RPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_s_barrier();
     read_frags(sfA, rfA, 0, 0);
   }
   int t = 0;
-  if (GROUPED && interior && !dmR.on && !dmS.on) {
+  if (GROUPED && interior) {
     // ---- steady state: tiles t, t+1 and t+2 are full tiles of the first K range ----
     auto steady = [&](auto order) {
       for (; t + 2 < nfull1; ++t) {
@@ -402,12 +381,16 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     if (two) mfmas(sfB, rfB);
   }
 
-  // ---- LoRA dropout, backward to the adapter input (drop_mode 3): C(m,n) += sum_j keep_j(m,n)/(1-p) * tb_j(m,:) . A_j(:,n).
+  // ---- LoRA dropout, backward to the adapter input: C(m,n) += sum_a keep_a(m,n)/(1-p) * tb_a(m,:) . A_a(:,n).
   // Each adapter's rank-r product of a 16x16 sub-tile is ONE MFMA (k = r <= 32, zero-padded) into a scratch
-  // accumulator, masked element-wise and added; one 64-bit hash per output element serves all adapters.
-  if (p.drop_mode == 3 && p.K2 > 0) {
+  // accumulator; the keep flags come from the adapters' dropped-flag bit planes (lora.hip: 8 bytes cover the
+  // 64 columns this wave owns of one row).
+  if (p.drop_bits && p.K2 > 0) {
     const int nad = p.K2 / p.drop_rank, kq = 8 * (lane >> 4);
     const bool kin = kq < p.drop_rank;
+    const int g4 = lane >> 4;
+    static_assert(WN == 64, "the masked LoRA epilogue reads one 8-byte flag word per row of the wave tile");
+    const long boff = min((long)((n0 + wc * WN) >> 3), p.drop_bits_ld - 8);
     for (int a = 0; a < nad; ++a) {
       bf16x8 s2[NI], r2[MI];
       const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -416,21 +399,26 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
         const int n = min(n0 + wc * WN + 16 * i + (lane & 15), p.N - 1);
         s2[i] = kin ? *reinterpret_cast<const bf16x8*>(p.S2 + (long)n * p.lds2 + a * p.drop_rank + kq) : zero8;
       }
+      uint2 fl[MI];
 #pragma unroll
       for (int j = 0; j < MI; ++j) {
         const int m = min(m0 + wr * WM + 16 * j + (lane & 15), p.M - 1);
         r2[j] = kin ? *reinterpret_cast<const bf16x8*>(p.R2 + (long)m * p.ldr2 + a * p.drop_rank + kq) : zero8;
+        fl[j] = *reinterpret_cast<const uint2*>(p.drop_bits + (long)a * p.drop_bits_stride + (long)m * p.drop_bits_ld + boff);
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
           const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s2[i], r2[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          const int n = n0 + wc * WN + 16 * i + (lane >> 4) * 4, m = m0 + wr * WM + 16 * j + (lane & 15);
-          const uint64_t idx = (uint64_t)m * (uint64_t)p.drop_ld + (uint64_t)n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (ur_keep16(p.drop_seed, idx + e, p.drop_slot + a, p.drop_thr16)) acc[i][j][e] += d[e] * p.drop_inv_keep;
+          // columns 16 i + 4 g4 .. + 3 of the wave tile: byte 2 i + (g4 >> 1) of the row's word, pair-interleaved
+          // flag order (lora.hip): element 4 q + e -> bit 2 q + (e >> 1) + 4 (e & 1), q = g4 & 1
+          const uint32_t wsel = (i & 2) ? fl[j].y : fl[j].x;
+          const uint32_t f = (wsel >> (16 * (i & 1) + 8 * (g4 >> 1) + 2 * (g4 & 1))) & 0x33u;
+          if (!(f & 0x01u)) acc[i][j][0] += d[0] * p.drop_inv_keep;
+          if (!(f & 0x10u)) acc[i][j][1] += d[1] * p.drop_inv_keep;
+          if (!(f & 0x02u)) acc[i][j][2] += d[2] * p.drop_inv_keep;
+          if (!(f & 0x20u)) acc[i][j][3] += d[3] * p.drop_inv_keep;
         }
     }
   }
@@ -555,21 +543,7 @@ int launch(const GemmP& p, int splits, hipStream_t st) {
   return launch_cfg<RK, SK, OUTF32, 128, 128, 2, 2>(p, splits, st);
 }
 
-__global__ void dropout_mask16_kernel(uint64_t seed, int slot, uint32_t thr16, long first, long n, uint8_t* out) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = ur_keep16(seed, (uint64_t)(first + i), slot, thr16) ? 1 : 0;
-}
-
 }  // namespace
-
-extern "C" int ur_dropout_mask16(uint64_t seed, int32_t slot, float p, int64_t first, int64_t n, uint8_t* out, void* stream) {
-  UR_REQUIRE(slot >= 0 && slot < 4 && p >= 0.f && p < 1.f && n >= 0 && first >= 0 && (n == 0 || out), "ur_dropout_mask16: bad argument");
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(dropout_mask16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, (int)slot,
-                     ur_drop_threshold16(p), (long)first, (long)n, out);
-  UR_CHECK_LAUNCH("ur_dropout_mask16");
-  return 0;
-}
 
 static inline bool splits_ok(const ur_gemm_args* a) { return a->split_k <= 1; }
 
@@ -615,18 +589,13 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
     UR_REQUIRE(!a->gelu_grad_aux || ((a->ldaux % 4) == 0 && (((uintptr_t)a->gelu_grad_aux) & 7) == 0), "ur_gemm: aux misaligned");
   }
   UR_REQUIRE(!a->bias || UR_ALIGNED16(a->bias), "ur_gemm: bias must be 16-byte aligned");
-  UR_REQUIRE(a->drop_mode >= 0 && a->drop_mode <= 3, "ur_gemm: drop_mode must be 0..3");
-  if (a->drop_mode != 0) {
-    UR_REQUIRE(a->drop_p > 0.f && a->drop_p < 1.f && a->drop_slot >= 0 && a->drop_slot < 4 && a->drop_ld > 0, "ur_gemm: bad LoRA dropout arguments");
-    if (a->drop_mode == 3) {
-      UR_REQUIRE(a->K2 > 0 && a->drop_rank >= 8 && a->drop_rank <= 32 && (a->drop_rank % 8) == 0 && (a->K2 % a->drop_rank) == 0 &&
-                 a->drop_slot + a->K2 / a->drop_rank <= 4 && a->r_kcontig && a->s_kcontig && splits_ok(a),
-                 "ur_gemm: drop_mode 3 needs K-contiguous operands, no split_k, rank in {8,16,24,32} and at most 4 adapters");
-    } else {
-      UR_REQUIRE(a->K2 == 0, "ur_gemm: drop_mode 1/2 cannot be combined with a second operand pair");
-    }
+  if (a->drop_bits) {
+    UR_REQUIRE(a->K2 > 0 && a->drop_rank >= 8 && a->drop_rank <= 32 && (a->drop_rank % 8) == 0 && (a->K2 % a->drop_rank) == 0 &&
+               a->K2 / a->drop_rank <= 4 && a->r_kcontig && a->s_kcontig && splits_ok(a) && !a->c_f32,
+               "ur_gemm: the masked LoRA epilogue needs K-contiguous operands, bf16 output, no split_k, rank in {8,16,24,32} and at most 4 adapters");
+    UR_REQUIRE(a->drop_p >= 0.f && a->drop_p < 1.f && (a->drop_bits_ld % 16) == 0 && a->drop_bits_ld * 8 >= a->N && (a->drop_bits_stride % 8) == 0 &&
+               ((uintptr_t)a->drop_bits & 15) == 0, "ur_gemm: bad LoRA dropout bit planes (rows of ur_lora_bits_ld(N) bytes, 16-byte aligned)");
   }
-
   GemmP p;
   p.R = (const bf16_t*)a->R; p.S = (const bf16_t*)a->S; p.ldr = a->ldr; p.lds = a->lds; p.K = a->K;
   p.R2 = (const bf16_t*)a->R2; p.S2 = (const bf16_t*)a->S2; p.ldr2 = a->ldr2; p.lds2 = a->lds2; p.K2 = a->K2;
@@ -634,9 +603,9 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
   p.bias = a->bias; p.res = (const bf16_t*)a->residual; p.ldres = a->ldres;
   p.gelu_out = (bf16_t*)a->gelu_out; p.ldg = a->ldg; p.aux = (const bf16_t*)a->gelu_grad_aux; p.ldaux = a->ldaux;
   p.gm = 0; p.gn = 0;   // set by launch_cfg for the chosen tile
-  p.drop_mode = a->drop_mode; p.drop_slot = a->drop_slot; p.drop_rank = a->drop_rank; p.drop_seed = a->drop_seed; p.drop_ld = a->drop_ld;
-  p.drop_thr16 = a->drop_mode ? ur_drop_threshold16(a->drop_p) : 0u;
-  p.drop_inv_keep = a->drop_mode ? 1.0f / (1.0f - a->drop_p) : 1.0f;
+  p.drop_bits = (const uint8_t*)a->drop_bits; p.drop_bits_ld = a->drop_bits_ld; p.drop_bits_stride = a->drop_bits_stride;
+  p.drop_rank = a->drop_rank;
+  p.drop_inv_keep = a->drop_bits ? 1.0f / (1.0f - a->drop_p) : 1.0f;
   p.slab_stride = 0;
   if (splits > 1) {
     int tiles = ur_cdiv(a->K, BK);

@@ -1,0 +1,476 @@
+// LoRA adapter side kernels (rank 16), gfx950 only.
+//
+// peft LoraLayer (call site training/train_item_individual_token_joint.py:121-131, r=16, lora_dropout=0.1):
+//     y = W x + s * B_a ( A_a dropout_a(x) )            one nn.Dropout per adapter a
+// The rank-16 products are HBM-bound streams over an [M, W] activation (M = tokens): running them through
+// the 128x128-tile GEMM wastes 8x of its MFMA work and LDS traffic, and masking the operand while it is
+// staged de-pipelines it.  Three kernels replace that:
+//   ur_lora_dropout_bits : the dropped flags of every adapter input element, ONE bit each, generated once per
+//                          (layer, adapter group, step) by a counter-based generator and kept for the backward
+//   ur_lora_project      : P[m, 16a+j] = alpha * sum_w keep_a(m,w) X[m, c0_a+w] U_a[j,w]   (reduction over columns)
+//                          forward  t  = s * dropout(x) A^T   (adapters share x, one bit plane each)
+//                          backward tb = s * dy_a B_a         (adapter a owns a column range of dy)
+//   ur_lora_reduce       : G_a[j,w]  = alpha * sum_m V[m,16a+j] keep_a(m,w) X[m, c0_a+w]   (reduction over tokens)
+//                          dA = tb^T dropout(x) ;  dB_a^T = t_a^T dy_a   (deterministic token split + slab sum)
+// Both read X exactly once for all adapters that share it; the MFMA operands come straight from global memory
+// (project) or through one LDS round trip with hardware-transposed reads (reduce).
+//
+// Bit layout (shared with ur_gemm's masked LoRA epilogue): plane a, row m, byte c/8 covers columns c..c+7
+// (c % 8 == 0): bit i (i < 4) = element c+2i dropped, bit 4+i = element c+2i+1 dropped -- the order in which
+// a 16-byte bf16x8 fragment keeps its elements in 32-bit pairs, so a byte expands to four pair masks with
+// one shift/and + one packed arithmetic shift each.
+#include "common.cuh"
+#include "unirec_hip.h"
+
+namespace {
+
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+typedef short ss2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, (us2_t)(__builtin_bit_cast(us2_t, a) - __builtin_bit_cast(us2_t, b)));
+}
+__device__ __forceinline__ uint32_t pk_sign16(uint32_t a) {          // each 16-bit half -> 0xffff if its sign bit is set
+  return __builtin_bit_cast(uint32_t, (ss2_t)(__builtin_bit_cast(ss2_t, a) >> 15));
+}
+// zero the dropped elements of a bf16x8 fragment (dropped-flag byte in the layout above)
+__device__ __forceinline__ uint4 drop_apply(uint4 x, uint32_t byte) {
+  const uint32_t z = (byte & 0xfu) | ((byte >> 4) << 16);
+  x.x &= ~pk_sign16((z << 15) & 0x80008000u);
+  x.y &= ~pk_sign16((z << 14) & 0x80008000u);
+  x.z &= ~pk_sign16((z << 13) & 0x80008000u);
+  x.w &= ~pk_sign16((z << 12) & 0x80008000u);
+  return x;
+}
+__device__ __forceinline__ int kc_g(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int f64sw(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
+
+// ---- dropped-flag bit planes ---------------------------------------------------------------------
+// thread <-> (row m, group q of 32 columns): one 32-bit word per adapter plane.  Every element draws a 15-bit
+// field of a murmur-finalised counter stream; dropped iff field < p * 2^15.
+__global__ void lora_bits_kernel(uint64_t seed, uint32_t thr15, int M, int W, int nad, long bits_ld, long bits_stride,
+                                 uint8_t* __restrict__ bits) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int ng = (int)(bits_ld >> 2);
+  const long m = gid / ng;
+  const int q = (int)(gid - m * ng);
+  if (m >= M) return;
+  const uint32_t thr_pk = thr15 * 0x10001u;
+  for (int a = 0; a < nad; ++a) {
+    uint32_t out = 0;
+    if (q * 32 < W) {
+      const uint64_t ctr = (((uint64_t)m * (uint64_t)ng + (uint64_t)q) << 2) + (uint64_t)a;
+      const uint32_t h = fmix32(((uint32_t)ctr ^ (uint32_t)seed) + fmix32((uint32_t)(ctr >> 32) + (uint32_t)(seed >> 32) + 0x9E3779B9u));
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t w = fmix32(h + (uint32_t)(4 * b + i + 1) * 0x9E3779B9u);
+          const uint32_t d = pk_sub16(w & 0x7fff7fffu, thr_pk);        // sign of each half set iff field < thr
+          v |= ((d >> 15) & 0x10001u) << i;
+        }
+        out |= ((v | (v >> 12)) & 0xffu) << (8 * b);
+      }
+    }
+    *reinterpret_cast<uint32_t*>(bits + (long)a * bits_stride + m * bits_ld + 4 * q) = out;
+  }
+}
+
+// ---- column-reduction products -------------------------------------------------------------------
+struct ProjP {
+  const bf16_t* X; long ldx; int M;
+  int col0[4], width[4];
+  const bf16_t* U[4]; long ldu[4];
+  const uint8_t* bits; long bits_ld, bits_stride;
+  bf16_t* P; long ldp;
+  float alpha;
+};
+
+// 256 threads = 4 waves, each wave 2 x 16 tokens, all of the entry's columns in chunks of 128.  NAD adapters share
+// the X fragments (NAD > 1: gridDim.y == 1); separate column ranges run as NAD = 1 with blockIdx.y = adapter.
+// X fragments are the MFMA column operand straight from global memory (lane: token lane&15, 8 consecutive
+// columns); the U chunk is staged once per block through a 2-slot LDS ring (GEMM K-contiguous image).
+template <int NAD, bool MASKED>
+__global__ __launch_bounds__(256) void lora_project_kernel(ProjP p) {
+  constexpr int RB = 2, KC = 128;
+  constexpr int SUB = NAD * 16 * 128;              // one 64-column sub-tile of the U chunk: rows x 128 B
+  constexpr int STAGE = 2 * SUB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int y = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int W = p.width[y], col0 = p.col0[y];
+  const int tok0 = blockIdx.x * (4 * RB * 16) + wave * (RB * 16);
+
+  f32x4 acc[RB][NAD];
+  const bf16_t* xrow[RB];
+  const uint8_t* brow[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int m = min(tok0 + 16 * rb + l15, p.M - 1);
+    xrow[rb] = p.X + (long)m * p.ldx + col0;
+    brow[rb] = MASKED ? p.bits + (long)m * p.bits_ld : nullptr;
+#pragma unroll
+    for (int a = 0; a < NAD; ++a) acc[rb][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nchunks = (W + KC - 1) / KC;
+  for (int c = 0; c < nchunks; ++c) {
+    const int kc = c * KC;
+    uint4 ureg[NAD];
+#pragma unroll
+    for (int i = 0; i < NAD; ++i) {
+      const int pi = tid + 256 * i, row = pi >> 4, k = kc + (pi & 15) * 8;
+      const int a = y + (row >> 4);
+      ureg[i] = (k < W) ? *reinterpret_cast<const uint4*>(p.U[a] + (long)(row & 15) * p.ldu[a] + k) : make_uint4(0, 0, 0, 0);
+    }
+    uint4 xf[RB][4], bw[RB][NAD];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int k = kc + 32 * s + 8 * g;
+        xf[rb][s] = (k < W) ? *reinterpret_cast<const uint4*>(xrow[rb] + k) : make_uint4(0, 0, 0, 0);
+      }
+      if (MASKED) {
+#pragma unroll
+        for (int a = 0; a < NAD; ++a) bw[rb][a] = *reinterpret_cast<const uint4*>(brow[rb] + (long)a * p.bits_stride + (kc >> 3));
+      }
+    }
+    char* st = smem + (c & 1) * STAGE;
+#pragma unroll
+    for (int i = 0; i < NAD; ++i) {
+      const int pi = tid + 256 * i, row = pi >> 4, c16 = pi & 15;
+      *reinterpret_cast<uint4*>(st + (c16 >> 3) * SUB + row * 128 + (((c16 & 7) ^ kc_g(row)) << 4)) = ureg[i];
+    }
+    __syncthreads();       // slot c&1 is re-written two chunks later: every wave has passed the next barrier by then
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+      for (int a = 0; a < NAD; ++a) {
+        const int row = a * 16 + l15, ch = 4 * (s & 1) + g;
+        const bf16x8 uf = *reinterpret_cast<const bf16x8*>(st + (s >> 1) * SUB + row * 128 + ((ch ^ kc_g(row)) << 4));
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          uint4 x = xf[rb][s];
+          if (MASKED) {
+            const uint32_t wsel = s == 0 ? bw[rb][a].x : s == 1 ? bw[rb][a].y : s == 2 ? bw[rb][a].z : bw[rb][a].w;
+            x = drop_apply(x, (wsel >> (8 * g)) & 0xffu);
+          }
+          acc[rb][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf, __builtin_bit_cast(bf16x8, x), acc[rb][a], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // lane holds P[token l15][16 (y + a) + 4 g .. + 3]
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int m = tok0 + 16 * rb + l15;
+    if (m < p.M) {
+#pragma unroll
+      for (int a = 0; a < NAD; ++a) {
+        const f32x4 v = acc[rb][a];
+        *reinterpret_cast<uint2*>(p.P + (long)m * p.ldp + 16 * (y + a) + 4 * g) =
+            make_uint2(pack_bf2(v[0] * p.alpha, v[1] * p.alpha), pack_bf2(v[2] * p.alpha, v[3] * p.alpha));
+      }
+    }
+  }
+}
+
+// ---- token-reduction products --------------------------------------------------------------------
+struct RedP {
+  const bf16_t* X; long ldx; int M;
+  int col0[4], width[4]; long goff[4];
+  const bf16_t* V; long ldv;
+  const uint8_t* bits; long bits_ld, bits_stride;
+  float* out; int transposed;
+  int tok_per_block;
+  float alpha;
+};
+
+// one pair of hardware-transposed reads: lane gets [column lane&15 of the 16-column segment][rows r0 .. r0+7]
+__device__ __forceinline__ void tr_pair(bf16x8 (&f)[2], uint32_t a0, uint32_t b0, uint32_t a1, uint32_t b1) {
+  const uint32_t a[2] = {a0, a1}, b[2] = {b0, b1};
+  tr_read(f, a, b);
+}
+
+// grid: x = 64-column block, y = token split, z = entry (separate column ranges, NAD == 1) or 0 (NAD adapters share X).
+// Per 64-token step the block stages X[64 tokens][64 columns] (one masked copy per adapter) and V[64 tokens][16 NAD]
+// row-major in LDS; ds_read_b64_tr_b16 turns both into token-packed MFMA operands.  Wave w owns columns 16w..16w+15.
+template <int NAD, bool MASKED>
+__global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
+  constexpr int XT = 64 * 128;
+  constexpr int VROW = NAD * 32;
+  __shared__ __attribute__((aligned(16))) char smem[NAD * XT + 64 * VROW];
+  char* vt = smem + NAD * XT;
+  const int e0 = blockIdx.z;
+  const int W = p.width[e0], col0 = p.col0[e0];
+  const int cb = blockIdx.x * 64;
+  if (cb >= W) return;                                   // uniform per block
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int tbeg = blockIdx.y * p.tok_per_block, tend = min(p.M, tbeg + p.tok_per_block);
+
+  // this thread's staging pieces
+  int prow[2], pch[2], pcol[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pi = tid + 256 * i;
+    prow[i] = pi >> 3; pch[i] = pi & 7;
+    pcol[i] = min(cb + 8 * pch[i], W - 8);
+  }
+  constexpr int VP = (64 * 2 * NAD + 255) / 256;           // V pieces (16 B) per thread: 64 rows x 2 NAD pieces
+  int vrow[VP], vpart[VP];
+  bool vthr[VP];
+#pragma unroll
+  for (int i = 0; i < VP; ++i) {
+    const int pi = tid + 256 * i;
+    vthr[i] = pi < 64 * 2 * NAD;
+    vrow[i] = pi / (2 * NAD); vpart[i] = pi % (2 * NAD);
+  }
+
+  uint4 xr[2], vr[VP];
+  uint32_t br[2][NAD];
+  auto gload = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = min(t0 + prow[i], p.M - 1);
+      xr[i] = *reinterpret_cast<const uint4*>(p.X + (long)m * p.ldx + col0 + pcol[i]);
+      if (MASKED) {
+#pragma unroll
+        for (int a = 0; a < NAD; ++a) br[i][a] = p.bits[(long)a * p.bits_stride + (long)m * p.bits_ld + (pcol[i] >> 3)];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < VP; ++i) {
+      vr[i] = make_uint4(0, 0, 0, 0);
+      if (vthr[i] && t0 + vrow[i] < tend) vr[i] = *reinterpret_cast<const uint4*>(p.V + (long)(t0 + vrow[i]) * p.ldv + 16 * e0 + 8 * vpart[i]);
+    }
+  };
+
+  f32x4 acc[NAD];
+#pragma unroll
+  for (int a = 0; a < NAD; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int q = l15 >> 2, pp = lane & 3;
+
+  if (tbeg < tend) gload(tbeg);
+  for (int t0 = tbeg; t0 < tend; t0 += 64) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = prow[i] * 128 + ((((pch[i] >> 1) ^ f64sw(prow[i])) << 5) | ((pch[i] & 1) << 4));
+#pragma unroll
+      for (int a = 0; a < NAD; ++a)
+        *reinterpret_cast<uint4*>(smem + a * XT + off) = MASKED ? drop_apply(xr[i], br[i][a]) : xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VP; ++i)
+      if (vthr[i]) *reinterpret_cast<uint4*>(vt + vrow[i] * VROW + vpart[i] * 16) = vr[i];
+    __syncthreads();
+    if (t0 + 64 < tend) gload(t0 + 64);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ka = 32 * ks + 8 * g + q;
+      const uint32_t xo = lds_off(smem) + ka * 128 + ((wave ^ f64sw(ka)) << 5) + pp * 8;
+      const uint32_t vo = lds_off(vt) + ka * VROW + pp * 8;
+#pragma unroll
+      for (int a = 0; a < NAD; ++a) {
+        bf16x8 f[2];      // f[0] = X fragment (index: column), f[1] = V fragment (index: rank row j)
+        tr_pair(f, xo + a * XT, xo + a * XT + 4 * 128, vo + a * 32, vo + a * 32 + 4 * VROW);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf16x8 fa = p.transposed ? f[1] : f[0], fb = p.transposed ? f[0] : f[1];
+        acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[a], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // partial (or final) result of this token range, dense layout: entry e at goff[e], [16][W] or [W][16]
+  long total = 0;
+  {
+    const int ne = gridDim.z > 1 ? (int)gridDim.z : NAD;
+    total = p.goff[ne - 1] + 16L * p.width[gridDim.z > 1 ? ne - 1 : 0];
+  }
+  float* base = p.out + (long)blockIdx.y * total;
+#pragma unroll
+  for (int a = 0; a < NAD; ++a) {
+    float* ge = base + p.goff[e0 + a];
+    const f32x4 v = acc[a] * p.alpha;
+    if (p.transposed) {            // D[j = 4g+e][w = l15]  ->  G[w][j]
+      const int w = cb + 16 * wave + l15;
+      if (w < W) *reinterpret_cast<float4*>(ge + (long)w * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {                       // D[w = 4g+e][j = l15]  ->  G[j][w]
+      const int w = cb + 16 * wave + 4 * g;
+      if (w < W) *reinterpret_cast<float4*>(ge + (long)l15 * W + w) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+__global__ void slab_sum_kernel(const float* __restrict__ ws, float* __restrict__ out, long total4, int splits) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float4* w4 = reinterpret_cast<const float4*>(ws);
+  for (; i < total4; i += stride) {
+    float4 a = w4[i];
+    for (int z = 1; z < splits; ++z) {
+      const float4 b = w4[i + (long)z * total4];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+  }
+}
+
+int validate_common(const ur_lora_args* a, const char* who) {
+  UR_REQUIRE(a != nullptr, "%s: null args", who);
+  UR_REQUIRE(a->M >= 0 && a->nad >= 1 && a->nad <= 4, "%s: M >= 0 and 1 <= nad <= 4 required (M=%d nad=%d)", who, a->M, a->nad);
+  UR_REQUIRE(a->rank == 16, "%s: the dedicated LoRA kernels are built for rank 16 (got %d)", who, a->rank);
+  UR_REQUIRE(a->X && UR_ALIGNED16(a->X) && (a->ldx % 8) == 0, "%s: X must be 16-byte aligned with ldx %% 8 == 0", who);
+  const int ne = a->shared ? 1 : a->nad;
+  for (int e = 0; e < ne; ++e) {
+    UR_REQUIRE(a->width[e] >= 8 && (a->width[e] % 8) == 0 && a->col0[e] >= 0 && (a->col0[e] % 8) == 0 &&
+               (int64_t)a->col0[e] + a->width[e] <= a->ldx, "%s: entry %d column range [%d, +%d) invalid (multiples of 8 inside ldx)",
+               who, e, a->col0[e], a->width[e]);
+  }
+  if (a->drop_bits) {
+    UR_REQUIRE(a->shared, "%s: dropout bit planes need adapters that share their input", who);
+    UR_REQUIRE(a->col0[0] == 0, "%s: dropout bit planes cover the input from column 0", who);
+    UR_REQUIRE((a->bits_ld % 16) == 0 && a->bits_ld * 8 >= a->width[0] && UR_ALIGNED16(a->drop_bits) && (a->bits_stride % 16) == 0,
+               "%s: bit planes need 16-byte aligned rows (bits_ld %% 16 == 0, bits_ld * 8 >= width)", who);
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t ur_lora_bits_ld(int32_t W) { return ((int64_t)W + 127) / 128 * 16; }
+
+extern "C" int ur_lora_dropout_bits(uint64_t seed, float p, int32_t M, int32_t W, int32_t nad, uint8_t* bits, int64_t bits_ld,
+                                    int64_t bits_stride, void* stream) {
+  UR_REQUIRE(p >= 0.f && p < 1.f && M >= 0 && W > 0 && nad >= 1 && nad <= 4, "ur_lora_dropout_bits: bad argument");
+  UR_REQUIRE(bits_ld == ur_lora_bits_ld(W) && bits_stride >= (int64_t)M * bits_ld && (bits_stride % 16) == 0 && (M == 0 || (bits && UR_ALIGNED16(bits))),
+             "ur_lora_dropout_bits: bits_ld must be ur_lora_bits_ld(W), planes 16-byte aligned and at least M rows apart");
+  if (M == 0) return 0;
+  double t = (double)p * 32768.0 + 0.5;
+  const uint32_t thr15 = t > 32767.0 ? 32767u : (uint32_t)t;
+  const long n = (long)M * (bits_ld / 4);
+  hipLaunchKernelGGL(lora_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, thr15, (int)M, (int)W,
+                     (int)nad, (long)bits_ld, (long)bits_stride, bits);
+  UR_CHECK_LAUNCH("ur_lora_dropout_bits");
+  return 0;
+}
+
+extern "C" int ur_lora_project(const ur_lora_args* a, void* stream) {
+  if (int rc = validate_common(a, "ur_lora_project")) return rc;
+  UR_REQUIRE(a->P && (((uintptr_t)a->P) & 7) == 0 && (a->ldp % 4) == 0 && a->ldp >= 16 * a->nad, "ur_lora_project: P must be 8-byte aligned, ldp %% 4 == 0, ldp >= 16 nad");
+  for (int e = 0; e < a->nad; ++e)
+    UR_REQUIRE(a->U[e] && UR_ALIGNED16(a->U[e]) && (a->ldu[e] % 8) == 0 && a->ldu[e] >= a->width[a->shared ? 0 : e],
+               "ur_lora_project: U[%d] must be a 16-byte aligned [16, width] bf16 matrix (ldu %% 8 == 0)", e);
+  if (a->M == 0) return 0;
+  ProjP p;
+  p.X = (const bf16_t*)a->X; p.ldx = a->ldx; p.M = a->M;
+  for (int e = 0; e < 4; ++e) {
+    const int s = a->shared ? 0 : (e < a->nad ? e : 0);
+    p.col0[e] = a->col0[s]; p.width[e] = a->width[s];
+    p.U[e] = (const bf16_t*)a->U[e < a->nad ? e : 0]; p.ldu[e] = a->ldu[e < a->nad ? e : 0];
+  }
+  p.bits = (const uint8_t*)a->drop_bits; p.bits_ld = a->bits_ld; p.bits_stride = a->bits_stride;
+  p.P = (bf16_t*)a->P; p.ldp = a->ldp; p.alpha = a->alpha;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned gx = (unsigned)ur_cdiv(a->M, 128);
+  const bool masked = a->drop_bits != nullptr;
+  if (!a->shared || a->nad == 1) {
+    dim3 grid(gx, a->nad);
+    if (masked) hipLaunchKernelGGL((lora_project_kernel<1, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((lora_project_kernel<1, false>), grid, dim3(256), 0, st, p);
+  } else {
+    dim3 grid(gx, 1);
+#define UR_PROJ(NAD)                                                                          \
+    if (masked) hipLaunchKernelGGL((lora_project_kernel<NAD, true>), grid, dim3(256), 0, st, p); \
+    else hipLaunchKernelGGL((lora_project_kernel<NAD, false>), grid, dim3(256), 0, st, p)
+    if (a->nad == 2) { UR_PROJ(2); } else if (a->nad == 3) { UR_PROJ(3); } else { UR_PROJ(4); }
+#undef UR_PROJ
+  }
+  UR_CHECK_LAUNCH("ur_lora_project");
+  return 0;
+}
+
+static inline int lora_reduce_splits(const ur_lora_args* a) {
+  int wmax = 0;
+  const int ne = a->shared ? 1 : a->nad;
+  for (int e = 0; e < ne; ++e) wmax = a->width[e] > wmax ? a->width[e] : wmax;
+  const long colblocks = (long)ur_cdiv(wmax, 64) * ne;
+  const int tiles = ur_cdiv(a->M, 64);
+  long want = (2048 + colblocks - 1) / colblocks;          // ~8 blocks per CU
+  if (want < 1) want = 1;
+  if (want > tiles) want = tiles;
+  if (want > 256) want = 256;
+  const int tiles_per = ur_cdiv(tiles, (int)want);
+  return ur_cdiv(tiles, tiles_per);
+}
+static inline int64_t lora_reduce_total(const ur_lora_args* a) {
+  int64_t t = 0;
+  for (int e = 0; e < a->nad; ++e) t += 16LL * a->width[a->shared ? 0 : e];
+  return t;
+}
+
+extern "C" int64_t ur_lora_reduce_workspace_bytes(const ur_lora_args* a) {
+  if (!a || a->M <= 0 || a->nad < 1 || a->nad > 4) return 0;
+  const int splits = lora_reduce_splits(a);
+  return splits > 1 ? (int64_t)splits * lora_reduce_total(a) * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int ur_lora_reduce(const ur_lora_args* a, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (int rc = validate_common(a, "ur_lora_reduce")) return rc;
+  UR_REQUIRE(a->V && UR_ALIGNED16(a->V) && (a->ldv % 8) == 0 && a->ldv >= 16 * a->nad, "ur_lora_reduce: V must be a 16-byte aligned [M, 16 nad] bf16 matrix");
+  UR_REQUIRE(a->G && UR_ALIGNED16(a->G), "ur_lora_reduce: G must be 16-byte aligned");
+  const int64_t total = lora_reduce_total(a);
+  hipStream_t st = (hipStream_t)stream;
+  if (a->M == 0) {
+    hipError_t e = hipMemsetAsync(a->G, 0, (size_t)total * sizeof(float), st);
+    if (e != hipSuccess) UR_FAIL((int)e, "ur_lora_reduce: memset failed");
+    return 0;
+  }
+  const int splits = lora_reduce_splits(a);
+  if (splits > 1)
+    UR_REQUIRE(workspace && UR_ALIGNED16(workspace) && workspace_bytes >= ur_lora_reduce_workspace_bytes(a),
+               "ur_lora_reduce: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)ur_lora_reduce_workspace_bytes(a));
+  RedP p;
+  p.X = (const bf16_t*)a->X; p.ldx = a->ldx; p.M = a->M;
+  long off = 0;
+  int wmax = 0;
+  for (int e = 0; e < 4; ++e) {
+    const int s = a->shared ? 0 : (e < a->nad ? e : 0);
+    p.col0[e] = a->col0[s]; p.width[e] = a->width[s];
+    p.goff[e] = off;
+    if (e < a->nad) { off += 16L * a->width[s]; wmax = a->width[s] > wmax ? a->width[s] : wmax; }
+  }
+  p.V = (const bf16_t*)a->V; p.ldv = a->ldv;
+  p.bits = (const uint8_t*)a->drop_bits; p.bits_ld = a->bits_ld; p.bits_stride = a->bits_stride;
+  p.out = splits > 1 ? (float*)workspace : (float*)a->G;
+  p.transposed = a->g_transposed ? 1 : 0;
+  const int tiles = ur_cdiv(a->M, 64);
+  p.tok_per_block = ur_cdiv(tiles, splits) * 64;
+  p.alpha = a->alpha;
+  const bool masked = a->drop_bits != nullptr;
+  if (!a->shared || a->nad == 1) {
+    dim3 grid(ur_cdiv(wmax, 64), splits, a->nad);
+    if (masked) hipLaunchKernelGGL((lora_reduce_kernel<1, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((lora_reduce_kernel<1, false>), grid, dim3(256), 0, st, p);
+  } else {
+    dim3 grid(ur_cdiv(wmax, 64), splits, 1);
+#define UR_RED(NAD)                                                                          \
+    if (masked) hipLaunchKernelGGL((lora_reduce_kernel<NAD, true>), grid, dim3(256), 0, st, p); \
+    else hipLaunchKernelGGL((lora_reduce_kernel<NAD, false>), grid, dim3(256), 0, st, p)
+    if (a->nad == 2) { UR_RED(2); } else if (a->nad == 3) { UR_RED(3); } else { UR_RED(4); }
+#undef UR_RED
+  }
+  UR_CHECK_LAUNCH("ur_lora_reduce");
+  if (splits > 1) {
+    const long total4 = total / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, (float*)a->G, total4, splits);
+    UR_CHECK_LAUNCH("ur_lora_reduce(slab_sum)");
+  }
+  return 0;
+}

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import AttnArgs, AttnBwdArgs, GemmArgs, check
+from ._lib import AttnArgs, AttnBwdArgs, GemmArgs, LoraArgs, check
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -53,7 +53,8 @@ def workspace(nbytes, device, tag="default"):
 def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=None, out_f32=False, alpha=1.0,
          bias=None, residual=None, gelu_out=None, gelu_grad_aux=None, R2=None, S2=None, split_k=1, drop=None):
     """C[M,N] = alpha*(R(m,k) S(n,k) + R2 S2) + epilogue.  R/S are 2-D bf16 (row stride = stride(0)).
-    drop = (mode, seed, slot, p, ld[, rank]): LoRA dropout, see ur_gemm_args in include/unirec_hip.h."""
+    drop = (bits, p, rank): masked LoRA epilogue (bits = hip.lora_dropout_bits planes of the adapters' shared input),
+    see ur_gemm_args in include/unirec_hip.h."""
     lib = _lib.load()
     for t, n in ((R, "R"), (S, "S")):
         if t.dtype != BF16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
@@ -86,9 +87,10 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
     if gelu_grad_aux is not None:
         a.gelu_grad_aux, a.ldaux = gelu_grad_aux.data_ptr(), gelu_grad_aux.stride(0)
     a.split_k = int(split_k)
-    if drop is not None and drop[3] > 0.0:
-        a.drop_mode, a.drop_seed, a.drop_slot, a.drop_p, a.drop_ld = int(drop[0]), int(drop[1]), int(drop[2]), float(drop[3]), int(drop[4])
-        a.drop_rank = int(drop[5]) if len(drop) > 5 else 0
+    if drop is not None:
+        bits, pdrop, rank = drop
+        a.drop_bits, a.drop_bits_ld, a.drop_bits_stride = bits.data_ptr(), bits.stride(1), bits.stride(0)
+        a.drop_p, a.drop_rank = float(pdrop), int(rank)
     ws, wsb = 0, 0
     if split_k > 1:
         wsb = lib.ur_gemm_workspace_bytes(ctypes.byref(a))
@@ -104,11 +106,78 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
     return out
 
 
-def dropout_mask16(seed, slot, p, n, device, first=0):
-    """The LoRA-dropout keep mask (uint8 0/1) of elements first .. first+n-1 -- test / inspection helper."""
+# ---- LoRA adapter products (rank 16): include/unirec_hip.h, csrc/lora.hip ---------------------------
+def lora_dropout_bits(seed, p, M, W, nad, device):
+    """Dropped-flag bit planes uint8 [nad, M, ur_lora_bits_ld(W)] of nad adapters that share an [M, W] input."""
     lib = _lib.load()
-    out = torch.empty((n,), dtype=torch.uint8, device=device)
-    check(lib.ur_dropout_mask16(int(seed), int(slot), float(p), int(first), int(n), out.data_ptr(), _stream()), "ur_dropout_mask16")
+    ld = int(lib.ur_lora_bits_ld(int(W)))
+    bits = torch.empty((nad, M, ld), dtype=torch.uint8, device=device)
+    check(lib.ur_lora_dropout_bits(int(seed), float(p), int(M), int(W), int(nad), bits.data_ptr(), ld, bits.stride(0), _stream()),
+          "ur_lora_dropout_bits")
+    return bits
+
+
+def lora_bits_to_keep(bits, W):
+    """Unpack bit planes into keep masks uint8 [nad, M, W] (1 = kept) -- test / inspection helper (torch ops)."""
+    nad, M, ld = bits.shape
+    b = bits.to(torch.int32)
+    pos = torch.tensor([0, 4, 1, 5, 2, 6, 3, 7], device=bits.device, dtype=torch.int32)     # element e of a byte -> bit
+    dropped = (b.unsqueeze(-1) >> pos) & 1
+    return (1 - dropped).reshape(nad, M, ld * 8)[:, :, :W].to(torch.uint8)
+
+
+def _lora_args(X, cols, shared, bits, alpha):
+    a = LoraArgs()
+    if X.dtype != BF16 or not X.is_cuda or X.dim() != 2 or X.stride(1) != 1:
+        raise ValueError("lora: X must be a 2-D bf16 device tensor with unit inner stride")
+    a.X, a.ldx, a.M = X.data_ptr(), X.stride(0), X.shape[0]
+    a.nad, a.rank, a.shared = len(cols), 16, int(shared)
+    for e, (c0, w) in enumerate(cols):
+        a.col0[e], a.width[e] = int(c0), int(w)
+    if bits is not None:
+        a.drop_bits, a.bits_ld, a.bits_stride = bits.data_ptr(), bits.stride(1), bits.stride(0)
+    a.alpha = float(alpha)
+    return a
+
+
+def lora_project(X, U, cols=None, alpha=1.0, bits=None, out=None):
+    """P[m, 16a+j] = alpha * sum_w keep_a(m,w) X[m, c0_a+w] U_a[j,w].  U: list of bf16 [16, width_a] matrices.
+    cols=None: the adapters share all of X's columns (optionally with dropout bit planes `bits`);
+    cols=[(c0, width), ...]: adapter a owns that column range of X."""
+    lib = _lib.load()
+    shared = cols is None
+    if shared:
+        cols = [(0, X.shape[1])] * len(U)
+    a = _lora_args(X, cols, shared, bits, alpha)
+    for e, u in enumerate(U):
+        if u.dtype != BF16 or u.shape[0] != 16 or u.stride(1) != 1 or u.shape[1] != cols[e][1]:
+            raise ValueError("lora_project: U[a] must be bf16 [16, width_a]")
+        a.U[e], a.ldu[e] = u.data_ptr(), u.stride(0)
+    if out is None:
+        out = torch.empty((X.shape[0], 16 * len(U)), dtype=BF16, device=X.device)
+    a.P, a.ldp = out.data_ptr(), out.stride(0)
+    check(lib.ur_lora_project(ctypes.byref(a), _stream()), "ur_lora_project")
+    return out
+
+
+def lora_reduce(X, V, out, cols=None, nad=None, alpha=1.0, bits=None, transposed=False):
+    """G_a[j,w] = alpha * sum_m V[m,16a+j] keep_a(m,w) X[m, c0_a+w] into the dense f32 tensor `out`
+    ([16 nad, W] for shared columns, or [sum width, 16] with transposed=True for per-adapter column ranges)."""
+    lib = _lib.load()
+    shared = cols is None
+    if shared:
+        cols = [(0, X.shape[1])] * int(nad)
+    a = _lora_args(X, cols, shared, bits, alpha)
+    if V.dtype != BF16 or V.stride(1) != 1 or V.shape[0] != X.shape[0] or V.shape[1] < 16 * len(cols):
+        raise ValueError("lora_reduce: V must be bf16 [M, >= 16 nad]")
+    _need(out, F32, "out")
+    if out.numel() != 16 * sum(w for _, w in cols):
+        raise ValueError("lora_reduce: out has the wrong size")
+    a.V, a.ldv = V.data_ptr(), V.stride(0)
+    a.G, a.g_transposed = out.data_ptr(), int(transposed)
+    wsb = lib.ur_lora_reduce_workspace_bytes(ctypes.byref(a))
+    ws = workspace(wsb, X.device, "lora").data_ptr() if wsb else 0
+    check(lib.ur_lora_reduce(ctypes.byref(a), ws, wsb, _stream()), "ur_lora_reduce")
     return out
 
 

@@ -250,20 +250,21 @@ class Qwen3LoRAModel(nn.Module):
 
     def lora_dropout_seed(self, step, layer, group):
         """Seed of the dropout masks of one adapter group (the adapters that share an input: 0 = q|k|v, 1 = o,
-        2 = gate|up, 3 = down) -- a pure function of (base seed, step, layer, group), so the backward regenerates
-        the masks instead of storing them and tests can export them (hip.dropout_mask16)."""
+        2 = gate|up, 3 = down) -- a pure function of (base seed, step, layer, group); tests regenerate the bit
+        planes from it (hip.lora_dropout_bits) and feed the unpacked masks to the oracle."""
         return (int(self.lora_seed) * 0x9E3779B1 + int(step) * 1000003 + layer * 8 + group) & 0x7FFFFFFFFFFFFFFF
 
     def _lora_down(self, xin, a_names, pack, sc, seed, p):
-        """t[M, nb*r] = s * dropout_j(x) A_j^T for the nb adapters that share the input x (one mask per adapter)."""
-        r = self.config.lora_r
-        if p <= 0.0:
+        """(t, bits): t[M, nb*r] = s * dropout_j(x) A_j^T for the nb adapters that share the input x (one dropped-flag
+        bit plane per adapter, generated once here and kept for the backward)."""
+        if self.config.lora_r != 16:
+            if p > 0.0:
+                raise hip._lib.UniRecHipError("LoRA dropout is implemented for rank 16 (the reference's r) only")
             A = pack.fused16(a_names) if len(a_names) > 1 else pack.w16(a_names[0])
-            return hip.gemm(xin, A, alpha=sc)
-        t = torch.empty((xin.shape[0], len(a_names) * r), dtype=BF16, device=xin.device)
-        for j, an in enumerate(a_names):
-            hip.gemm(xin, pack.w16(an), out=t[:, j * r:(j + 1) * r], alpha=sc / (1.0 - p), drop=(1, seed, j, p, xin.shape[1]))
-        return t
+            return hip.gemm(xin, A, alpha=sc), None
+        bits = hip.lora_dropout_bits(seed, p, xin.shape[0], xin.shape[1], len(a_names), xin.device) if p > 0.0 else None
+        t = hip.lora_project(xin, [pack.w16(n) for n in a_names], alpha=sc / (1.0 - p), bits=bits)
+        return t, bits
 
     def _forward_impl(self, item_tokens16, input_ids, mask_u8, first_special_id):
         c = self.config
@@ -293,8 +294,8 @@ class Qwen3LoRAModel(nn.Module):
             h, rstd1 = hip.rmsnorm_fwd(x, fl["ln1"], eps)
             qkv = torch.empty((M, NQ + 2 * NKV), dtype=BF16, device=dev)
             if pack is not None:
-                t_qkv = self._lora_down(h, [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"], pack, sc,
-                                        self.lora_dropout_seed(step, i, 0), pdrop)     # [M,3r] = s * dropout(h) A^T
+                t_qkv, L["bits_qkv"] = self._lora_down(h, [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"], pack, sc,
+                                                       self.lora_dropout_seed(step, i, 0), pdrop)     # [M,3r] = s * dropout(h) A^T
                 col = 0
                 for j, (p, n) in enumerate((("q", NQ), ("k", NKV), ("v", NKV))):
                     hip.gemm(h, fl["qkv"][col:col + n], out=qkv[:, col:col + n], R2=t_qkv[:, j * r:(j + 1) * r],
@@ -308,7 +309,7 @@ class Qwen3LoRAModel(nn.Module):
             att, actx = hip.attn_fwd(q_r.view(B, S, nq, hd), k_r.view(B, S, nkv, hd), v4, causal=True, key_mask=mask_u8)
             att2 = att.view(M, NQ)
             if pack is not None:
-                t_o = self._lora_down(att2, [lp + "self_attn.o_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 1), pdrop)
+                t_o, L["bits_o"] = self._lora_down(att2, [lp + "self_attn.o_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 1), pdrop)
                 x2 = hip.gemm(att2, fl["o"], residual=x, R2=t_o, S2=pack.w16(lp + "self_attn.o_proj.lora_B.weight"))
                 L["t_o"] = t_o
             else:
@@ -316,8 +317,8 @@ class Qwen3LoRAModel(nn.Module):
             h2, rstd2 = hip.rmsnorm_fwd(x2, fl["ln2"], eps)
             gu = torch.empty((M, 2 * I), dtype=BF16, device=dev)
             if pack is not None:
-                t_gu = self._lora_down(h2, [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"], pack, sc,
-                                       self.lora_dropout_seed(step, i, 2), pdrop)
+                t_gu, L["bits_gu"] = self._lora_down(h2, [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"], pack, sc,
+                                                     self.lora_dropout_seed(step, i, 2), pdrop)
                 for j, p in enumerate(("gate", "up")):
                     hip.gemm(h2, fl["gu"][j * I:(j + 1) * I], out=gu[:, j * I:(j + 1) * I], R2=t_gu[:, j * r:(j + 1) * r],
                              S2=pack.w16(lp + f"mlp.{p}_proj.lora_B.weight"))
@@ -326,7 +327,7 @@ class Qwen3LoRAModel(nn.Module):
                 hip.gemm(h2, fl["gu"], out=gu)
             act = hip.swiglu_fwd(gu, I)
             if pack is not None:
-                t_d = self._lora_down(act, [lp + "mlp.down_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 3), pdrop)
+                t_d, L["bits_d"] = self._lora_down(act, [lp + "mlp.down_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 3), pdrop)
                 x3 = hip.gemm(act, fl["d"], residual=x2, R2=t_d, S2=pack.w16(lp + "mlp.down_proj.lora_B.weight"))
                 L["t_d"] = t_d
             else:
@@ -356,30 +357,33 @@ class Qwen3LoRAModel(nn.Module):
 
         pdrop, step = saved["pdrop"], saved["step"]
 
-        def lora_grads(dy, t, xin, a_names, b_specs, seed):
+        def lora_grads(dy, t, xin, a_names, b_specs, bits):
             """dB_p = dy_p^T t_p ; tb = s * dy B ; dA_p = tb_p^T dropout_p(x).  Returns tb [M, len(b)*r] (bf16)."""
             nb = len(b_specs)
-            tb = torch.empty((M, nb * r), dtype=BF16, device=dev)
-            for j, (bname, c0, n) in enumerate(b_specs):
-                dyp = dy[:, c0:c0 + n]
-                hip.gemm(dyp, t[:, j * r:(j + 1) * r], r_kcontig=False, s_kcontig=False, out=pack.g32(bname), split_k=_split_k(M, n, r))
-                hip.gemm(dyp, pack.w16(bname), s_kcontig=False, out=tb[:, j * r:(j + 1) * r], alpha=sc)
-                touched.append(bname)
-            if pdrop > 0.0:
-                for j, an in enumerate(a_names):      # one mask per adapter: the token reduction runs per adapter
-                    hip.gemm(tb[:, j * r:(j + 1) * r], xin, r_kcontig=False, s_kcontig=False, out=pack.g32(an),
-                             split_k=_split_k(M, r, xin.shape[1]), alpha=1.0 / (1.0 - pdrop), drop=(2, seed, j, pdrop, xin.shape[1]))
-            else:
+            touched.extend([b for b, _, _ in b_specs] + list(a_names))
+            if r != 16:           # generic tiles (no dropout: _lora_down refused it)
+                tb = torch.empty((M, nb * r), dtype=BF16, device=dev)
+                for j, (bname, c0, n) in enumerate(b_specs):
+                    dyp = dy[:, c0:c0 + n]
+                    hip.gemm(dyp, t[:, j * r:(j + 1) * r], r_kcontig=False, s_kcontig=False, out=pack.g32(bname), split_k=_split_k(M, n, r))
+                    hip.gemm(dyp, pack.w16(bname), s_kcontig=False, out=tb[:, j * r:(j + 1) * r], alpha=sc)
                 gA = pack.fusedg(a_names) if len(a_names) > 1 else pack.g32(a_names[0])
                 hip.gemm(tb, xin, r_kcontig=False, s_kcontig=False, out=gA, split_k=_split_k(M, nb * r, xin.shape[1]))
-            touched.extend(a_names)
+                return tb
+            cols = [(c0, n) for _, c0, n in b_specs]
+            bnames = [b for b, _, _ in b_specs]
+            gB = pack.fusedg(bnames) if nb > 1 else pack.g32(bnames[0])            # [sum n, r]: adapter ranges in order
+            hip.lora_reduce(dy, t, gB, cols=cols, transposed=True)
+            tb = hip.lora_project(dy, [hip.transpose_bf16(pack.w16(b)) for b in bnames], cols=cols, alpha=sc)
+            gA = pack.fusedg(a_names) if len(a_names) > 1 else pack.g32(a_names[0])
+            hip.lora_reduce(xin, tb, gA, nad=len(a_names), alpha=1.0 / (1.0 - pdrop), bits=bits)
             return tb
 
-        def dx_gemm(dy, wT, tb, a_names, seed, n_in):
+        def dx_gemm(dy, wT, tb, a_names, bits):
             """dx = dy W + sum_j mask_j * (tb_j A_j): the adapters' part joins the main reduction when there is no
-            dropout, and is a masked rank-r epilogue (ur_gemm drop_mode 3) when there is."""
+            dropout, and is a masked rank-r epilogue (ur_gemm drop_bits) when there is."""
             A = pack.fused16(a_names) if len(a_names) > 1 else pack.w16(a_names[0])
-            drop = (3, seed, 0, pdrop, n_in, r) if pdrop > 0.0 else None
+            drop = (bits, pdrop, r) if bits is not None else None
             return hip.gemm(dy, wT, R2=tb, S2=hip.transpose_bf16(A), drop=drop)
 
         for i in reversed(range(len(fz["layers"]))):
@@ -389,27 +393,24 @@ class Qwen3LoRAModel(nn.Module):
             # ---- MLP: x3 = x2 + down(silu(gate) * up)
             act = L["act"]
             if pack is not None:
-                sd = self.lora_dropout_seed(step, i, 3)
-                tb = lora_grads(dx, L["t_d"], act, [lp + "mlp.down_proj.lora_A.weight"], [(lp + "mlp.down_proj.lora_B.weight", 0, D)], sd)
-                dact = dx_gemm(dx, fl["dT"], tb, [lp + "mlp.down_proj.lora_A.weight"], sd, I)
+                tb = lora_grads(dx, L["t_d"], act, [lp + "mlp.down_proj.lora_A.weight"], [(lp + "mlp.down_proj.lora_B.weight", 0, D)], L["bits_d"])
+                dact = dx_gemm(dx, fl["dT"], tb, [lp + "mlp.down_proj.lora_A.weight"], L["bits_d"])
             else:
                 dact = hip.gemm(dx, fl["dT"])
             dgu = hip.swiglu_bwd(dact, gu, I)
             h2, _ = hip.rmsnorm_fwd(x2, fl["ln2"], eps)                   # recomputed
             if pack is not None:
                 a_names = [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"]
-                sd = self.lora_dropout_seed(step, i, 2)
-                tb = lora_grads(dgu, L["t_gu"], h2, a_names, [(lp + "mlp.gate_proj.lora_B.weight", 0, I), (lp + "mlp.up_proj.lora_B.weight", I, I)], sd)
-                dh2 = dx_gemm(dgu, fl["guT"], tb, a_names, sd, D)
+                tb = lora_grads(dgu, L["t_gu"], h2, a_names, [(lp + "mlp.gate_proj.lora_B.weight", 0, I), (lp + "mlp.up_proj.lora_B.weight", I, I)], L["bits_gu"])
+                dh2 = dx_gemm(dgu, fl["guT"], tb, a_names, L["bits_gu"])
             else:
                 dh2 = hip.gemm(dgu, fl["guT"])
             dx2 = hip.rmsnorm_bwd(dh2, x2, fl["ln2"], L["rstd2"], add=dx)
             # ---- attention: x2 = x + o(attn)
             att = L["att"]
             if pack is not None:
-                sd = self.lora_dropout_seed(step, i, 1)
-                tb = lora_grads(dx2, L["t_o"], att, [lp + "self_attn.o_proj.lora_A.weight"], [(lp + "self_attn.o_proj.lora_B.weight", 0, D)], sd)
-                datt = dx_gemm(dx2, fl["oT"], tb, [lp + "self_attn.o_proj.lora_A.weight"], sd, NQ)
+                tb = lora_grads(dx2, L["t_o"], att, [lp + "self_attn.o_proj.lora_A.weight"], [(lp + "self_attn.o_proj.lora_B.weight", 0, D)], L["bits_o"])
+                datt = dx_gemm(dx2, fl["oT"], tb, [lp + "self_attn.o_proj.lora_A.weight"], L["bits_o"])
             else:
                 datt = hip.gemm(dx2, fl["oT"])
             dqkv = torch.empty_like(qkv)
@@ -423,9 +424,8 @@ class Qwen3LoRAModel(nn.Module):
                 a_names = [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"]
                 specs = [(lp + "self_attn.q_proj.lora_B.weight", 0, NQ), (lp + "self_attn.k_proj.lora_B.weight", NQ, NKV),
                          (lp + "self_attn.v_proj.lora_B.weight", NQ + NKV, NKV)]
-                sd = self.lora_dropout_seed(step, i, 0)
-                tb = lora_grads(dqkv, L["t_qkv"], h, a_names, specs, sd)
-                dh = dx_gemm(dqkv, fl["qkvT"], tb, a_names, sd, D)
+                tb = lora_grads(dqkv, L["t_qkv"], h, a_names, specs, L["bits_qkv"])
+                dh = dx_gemm(dqkv, fl["qkvT"], tb, a_names, L["bits_qkv"])
             else:
                 dh = hip.gemm(dqkv, fl["qkvT"])
             dx = hip.rmsnorm_bwd(dh, x, fl["ln1"], L["rstd1"], add=dx2)
