@@ -125,12 +125,37 @@ def test_gemm_ring_stress_exact(rk, sk):
     ref = (Rm.to(DEV).double() @ Sm.to(DEV).double().t()).float()
     big = torch.randn(64 * 1024 * 1024, device=DEV)          # memory traffic beside the GEMMs
     s2 = torch.cuda.Stream()
+    torch.cuda.synchronize()      # `big` may reuse memory the reference's temporaries just freed: s2 must not run ahead of them
     for it in range(6):
         with torch.cuda.stream(s2):
             big.mul_(1.0001)
         out = hip.gemm(R, S, r_kcontig=rk, s_kcontig=sk, out_f32=True)
         assert torch.equal(out, ref), f"iteration {it}: {(out - ref).abs().max().item()}"
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 8192, 1024), (16384, 4096, 4096), (8192 + 256, 8192, 192 + 64), (12288, 6144, 1024 + 48)])
+def test_gemm_8phase_stress_exact(M, N, K):
+    """The 256x256 8-phase ping-pong loop (K-contiguous operands, >= 256 workgroups) keeps 7 half tiles of LDS-DMA in
+    flight under counted vmcnt waits and two staggered wave groups: exact integer results, repeated under memory
+    load from a second stream, f32 and bf16 outputs, K tails and the second (LoRA) K range handed to the generic tiles."""
+    Rm, Sm = _ints((M, K), lo=-2, hi=3, seed=21), _ints((N, K), lo=-2, hi=3, seed=22)
+    R, S = _bf(Rm), _bf(Sm)
+    ref = (Rm.to(DEV).double() @ Sm.to(DEV).double().t()).float()
+    big = torch.randn(64 * 1024 * 1024, device=DEV)
+    s2 = torch.cuda.Stream()
+    torch.cuda.synchronize()      # `big` may reuse memory the reference's temporaries just freed: s2 must not run ahead of them
+    for it in range(4):
+        with torch.cuda.stream(s2):
+            big.mul_(1.0001)
+        out = hip.gemm(R, S, out_f32=True)
+        assert torch.equal(out, ref), f"iteration {it}: {(out - ref).abs().max().item()}"
+    torch.cuda.synchronize()
+    r = 16
+    R2m, S2m = _ints((M, r), lo=-1, hi=2, seed=23), _ints((N, r), lo=-1, hi=2, seed=24)
+    out16 = hip.gemm(R, S, R2=_bf(R2m), S2=_bf(S2m), alpha=1.0 / 64)
+    ref2 = ((ref.double() + R2m.to(DEV).double() @ S2m.to(DEV).double().t()) / 64).to(torch.bfloat16)
+    assert torch.equal(out16, ref2)
 
 
 def test_gemm_rejects_bad_arguments():

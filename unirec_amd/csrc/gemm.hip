@@ -26,6 +26,9 @@
 
 namespace {
 
+#ifndef UR_GEMM_NO_PH8
+#define UR_GEMM_NO_PH8 0          // lab builds only: 1 = keep the grouped 2-slot loop for the 256x256 tile (A/B against the 8-phase loop)
+#endif
 #ifndef UR_GEMM_ABLATE
 #define UR_GEMM_ABLATE 0          // lab builds only (tools/lab): 1 = no LDS-DMA in the steady state, 2 = no MFMAs, 3 = no barrier
 #endif
@@ -152,7 +155,7 @@ __device__ __forceinline__ void reg_tile(char* tile, const bf16_t* __restrict__ 
 // ---- LDS -> MFMA fragments of k-half h (k = 32h .. 32h+31 of the stage):
 //      lane holds [idx = idx0 + 16*i + (lane&15)][k = 32h + 8*(lane>>4) + 0..7] ---------------------------------
 template <bool KC, int T, int N>
-__device__ __forceinline__ void lds_frags(bf16x8 (&f)[N], const char* tile, int idx0, int h, int lane) {
+__device__ __forceinline__ void lds_frags(bf16x8* f, const char* tile, int idx0, int h, int lane) {
   if (KC) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -160,25 +163,37 @@ __device__ __forceinline__ void lds_frags(bf16x8 (&f)[N], const char* tile, int 
       f[i] = *reinterpret_cast<const bf16x8*>(tile + idx * KC_ROWB + (((4 * h + (lane >> 4)) ^ kc_g(idx)) << 4));
     }
   } else {
+    static_assert(N == 1 || (N % 2) == 0, "transposed fragment reads go in groups of 4 or 2");
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     const int ka = 32 * h + 8 * g + q;                  // k-rows ka (elements 0..3) and ka+4 (elements 4..7)
     const uint32_t ra = lds_off(tile) + ka * Tile<T>::KS_ROWB + pp * 8, rb = ra + 4 * Tile<T>::KS_ROWB;
     const int fa = ks_f(ka), fb = ks_f(ka + 4);
-    if (N >= 4) {
 #pragma unroll
-      for (int i0 = 0; i0 < N; i0 += 4) {
-        uint32_t a[4], b[4];
-        bf16x8 t4[4];
+    for (int i0 = 0; i0 + 4 <= N; i0 += 4) {
+      uint32_t a[4], b[4];
+      bf16x8 t4[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int seg = (idx0 >> 4) + i0 + i;           // 32-byte segment of this 16-column block
-          a[i] = ra + ((seg ^ fa) << 5);
-          b[i] = rb + ((seg ^ fb) << 5);
-        }
-        tr_read(t4, a, b);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) f[i0 + i] = t4[i];
+      for (int i = 0; i < 4; ++i) {
+        const int seg = (idx0 >> 4) + i0 + i;           // 32-byte segment of this 16-column block
+        a[i] = ra + ((seg ^ fa) << 5);
+        b[i] = rb + ((seg ^ fb) << 5);
       }
+      tr_read(t4, a, b);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f[i0 + i] = t4[i];
+    }
+    if ((N % 4) == 2) {
+      constexpr int i0 = N - 2;
+      uint32_t a[2], b[2];
+      bf16x8 t2[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int seg = (idx0 >> 4) + i0 + i;
+        a[i] = ra + ((seg ^ fa) << 5);
+        b[i] = rb + ((seg ^ fb) << 5);
+      }
+      tr_read(t2, a, b);
+      f[i0] = t2[0]; f[i0 + 1] = t2[1];
     }
   }
 }
@@ -194,9 +209,16 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   constexpr int WM = BM / NWM, WN = BN / NWN;       // wave tile
   constexpr int MI = WM / 16, NI = WN / 16;         // 16x16 MFMA tiles per wave
   static_assert((MI % 4) == 0 && (NI % 4) == 0, "fragment reads go in groups of 4");
+  // A wave owns TWO row groups of each operand tile, one in each half of the tile: R rows rh*BM/2 + wr*WM/2 + [0, WM/2)
+  // and S rows sh*BN/2 + wc*WN/2 + [0, WN/2) (rh, sh = 0, 1).  Each half tile (128 rows of a 256-row tile) is then one
+  // contiguous 16 KiB LDS region that all waves stop reading at the same phase of the 8-phase loop below, and
+  // that two LDS-DMA pieces per wave refill.
+  constexpr int HM = WM / 2, HN = WN / 2, MH = MI / 2, NH = NI / 2;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / NWN, wc = wave % NWN;
+  auto s_row = [&](int i) { return (i / (NI / 2)) * (BN / 2) + wc * (BN / NWN / 2) + (i % (NI / 2)) * 16; };     // tile row of S block i
+  auto r_row = [&](int j) { return (j / (MI / 2)) * (BM / 2) + wr * (BM / NWM / 2) + (j % (MI / 2)) * 16; };     // tile row of R block j
 
   // XCD-aware tile order: blocks sharing (id % 8) sit on one XCD (speed only); give each XCD a
   // contiguous run of tiles, column-tile fastest, so an R panel is re-read from that XCD's L2.
@@ -240,8 +262,10 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   };
   auto read_frags = [&](bf16x8 (&sf)[NI], bf16x8 (&rf)[MI], int t, int h) {
     const char* sb = smem + (t & 1) * STAGE;
-    lds_frags<SK, BN, NI>(sf, sb, wc * WN, h, lane);
-    lds_frags<RK, BM, MI>(rf, sb + S_BYTES, wr * WM, h, lane);
+    lds_frags<SK, BN, NH>(sf, sb, wc * HN, h, lane);
+    lds_frags<SK, BN, NH>(sf + NH, sb, BN / 2 + wc * HN, h, lane);
+    lds_frags<RK, BM, MH>(rf, sb + S_BYTES, wr * HM, h, lane);
+    lds_frags<RK, BM, MH>(rf + MH, sb + S_BYTES, BM / 2 + wr * HM, h, lane);
   };
   auto mfmas = [&](const bf16x8 (&sf)[NI], const bf16x8 (&rf)[MI]) {
 #pragma unroll
@@ -299,8 +323,8 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     constexpr bool LF = decltype(loads_first)::value;
     auto loads = [&](int j) {
       bf16x8 one[1];
-      if (j >= 1) { lds_frags<true, BM, 1>(one, nb + S_BYTES, wr * WM + 16 * (j - 1), nh, lane); crf[j - 1] = one[0]; }
-      if (j < NI) { lds_frags<true, BN, 1>(one, nb, wc * WN + 16 * j, nh, lane); nsf[j] = one[0]; }
+      if (j >= 1) { lds_frags<true, BM, 1>(one, nb + S_BYTES, r_row(j - 1), nh, lane); crf[j - 1] = one[0]; }
+      if (j < NI) { lds_frags<true, BN, 1>(one, nb, s_row(j), nh, lane); nsf[j] = one[0]; }
       extra(j);
     };
 #pragma unroll
@@ -316,14 +340,151 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
       __builtin_amdgcn_sched_barrier(0);
       if (!LF) { loads(j); __builtin_amdgcn_sched_barrier(0); }
     }
-    { bf16x8 one[1]; lds_frags<true, BM, 1>(one, nb + S_BYTES, wr * WM + 16 * (MI - 1), nh, lane); crf[MI - 1] = one[0]; }
+    { bf16x8 one[1]; lds_frags<true, BM, 1>(one, nb + S_BYTES, r_row(MI - 1), nh, lane); crf[MI - 1] = one[0]; }
   };
   bf16x8 sfA[NI], rfA[MI], sfB[NI], rfB[MI];
+  int t = 0;
+
+  // ==== 8-phase ping-pong steady state (256x256 tile, both operands K-contiguous, interior blocks) ==================
+  // One K tile = 4 phases, one C quadrant (64 m x 32 n per wave, 16 MFMAs over the tile's 64 k) each:
+  //   phase   LDS reads (load segment)        MFMAs (matrix segment)      LDS-DMA issued (tile t+2, same ring slot)
+  //   1       S half 0 of tile t   (4)        Q(s0, r0)                   R half 0   (free since phase 4 of tile t-1)
+  //   2       S half 1 of tile t   (4)        Q(s1, r0)                   S half 0   (free since phase 1)
+  //   3       R half 1 of tile t   (8)        Q(s1, r1)                   S half 1   (free since phase 2)
+  //   4       R half 0 of tile t+1 (8)        Q(s0, r1)                   R half 1   (free since phase 3)
+  // Every phase is  [reads | 2 DMA pieces | vmcnt(12) | lgkmcnt(0)] barrier [16 MFMAs at priority 1] barrier.  The waves
+  // with wr = 1 run one barrier interval behind the waves with wr = 0, so on every SIMD (one wave of each group) one
+  // wave feeds the matrix pipe while the other reads LDS and issues DMA.
+  // Hazards: a half tile is read 7 phases after its DMA was issued; the counted wait that retires it (this wave's two
+  // pieces; 12 = the two pieces of each of the six phases issued after them) sits in the load segment of the phase
+  // BEFORE the read, and a barrier follows it in both wave groups before either group reads.  A half tile's buffer is
+  // re-filled one phase after its last read; lgkmcnt(0) before the load segment's closing barrier makes those reads
+  // complete before any wave can issue the refill.
+  constexpr bool PH8 = RK && SK && BM == 256 && BN == 256 && NWM == 2 && NWN == 4 && (UR_GEMM_ABLATE == 0) && !UR_GEMM_NO_PH8;
+  if constexpr (PH8) {
+    if (interior && nfull1 >= 3) {
+      const int l15 = lane & 15, g4 = lane >> 4;
+      const uint32_t lo0 = l15 * 128 + (((g4) ^ ((l15 >> 1) & 7)) << 4), lo1 = l15 * 128 + (((4 + g4) ^ ((l15 >> 1) & 7)) << 4);
+      bf16x8 R0[4][2], R1[4][2], S0[2][2], S1[2][2];
+      auto rdR = [&](bf16x8 (&F)[4][2], const char* slot, int rh) {
+        const char* b = slot + S_BYTES + (rh * 128 + wr * 64) * 128;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          F[jj][0] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + lo0);
+          F[jj][1] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + lo1);
+        }
+      };
+      auto rdS = [&](bf16x8 (&F)[2][2], const char* slot, int sh) {
+        const char* b = slot + (sh * 128 + wc * 32) * 128;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+          F[ii][0] = *reinterpret_cast<const bf16x8*>(b + ii * 2048 + lo0);
+          F[ii][1] = *reinterpret_cast<const bf16x8*>(b + ii * 2048 + lo1);
+        }
+      };
+      auto quad = [&](const bf16x8 (&S)[2][2], const bf16x8 (&R)[4][2], auto shc, auto rhc) {
+        constexpr int sh = decltype(shc)::value, rh = decltype(rhc)::value;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              acc[2 * sh + ii][4 * rh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S[ii][h], R[jj][h], acc[2 * sh + ii][4 * rh + jj], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      };
+      // the two LDS-DMA pieces of this wave for half `hf` (rows 128 hf ..) of an operand tile whose k position is in `ub`
+      auto dma_half = [&](char* slot, auto is_s, int hf, const char* ub) {
+        constexpr bool IS_S = decltype(is_s)::value;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const int li = 2 * hf + d;
+          const char* src = ub + li * (IS_S ? spiece : rpiece) + (IS_S ? svoff0 : rvoff0);
+          char* dst = slot + (IS_S ? 0 : S_BYTES) + (li * (NT / 64) + uwave) * 1024;
+          __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+        }
+      };
+      auto seg_end = [&]() {            // end of a load segment
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto mat_end = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      const std::integral_constant<int, 0> c0;
+      const std::integral_constant<int, 1> c1;
+      // prologue: both tiles' half tiles in consumption order R0 S0 S1 R1 (the loop's issue order shifted back 8 phases)
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt) {
+        const long kn = kbeg + (long)tt * BK;
+        const char* const ubs = uniform_ptr(sbase + kn * skstep);
+        const char* const ubr = uniform_ptr(rbase + kn * rkstep);
+        char* slot = smem + tt * STAGE;
+        // the counted waits rely on this issue order: keep the scheduler from re-ordering the pieces
+        dma_half(slot, std::false_type{}, 0, ubr); __builtin_amdgcn_sched_barrier(0);
+        dma_half(slot, std::true_type{}, 0, ubs);  __builtin_amdgcn_sched_barrier(0);
+        dma_half(slot, std::true_type{}, 1, ubs);  __builtin_amdgcn_sched_barrier(0);
+        dma_half(slot, std::false_type{}, 1, ubr); __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // R half 0 and S half 0 of tile 0 have landed (this wave's pieces)
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      rdR(R0, smem, 0);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      if (wr == 1) __builtin_amdgcn_s_barrier();               // stagger: this group now runs one interval behind
+      __builtin_amdgcn_sched_barrier(0);
+      for (; t + 2 < nfull1; ++t) {
+        char* slot = smem + (t & 1) * STAGE;
+        const char* nslot = smem + ((t + 1) & 1) * STAGE;
+        const long kn = kbeg + (long)(t + 2) * BK;
+        const char* const ubs = uniform_ptr(sbase + kn * skstep);
+        const char* const ubr = uniform_ptr(rbase + kn * rkstep);
+        // phase 1
+        rdS(S0, slot, 0);
+        dma_half(slot, std::false_type{}, 0, ubr);
+        seg_end();
+        quad(S0, R0, c0, c0);
+        mat_end();
+        // phase 2
+        rdS(S1, slot, 1);
+        dma_half(slot, std::true_type{}, 0, ubs);
+        seg_end();
+        quad(S1, R0, c1, c0);
+        mat_end();
+        // phase 3
+        rdR(R1, slot, 1);
+        dma_half(slot, std::true_type{}, 1, ubs);
+        seg_end();
+        quad(S1, R1, c1, c1);
+        mat_end();
+        // phase 4
+        rdR(R0, nslot, 0);
+        dma_half(slot, std::false_type{}, 1, ubr);
+        seg_end();
+        quad(S0, R1, c0, c1);
+        mat_end();
+      }
+      // hand over to the generic loop: tiles t and t+1 are issued (t+1 possibly still in flight); re-join the groups
+      if (wr == 0) __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(sfA, rfA, t, 0);
+    }
+  }
 
   // prologue: tiles 0 and 1 issued, tile 0 landed, its half-0 fragments in A
-  if (nt > 0) stage(0, smem);
-  if (nt > 1) stage(1, smem + STAGE);
-  if (nt > 0) {
+  if (t == 0 && nt > 0) stage(0, smem);
+  if (t == 0 && nt > 1) stage(1, smem + STAGE);
+  if (t == 0 && nt > 0) {
     // a K-tail tile staged through registers issues no DMA; its own (compiler-waited) loads are older
     if (nt > 1 && nfull1 >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SPW + RPW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -331,8 +492,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     __builtin_amdgcn_s_barrier();
     read_frags(sfA, rfA, 0, 0);
   }
-  int t = 0;
-  if (GROUPED && interior) {
+  if (!PH8 && GROUPED && interior) {
     // ---- steady state: tiles t, t+1 and t+2 are full tiles of the first K range ----
     auto steady = [&](auto order) {
       for (; t + 2 < nfull1; ++t) {
@@ -389,32 +549,34 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     const int nad = p.K2 / p.drop_rank, kq = 8 * (lane >> 4);
     const bool kin = kq < p.drop_rank;
     const int g4 = lane >> 4;
-    static_assert(WN == 64, "the masked LoRA epilogue reads one 8-byte flag word per row of the wave tile");
-    const long boff = min((long)((n0 + wc * WN) >> 3), p.drop_bits_ld - 8);
+    static_assert(HN == 32, "the masked LoRA epilogue reads one 4-byte flag word per row and column half of the wave tile");
+    const long boff0 = min((long)((n0 + wc * HN) >> 3), p.drop_bits_ld - 4);
+    const long boff1 = min((long)((n0 + BN / 2 + wc * HN) >> 3), p.drop_bits_ld - 4);
     for (int a = 0; a < nad; ++a) {
       bf16x8 s2[NI], r2[MI];
       const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int n = min(n0 + wc * WN + 16 * i + (lane & 15), p.N - 1);
+        const int n = min(n0 + s_row(i) + (lane & 15), p.N - 1);
         s2[i] = kin ? *reinterpret_cast<const bf16x8*>(p.S2 + (long)n * p.lds2 + a * p.drop_rank + kq) : zero8;
       }
       uint2 fl[MI];
 #pragma unroll
       for (int j = 0; j < MI; ++j) {
-        const int m = min(m0 + wr * WM + 16 * j + (lane & 15), p.M - 1);
+        const int m = min(m0 + r_row(j) + (lane & 15), p.M - 1);
         r2[j] = kin ? *reinterpret_cast<const bf16x8*>(p.R2 + (long)m * p.ldr2 + a * p.drop_rank + kq) : zero8;
-        fl[j] = *reinterpret_cast<const uint2*>(p.drop_bits + (long)a * p.drop_bits_stride + (long)m * p.drop_bits_ld + boff);
+        const uint8_t* brow = p.drop_bits + (long)a * p.drop_bits_stride + (long)m * p.drop_bits_ld;
+        fl[j] = make_uint2(*reinterpret_cast<const uint32_t*>(brow + boff0), *reinterpret_cast<const uint32_t*>(brow + boff1));
       }
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
           const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s2[i], r2[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          // columns 16 i + 4 g4 .. + 3 of the wave tile: byte 2 i + (g4 >> 1) of the row's word, pair-interleaved
-          // flag order (lora.hip): element 4 q + e -> bit 2 q + (e >> 1) + 4 (e & 1), q = g4 & 1
-          const uint32_t wsel = (i & 2) ? fl[j].y : fl[j].x;
-          const uint32_t f = (wsel >> (16 * (i & 1) + 8 * (g4 >> 1) + 2 * (g4 & 1))) & 0x33u;
+          // columns 16 (i % 2) + 4 g4 .. + 3 of column half i / 2: byte 2 (i % 2) + (g4 >> 1) of that half's word,
+          // pair-interleaved flag order (lora.hip): element 4 q + e -> bit 2 q + (e >> 1) + 4 (e & 1), q = g4 & 1
+          const uint32_t wsel = (i >= NH) ? fl[j].y : fl[j].x;
+          const uint32_t f = (wsel >> (16 * (i % NH) + 8 * (g4 >> 1) + 2 * (g4 & 1))) & 0x33u;
           if (!(f & 0x01u)) acc[i][j][0] += d[0] * p.drop_inv_keep;
           if (!(f & 0x10u)) acc[i][j][1] += d[1] * p.drop_inv_keep;
           if (!(f & 0x02u)) acc[i][j][2] += d[2] * p.drop_inv_keep;
@@ -432,7 +594,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   if (!OUTF32) __syncthreads();                   // every wave is done with the ring
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
-    const int nl = wc * WN + i * 16 + nq;
+    const int nl = s_row(i) + nq;
     const int n = n0 + nl;
     const bool nok = n < p.N;
     float b4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -442,7 +604,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     }
 #pragma unroll
     for (int j = 0; j < MI; ++j) {
-      const int mloc = wr * WM + j * 16 + ml;
+      const int mloc = r_row(j) + ml;
       const int m = m0 + mloc;
       const bool ok = nok && m < p.M;
       float v[4];
