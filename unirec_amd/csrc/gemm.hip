@@ -29,6 +29,15 @@ namespace {
 #ifndef UR_GEMM_NO_PH8
 #define UR_GEMM_NO_PH8 0          // lab builds only: 1 = keep the grouped 2-slot loop for the 256x256 tile (A/B against the 8-phase loop)
 #endif
+#ifndef UR_GEMM_STAMPS
+#define UR_GEMM_STAMPS 0          // lab builds only: 1 = thread 0 of every workgroup logs s_memtime at 8 points (ur_lab_gemm_stamps)
+#endif
+#if UR_GEMM_STAMPS
+__device__ long long g_gemm_stamps[8192 * 8];
+#define UR_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.z == 0) g_gemm_stamps[blockIdx.x * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define UR_STAMP(k) do { } while (0)
+#endif
 #ifndef UR_GEMM_ABLATE
 #define UR_GEMM_ABLATE 0          // lab builds only (tools/lab): 1 = no LDS-DMA in the steady state, 2 = no MFMAs, 3 = no barrier
 #endif
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   const int bm = id / p.gn, bn = id - bm * p.gn;
   const int m0 = bm * BM, n0 = bn * BN;
   const int z = blockIdx.z;
+  UR_STAMP(0);
 
   int kbeg = z * p.ksplit_len;
   int kend = min(p.K, kbeg + p.ksplit_len);
@@ -240,10 +250,13 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   const int nfull1 = (kend > kbeg) ? (kend - kbeg) / BK : 0;      // leading full tiles of the first K range
 
   f32x4 acc[NI][MI];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < MI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  bool acc_zeroed = false;
 
   // k extent of tile t (how many of its two 32-deep halves carry data)
   auto tile_k = [&](int t, int& k0, int& ke) {
@@ -432,12 +445,17 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
         dma_half(slot, std::true_type{}, 1, ubs);  __builtin_amdgcn_sched_barrier(0);
         dma_half(slot, std::false_type{}, 1, ubr); __builtin_amdgcn_sched_barrier(0);
       }
+      UR_STAMP(1);
+      zero_acc();                                              // under the first pieces' flight
+      acc_zeroed = true;
+      __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // R half 0 and S half 0 of tile 0 have landed (this wave's pieces)
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       rdR(R0, smem, 0);
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_s_barrier();
+      UR_STAMP(2);
       if (wr == 1) __builtin_amdgcn_s_barrier();               // stagger: this group now runs one interval behind
       __builtin_amdgcn_sched_barrier(0);
       for (; t + 2 < nfull1; ++t) {
@@ -478,9 +496,11 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       read_frags(sfA, rfA, t, 0);
+      UR_STAMP(3);
     }
   }
 
+  if (!acc_zeroed) zero_acc();
   // prologue: tiles 0 and 1 issued, tile 0 landed, its half-0 fragments in A
   if (t == 0 && nt > 0) stage(0, smem);
   if (t == 0 && nt > 1) stage(1, smem + STAGE);
@@ -541,6 +561,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     if (two) mfmas(sfB, rfB);
   }
 
+  UR_STAMP(4);
   // ---- LoRA dropout, backward to the adapter input: C(m,n) += sum_a keep_a(m,n)/(1-p) * tb_a(m,:) . A_a(:,n).
   // Each adapter's rank-r product of a 16x16 sub-tile is ONE MFMA (k = r <= 32, zero-padded) into a scratch
   // accumulator; the keep flags come from the adapters' dropped-flag bit planes (lora.hip: 8 bytes cover the
@@ -585,78 +606,161 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     }
   }
 
-  // ---- epilogue: lane holds n = n0 + wc*WN + i*16 + (lane>>4)*4 + 0..3, m = m0 + wr*WM + j*16 + (lane&15)
-  // bf16 output: the finished tile goes through LDS (the ring is free now) and leaves as whole rows,
-  // 16 B per lane = 512 contiguous bytes per row of a 256-wide tile; direct 8-byte stores from the MFMA
-  // layout (16 rows x 4 pieces per instruction) ran at ~1.8 TB/s and cost ~30 % of a K=1024 GEMM.
-  constexpr int CROWB = BN * 2 + 16;              // padded LDS row of the C tile
+  // ---- epilogue: lane holds n = n0 + s_row(i) + (lane>>4)*4 + 0..3, m = m0 + r_row(j) + (lane&15).
+  // Measured with in-kernel stamps (tools/lab/gemm_stamps.py): a per-element epilogue in the MFMA layout (32 (i, j)
+  // sub-tiles, each with its own predicates, scalar-pointer checks and 8-byte residual / aux loads waited one by one)
+  // cost 27k cycles per 256x256 tile, as much as 11 K tiles of the main loop.  So:
+  //   f32 output        : float4 stores from the accumulators, predicates only on edge tiles.
+  //   bf16, plain       : (no bias / residual / aux / gelu_out) alpha * acc -> bf16 -> LDS tile -> whole rows.
+  //   bf16, rich        : the tile goes through LDS in f32, one column half at a time; bias, residual, gelu' and the
+  //                       GELU second output are applied on the way out, where every access is a coalesced 16-byte
+  //                       piece of a row (and the f32 sum is rounded once, as before).
   const int nq = (lane >> 4) * 4, ml = lane & 15;
-  if (!OUTF32) __syncthreads();                   // every wave is done with the ring
+  if (OUTF32) {
+    float* Cf = reinterpret_cast<float*>(p.C) + (long)z * p.slab_stride;
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int nl = s_row(i) + nq;
-    const int n = n0 + nl;
-    const bool nok = n < p.N;
-    float b4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && nok) {
-      const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-      b4[0] = bb.x; b4[1] = bb.y; b4[2] = bb.z; b4[3] = bb.w;
-    }
+    for (int i = 0; i < NI; ++i) {
+      const int n = n0 + s_row(i) + nq;
+      float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias && n < p.N) bb = *reinterpret_cast<const float4*>(p.bias + n);
 #pragma unroll
-    for (int j = 0; j < MI; ++j) {
-      const int mloc = r_row(j) + ml;
-      const int m = m0 + mloc;
-      const bool ok = nok && m < p.M;
-      float v[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * p.alpha + b4[e];
-      if (OUTF32) {
-        if (ok) {
-          float* c = reinterpret_cast<float*>(p.C) + (long)z * p.slab_stride + (long)m * p.ldc + n;
-          *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-        }
-      } else {
-        if (ok && p.res) {
-          const uint2 r = *reinterpret_cast<const uint2*>(p.res + (long)m * p.ldres + n);
-          v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
-        }
-        if (ok && p.aux) {
-          const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (long)m * p.ldaux + n);
-          v[0] *= gelu_erf_grad_f(bf_lo(a.x)); v[1] *= gelu_erf_grad_f(bf_hi(a.x));
-          v[2] *= gelu_erf_grad_f(bf_lo(a.y)); v[3] *= gelu_erf_grad_f(bf_hi(a.y));
-        }
-        *reinterpret_cast<uint2*>(smem + mloc * CROWB + nl * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
-        if (ok && p.gelu_out) {
-          // GELU of the bf16-ROUNDED pre-activation, so backward's gelu'(u) sees the same u
-          float u0 = bf2f(f2bf(v[0])), u1 = bf2f(f2bf(v[1])), u2 = bf2f(f2bf(v[2])), u3 = bf2f(f2bf(v[3]));
-          bf16_t* g = p.gelu_out + (long)m * p.ldg + n;
-          *reinterpret_cast<uint2*>(g) = make_uint2(pack_bf2(gelu_erf_f(u0), gelu_erf_f(u1)),
-                                                     pack_bf2(gelu_erf_f(u2), gelu_erf_f(u3)));
-        }
+      for (int j = 0; j < MI; ++j) {
+        const int m = m0 + r_row(j) + ml;
+        const f32x4 a = acc[i][j];
+        const float4 v = make_float4(a[0] * p.alpha + bb.x, a[1] * p.alpha + bb.y, a[2] * p.alpha + bb.z, a[3] * p.alpha + bb.w);
+        if (interior || (n < p.N && m < p.M)) *reinterpret_cast<float4*>(Cf + (long)m * p.ldc + n) = v;
       }
     }
-  }
-  if (!OUTF32) {
-    __syncthreads();
+  } else {
     bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
-    const bool wide = ((p.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
-    constexpr int CPR = BN / 8;                   // 16-byte chunks per tile row
+    const bool rich = p.bias || p.res || p.aux || p.gelu_out;        // uniform
+    __syncthreads();                                                   // every wave is done with the ring
+    if (!rich) {
+      constexpr int CROWB = BN * 2 + 16;            // padded LDS row of the bf16 C tile
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+          const f32x4 a = acc[i][j];
+          *reinterpret_cast<uint2*>(smem + (r_row(j) + ml) * CROWB + (s_row(i) + nq) * 2) =
+              make_uint2(pack_bf2(a[0] * p.alpha, a[1] * p.alpha), pack_bf2(a[2] * p.alpha, a[3] * p.alpha));
+        }
+      __syncthreads();
+      const bool wide = ((p.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+      constexpr int CPR = BN / 8;                   // 16-byte chunks per tile row
 #pragma unroll 4
-    for (int c = tid; c < BM * CPR; c += NT) {
-      const int row = c / CPR, ch = c % CPR;
-      const int m = m0 + row, n = n0 + ch * 8;
-      if (m < p.M && n < p.N) {
-        const uint4 val = *reinterpret_cast<const uint4*>(smem + row * CROWB + ch * 16);
-        bf16_t* dst = Cb + (long)m * p.ldc + n;
-        if (wide && n + 8 <= p.N) {
-          *reinterpret_cast<uint4*>(dst) = val;
+      for (int c = tid; c < BM * CPR; c += NT) {
+        const int row = c / CPR, ch = c % CPR;
+        const int m = m0 + row, n = n0 + ch * 8;
+        if (interior || (m < p.M && n < p.N)) {
+          const uint4 val = *reinterpret_cast<const uint4*>(smem + row * CROWB + ch * 16);
+          bf16_t* dst = Cb + (long)m * p.ldc + n;
+          if (wide && (interior || n + 8 <= p.N)) {
+            *reinterpret_cast<uint4*>(dst) = val;
+          } else {
+            *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);                       // N % 4 == 0: first half always fits
+            if (n + 8 <= p.N) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(val.z, val.w);
+          }
+        }
+      }
+    } else {
+      constexpr int FROWB = (BN / 2) * 4 + 16;      // padded LDS row of one f32 column half of the C tile
+      const bool wide8 = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                         (!p.res || (((p.ldres & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0))) &&
+                         (!p.aux || (((p.ldaux & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.aux) & 15) == 0))) &&
+                         (!p.gelu_out || (((p.ldg & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.gelu_out) & 15) == 0)));
+      // pieces of 8 columns (16 bytes) when everything is 16-byte addressable, else of 4 columns (N, ld % 4 == 0 always)
+      const int cw = wide8 ? 8 : 4, cpr = (BN / 2) / cw, ch = tid % cpr, rstep = NT / cpr;
+      auto ldp = [&](const bf16_t* q, uint32_t (&w)[4]) {
+        if (wide8) { const uint4 t4 = *reinterpret_cast<const uint4*>(q); w[0] = t4.x; w[1] = t4.y; w[2] = t4.z; w[3] = t4.w; }
+        else { const uint2 t2 = *reinterpret_cast<const uint2*>(q); w[0] = t2.x; w[1] = t2.y; w[2] = w[3] = 0; }
+      };
+      auto stp = [&](bf16_t* q, const uint32_t (&w)[4]) {
+        if (wide8) *reinterpret_cast<uint4*>(q) = make_uint4(w[0], w[1], w[2], w[3]);
+        else *reinterpret_cast<uint2*>(q) = make_uint2(w[0], w[1]);
+      };
+#pragma unroll 1
+      for (int sh = 0; sh < 2; ++sh) {
+        if (sh) __syncthreads();                    // the copy-out of half 0 has read the tile
+        if (sh == 0) {
+#pragma unroll
+          for (int ii = 0; ii < NH; ++ii)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+              const f32x4 a = acc[ii][j];
+              *reinterpret_cast<float4*>(smem + (r_row(j) + ml) * FROWB + (wc * HN + ii * 16 + nq) * 4) =
+                  make_float4(a[0] * p.alpha, a[1] * p.alpha, a[2] * p.alpha, a[3] * p.alpha);
+            }
         } else {
-          *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);                       // N % 4 == 0: first half always fits
-          if (n + 8 <= p.N) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(val.z, val.w);
+#pragma unroll
+          for (int ii = 0; ii < NH; ++ii)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) {
+              const f32x4 a = acc[NH + ii][j];
+              *reinterpret_cast<float4*>(smem + (r_row(j) + ml) * FROWB + (wc * HN + ii * 16 + nq) * 4) =
+                  make_float4(a[0] * p.alpha, a[1] * p.alpha, a[2] * p.alpha, a[3] * p.alpha);
+            }
+        }
+        __syncthreads();
+        const int n = n0 + sh * (BN / 2) + ch * cw;
+        const bool nok = interior || n < p.N;
+        float bsv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (p.bias && nok) {
+          const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n);
+          bsv[0] = b0.x; bsv[1] = b0.y; bsv[2] = b0.z; bsv[3] = b0.w;
+          if (wide8) {
+            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            bsv[4] = b1.x; bsv[5] = b1.y; bsv[6] = b1.z; bsv[7] = b1.w;
+          }
+        }
+        // four rows per trip: their residual / aux pieces go out together (one wait instead of one per row)
+#pragma unroll 1
+        for (int r0 = tid / cpr; r0 < BM; r0 += 4 * rstep) {
+          uint32_t rw[4][4], aw[4][4];
+          bool ok[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int row = r0 + k * rstep, m = m0 + row;
+            ok[k] = nok && row < BM && (interior || m < p.M);
+            rw[k][0] = rw[k][1] = rw[k][2] = rw[k][3] = 0;
+            aw[k][0] = aw[k][1] = aw[k][2] = aw[k][3] = 0;
+            if (p.res && ok[k]) ldp(p.res + (long)m * p.ldres + n, rw[k]);
+            if (p.aux && ok[k]) ldp(p.aux + (long)m * p.ldaux + n, aw[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int row = r0 + k * rstep, m = m0 + row;
+            if (!ok[k]) continue;
+            const char* lrow = smem + row * FROWB + ch * cw * 4;
+            const float4 f0 = *reinterpret_cast<const float4*>(lrow);
+            float4 f1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wide8) f1 = *reinterpret_cast<const float4*>(lrow + 16);
+            float v[8] = {f0.x + bsv[0], f0.y + bsv[1], f0.z + bsv[2], f0.w + bsv[3], f1.x + bsv[4], f1.y + bsv[5], f1.z + bsv[6], f1.w + bsv[7]};
+            if (p.res) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(rw[k][e]); v[2 * e + 1] += bf_hi(rw[k][e]); }
+            }
+            if (p.aux) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { v[2 * e] *= gelu_erf_grad_f(bf_lo(aw[k][e])); v[2 * e + 1] *= gelu_erf_grad_f(bf_hi(aw[k][e])); }
+            }
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+            stp(Cb + (long)m * p.ldc + n, o);
+            if (p.gelu_out) {
+              // GELU of the bf16-ROUNDED pre-activation, so backward's gelu'(u) sees the same u
+              uint32_t gq[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) gq[e] = pack_bf2(gelu_erf_f(bf_lo(o[e])), gelu_erf_f(bf_hi(o[e])));
+              stp(p.gelu_out + (long)m * p.ldg + n, gq);
+            }
+          }
         }
       }
     }
   }
+  UR_STAMP(5);
 }
 
 // deterministic split-K combine: C[m][n] = sum_z slab[z][m][n]  (f32, vectorised)
@@ -680,7 +784,7 @@ template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN>
 int launch_cfg(GemmP p, int splits, hipStream_t st) {
   constexpr int S_BYTES = SK ? Tile<BN>::KC_BYTES : Tile<BN>::KS_BYTES;
   constexpr int R_BYTES = RK ? Tile<BM>::KC_BYTES : Tile<BM>::KS_BYTES;
-  constexpr int RING = NSTAGE * (S_BYTES + R_BYTES), CTILE = BM * (BN * 2 + 16);
+  constexpr int RING = NSTAGE * (S_BYTES + R_BYTES), CTILE = BM * (BN * 2 + 16);      // bf16 tile == f32 half tile rows
   constexpr int SMEM = OUTF32 ? RING : (RING > CTILE ? RING : CTILE);
   static bool attr_set = false;   // idempotent; a race only repeats the call
   if (!attr_set) {
@@ -708,6 +812,12 @@ int launch(const GemmP& p, int splits, hipStream_t st) {
 }  // namespace
 
 static inline bool splits_ok(const ur_gemm_args* a) { return a->split_k <= 1; }
+
+#if UR_GEMM_STAMPS
+extern "C" int ur_lab_gemm_stamps(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamps), sizeof(long long) * n);
+}
+#endif
 
 extern "C" int64_t ur_gemm_workspace_bytes(const ur_gemm_args* a) {
   if (!a || a->split_k <= 1) return 0;
