@@ -219,6 +219,24 @@ int ur_mean_pool_fwd(const void* x, float* out_f32, void* out_bf16, int32_t B, i
 int ur_mean_pool_bwd(const float* dout_f32, const void* dout_bf16, void* dx, int32_t B, int32_t S, int32_t D, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Data path either side of the hot path.
+ * ur_gather_rows: out[i] = src[idx[i]] for rows of row_elems elements; idx < 0 or >= n_src gives a zero row -- the
+ *   packed form of training/train_item_individual_token_joint.py:557-577 (_get_history_qformer_inputs: per history slot
+ *   the cached [F,1024] field vectors and [F] mask, zeros for padding / unknown items) and :246-255 (cached item query
+ *   tokens).  Kinds: UR_KIND_U8 / UR_KIND_BF16 / UR_KIND_F32; f32 rows may be written as bf16.
+ * ur_catalog_scores: scores[b][n] = cos(user_b, item_n) against a shared catalogue [N,D] f32 (F.normalize eps 1e-12,
+ *   :408-415 with pool = all items); writes user_inv_norm [B], and cat_inv_norm [N] unless cat_norm_ready.
+ * ur_rank_of_index: rank_b = 1 + #{n : s_bn > s_b,gt_b} (:416-417; the positive wins ties as in ur_mrr_rank). */
+#define UR_KIND_U8 0
+#define UR_KIND_BF16 1
+#define UR_KIND_F32 2
+int ur_gather_rows(const void* src, int32_t src_kind, void* out, int32_t out_kind, const int64_t* idx, int64_t row_elems,
+                   int64_t n_out, int64_t n_src, void* stream);
+int ur_catalog_scores(const float* user, const float* catalog, float* scores, float* user_inv_norm, float* cat_inv_norm,
+                      int32_t cat_norm_ready, int32_t B, int64_t N, int32_t D, void* stream);
+int ur_rank_of_index(const float* scores, const int64_t* gt_index, int32_t* rank, int32_t B, int64_t N, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Ranking head -- train_item_individual_token_joint.py:331-352 (InfoNCELoss), :392-419 (MRR).
  * ur_cosine_scores: scores[b][0] = cos(user_b, pos_b), scores[b][1+n] = cos(user_b, neg_{b,n})
  *   (F.normalize eps 1e-12), all f32; user [B,D], pos [B,D], neg [B,N,D]; cand_inv_norm [B,N+1].

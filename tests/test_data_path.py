@@ -1,0 +1,73 @@
+"""CPU: the data path either side of the hot path -- the oracle restatement and
+the host side of the product classes against golden vectors produced by the reference's own classes
+(tests/golden/make_golden_data.py)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import data_ref as D
+from tests.golden import data_cases as dc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "data_path.npz"))
+T = json.load(open(os.path.join(HERE, "golden", "data_path.json")))
+
+
+def test_oracle_field_cache_matches_reference():
+    samples, _ = dc.item_samples()
+    fields = D.analyze_fields(samples)
+    assert fields == T["available_fields"]
+    emb, msk = D.precompute_cache(samples, dc.FakeItemEncoder().encode_batch_by_field, fields, 5)
+    assert np.array_equal(emb, G["embeddings"]) and np.array_equal(msk, G["masks"])
+    assert msk[5, fields.index("brand")] == 0 and msk[9].sum() == 2          # missing fields are masked out
+
+
+def test_oracle_history_assembly_and_prompt_match_reference():
+    samples, item_dict = dc.item_samples()
+    idx = {s["item_id"]: i for i, s in enumerate(samples)}
+    for b, h in enumerate(dc.histories()):
+        e, m = D.history_qformer_inputs(h, idx, G["embeddings"], G["masks"], dc.HIST)
+        assert np.array_equal(e, G["history_field_embeddings"][b]) and np.array_equal(m, G["history_attention_mask"][b])
+        assert D.construct_input_text(h, item_dict, dc.HIST, dc.QI) == T["input_texts"][b]
+
+
+def test_oracle_mrr_matches_reference():
+    users, pos, negs = dc.mrr_inputs()
+    ranks = [D.mrr_rank(users[b], pos[b], negs[b])[0] for b in range(len(users))]
+    assert np.allclose(1.0 / np.array(ranks), G["batch_mrr"], rtol=0, atol=1e-12)
+    assert ranks[2] >= 2                                                       # the planted stronger negative counts
+
+
+def test_product_dataset_host_side_and_cache_format(tmp_path):
+    """QFormerDataset (no GPU involved): same fields / vectors / masks as the reference, the reference's cache files,
+    and a cache written in the reference's dict-of-tensors format loads back."""
+    from unirec_amd.data import QFormerDataset
+    from unirec_amd.evaluation import construct_input_text
+    samples, item_dict = dc.item_samples()
+    cache = str(tmp_path / "cache")
+    ds = QFormerDataset(samples, dc.FakeItemEncoder(), cache_dir=cache, precompute_batch_size=5)
+    assert ds.available_fields == T["available_fields"] and len(ds) == len(samples)
+    assert np.array_equal(ds.fields.numpy(), G["embeddings"]) and np.array_equal(ds.masks.numpy(), G["masks"])
+    assert sorted(os.listdir(cache)) == T["cache_files"]
+    it = ds[3]
+    assert sorted(it.keys()) == T["getitem_keys"] and it["item_id"] == T["getitem_item_id"]
+    assert torch.equal(ds.embedding_cache[3], it["field_embeddings"]) and len(ds.mask_cache) == len(samples)
+    emb = torch.load(os.path.join(cache, "embeddings.pt"))
+    assert isinstance(emb, dict) and emb[0].dtype == torch.float32 and tuple(emb[0].shape) == G["embeddings"].shape[1:]
+
+    class Boom:
+        def encode_batch_by_field(self, *a):
+            raise AssertionError("a valid cache must not re-encode")
+    ds2 = QFormerDataset(samples, Boom(), cache_dir=cache)
+    assert np.array_equal(ds2.fields.numpy(), G["embeddings"]) and np.array_equal(ds2.masks.numpy(), G["masks"])
+    # a different field list invalidates the cache (qformer_utils.py:137-143)
+    other = [dict(s, extra="1") for s in samples]
+    try:
+        QFormerDataset(other, Boom(), cache_dir=cache)
+        assert False, "stale cache was accepted"
+    except AssertionError as e:
+        assert "re-encode" in str(e)
+    for b, h in enumerate(dc.histories()):
+        assert construct_input_text(h, item_dict, dc.HIST, dc.QI) == T["input_texts"][b]

@@ -98,6 +98,9 @@ SIGNATURES = {
     "ur_infonce_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "ur_infonce_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p,
                                    c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
+    "ur_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_i64, c_i64, c_i64, c_void_p]),
+    "ur_catalog_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_i64, c_int, c_void_p]),
+    "ur_rank_of_index": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p]),
     "ur_mrr_rank": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ur_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_heads_workspace_bytes": (c_i64, [c_int, c_int]),

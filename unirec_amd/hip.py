@@ -495,6 +495,56 @@ def topk(scores, K):
     return idx, val
 
 
+# ---- data path: csrc/catalog.hip ----------------------------------
+_KIND = {torch.uint8: 0, BF16: 1, F32: 2}
+
+
+def gather_rows(src, idx, out_dtype=None):
+    """out[i] = src[idx[i]] over the leading axis (idx int64, any shape; negative / out-of-range -> zero row).
+    f32 sources may be gathered straight to bf16.  Returns idx.shape + src.shape[1:]."""
+    lib = _lib.load()
+    if not src.is_cuda or not src.is_contiguous() or src.dtype not in _KIND:
+        raise ValueError("gather_rows: src must be a contiguous uint8 / bf16 / f32 device tensor")
+    out_dtype = src.dtype if out_dtype is None else out_dtype
+    idx = idx.to(device=src.device, dtype=torch.int64).contiguous()
+    row = 1
+    for s_ in src.shape[1:]:
+        row *= s_
+    out = torch.empty(tuple(idx.shape) + tuple(src.shape[1:]), dtype=out_dtype, device=src.device)
+    check(lib.ur_gather_rows(src.data_ptr(), _KIND[src.dtype], out.data_ptr(), _KIND[out_dtype], idx.data_ptr(), row, idx.numel(),
+                             src.shape[0], _stream()), "ur_gather_rows")
+    return out
+
+
+def catalog_scores(user, catalog, cat_inv_norm=None):
+    """cosine scores [B,N] of user [B,D] f32 against a shared catalogue [N,D] f32; returns (scores, cat_inv_norm)
+    so repeated calls over the same catalogue skip its norm pass."""
+    lib = _lib.load()
+    _need(user, F32, "user")
+    _need(catalog, F32, "catalog")
+    B, D = user.shape
+    N = catalog.shape[0]
+    scores = torch.empty((B, N), dtype=F32, device=user.device)
+    uinv = torch.empty((B,), dtype=F32, device=user.device)
+    ready = cat_inv_norm is not None
+    if not ready:
+        cat_inv_norm = torch.empty((N,), dtype=F32, device=user.device)
+    check(lib.ur_catalog_scores(user.data_ptr(), catalog.data_ptr(), scores.data_ptr(), uinv.data_ptr(), cat_inv_norm.data_ptr(),
+                                int(ready), B, N, D, _stream()), "ur_catalog_scores")
+    return scores, cat_inv_norm
+
+
+def rank_of_index(scores, gt_index):
+    """1-based rank of column gt_index[b] in the descending order of scores[b] (ties go to the ground truth)."""
+    lib = _lib.load()
+    _need(scores, F32, "scores")
+    B, N = scores.shape
+    gt = gt_index.to(device=scores.device, dtype=torch.int64).contiguous()
+    rank = torch.empty((B,), dtype=torch.int32, device=scores.device)
+    check(lib.ur_rank_of_index(scores.data_ptr(), gt.data_ptr(), rank.data_ptr(), B, N, _stream()), "ur_rank_of_index")
+    return rank
+
+
 # ---- heads / losses ------------------------------------------------------------------------------
 def gelu_bwd(dy, u):
     lib = _lib.load()
