@@ -235,6 +235,11 @@ int ur_gather_rows(const void* src, int32_t src_kind, void* out, int32_t out_kin
 int ur_catalog_scores(const float* user, const float* catalog, float* scores, float* user_inv_norm, float* cat_inv_norm,
                       int32_t cat_norm_ready, int32_t B, int64_t N, int32_t D, void* stream);
 int ur_rank_of_index(const float* scores, const int64_t* gt_index, int32_t* rank, int32_t B, int64_t N, void* stream);
+/* ur_context_mlp1: first layer of the event-context MLPs of models/user_sequence_encoder.py:118-121:
+ *   kind 0 = TimestampEncoder (models/mwne.py:525-565; in = timestamps.float() [n]; 9 features),
+ *   kind 1 = GeoCoordinateEncoder (models/mwne.py:586-607; in = (lat, lon) degrees [n,2]; 3 features);
+ *   out[n][j] = bf16(gelu(b1[j] + sum_f W1[j][f] feat_f)), W1 f32 [H2, 9 or 3].  The second Linear is ur_gemm. */
+int ur_context_mlp1(const float* in, int32_t kind, const float* W1, const float* b1, void* out, int64_t n, int32_t H2, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ranking head -- train_item_individual_token_joint.py:331-352 (InfoNCELoss), :392-419 (MRR).

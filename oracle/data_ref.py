@@ -84,3 +84,40 @@ def catalog_eval(users, catalog, gt_index, k):
     rank = np.array([1 + int((s[b] > s[b, gt_index[b]]).sum()) for b in range(s.shape[0])], dtype=np.int64)
     order = np.argsort(-s, axis=1, kind="stable")[:, :k]
     return s, rank, order
+
+
+# ---- event context encoders ---------------------------------------------------------------------------
+def context_mlp_shapes(H, nfeat):
+    return {"projection.0.weight": (2 * H, nfeat), "projection.0.bias": (2 * H,), "projection.2.weight": (H, 2 * H), "projection.2.bias": (H,)}
+
+
+def timestamp_features(ts):
+    """models/mwne.py:525-565, every step in float32 exactly as torch evaluates it on ``timestamps.float()``."""
+    f32 = np.float32
+    x = np.asarray(ts, dtype=np.float64).astype(f32).reshape(-1, 1)
+    year, day, two_pi = f32(365.25 * 24 * 60 * 60), f32(24 * 60 * 60), f32(2 * np.pi)
+    comps = [x / year]
+    day_phase = np.mod(x, day) / day
+    comps += [np.sin(two_pi * day_phase), np.cos(two_pi * day_phase)]
+    week_phase = ((x / day) + f32(4)) / f32(7)
+    comps += [np.sin(two_pi * week_phase), np.cos(two_pi * week_phase)]
+    year_phase = np.mod(x, year) / year
+    comps += [np.sin(two_pi * year_phase), np.cos(two_pi * year_phase)]
+    month_phase = year_phase * f32(12)
+    comps += [np.sin(two_pi * month_phase), np.cos(two_pi * month_phase)]
+    return np.concatenate([c.astype(f32) for c in comps], axis=-1)
+
+
+def geo_features(coords):
+    """models/mwne.py:586-607."""
+    c = np.asarray(coords, dtype=np.float32)
+    lat, lon = np.deg2rad(c[:, 0]).astype(np.float32), np.deg2rad(c[:, 1]).astype(np.float32)
+    return np.stack([np.cos(lat) * np.cos(lon), np.cos(lat) * np.sin(lon), np.sin(lat)], axis=-1).astype(np.float32)
+
+
+def context_mlp(feat, P):
+    """nn.Sequential(Linear, GELU(erf), Linear) in f32 (models/mwne.py:519-523, :579-583)."""
+    from math import erf
+    h = feat @ P["projection.0.weight"].T + P["projection.0.bias"]
+    g = 0.5 * h * (1.0 + np.vectorize(erf)(h / np.sqrt(2.0)))
+    return (g.astype(np.float32) @ P["projection.2.weight"].T + P["projection.2.bias"]).astype(np.float32)

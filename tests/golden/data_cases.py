@@ -62,3 +62,34 @@ def mrr_inputs():
     negs = [rng.randn(n, D).astype(np.float32) for n in (7, 1, 19, 12, 3)]
     negs[2][4] = users[2] * 3.0          # a negative that beats the positive
     return users, pos, negs
+
+
+# ---- event context ----
+CTX_H, CTX_SEED = 128, 2024
+
+
+def context_inputs():
+    """Unix timestamps (seconds; python ints) and (lat, lon) degrees."""
+    rng = np.random.RandomState(5)
+    ts = [int(t) for t in (1.2e9 + rng.rand(9) * 5e8)]
+    co = [[float(rng.uniform(-89, 89)), float(rng.uniform(-179, 179))] for _ in range(9)]
+    return ts, co
+
+
+def event_tokens():
+    """cached item query tokens item_id -> [QI, CTX_H] f32 (bf16-representable values, so a bf16 cache is exact)."""
+    import torch
+    rng = np.random.RandomState(9)
+    out = {}
+    for i in range(14):
+        t = torch.from_numpy((rng.randn(QI, CTX_H) * 0.8).astype(np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+        out[f"B{i:03d}"] = t
+    return out
+
+
+def user_events():
+    """two users: 5 and 2 events, each {'item_id', 'item_data', 'timestamp', 'coordinates'}."""
+    ts, co = context_inputs()
+    ids = ["B001", "B005", "B009", "B013", "B002", "B003", "B004"]
+    ev = [{"item_id": ids[i], "item_data": {"item_id": ids[i]}, "timestamp": ts[i], "coordinates": co[i]} for i in range(7)]
+    return [ev[:5], ev[5:7]]

@@ -72,6 +72,31 @@ def main():
              "positive_item_embeddings": torch.from_numpy(pos), "negative_item_embeddings": [torch.from_numpy(n) for n in negs]}
     with torch.no_grad():
         res["batch_mrr"] = np.array(ev._compute_batch_mrr(batch), dtype=np.float64)
+    # event-context encoders and one user's encoded sequence (models/user_sequence_encoder.py:101-142)
+    import types
+    from models.mwne import TimestampEncoder as RefTime, GeoCoordinateEncoder as RefGeo
+    import models.user_sequence_encoder as ruse
+    from oracle import weights as W
+    from oracle import data_ref as D
+    H = dc.CTX_H
+    te, ge = RefTime(H), RefGeo(H)
+    te.load_state_dict({k: torch.from_numpy(v) for k, v in W.fill_state_dict(D.context_mlp_shapes(H, 9), dc.CTX_SEED).items()})
+    ge.load_state_dict({k: torch.from_numpy(v) for k, v in W.fill_state_dict(D.context_mlp_shapes(H, 3), dc.CTX_SEED + 1).items()})
+    ts, co = dc.context_inputs()
+    with torch.no_grad():
+        res["time_emb"] = te(torch.tensor(ts)).numpy()
+        res["geo_emb"] = ge(torch.tensor(co)).numpy()
+    toks = dc.event_tokens()
+    use = ruse.UserSequenceEncoder.__new__(ruse.UserSequenceEncoder)
+    use.device = torch.device("cpu")
+    use.embedding_dim = H
+    use.timestamp_encoder, use.geo_encoder = te, ge
+    use.positional_encoder = ruse.PositionalEncoding(d_model=H).eval()          # dropout off for the fixture
+    use.item_qformer = types.SimpleNamespace(num_query_tokens=dc.QI)
+    use._get_item_query_tokens_batch = lambda item_samples: torch.from_numpy(np.stack([toks[s["item_id"]] for s in item_samples]))
+    hist = dc.user_events()[0]
+    with torch.no_grad():
+        res["encoded_user_sequence"] = use.encode_user_sequence(hist).numpy()
     np.savez_compressed(os.path.join(HERE, "data_path.npz"), **res)
     with open(os.path.join(HERE, "data_path.json"), "w") as f:
         json.dump(txt, f, indent=1)

@@ -71,3 +71,22 @@ def test_product_dataset_host_side_and_cache_format(tmp_path):
         assert "re-encode" in str(e)
     for b, h in enumerate(dc.histories()):
         assert construct_input_text(h, item_dict, dc.HIST, dc.QI) == T["input_texts"][b]
+
+
+def test_oracle_context_encoders_match_reference():
+    """TimestampEncoder / GeoCoordinateEncoder (models/mwne.py:504-607) and one user's encode_user_sequence
+    (models/user_sequence_encoder.py:101-142, dropout off) from cached item tokens."""
+    from oracle import weights as W
+    from oracle import qformer_ref as R
+    H = dc.CTX_H
+    PT = W.fill_state_dict(D.context_mlp_shapes(H, 9), dc.CTX_SEED)
+    PG = W.fill_state_dict(D.context_mlp_shapes(H, 3), dc.CTX_SEED + 1)
+    ts, co = dc.context_inputs()
+    te, ge = D.context_mlp(D.timestamp_features(ts), PT), D.context_mlp(D.geo_features(co), PG)
+    assert np.abs(te - G["time_emb"]).max() < 2e-4 * np.abs(G["time_emb"]).max()
+    assert np.abs(ge - G["geo_emb"]).max() < 2e-5
+    ev = dc.user_events()[0]
+    toks = dc.event_tokens()
+    ctx = torch.from_numpy(te[:len(ev)] + ge[:len(ev)])
+    seq = R.assemble_user_sequence(torch.from_numpy(np.stack([toks[e["item_id"]] for e in ev])), ctx).numpy()
+    assert np.abs(seq - G["encoded_user_sequence"]).max() < 5e-4

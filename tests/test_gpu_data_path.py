@@ -132,3 +132,33 @@ def test_special_token_positions():
     ids = torch.tensor([[5, 100, 7, 101, 9, 103], [102, 1, 1, 100, 1, 1]], device=DEV)
     pos = special_token_positions(ids, 100, 4)
     assert pos.cpu().tolist() == [[1, 3, -1, 5], [3, -1, 0, -1]]
+
+
+def test_cached_user_sequence_encoder_matches_reference():
+    """timestamp / geo encoders and the batched sequence encoding from the token cache against the
+    reference's own TimestampEncoder / GeoCoordinateEncoder / encode_user_sequence outputs (golden)."""
+    from oracle import weights as W
+    from unirec_amd.data import ItemTokenCache
+    from unirec_amd.user_sequence_encoder import CachedUserSequenceEncoder
+    H = dc.CTX_H
+    toks = dc.event_tokens()
+    ids = sorted(toks)
+    cache = ItemTokenCache(torch.from_numpy(np.stack([toks[k] for k in ids])).to(DEV).to(torch.bfloat16), ids)
+    enc = CachedUserSequenceEncoder(cache, embedding_dim=H).to(DEV)
+    enc.timestamp_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in W.fill_state_dict(D.context_mlp_shapes(H, 9), dc.CTX_SEED).items()})
+    enc.geo_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in W.fill_state_dict(D.context_mlp_shapes(H, 3), dc.CTX_SEED + 1).items()})
+    enc.to(DEV)
+    ts, co = dc.context_inputs()
+    te = enc.timestamp_encoder(torch.tensor(ts).to(DEV)).float().cpu().numpy()
+    ge = enc.geo_encoder(torch.tensor(co).to(DEV)).float().cpu().numpy()
+    assert np.linalg.norm(te - G["time_emb"]) <= 2e-2 * np.linalg.norm(G["time_emb"])
+    assert np.linalg.norm(ge - G["geo_emb"]) <= 2e-2 * np.linalg.norm(G["geo_emb"])
+    users = dc.user_events()
+    L = 6
+    x, mask = enc.encode_user_sequences(users, L)
+    assert tuple(x.shape) == (2, L * dc.QI, H) and tuple(mask.shape) == (2, L * dc.QI)
+    assert mask.sum(1).tolist() == [5 * dc.QI, 2 * dc.QI]
+    want = G["encoded_user_sequence"]                                      # user 0: 5 events
+    got = x[0, :5 * dc.QI].float().cpu().numpy()
+    assert np.linalg.norm(got - want) <= 2e-2 * np.linalg.norm(want)
+    assert (x[0, 5 * dc.QI:].float().abs().max().item() == 0) and (x[1, 2 * dc.QI:].float().abs().max().item() == 0)

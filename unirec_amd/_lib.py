@@ -101,6 +101,7 @@ SIGNATURES = {
     "ur_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_i64, c_i64, c_i64, c_void_p]),
     "ur_catalog_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_i64, c_int, c_void_p]),
     "ur_rank_of_index": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_i64, c_void_p]),
+    "ur_context_mlp1": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p]),
     "ur_mrr_rank": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ur_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_heads_workspace_bytes": (c_i64, [c_int, c_int]),

@@ -125,6 +125,46 @@ __global__ void rank_of_index_kernel(const float* __restrict__ scores, const lon
   if (threadIdx.x == 0) rank[b] = 1 + part[0] + part[1] + part[2] + part[3];
 }
 
+// Context MLP, first layer: h1[n][j] = gelu(b1[j] + sum_f W1[j][f] * feat_f(n)), bf16 out.
+//   KIND 0: TimestampEncoder features, models/mwne.py:525-565 (9 = secular + 4 sin/cos pairs, all in f32 as the
+//           reference computes them from timestamps.float()).
+//   KIND 1: GeoCoordinateEncoder features, models/mwne.py:586-607 (lat/lon degrees -> unit-sphere x, y, z).
+// The 9- / 3-wide contraction stays on the vector units in f32 (exact features, no padding to an MFMA k-step); the
+// second Linear (2H -> H) is an ordinary ur_gemm.
+template <int KIND>
+__global__ void context_mlp1_kernel(const float* __restrict__ in, const float* __restrict__ W1, const float* __restrict__ b1,
+                                    bf16_t* __restrict__ out, long n, int H2) {
+  const long row = blockIdx.x;
+  if (row >= n) return;
+  constexpr int NF = KIND == 0 ? 9 : 3;
+  float f[NF];
+  if (KIND == 0) {
+    const float x = in[row];
+    const float year = 31557600.0f, day = 86400.0f, two_pi = 6.283185307179586f;
+    f[0] = x / year;
+    float r = fmodf(x, day); if (r < 0.f) r += day;              // torch `%` is a floor-mod
+    const float day_phase = r / day;
+    f[1] = sinf(two_pi * day_phase); f[2] = cosf(two_pi * day_phase);
+    const float week_phase = ((x / day) + 4.0f) / 7.0f;
+    f[3] = sinf(two_pi * week_phase); f[4] = cosf(two_pi * week_phase);
+    float ry = fmodf(x, year); if (ry < 0.f) ry += year;
+    const float year_phase = ry / year;
+    f[5] = sinf(two_pi * year_phase); f[6] = cosf(two_pi * year_phase);
+    const float month_phase = year_phase * 12.0f;
+    f[7] = sinf(two_pi * month_phase); f[8] = cosf(two_pi * month_phase);
+  } else {
+    const float d2r = 0.017453292519943295f;
+    const float lat = in[2 * row] * d2r, lon = in[2 * row + 1] * d2r;
+    f[0] = cosf(lat) * cosf(lon); f[1] = cosf(lat) * sinf(lon); f[2] = sinf(lat);
+  }
+  for (int j = threadIdx.x; j < H2; j += blockDim.x) {
+    float a = b1[j];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) a = fmaf(W1[(long)j * NF + k], f[k], a);
+    out[row * H2 + j] = f2bf(gelu_erf_f(a));
+  }
+}
+
 }  // namespace
 
 extern "C" int ur_gather_rows(const void* src, int32_t src_kind, void* out, int32_t out_kind, const int64_t* idx, int64_t row_elems,
@@ -193,5 +233,16 @@ extern "C" int ur_rank_of_index(const float* scores, const int64_t* gt_index, in
   UR_REQUIRE(scores && gt_index && rank, "ur_rank_of_index: null pointer");
   hipLaunchKernelGGL(rank_of_index_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, scores, (const long*)gt_index, rank, (long)N);
   UR_CHECK_LAUNCH("ur_rank_of_index");
+  return 0;
+}
+
+extern "C" int ur_context_mlp1(const float* in, int32_t kind, const float* W1, const float* b1, void* out, int64_t n, int32_t H2, void* stream) {
+  UR_REQUIRE((kind == 0 || kind == 1) && n >= 0 && H2 > 0, "ur_context_mlp1: kind must be 0 (timestamp) or 1 (lat/lon), n >= 0");
+  if (n == 0) return 0;
+  UR_REQUIRE(in && W1 && b1 && out, "ur_context_mlp1: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (kind == 0) hipLaunchKernelGGL((context_mlp1_kernel<0>), dim3((unsigned)n), dim3(256), 0, st, in, W1, b1, (bf16_t*)out, (long)n, (int)H2);
+  else hipLaunchKernelGGL((context_mlp1_kernel<1>), dim3((unsigned)n), dim3(256), 0, st, in, W1, b1, (bf16_t*)out, (long)n, (int)H2);
+  UR_CHECK_LAUNCH("ur_context_mlp1");
   return 0;
 }

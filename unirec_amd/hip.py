@@ -545,6 +545,18 @@ def rank_of_index(scores, gt_index):
     return rank
 
 
+def context_mlp1(x, kind, W1, b1):
+    """bf16 [n, 2H] = gelu(W1 feat(x) + b1); kind 0: x = f32 timestamps [n]; kind 1: x = f32 (lat, lon) [n,2]."""
+    lib = _lib.load()
+    _need(x, F32, "x")
+    _need(W1, F32, "W1")
+    _need(b1, F32, "b1")
+    n = x.shape[0]
+    out = torch.empty((n, W1.shape[0]), dtype=BF16, device=x.device)
+    check(lib.ur_context_mlp1(x.data_ptr(), int(kind), W1.data_ptr(), b1.data_ptr(), out.data_ptr(), n, W1.shape[0], _stream()), "ur_context_mlp1")
+    return out
+
+
 # ---- heads / losses ------------------------------------------------------------------------------
 def gelu_bwd(dy, u):
     lib = _lib.load()

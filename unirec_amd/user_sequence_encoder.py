@@ -38,3 +38,87 @@ class UserSequenceAssembler:
         self._step += 1
         p = self.positional_encoder.p if self.training else 0.0
         return hip.user_sequence_assemble(t.contiguous(), c.contiguous(), lengths.to(torch.int32).contiguous(), p, 0xA55E + self._step)
+
+
+# ---- event context encoders + batched sequence encoding from the token cache --------
+class _ContextMLP(torch.nn.Module):
+    """Linear(nf, 2H) -> GELU -> Linear(2H, H) with the reference's parameter names (``projection.0`` / ``projection.2``).
+    Forward only: the reference never trains these (models/user_sequence_encoder.py:118-121 runs them under no_grad)."""
+    kind, nfeat = 0, 9
+
+    def __init__(self, embedding_dim: int):
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.projection = torch.nn.Sequential(torch.nn.Linear(self.nfeat, embedding_dim * 2), torch.nn.GELU(),
+                                              torch.nn.Linear(embedding_dim * 2, embedding_dim))
+        self._w2 = None
+
+    def _second(self, dev):
+        w = self.projection[2].weight
+        key = (w.data_ptr(), w._version, str(dev))
+        if self._w2 is None or self._w2[0] != key:
+            self._w2 = (key, hip.cast_f32_to_bf16(w.detach().to(dev, torch.float32).contiguous()),
+                        self.projection[2].bias.detach().to(dev, torch.float32).contiguous())
+        return self._w2[1], self._w2[2]
+
+    def _run(self, x32):
+        if not x32.is_cuda:
+            raise hip._lib.UniRecHipError(f"{type(self).__name__} runs on the MI355X only")
+        l0 = self.projection[0]
+        h1 = hip.context_mlp1(x32.contiguous(), self.kind, l0.weight.detach().to(x32.device, torch.float32).contiguous(),
+                              l0.bias.detach().to(x32.device, torch.float32).contiguous())
+        w2, b2 = self._second(x32.device)
+        return hip.gemm(h1, w2, bias=b2)            # [n, H] bf16
+
+
+class TimestampEncoder(_ContextMLP):
+    """models/mwne.py:504-565: secular + time-of-day / day-of-week / day-of-year / month sin-cos features (f32, as the
+    reference computes them from ``timestamps.float()``), then the two-layer projection."""
+    kind, nfeat = 0, 9
+
+    def forward(self, timestamps):
+        return self._run(timestamps.float().view(-1))
+
+
+class GeoCoordinateEncoder(_ContextMLP):
+    """models/mwne.py:568-607: (lat, lon) degrees -> unit-sphere (x, y, z) -> projection."""
+    kind, nfeat = 1, 3
+
+    def forward(self, coordinates):
+        if coordinates.dim() != 2 or coordinates.shape[1] != 2:
+            raise ValueError("Input coordinates must be of shape [batch_size, 2]")
+        return self._run(coordinates.float())
+
+
+class CachedUserSequenceEncoder:
+    """Batched ``UserSequenceEncoder.encode_user_sequence`` (models/user_sequence_encoder.py:101-142) + the collate
+    padding of training/user_qformer_training.py:138-163, from CACHED item query tokens (data.ItemTokenCache) instead
+    of re-running the frozen modality encoders: tokens + (time + geo) context, flatten, positional encoding, pad, mask
+    -- one gather, two tiny MLPs and one assembly kernel per batch of users, no per-user Python tensor work."""
+
+    def __init__(self, token_cache, embedding_dim=1024, dropout=0.1, training=False):
+        self.token_cache = token_cache
+        self.embedding_dim = embedding_dim
+        self.timestamp_encoder = TimestampEncoder(embedding_dim)
+        self.geo_encoder = GeoCoordinateEncoder(embedding_dim)
+        self.assembler = UserSequenceAssembler(embedding_dim, token_cache.tokens.shape[1], dropout, training)
+
+    def to(self, device):
+        self.timestamp_encoder.to(device)
+        self.geo_encoder.to(device)
+        return self
+
+    def encode_user_sequences(self, user_histories, max_events):
+        """user_histories: list (users) of lists of events {'item_id', 'timestamp', 'coordinates': (lat, lon)}.
+        -> (padded_inputs [B, max_events*Q, H] bf16, attention_mask [B, max_events*Q] float)."""
+        dev = self.token_cache.tokens.device
+        B, L = len(user_histories), max_events
+        ts = torch.zeros((B, L), dtype=torch.float64)
+        co = torch.zeros((B, L, 2), dtype=torch.float32)
+        for b, h in enumerate(user_histories):
+            for i, ev in enumerate(h[:L]):
+                ts[b, i] = float(ev["timestamp"])
+                co[b, i, 0], co[b, i, 1] = float(ev["coordinates"][0]), float(ev["coordinates"][1])
+        toks, n = self.token_cache.history_tokens([[ev["item_id"] for ev in h] for h in user_histories], L)
+        ctx = hip.add_bf16(self.timestamp_encoder(ts.to(dev).view(-1)), self.geo_encoder(co.to(dev).view(-1, 2)))
+        return self.assembler.encode_user_sequences(toks, ctx.view(B, L, self.embedding_dim), n.to(dev))
