@@ -129,6 +129,7 @@ class Qwen3LoRAModel(nn.Module):
         self.grad_ready_hook = None
         self.lora_seed = 0x5EED        # base seed of the LoRA dropout masks (set per rank / per run by the trainer)
         self._lora_step = 0            # forward calls with dropout so far: every step draws new masks
+        self.keep_norm_outputs = True   # keep the two RMSNorm outputs per layer for the backward (memory for time); False recomputes them
         self.reset_parameters()
 
     def reset_parameters(self, lora_b_std=0.0):
@@ -333,6 +334,8 @@ class Qwen3LoRAModel(nn.Module):
             else:
                 x3 = hip.gemm(act, fl["d"], residual=x2)
             L.update(rstd1=rstd1, qkv=qkv, actx=actx, att=att2, x2=x2, rstd2=rstd2, gu=gu, act=act)
+            if self.keep_norm_outputs:       # 2 x [M,D] bf16 per layer (15 GB at C4) instead of two RMSNorm recomputes
+                L.update(h=h, h2=h2)
             saved["layers"].append(L)
             x = x3
         last, rstd_f = hip.rmsnorm_fwd(x, fz["norm"], eps)
@@ -398,7 +401,7 @@ class Qwen3LoRAModel(nn.Module):
             else:
                 dact = hip.gemm(dx, fl["dT"])
             dgu = hip.swiglu_bwd(dact, gu, I)
-            h2, _ = hip.rmsnorm_fwd(x2, fl["ln2"], eps)                   # recomputed
+            h2 = L["h2"] if "h2" in L else hip.rmsnorm_fwd(x2, fl["ln2"], eps)[0]          # kept, or recomputed
             if pack is not None:
                 a_names = [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"]
                 tb = lora_grads(dgu, L["t_gu"], h2, a_names, [(lp + "mlp.gate_proj.lora_B.weight", 0, I), (lp + "mlp.up_proj.lora_B.weight", I, I)], L["bits_gu"])
@@ -419,7 +422,7 @@ class Qwen3LoRAModel(nn.Module):
             hip.attn_bwd(L["actx"], datt.view(B, S, nq, hd), dq=dq_r.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd),
                          dv=dqkv[:, NQ + NKV:].view(B, S, nkv, hd))
             hip.qknorm_rope_bwd(dq_r, dk_r, qkv, fl["qn"], fl["kn"], cos, sin, dqkv, S, nq, nkv, hd, eps)
-            h, _ = hip.rmsnorm_fwd(x, fl["ln1"], eps)                     # recomputed
+            h = L["h"] if "h" in L else hip.rmsnorm_fwd(x, fl["ln1"], eps)[0]              # kept, or recomputed
             if pack is not None:
                 a_names = [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"]
                 specs = [(lp + "self_attn.q_proj.lora_B.weight", 0, NQ), (lp + "self_attn.k_proj.lora_B.weight", NQ, NKV),
