@@ -1,0 +1,88 @@
+"""GPU: the joint step at BASELINE.json's full C4 size (B=64 x S=2048, hist 50, pool 1000, 28 Qwen3 layers, item
+Q-Former L12 H1024) through SIZE-INDEPENDENT properties -- the oracle cannot run this size in seconds:
+  * shard invariance: a user's embedding does not depend on which other users share the launch (the property data
+    parallelism rests on: rank r's shard of the global batch gives the rows the global batch would), bit for bit;
+  * gradient additivity: the gradients of a batch are the sum of the gradients of its two halves (what the RCCL
+    all-reduce of per-rank gradients reproduces), to f32 summation-order tolerance;
+  * ranking integers: MRR ranks and top-K over the 1000-candidate pool equal torch's own sort of the same scores, exactly;
+  * run-to-run determinism of forward, loss and every gradient (no atomics on the path)."""
+import argparse
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def full():
+    import bench
+    from unirec_amd import hip
+    args = argparse.Namespace(layers=28, hist=50, seq=2048, pool=1000, no_dropout=True, lora_dropout=0.0)
+    model, qf, cfg, (Qi, F, E, D) = bench.build(args, torch.device(DEV))
+    batch = bench.make_batch(64, args.hist, args.seq, args.pool, F, E, D, Qi, model.first_special_id, model.first_special_id, 4321, DEV)
+    return model, qf, batch, hip
+
+
+def _sub(batch, sl):
+    return {k: (v[sl] if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+def _step(model, qf, b, loss_scale=1.0):
+    from unirec_amd.joint import InfoNCELoss
+    for p in list(model.parameters()) + list(qf.parameters()):
+        p.grad = None
+    u = model(b["input_ids"], b["attention_mask"], b["history_field_embeddings"], b["history_attention_mask"])
+    loss = InfoNCELoss()(u, b["positive_item_embeddings"], b["negative_item_embeddings"]) * loss_scale
+    loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in list(model.named_parameters()) + [("qf." + k, v) for k, v in qf.named_parameters()]
+             if p.grad is not None}
+    return u.detach().clone(), loss.detach().clone(), grads
+
+
+def test_full_size_shard_invariance_additivity_and_determinism(full):
+    model, qf, batch, hip = full
+    model.train()          # dropout probabilities are 0: training-mode code path, deterministic arithmetic
+    u, loss, g = _step(model, qf, batch)
+    assert torch.isfinite(u).all() and torch.isfinite(loss)
+    u2, loss2, g2 = _step(model, qf, batch)
+    assert torch.equal(u, u2) and torch.equal(loss, loss2)
+    assert sorted(g) == sorted(g2) and all(torch.equal(g[k], g2[k]) for k in g)
+    # shard invariance (forward): 16-user shards give the same rows, bit for bit
+    with torch.no_grad():
+        for r in (0, 3):
+            sl = slice(16 * r, 16 * r + 16)
+            b = _sub(batch, sl)
+            ur = model(b["input_ids"], b["attention_mask"], b["history_field_embeddings"], b["history_attention_mask"])
+            assert torch.equal(ur, u[sl]), f"shard {r}: max diff {(ur - u[sl]).abs().max().item()}"
+    # gradient additivity: mean-loss of the batch = (mean-loss(half A) + mean-loss(half B)) / 2
+    _, la, ga = _step(model, qf, _sub(batch, slice(0, 32)), 0.5)
+    _, lb, gb = _step(model, qf, _sub(batch, slice(32, 64)), 0.5)
+    assert abs((la + lb).item() - loss.item()) <= 1e-5 * abs(loss.item())
+    worst = 0.0
+    for k in g:
+        s = ga[k].float() + gb[k].float()
+        rel = ((s - g[k].float()).norm() / (g[k].float().norm() + 1e-20)).item()
+        worst = max(worst, rel)
+    assert worst < 2e-2, worst          # bf16 activations of a 28-layer chain: the halves round differently
+    assert len([k for k in g if ".lora_" in k]) == 28 * 14 and any(k.startswith("qf.") for k in g)
+
+
+def test_full_size_ranking_integers_are_exact(full):
+    model, qf, batch, hip = full
+    from unirec_amd.joint import mrr_ranks
+    model.eval()
+    with torch.no_grad():
+        u = model(batch["input_ids"], batch["attention_mask"], batch["history_field_embeddings"], batch["history_attention_mask"])
+    scores, rank = mrr_ranks(u, batch["positive_item_embeddings"], batch["negative_item_embeddings"])
+    assert tuple(scores.shape) == (64, 1000)
+    want_rank = 1 + (scores[:, 1:] > scores[:, :1]).sum(1)
+    assert torch.equal(rank.long(), want_rank)
+    idx, val = hip.topk(scores, 10)
+    order = torch.sort(scores, dim=1, descending=True, stable=True)
+    assert torch.equal(idx.long(), order.indices[:, :10]) and torch.equal(val, order.values[:, :10])
+    # idempotence: the top-10 of the top-10 values is the identity
+    idx2, val2 = hip.topk(val.contiguous(), 10)
+    assert torch.equal(idx2.long(), torch.arange(10, device=DEV).expand(64, 10)) and torch.equal(val2, val)
