@@ -65,8 +65,10 @@ def test_gemm_random_tolerance(rk, sk):
     assert (out - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-4
 
 
-def test_gemm_epilogues():
-    M, N, K = 200, 136, 256
+@pytest.mark.parametrize("M,N,K", [(200, 136, 256), (200, 132, 256), (8192, 4096, 192), (8200, 4104, 128), (4352, 4100, 64)])
+def test_gemm_epilogues(M, N, K):
+    """bias / residual / GELU second output / gelu' epilogues on both tile configurations (128x128 and, from 256
+    workgroups on, 256x256), 16-byte pieces (N % 8 == 0) and 8-byte pieces (N % 8 == 4), interior and edge tiles."""
     Rm, Sm = _randn((M, K), 5), _randn((N, K), 6, std=0.1)
     R, S = _bf(Rm), _bf(Sm)
     bias = _randn((N,), 7).to(DEV)
