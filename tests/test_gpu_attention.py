@@ -118,3 +118,28 @@ def test_attention_dropout_is_deterministic_and_unbiased():
     lhs = (dout.float() * o1.float()).sum().item()
     rhs = (dv.float() * v.float()).sum().item()
     assert abs(lhs - rhs) <= 2e-2 * abs(lhs) + 1.0
+
+
+@pytest.mark.parametrize("spike_key,gain", [(200, 6.0), (31, 3.0), (449, 12.0), (64, 1.5)])
+def test_deferred_max_rescale_is_exact_when_forced(spike_key, gain):
+    """The forward defers the running-maximum update while the maximum grows by less than 2^6: a rare, data-dependent
+    branch.  Force it both ways: one key row aligned with the query rows makes the row maximum jump at a chosen tile
+    (by more than the threshold for large gains, by less for small ones), against a full-tensor f32 reference,
+    forward and backward (the backward re-derives P from the saved log-sum-exp, so a wrong l or m shows there too)."""
+    B, S, nq, nkv, hd = 1, 512, 2, 1, 128
+    q = _randn((B, S, nq, hd), 11, std=0.5)
+    k = _randn((B, S, nkv, hd), 12, std=0.5)
+    v = _randn((B, S, nkv, hd), 13)
+    direction = torch.nn.functional.normalize(torch.ones(hd), dim=0).to(DEV)
+    q = (q.float() + 2.0 * direction).to(torch.bfloat16)          # every query has a component along `direction`
+    k[0, spike_key, 0] = (gain * 4.0 * direction).to(torch.bfloat16)      # ... and one key is far along it
+    dout = _randn((B, S, nq, hd), 14)
+    o, ctx = hip.attn_fwd(q, k, v, causal=True)
+    dq, dk, dv = hip.attn_bwd(ctx, dout)
+    qf, kf, vf = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
+    ref = _ref(qf, kf, vf, None, True)
+    ref.backward(dout.float())
+    assert torch.allclose(o.float(), ref, rtol=2e-2, atol=2e-2), (o.float() - ref).abs().max().item()
+    for name, got, want in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+        err, scale = (got.float() - want).abs().max().item(), want.abs().max().item()
+        assert err <= 2e-2 * scale + 2e-2, f"{name}: max err {err} (scale {scale})"

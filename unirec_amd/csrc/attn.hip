@@ -29,6 +29,10 @@ constexpr float NEG_INF = -__builtin_huge_valf();
 constexpr float F32_MIN = -3.4028234663852886e38f;   // torch.finfo(torch.float32).min
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int KT = 64;                                // keys (or queries, in dK/dV) staged per LDS tile
+#ifndef UR_ATTN_DEFER_MAX
+#define UR_ATTN_DEFER_MAX 1                           // lab: 0 = rescale O at every 32-key sub-tile
+#endif
+constexpr float DEFER_NAT = 6.0f * 0.6931471805599453f;   // defer the running-max update while it grows by < 2^6 (natural-log units)
 
 template <int HD> struct Cfg {
   static constexpr int ROWB = (HD == 128) ? 256 : 144;
@@ -293,14 +297,23 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
     }
     KeyBits kbits; kbits.valid = kwords[2 * t]; kbits.inr = kwords[2 * t + 1];
     if (qblk < p.Sq) {
-#pragma unroll
-      for (int sub = 0; sub < 2; ++sub) {
-        const int kbase = k0 + 32 * sub;
-        if (kbase >= kend || (CAUSAL && kbase > qblk + 31)) break;
-        f32x16 s = zero16();
+      // both 32-key sub-tiles' S = K Q^T chains are issued before the first softmax: the second chain runs on the
+      // matrix pipe while the vector units do the first sub-tile's maximum / exp2 / row sum
+      const bool act0 = k0 < kend && !(CAUSAL && k0 > qblk + 31);
+      const bool act1 = (k0 + 32) < kend && !(CAUSAL && k0 + 32 > qblk + 31);
+      f32x16 sA = zero16(), sB = zero16();
+      if (act0) {
 #pragma unroll
         for (int st = 0; st < C::NS; ++st)
-          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ktile, 32 * sub, st, lane), qf[st], s, 0, 0, 0);
+          sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ktile, 0, st, lane), qf[st], sA, 0, 0, 0);
+      }
+      if (act1) {
+#pragma unroll
+        for (int st = 0; st < C::NS; ++st)
+          sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ktile, 32, st, lane), qf[st], sB, 0, 0, 0);
+      }
+      auto soft_pv = [&](const int sub, f32x16& s) {
+        const int kbase = k0 + 32 * sub;
         const uint32_t v32 = (uint32_t)(kbits.valid >> (32 * sub)), i32 = (uint32_t)(kbits.inr >> (32 * sub));
         const bool fast = (v32 == 0xffffffffu) && (!CAUSAL || kbase + 31 <= qblk) && !dropping;
         float mx = NEG_INF;
@@ -321,6 +334,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // branch-free rescale (alpha == 1 exactly when the max did not move): keeps the O accumulators
         // in place across the loop (a conditional rescale made hipcc copy all 64 registers per sub-tile)
+#if UR_ATTN_DEFER_MAX
+        // deferred running maximum: O and l are rescaled only when some row's maximum grew by more than 2^DEFER_LOG2
+        // (wave-uniform branch); until then p = exp2(c*s - m_old) may exceed 1 by at most that factor, which f32 sums
+        // and the bf16 P fragments carry at unchanged relative precision.  m = -inf (first tile) always takes the branch.
+        if (__builtin_amdgcn_ballot_w64(!(mx <= m + DEFER_NAT)) != 0ull) {
+          const float mnew = fmaxf(m, mx);
+          const float mu = (mnew == NEG_INF) ? 0.f : mnew;
+          const float alpha = fast_exp2((m - mu) * LOG2E);
+          l *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+          m = mnew;
+        }
+#else
         {
           const float mnew = fmaxf(m, mx);
           const float mu = (mnew == NEG_INF) ? 0.f : mnew;
@@ -332,6 +361,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
             for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
           m = mnew;
         }
+#endif
         const float muse = (m == NEG_INF) ? 0.f : m;
         const float mc = muse * LOG2E;
         float rs = 0.f;
@@ -357,7 +387,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
           for (int dt = 0; dt < C::NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[dt], pf, o[dt], 0, 0, 0);
         }
-      }
+      };
+      if (act0) soft_pv(0, sA);
+      if (act1) soft_pv(1, sB);
     }
     if (t + 1 < ntiles) {
       ks.commit(nk, tid);
