@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmarks of the individual hot kernels (attention fwd/bwd, projection GEMMs) at the C4
 shapes; used under rocprofv3 (--kernel-trace / --pmc) when tuning.  Usage:
-    python tools/kernel_bench.py attn|gemm [--B 8] [--iters 5]"""
+    python tools/kernel_bench.py attn|gemm|lora [--B 8] [--iters 5]"""
 import argparse
 import os
 import sys
@@ -48,11 +48,33 @@ def gemm(args):
         print(f"gemm {name:12s} M={M} N={N} K={K}: {t:.3f} ms  {2 * M * N * K / t / 1e9:.1f} TFLOP/s")
 
 
+def lora(args):
+    """The rank-16 LoRA side kernels at the C4 shapes (M = B*S tokens): GB/s of the activation they stream."""
+    M, r = args.B * args.S, 16
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(M, 1024, generator=g).cuda().to(torch.bfloat16)
+    dy = torch.randn(M, 4096, generator=g).cuda().to(torch.bfloat16)
+    A = [(torch.randn(r, 1024, generator=g) * 0.1).cuda().to(torch.bfloat16) for _ in range(3)]
+    cols = [(0, 2048), (2048, 1024), (3072, 1024)]
+    Bt = [(torch.randn(r, n, generator=g) * 0.1).cuda().to(torch.bfloat16) for _, n in cols]
+    t = torch.randn(M, 3 * r, generator=g).cuda().to(torch.bfloat16)
+    bits = hip.lora_dropout_bits(1, 0.1, M, 1024, 3, "cuda")
+    gA, gB = torch.empty(3 * r, 1024, device="cuda"), torch.empty(4096, r, device="cuda")
+    for name, fn, nbytes in (
+            ("bits   3 planes of [M,1024]", lambda: hip.lora_dropout_bits(1, 0.1, M, 1024, 3, "cuda"), 3 * M * 1024 / 8),
+            ("project t  = drop(x) A^T (3)", lambda: hip.lora_project(x, A, bits=bits), x.numel() * 2),
+            ("project tb = dy B        (3)", lambda: hip.lora_project(dy, Bt, cols=cols), dy.numel() * 2),
+            ("reduce  dB = dy^T t      (3)", lambda: hip.lora_reduce(dy, t, gB, cols=cols, transposed=True), dy.numel() * 2),
+            ("reduce  dA = tb^T drop(x)(3)", lambda: hip.lora_reduce(x, t, gA, nad=3, bits=bits), x.numel() * 2)):
+        ms = timeit(fn, args.iters)
+        print(f"lora {name}: {ms * 1e3:7.1f} us  {nbytes / ms / 1e6:7.1f} GB/s")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["attn", "gemm"])
+    ap.add_argument("what", choices=["attn", "gemm", "lora"])
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--S", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=5)
     a = ap.parse_args()
-    {"attn": attn, "gemm": gemm}[a.what](a)
+    {"attn": attn, "gemm": gemm, "lora": lora}[a.what](a)

@@ -202,9 +202,11 @@ __device__ __forceinline__ void tr_pair(bf16x8 (&f)[2], uint32_t a0, uint32_t b0
 // row-major in LDS; ds_read_b64_tr_b16 turns both into token-packed MFMA operands.  Wave w owns columns 16w..16w+15.
 template <int NAD, bool MASKED>
 __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
-  constexpr int XT = 64 * 128;
+  constexpr int TOK = NAD <= 3 ? 128 : 64;          // tokens per step (two barriers per step)
+  constexpr int XP = TOK / 32;                       // X pieces (16 B) per thread and step
+  constexpr int XT = TOK * 128;
   constexpr int VROW = NAD * 32;
-  __shared__ __attribute__((aligned(16))) char smem[NAD * XT + 64 * VROW];
+  __shared__ __attribute__((aligned(16))) char smem[NAD * XT + TOK * VROW];
   char* vt = smem + NAD * XT;
   const int e0 = blockIdx.z;
   const int W = p.width[e0], col0 = p.col0[e0];
@@ -214,28 +216,28 @@ __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
   const int tbeg = blockIdx.y * p.tok_per_block, tend = min(p.M, tbeg + p.tok_per_block);
 
   // this thread's staging pieces
-  int prow[2], pch[2], pcol[2];
+  int prow[XP], pch[XP], pcol[XP];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < XP; ++i) {
     const int pi = tid + 256 * i;
     prow[i] = pi >> 3; pch[i] = pi & 7;
     pcol[i] = min(cb + 8 * pch[i], W - 8);
   }
-  constexpr int VP = (64 * 2 * NAD + 255) / 256;           // V pieces (16 B) per thread: 64 rows x 2 NAD pieces
+  constexpr int VP = (TOK * 2 * NAD + 255) / 256;          // V pieces (16 B) per thread: TOK rows x 2 NAD pieces
   int vrow[VP], vpart[VP];
   bool vthr[VP];
 #pragma unroll
   for (int i = 0; i < VP; ++i) {
     const int pi = tid + 256 * i;
-    vthr[i] = pi < 64 * 2 * NAD;
+    vthr[i] = pi < TOK * 2 * NAD;
     vrow[i] = pi / (2 * NAD); vpart[i] = pi % (2 * NAD);
   }
 
-  uint4 xr[2], vr[VP];
-  uint32_t br[2][NAD];
+  uint4 xr[XP], vr[VP];
+  uint32_t br[XP][NAD];
   auto gload = [&](int t0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < XP; ++i) {
       const int m = min(t0 + prow[i], p.M - 1);
       xr[i] = *reinterpret_cast<const uint4*>(p.X + (long)m * p.ldx + col0 + pcol[i]);
       if (MASKED) {
@@ -256,9 +258,9 @@ __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
   const int q = l15 >> 2, pp = lane & 3;
 
   if (tbeg < tend) gload(tbeg);
-  for (int t0 = tbeg; t0 < tend; t0 += 64) {
+  for (int t0 = tbeg; t0 < tend; t0 += TOK) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < XP; ++i) {
       const int off = prow[i] * 128 + ((((pch[i] >> 1) ^ f64sw(prow[i])) << 5) | ((pch[i] & 1) << 4));
 #pragma unroll
       for (int a = 0; a < NAD; ++a)
@@ -268,9 +270,9 @@ __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
     for (int i = 0; i < VP; ++i)
       if (vthr[i]) *reinterpret_cast<uint4*>(vt + vrow[i] * VROW + vpart[i] * 16) = vr[i];
     __syncthreads();
-    if (t0 + 64 < tend) gload(t0 + 64);
+    if (t0 + TOK < tend) gload(t0 + TOK);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < TOK / 32; ++ks) {
       const int ka = 32 * ks + 8 * g + q;
       const uint32_t xo = lds_off(smem) + ka * 128 + ((wave ^ f64sw(ka)) << 5) + pp * 8;
       const uint32_t vo = lds_off(vt) + ka * VROW + pp * 8;
@@ -399,7 +401,7 @@ static inline int lora_reduce_splits(const ur_lora_args* a) {
   const int ne = a->shared ? 1 : a->nad;
   for (int e = 0; e < ne; ++e) wmax = a->width[e] > wmax ? a->width[e] : wmax;
   const long colblocks = (long)ur_cdiv(wmax, 64) * ne;
-  const int tiles = ur_cdiv(a->M, 64);
+  const int tiles = ur_cdiv(a->M, 128);
   long want = (2048 + colblocks - 1) / colblocks;          // ~8 blocks per CU
   if (want < 1) want = 1;
   if (want > tiles) want = tiles;
@@ -448,8 +450,8 @@ extern "C" int ur_lora_reduce(const ur_lora_args* a, void* workspace, int64_t wo
   p.bits = (const uint8_t*)a->drop_bits; p.bits_ld = a->bits_ld; p.bits_stride = a->bits_stride;
   p.out = splits > 1 ? (float*)workspace : (float*)a->G;
   p.transposed = a->g_transposed ? 1 : 0;
-  const int tiles = ur_cdiv(a->M, 64);
-  p.tok_per_block = ur_cdiv(tiles, splits) * 64;
+  const int tiles = ur_cdiv(a->M, 128);
+  p.tok_per_block = ur_cdiv(tiles, splits) * 128;
   p.alpha = a->alpha;
   const bool masked = a->drop_bits != nullptr;
   if (!a->shared || a->nad == 1) {
