@@ -143,3 +143,33 @@ def test_deferred_max_rescale_is_exact_when_forced(spike_key, gain):
     for name, got, want in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
         err, scale = (got.float() - want).abs().max().item(), want.abs().max().item()
         assert err <= 2e-2 * scale + 2e-2, f"{name}: max err {err} (scale {scale})"
+
+
+@pytest.mark.parametrize("S,pads", [(512, (200, 130)), (384, (383, 64)), (1024, (0, 700))])
+def test_causal_left_padding_skips_whole_tiles(S, pads):
+    """Left padding long enough to cover whole 64-key tiles and whole 128-key blocks: the causal kernels skip those
+    (forward / dQ: leading key tiles and their K/V loads; dK/dV: whole key blocks) -- outputs and every gradient must
+    still equal the dense masked reference, zero rows included (padded queries: o = 0; padded keys: dK = dV = 0)."""
+    B, nq, nkv, hd = 2, 4, 2, 128
+    q, k, v = _randn((B, S, nq, hd), 21), _randn((B, S, nkv, hd), 22), _randn((B, S, nkv, hd), 23)
+    km = torch.ones((B, S), dtype=torch.uint8)
+    for b, npad in enumerate(pads):
+        km[b, :npad] = 0
+    km[1, min(S - 1, pads[1] + 70)] = 0              # plus one masked key in the middle of the valid range
+    km = km.to(DEV)
+    dout = _randn((B, S, nq, hd), 24)
+    o, ctx = hip.attn_fwd(q, k, v, causal=True, key_mask=km)
+    dq, dk, dv = hip.attn_bwd(ctx, dout)
+    qf, kf, vf = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
+    ref = _ref(qf, kf, vf, km, True)
+    ref.backward(dout.float())
+    assert torch.isfinite(o.float()).all()
+    assert torch.allclose(o.float(), ref, rtol=2e-2, atol=2e-2), (o.float() - ref).abs().max().item()
+    for b, npad in enumerate(pads):
+        assert o[b, :npad].float().abs().max().item() == 0 if npad else True
+        if npad:
+            assert dk[b, :npad].float().abs().max().item() == 0 and dv[b, :npad].float().abs().max().item() == 0
+            assert dq[b, :npad].float().abs().max().item() == 0
+    for name, got, want in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+        err, scale = (got.float() - want).abs().max().item(), want.abs().max().item()
+        assert err <= 2e-2 * scale + 2e-2, f"{name}: max err {err} (scale {scale})"

@@ -216,6 +216,16 @@ __device__ __forceinline__ void fill_key_words(unsigned long long* kw, const uin
   }
 }
 
+// Causal (SDPA) semantics only: a key tile without a single valid key contributes exactly nothing (its scores are
+// -inf for every query), so the leading run of such tiles -- the left padding of a prompt, which every later query
+// block of the sequence would otherwise sweep -- is skipped together with its K/V loads.  The Q-Former's additive
+// finfo.min mask must NOT take this path: a fully masked row is a uniform softmax over all keys there.
+__device__ __forceinline__ int first_valid_tile(const unsigned long long* kw, int ntiles) {
+  int t = 0;
+  while (t < ntiles && kw[2 * t] == 0ull) ++t;
+  return t;
+}
+
 // Workgroup -> (x block, head, batch).  The grid is 1-D.  Consecutive workgroup ids are dealt round-robin to
 // the 8 XCDs, each with its own L2, so the ids are re-read as (xcd = id % 8, slot = id / 8): every (batch,
 // kv head) group -- whose blocks stream the same K/V (forward, dQ) or the same Q/dO (dK/dV) -- gets all its
@@ -278,15 +288,23 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
 
   unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + 4 * C::TILE);
   fill_key_words(kwords, km, ntiles, p.Sk, tid, NW * 64);
+  int t_first = 0;
+  if (CAUSAL && km != nullptr) {
+    __syncthreads();
+    t_first = first_valid_tile(kwords, ntiles);
+  }
   Loader<HD, NW * 64> ks, vs;
   ks.init(p.ldk, tid); vs.init(p.ldv, tid);
-  ks.issue(smem, kb, p.ldk, 0, p.Sk, tid);
-  vs.issue(smem + C::TILE, vb, p.ldv, 0, p.Sk, tid);
-  ks.commit(smem, tid);
-  vs.commit(smem + C::TILE, tid);
+  if (t_first < ntiles) {
+    char* first = smem + (t_first & 1) * 2 * C::TILE;
+    ks.issue(first, kb, p.ldk, t_first * KT, p.Sk, tid);
+    vs.issue(first + C::TILE, vb, p.ldv, t_first * KT, p.Sk, tid);
+    ks.commit(first, tid);
+    vs.commit(first + C::TILE, tid);
+  }
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = t_first; t < ntiles; ++t) {
     const int k0 = t * KT;
     const char* ktile = smem + (t & 1) * 2 * C::TILE;
     const char* vtile = ktile + C::TILE;
@@ -299,8 +317,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
     if (qblk < p.Sq) {
       // both 32-key sub-tiles' S = K Q^T chains are issued before the first softmax: the second chain runs on the
       // matrix pipe while the vector units do the first sub-tile's maximum / exp2 / row sum
-      const bool act0 = k0 < kend && !(CAUSAL && k0 > qblk + 31);
-      const bool act1 = (k0 + 32) < kend && !(CAUSAL && k0 + 32 > qblk + 31);
+      // causal: a 32-key sub-tile without a valid key adds nothing (see first_valid_tile)
+      const bool act0 = k0 < kend && !(CAUSAL && (k0 > qblk + 31 || (uint32_t)kbits.valid == 0u));
+      const bool act1 = (k0 + 32) < kend && !(CAUSAL && (k0 + 32 > qblk + 31 || (uint32_t)(kbits.valid >> 32) == 0u));
       f32x16 sA = zero16(), sB = zero16();
       if (act0) {
 #pragma unroll
@@ -481,15 +500,23 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
 
   unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + 4 * C::TILE);
   fill_key_words(kwords, km, ntiles, p.Sk, tid, NW * 64);
+  int t_first = 0;
+  if (CAUSAL && km != nullptr) {
+    __syncthreads();
+    t_first = first_valid_tile(kwords, ntiles);
+  }
   Loader<HD, NW * 64> ks, vs;
   ks.init(p.ldk, tid); vs.init(p.ldv, tid);
-  ks.issue(smem, kb, p.ldk, 0, p.Sk, tid);
-  vs.issue(smem + C::TILE, vb, p.ldv, 0, p.Sk, tid);
-  ks.commit(smem, tid);
-  vs.commit(smem + C::TILE, tid);
+  if (t_first < ntiles) {
+    char* first = smem + (t_first & 1) * 2 * C::TILE;
+    ks.issue(first, kb, p.ldk, t_first * KT, p.Sk, tid);
+    vs.issue(first + C::TILE, vb, p.ldv, t_first * KT, p.Sk, tid);
+    ks.commit(first, tid);
+    vs.commit(first + C::TILE, tid);
+  }
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
+  for (int t = t_first; t < ntiles; ++t) {
     const int k0 = t * KT;
     const char* ktile = smem + (t & 1) * 2 * C::TILE;
     const char* vtile = ktile + C::TILE;
@@ -504,6 +531,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
       for (int sub = 0; sub < 2; ++sub) {
         const int kbase = k0 + 32 * sub;
         if (kbase >= kend || (CAUSAL && kbase > qblk + 31)) break;
+        if (CAUSAL && (uint32_t)(kbits.valid >> (32 * sub)) == 0u) continue;      // no valid key: dS = 0
         f32x16 s = zero16(), dp = zero16();
 #pragma unroll
         for (int st = 0; st < C::NS; ++st) {
@@ -580,6 +608,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   f32x16 dk[C::NDT], dv[C::NDT];
 #pragma unroll
   for (int dt = 0; dt < C::NDT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
+
+  // causal (SDPA) semantics: a key block without a single valid key (the left padding of a prompt: the blocks with
+  // the MOST query tiles to sweep) has P = 0 everywhere: dK = dV = 0 without reading Q or dO
+  if (CAUSAL && p.kmask != nullptr) {
+    if (!__syncthreads_or(kvalid ? 1 : 0)) {
+      if (kok) {
+        store_T<HD>(p.dk + ((long)b * p.Sk + key) * p.lddk + (long)kvh * HD, dk, 0.f, lane);
+        store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 0.f, lane);
+      }
+      return;
+    }
+  }
 
   const int qstart = CAUSAL ? ((bm.x * (32 * NW)) / KT) * KT : 0;
   const int ntq = (p.Sq - qstart + KT - 1) / KT;
@@ -841,6 +881,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   f32x16 dk[C::NDT], dv[C::NDT];
 #pragma unroll
   for (int dt = 0; dt < C::NDT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
+
+  // causal (SDPA) semantics: a key block without a single valid key (the left padding of a prompt: the blocks with
+  // the MOST query tiles to sweep) has P = 0 everywhere: dK = dV = 0 without reading Q or dO
+  if (CAUSAL && p.kmask != nullptr) {
+    if (!__syncthreads_or(kvalid ? 1 : 0)) {
+      if (kok) {
+        store_T<HD>(p.dk + ((long)b * p.Sk + key) * p.lddk + (long)kvh * HD, dk, 0.f, lane);
+        store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 0.f, lane);
+      }
+      return;
+    }
+  }
 
   const int qstart = CAUSAL ? ((bm.x * (32 * NW)) / KT) * KT : 0;
   const int ntq = (p.Sq - qstart + KT - 1) / KT;
