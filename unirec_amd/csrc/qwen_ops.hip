@@ -28,7 +28,9 @@ __global__ void rope_table_kernel(float* __restrict__ cs, float* __restrict__ sn
   sn[i] = sinf(ang);
 }
 
-// One (token, head) row of hd elements per LPH = hd/8 lanes.  Heads 0..nq-1 are q, nq..nq+nkv-1 are k.
+// One token per group of LPH = hd/8 lanes; the group walks the token's nq + nkv heads (0..nq-1 are q, the rest k), so
+// the position's cos / sin row and the two norm weight vectors are loaded ONCE per token instead of once per
+// (token, head) row -- they were 6 of the 7 loads of a row (table reads 2x the payload bytes).
 template <int HD, bool BWD>
 __global__ __launch_bounds__(256) void qknorm_rope_kernel(const bf16_t* __restrict__ raw, long ldraw,
                                                           const float* __restrict__ qw, const float* __restrict__ kw,
@@ -39,55 +41,57 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const bf16_t* __restri
   constexpr int LPH = HD / 8, HALF = HD / 2;
   const int lane = threadIdx.x & 63;
   const int li = lane % LPH;
-  const long nrows = M * (nq + nkv);
-  const long rows_per_block = 256 / LPH;
-  // all LPH lanes of a group share `row`, so the group shuffles below never see a diverged partner
-  for (long row = (long)blockIdx.x * rows_per_block + threadIdx.x / LPH; row < nrows; row += (long)gridDim.x * rows_per_block) {
-    const bool ok = true;
-    const long m = row / (nq + nkv);
-    const int hh = (int)(row - m * (nq + nkv));
-    const bool isq = hh < nq;
+  const long toks_per_block = 256 / LPH;
+  float wq[8], wk[8];
+  ld8f(qw + li * 8, wq);
+  ld8f(kw + li * 8, wk);
+  const float sign = (li < LPH / 2) ? -1.f : 1.f;       // rotate_half: first half gets -x[d+half]
+  // all LPH lanes of a group share the token, so the group shuffles below never see a diverged partner
+  for (long m = (long)blockIdx.x * toks_per_block + threadIdx.x / LPH; m < M; m += (long)gridDim.x * toks_per_block) {
     const int pos = (int)(m % S);
-    const float* w = isq ? qw : kw;
-    float x[8], ww[8], c[8], s[8];
-    un8(*reinterpret_cast<const uint4*>(raw + m * ldraw + (long)hh * HD + li * 8), x);
-    ld8f(w + li * 8, ww);
+    float c[8], s[8];
     ld8f(cs + (long)pos * HALF + (li % (LPH / 2)) * 8, c);
     ld8f(sn + (long)pos * HALF + (li % (LPH / 2)) * 8, s);
-    float ss = 0.f;
+    for (int hh = 0; hh < nq + nkv; ++hh) {
+      const bool isq = hh < nq;
+      float x[8], ww[8];
+      un8(*reinterpret_cast<const uint4*>(raw + m * ldraw + (long)hh * HD + li * 8), x);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-    ss = group_sum<LPH>(ss);
-    const float rs = rsqrtf(ss / (float)HD + eps);
-    const float sign = (li < LPH / 2) ? -1.f : 1.f;     // rotate_half: first half gets -x[d+half]
-    bf16_t* op = isq ? (qo + m * (long)nq * HD + (long)hh * HD) : (ko + m * (long)nkv * HD + (long)(hh - nq) * HD);
-    if (!BWD) {
-      float xn[8], o[8];
+      for (int e = 0; e < 8; ++e) ww[e] = isq ? wq[e] : wk[e];
+      float ss = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xn[e] = x[e] * rs * ww[e];
+      for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+      ss = group_sum<LPH>(ss);
+      const float rs = rsqrtf(ss / (float)HD + eps);
+      bf16_t* op = isq ? (qo + m * (long)nq * HD + (long)hh * HD) : (ko + m * (long)nkv * HD + (long)(hh - nq) * HD);
+      if (!BWD) {
+        float xn[8], o[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float partner = __shfl_xor(xn[e], LPH / 2, 64);
-        o[e] = xn[e] * c[e] + sign * partner * s[e];
+        for (int e = 0; e < 8; ++e) xn[e] = x[e] * rs * ww[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float partner = __shfl_xor(xn[e], LPH / 2, 64);
+          o[e] = xn[e] * c[e] + sign * partner * s[e];
+        }
+        *reinterpret_cast<uint4*>(op + li * 8) = pk8(o);
+      } else {
+        float dy[8], g[8], xh[8];
+        un8(*reinterpret_cast<const uint4*>(op + li * 8), dy);
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float partner = __shfl_xor(dy[e] * s[e], LPH / 2, 64);   // (dout*sin) of the paired element
+          const float dxn = dy[e] * c[e] - sign * partner;               // d<half: +partner, d>=half: -partner
+          g[e] = dxn * ww[e];
+          xh[e] = x[e] * rs;
+          t += g[e] * xh[e];
+        }
+        t = group_sum<LPH>(t) / (float)HD;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = rs * (g[e] - xh[e] * t);
+        *reinterpret_cast<uint4*>(draw + m * lddraw + (long)hh * HD + li * 8) = pk8(o);
       }
-      if (ok) *reinterpret_cast<uint4*>(op + li * 8) = pk8(o);
-    } else {
-      float dy[8], g[8], xh[8];
-      un8(*reinterpret_cast<const uint4*>(op + li * 8), dy);
-      float t = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float partner = __shfl_xor(dy[e] * s[e], LPH / 2, 64);   // (dout*sin) of the paired element
-        const float dxn = dy[e] * c[e] - sign * partner;               // d<half: +partner, d>=half: -partner
-        g[e] = dxn * ww[e];
-        xh[e] = x[e] * rs;
-        t += g[e] * xh[e];
-      }
-      t = group_sum<LPH>(t) / (float)HD;
-      float o[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = rs * (g[e] - xh[e] * t);
-      if (ok) *reinterpret_cast<uint4*>(draw + m * lddraw + (long)hh * HD + li * 8) = pk8(o);
     }
   }
 }
@@ -265,9 +269,8 @@ extern "C" int ur_qknorm_rope_fwd(const void* qkv_raw, int64_t ldraw, const floa
   if (rc) return rc;
   if (M == 0) return 0;
   UR_REQUIRE(q_out && k_out && UR_ALIGNED16(q_out) && UR_ALIGNED16(k_out), "ur_qknorm_rope_fwd: bad outputs");
-  const long nrows = (long)M * (nq + nkv);
-  const int rpb = 256 / (head_dim / 8);
-  const int grid = grid_cap((nrows + rpb - 1) / rpb, 256 * 16);
+  const int tpb = 256 / (head_dim / 8);                    // tokens per workgroup
+  const int grid = grid_cap(((long)M + tpb - 1) / tpb, 256 * 16);
   if (head_dim == 128)
     hipLaunchKernelGGL((qknorm_rope_kernel<128, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv_raw, (long)ldraw,
                        q_norm_w, k_norm_w, cos_tab, sin_tab, (bf16_t*)q_out, (bf16_t*)k_out, (bf16_t*)nullptr, 0L, (long)M, S, nq, nkv, eps);
@@ -287,9 +290,8 @@ extern "C" int ur_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const 
   if (M == 0) return 0;
   UR_REQUIRE(dq_out && dk_out && dqkv_raw && UR_ALIGNED16(dq_out) && UR_ALIGNED16(dk_out) && UR_ALIGNED16(dqkv_raw) && (lddraw % 8) == 0 &&
              lddraw >= (int64_t)(nq + nkv) * head_dim, "ur_qknorm_rope_bwd: bad gradient buffers");
-  const long nrows = (long)M * (nq + nkv);
-  const int rpb = 256 / (head_dim / 8);
-  const int grid = grid_cap((nrows + rpb - 1) / rpb, 256 * 16);
+  const int tpb = 256 / (head_dim / 8);                    // tokens per workgroup
+  const int grid = grid_cap(((long)M + tpb - 1) / tpb, 256 * 16);
   if (head_dim == 128)
     hipLaunchKernelGGL((qknorm_rope_kernel<128, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv_raw, (long)ldraw,
                        q_norm_w, k_norm_w, cos_tab, sin_tab, (bf16_t*)dq_out, (bf16_t*)dk_out, (bf16_t*)dqkv_raw, (long)lddraw, (long)M, S, nq, nkv, eps);
