@@ -427,39 +427,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   }
 }
 
-// Row constants of the backward, two planes of n = B*nq*Sq floats in the caller's scratch:
-//   plane 0: nd[row] = -sum_d dO[q][d] * O[q][d]                      (dS = P * (dP + nd))
-//   plane 1: ns[row] = -(m + ln l) / scale = -LSE / scale             (P = exp2(scale*log2e * (S_raw + ns)))
-// The dK/dV kernel loads both as the INITIAL MFMA accumulators of S and dP, so an interior tile's softmax
-// is one multiply and one exp2 per element with no row maximum, no subtraction and no normaliser.
-// A row without any allowed key (l = 0, SDPA semantics) gets ns = -inf: P = 0.
-template <int HD>
-__global__ void attn_delta_kernel(AttnP p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int LPR = HD / 8;           // lanes per row (16 B each)
-  constexpr int RPW = 64 / LPR;         // rows per wave
-  const long nrows = (long)p.B * p.Sq * p.nq;
-  const long row = ((long)blockIdx.x * 4 + wave) * RPW + lane / LPR;
-  float acc = 0.f;
-  long b = 0; int hq = 0, q = 0;
-  if (row < nrows) {
-    hq = (int)(row % p.nq); const long t = row / p.nq; q = (int)(t % p.Sq); b = t / p.Sq;
-    const int c = (lane % LPR) * 8;
-    const uint4 a = *reinterpret_cast<const uint4*>(p.dout + (b * p.Sq + q) * p.lddo + (long)hq * HD + c);
-    const uint4 o = *reinterpret_cast<const uint4*>(p.o + (b * p.Sq + q) * p.ldo + (long)hq * HD + c);
-    acc = bf_lo(a.x) * bf_lo(o.x) + bf_hi(a.x) * bf_hi(o.x) + bf_lo(a.y) * bf_lo(o.y) + bf_hi(a.y) * bf_hi(o.y) +
-          bf_lo(a.z) * bf_lo(o.z) + bf_hi(a.z) * bf_hi(o.z) + bf_lo(a.w) * bf_lo(o.w) + bf_hi(a.w) * bf_hi(o.w);
-  }
-  acc = group_sum<LPR>(acc);
-  if (row < nrows && (lane % LPR) == 0) {
-    const long r = (b * p.nq + hq) * p.Sq + q;
-    float* ws = const_cast<float*>(p.delta);
-    ws[r] = -acc;
-    const float m = p.stats[2 * r], inv = p.stats[2 * r + 1];
-    ws[nrows + r] = (inv > 0.f) ? -(m - __logf(inv)) / p.scale : NEG_INF;
-  }
-}
-
 // ================================================================================================
 // dQ: same decomposition as forward.  dQ^T[d][q] += K^T[d][key] * dS^T[key][q]
 template <int HD, bool CAUSAL, int NW>
@@ -481,7 +448,25 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
     dof[s] = g_frag(p.dout + qtok * p.lddo + (long)hq * HD, s, lane, qok);
   }
   const long srow = ((long)b * p.nq + hq) * p.Sq + (qok ? q : 0);
-  const float m = p.stats[srow * 2], inv = qok ? p.stats[srow * 2 + 1] : 0.f, dlt = -p.delta[srow];
+  const float m = p.stats[srow * 2], inv = qok ? p.stats[srow * 2 + 1] : 0.f;
+  // Row constants of the backward, computed here for this block's query rows (the two lane halves of a row hold
+  // complementary halves of head_dim) and published for the dK/dV kernel that runs next on the stream:
+  //   plane 0: nd[row] = -sum_d dO[q][d] * O[q][d]        plane 1: ns[row] = -(m + ln l) / scale = -LSE / scale
+  // (a row without any allowed key, l = 0 under SDPA semantics, gets ns = -inf: P = 0)
+  float dlt = 0.f;
+#pragma unroll
+  for (int s = 0; s < C::NS; ++s) {
+    const bf16x8 of = g_frag(p.o + qtok * p.ldo + (long)hq * HD, s, lane, qok);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dlt = fmaf(bf2f((bf16_t)dof[s][e]), bf2f((bf16_t)of[e]), dlt);
+  }
+  dlt += __shfl_xor(dlt, 32, 64);
+  if (qok && h == 0) {
+    float* ws = const_cast<float*>(p.delta);
+    const long nrows = (long)p.B * p.nq * p.Sq;
+    ws[srow] = -dlt;
+    ws[nrows + srow] = (inv > 0.f) ? -(m - __logf(inv)) / p.scale : NEG_INF;
+  }
   const float c2 = p.scale * LOG2E, mc = m * LOG2E;
   const float invs = inv * p.scale;    // fold the 1/sqrt(d) of dS into the normaliser
 
@@ -825,7 +810,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 // dK/dV for head_dim 128, 4 waves (the Qwen3 shape): same decomposition as attn_bwd_dkv_kernel, one wave per
 // SIMD with the whole register file, but built for instruction ISSUE, which bounded the first version
 // (10 vector instructions per MFMA, 175 accumulator moves per tile):
-//   * interior tiles load -LSE/scale and -delta (attn_delta_kernel) as the INITIAL accumulators of the S and
+//   * interior tiles load -LSE/scale and -delta (published by the dQ kernel) as the INITIAL accumulators of the S and
 //     dP chains: P = exp2(c * S'), dS = P * dP' -- three vector instructions per element, no row constants
 //     held in registers;
 //   * lane-constant LDS offsets (row fragments, transposed fragments) are computed once per workgroup;
@@ -1206,13 +1191,7 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
   p.dout = (const bf16_t*)g->dout; p.dq = (bf16_t*)g->dq; p.dk = (bf16_t*)g->dk; p.dv = (bf16_t*)g->dv; p.delta = g->delta;
   p.lddo = g->lddo; p.lddq = g->lddq; p.lddk = g->lddk; p.lddv = g->lddv;
   hipStream_t st = (hipStream_t)stream;
-  const long nrows = (long)p.B * p.Sq * p.nq;
-  if (a->head_dim == 64) {
-    hipLaunchKernelGGL((attn_delta_kernel<64>), dim3(ur_cdiv(nrows, 4 * 8)), dim3(256), 0, st, p);
-  } else {
-    hipLaunchKernelGGL((attn_delta_kernel<128>), dim3(ur_cdiv(nrows, 4 * 4)), dim3(256), 0, st, p);
-  }
-  UR_CHECK_LAUNCH("ur_attn_bwd(delta)");
+  // the dQ kernel also computes the row constants (delta, -LSE/scale) and leaves them in `delta` for dK/dV
   rc = do_dq(p, a->head_dim, a->causal != 0, st);
   if (rc) return rc;
   return do_dkv(p, a->head_dim, a->causal != 0, st);
