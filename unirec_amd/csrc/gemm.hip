@@ -611,7 +611,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   // sub-tiles, each with its own predicates, scalar-pointer checks and 8-byte residual / aux loads waited one by one)
   // cost 27k cycles per 256x256 tile, as much as 11 K tiles of the main loop.  So:
   //   f32 output        : float4 stores from the accumulators, predicates only on edge tiles.
-  //   bf16, plain       : (no bias / residual / aux / gelu_out) alpha * acc -> bf16 -> LDS tile -> whole rows.
+  //   bf16, plain       : (no residual / aux / gelu_out) alpha * acc + bias -> bf16 -> LDS tile -> whole rows.
   //   bf16, rich        : the tile goes through LDS in f32, one column half at a time; bias, residual, gelu' and the
   //                       GELU second output are applied on the way out, where every access is a coalesced 16-byte
   //                       piece of a row (and the f32 sum is rounded once, as before).
@@ -633,18 +633,21 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     }
   } else {
     bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
-    const bool rich = p.bias || p.res || p.aux || p.gelu_out;        // uniform
+    const bool rich = p.res || p.aux || p.gelu_out;                  // uniform (a bias alone stays on the plain path)
     __syncthreads();                                                   // every wave is done with the ring
     if (!rich) {
       constexpr int CROWB = BN * 2 + 16;            // padded LDS row of the bf16 C tile
 #pragma unroll
-      for (int i = 0; i < NI; ++i)
+      for (int i = 0; i < NI; ++i) {
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);                  // the lane's four columns of this block
+        if (p.bias && n0 + s_row(i) + nq < p.N) bb = *reinterpret_cast<const float4*>(p.bias + n0 + s_row(i) + nq);
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
           const f32x4 a = acc[i][j];
           *reinterpret_cast<uint2*>(smem + (r_row(j) + ml) * CROWB + (s_row(i) + nq) * 2) =
-              make_uint2(pack_bf2(a[0] * p.alpha, a[1] * p.alpha), pack_bf2(a[2] * p.alpha, a[3] * p.alpha));
+              make_uint2(pack_bf2(fmaf(a[0], p.alpha, bb.x), fmaf(a[1], p.alpha, bb.y)), pack_bf2(fmaf(a[2], p.alpha, bb.z), fmaf(a[3], p.alpha, bb.w)));
         }
+      }
       __syncthreads();
       const bool wide = ((p.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
       constexpr int CPR = BN / 8;                   // 16-byte chunks per tile row
