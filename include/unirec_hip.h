@@ -104,6 +104,11 @@ int ur_lora_dropout_bits(uint64_t seed, float p, int32_t M, int32_t W, int32_t n
 int ur_lora_project(const ur_lora_args* a, void* stream);
 int64_t ur_lora_reduce_workspace_bytes(const ur_lora_args* a);
 int ur_lora_reduce(const ur_lora_args* a, void* workspace, int64_t workspace_bytes, void* stream);
+/* ur_lora_bgrad: the B side of the backward in ONE pass over dy (shared = 0, no dropout planes): P = tb = alpha * dy_a B_a
+ * (as ur_lora_project with U_a = B_a^T) AND G = dB, [sum width, 16] f32 dense (as ur_lora_reduce with V = t,
+ * g_transposed = 1, scale 1); partial slabs of ceil(M / 512) token blocks live in the caller's workspace. */
+int64_t ur_lora_bgrad_workspace_bytes(const ur_lora_args* a);
+int ur_lora_bgrad(const ur_lora_args* a, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * LayerNorm (+ fused dropout / residual) -- models/qformer.py:64,106-107 (embeddings: LN then

@@ -335,6 +335,15 @@ def test_lora_kernels_on_column_ranges(M):
     again = torch.empty_like(gB)
     hip.lora_reduce(dy, t, again, cols=cols, transposed=True)
     assert torch.equal(gB, again)                                                          # deterministic token split
+    # the fused B-side backward (one pass over dy) gives the same two results
+    gB2 = torch.empty_like(gB)
+    tb2 = hip.lora_bgrad(dy, t, [hip.transpose_bf16(b) for b in B], cols, gB2, alpha=2.0).float()
+    want_tb = torch.cat([2.0 * dy[:, c0:c0 + n].float() @ B[a].float() for a, (c0, n) in enumerate(cols)], 1)
+    assert (tb2 - want_tb).abs().max().item() <= 2e-2 * want_tb.abs().max().item() + 1e-2
+    assert (gB2 - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
+    gB3 = torch.empty_like(gB)
+    hip.lora_bgrad(dy, t, [hip.transpose_bf16(b) for b in B], cols, gB3, alpha=2.0)
+    assert torch.equal(gB2, gB3)
     # shared input, no dropout
     x = dy[:, :200]
     A = (torch.randn(2 * r, 200, generator=g) * 0.2).to(DEV).to(torch.bfloat16)

@@ -65,6 +65,7 @@ def lora(args):
             ("project t  = drop(x) A^T (3)", lambda: hip.lora_project(x, A, bits=bits), x.numel() * 2),
             ("project tb = dy B        (3)", lambda: hip.lora_project(dy, Bt, cols=cols), dy.numel() * 2),
             ("reduce  dB = dy^T t      (3)", lambda: hip.lora_reduce(dy, t, gB, cols=cols, transposed=True), dy.numel() * 2),
+            ("bgrad   tb and dB, one pass(3)", lambda: hip.lora_bgrad(dy, t, Bt, cols, gB), dy.numel() * 2),
             ("reduce  dA = tb^T drop(x)(3)", lambda: hip.lora_reduce(x, t, gA, nad=3, bits=bits), x.numel() * 2)):
         ms = timeit(fn, args.iters)
         print(f"lora {name}: {ms * 1e3:7.1f} us  {nbytes / ms / 1e6:7.1f} GB/s")

@@ -71,6 +71,8 @@ SIGNATURES = {
     "ur_lora_project": (c_int, [ctypes.POINTER(LoraArgs), c_void_p]),
     "ur_lora_reduce_workspace_bytes": (c_i64, [ctypes.POINTER(LoraArgs)]),
     "ur_lora_reduce": (c_int, [ctypes.POINTER(LoraArgs), c_void_p, c_i64, c_void_p]),
+    "ur_lora_bgrad_workspace_bytes": (c_i64, [ctypes.POINTER(LoraArgs)]),
+    "ur_lora_bgrad": (c_int, [ctypes.POINTER(LoraArgs), c_void_p, c_i64, c_void_p]),
     "ur_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_float, c_float, c_u64, c_float, c_u64, c_void_p]),
     "ur_layernorm_bwd_workspace_bytes": (c_i64, [c_int]),

@@ -308,6 +308,128 @@ __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
   }
 }
 
+// ---- backward of the B side in ONE pass over dy: tb = alpha * dy_e B_e (column reduction) and the partial
+// dB_e^T = t_e^T dy_e of this block's tokens (token reduction) from the same fragments ---------------------
+struct BgradP {
+  const bf16_t* X; long ldx; int M;
+  int col0[4], width[4]; long goff[4];
+  const bf16_t* U[4]; long ldu[4];        // B_e^T [16, width_e]
+  const bf16_t* V; long ldv;              // t [M, 16 nad]
+  bf16_t* P; long ldp;                    // tb [M, 16 nad]
+  float* slabs; long total;               // [gridDim.x][total]: partial dB, entry e at goff[e], layout [w][16]
+  float alpha;
+};
+
+// grid: x = block of 512 tokens, y = adapter entry.  4 waves, each 128 tokens (8 row blocks of 16).  Per 64-column
+// chunk a wave loads its [128 tokens x 64 columns] of dy ONCE as MFMA column operands (token on the lane), feeds the
+// tb accumulators, parks the same fragments row-major in its private LDS tile and reads them back transposed
+// (ds_read_b64_tr_b16) as the operands of dB^T[16 x 64] += t^T[16 x 128] dy[128 x 64]; the four waves' partials are
+// summed through LDS and leave as this block's slab.  dy is read once where ur_lora_project + ur_lora_reduce read it twice.
+constexpr int BG_TOK = 512, BG_WTOK = 128;
+constexpr int BG_XT = BG_WTOK * 128;                 // a wave's X tile: 128 tokens x 64 columns bf16
+constexpr int BG_SMEM = 4 * BG_XT + 4 * 16 * 64 * 4; // + cross-wave reduction of the [16 x 64] f32 partials
+__global__ __launch_bounds__(256, 2) void lora_bgrad_kernel(BgradP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int e = blockIdx.y;
+  const int W = p.width[e], col0 = p.col0[e];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int q = l15 >> 2, pp = lane & 3;
+  const int tok0 = blockIdx.x * BG_TOK + wave * BG_WTOK;
+  char* xt = smem + wave * BG_XT;
+  float* red = reinterpret_cast<float*>(smem + 4 * BG_XT);
+
+  // t^T fragments of this wave's 128 tokens (MFMA row operand of the dB product: rank row j on l15, 8 tokens per lane):
+  // staged once through the wave's tile as [128 tokens][16] rows of 32 bytes, read back transposed
+  bf16x8 tT[4];
+  {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pi = lane + 64 * i, r = pi >> 1, part2 = pi & 1;
+      const int m = tok0 + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < p.M) v = *reinterpret_cast<const uint4*>(p.V + (long)m * p.ldv + 16 * e + 8 * part2);
+      *reinterpret_cast<uint4*>(xt + r * 32 + part2 * 16) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+      bf16x8 f[2];
+      const uint32_t a0 = lds_off(xt) + (32 * k + 8 * g + q) * 32 + pp * 8, a1 = a0 + 32 * 32;
+      tr_pair(f, a0, a0 + 4 * 32, a1, a1 + 4 * 32);
+      tT[k] = f[0]; tT[k + 1] = f[1];
+    }
+  }
+  f32x4 tb[8];
+#pragma unroll
+  for (int rb = 0; rb < 8; ++rb) tb[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16_t* xrow[8];
+#pragma unroll
+  for (int rb = 0; rb < 8; ++rb) xrow[rb] = p.X + (long)min(tok0 + 16 * rb + l15, p.M - 1) * p.ldx + col0;
+  const bf16_t* urow = p.U[e] + (long)l15 * p.ldu[e];
+  float* slab = p.slabs + (long)blockIdx.x * p.total + p.goff[e];
+
+  for (int c0 = 0; c0 < W; c0 += 64) {
+    // this chunk's fragments: dy (token l15 of row block rb, 8 columns) and B^T (rank row l15, the same 8 columns)
+    uint4 xf[8][2], uf[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int k = c0 + 32 * s2 + 8 * g;
+      const bool ok = k < W;
+      uf[s2] = ok ? *reinterpret_cast<const uint4*>(urow + k) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int rb = 0; rb < 8; ++rb) xf[rb][s2] = ok ? *reinterpret_cast<const uint4*>(xrow[rb] + k) : make_uint4(0, 0, 0, 0);
+    }
+    // (the previous chunk's transposed reads of this tile are complete: lgkmcnt(0) below precedes the MFMAs)
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int rb = 0; rb < 8; ++rb) {
+        tb[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, uf[s2]), __builtin_bit_cast(bf16x8, xf[rb][s2]), tb[rb], 0, 0, 0);
+        const int row = 16 * rb + l15, ch = 4 * s2 + g;
+        *reinterpret_cast<uint4*>(xt + row * 128 + ((((ch >> 1) ^ f64sw(row)) << 5) | ((ch & 1) << 4))) = xf[rb][s2];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own writes have landed (private tile: no barrier)
+    f32x4 db[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) db[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ka = 32 * k + 8 * g + q;
+#pragma unroll
+      for (int cb = 0; cb < 4; cb += 2) {
+        bf16x8 f[2];
+        const uint32_t a0 = lds_off(xt) + ka * 128 + ((cb ^ f64sw(ka)) << 5) + pp * 8;
+        const uint32_t a1 = lds_off(xt) + ka * 128 + (((cb + 1) ^ f64sw(ka)) << 5) + pp * 8;
+        tr_pair(f, a0, a0 + 4 * 128, a1, a1 + 4 * 128);
+        db[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT[k], f[0], db[cb], 0, 0, 0);            // D[j = 4g+e][w = l15]
+        db[cb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT[k], f[1], db[cb + 1], 0, 0, 0);
+      }
+    }
+    // cross-wave sum: red[wave][w (64)][j (16)]
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+      *reinterpret_cast<float4*>(red + wave * 1024 + (16 * cb + l15) * 16 + 4 * g) = make_float4(db[cb][0], db[cb][1], db[cb][2], db[cb][3]);
+    __syncthreads();
+    {
+      const float4 r0 = *reinterpret_cast<const float4*>(red + tid * 4), r1 = *reinterpret_cast<const float4*>(red + 1024 + tid * 4);
+      const float4 r2 = *reinterpret_cast<const float4*>(red + 2048 + tid * 4), r3 = *reinterpret_cast<const float4*>(red + 3072 + tid * 4);
+      const int w = c0 + (tid >> 2);                        // element 4 tid = (w = tid / 4, j = 4 (tid % 4))
+      if (w < W)
+        *reinterpret_cast<float4*>(slab + (long)w * 16 + 4 * (tid & 3)) =
+            make_float4(r0.x + r1.x + r2.x + r3.x, r0.y + r1.y + r2.y + r3.y, r0.z + r1.z + r2.z + r3.z, r0.w + r1.w + r2.w + r3.w);
+    }
+    __syncthreads();
+  }
+  // tb: lane holds rows j = 4 g .. + 3 of token l15
+#pragma unroll
+  for (int rb = 0; rb < 8; ++rb) {
+    const int m = tok0 + 16 * rb + l15;
+    if (m < p.M)
+      *reinterpret_cast<uint2*>(p.P + (long)m * p.ldp + 16 * e + 4 * g) =
+          make_uint2(pack_bf2(tb[rb][0] * p.alpha, tb[rb][1] * p.alpha), pack_bf2(tb[rb][2] * p.alpha, tb[rb][3] * p.alpha));
+  }
+}
+
 __global__ void slab_sum_kernel(const float* __restrict__ ws, float* __restrict__ out, long total4, int splits) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -474,5 +596,59 @@ extern "C" int ur_lora_reduce(const ur_lora_args* a, void* workspace, int64_t wo
     hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, (float*)a->G, total4, splits);
     UR_CHECK_LAUNCH("ur_lora_reduce(slab_sum)");
   }
+  return 0;
+}
+
+extern "C" int64_t ur_lora_bgrad_workspace_bytes(const ur_lora_args* a) {
+  if (!a || a->M <= 0 || a->nad < 1 || a->nad > 4) return 0;
+  int64_t total = 0;
+  for (int e = 0; e < a->nad; ++e) total += 16LL * a->width[e];
+  return (int64_t)ur_cdiv(a->M, BG_TOK) * total * (int64_t)sizeof(float);
+}
+
+extern "C" int ur_lora_bgrad(const ur_lora_args* a, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (int rc = validate_common(a, "ur_lora_bgrad")) return rc;
+  UR_REQUIRE(!a->shared && !a->drop_bits, "ur_lora_bgrad: adapters own column ranges of X (shared = 0), no dropout planes");
+  UR_REQUIRE(a->P && (((uintptr_t)a->P) & 7) == 0 && (a->ldp % 4) == 0 && a->ldp >= 16 * a->nad, "ur_lora_bgrad: P must be 8-byte aligned, ldp %% 4 == 0, ldp >= 16 nad");
+  UR_REQUIRE(a->V && UR_ALIGNED16(a->V) && (a->ldv % 8) == 0 && a->ldv >= 16 * a->nad, "ur_lora_bgrad: V must be a 16-byte aligned [M, 16 nad] bf16 matrix");
+  UR_REQUIRE(a->G && UR_ALIGNED16(a->G), "ur_lora_bgrad: G must be 16-byte aligned");
+  for (int e = 0; e < a->nad; ++e)
+    UR_REQUIRE(a->U[e] && UR_ALIGNED16(a->U[e]) && (a->ldu[e] % 8) == 0 && a->ldu[e] >= a->width[e],
+               "ur_lora_bgrad: U[%d] must be a 16-byte aligned [16, width] bf16 matrix (ldu %% 8 == 0)", e);
+  hipStream_t st = (hipStream_t)stream;
+  BgradP p;
+  long off = 0;
+  for (int e = 0; e < 4; ++e) {
+    const int s = e < a->nad ? e : 0;
+    p.col0[e] = a->col0[s]; p.width[e] = a->width[s]; p.goff[e] = off;
+    p.U[e] = (const bf16_t*)a->U[s]; p.ldu[e] = a->ldu[s];
+    if (e < a->nad) off += 16L * a->width[s];
+  }
+  const int64_t total = off;
+  if (a->M == 0) {
+    hipError_t er = hipMemsetAsync(a->G, 0, (size_t)total * sizeof(float), st);
+    if (er != hipSuccess) UR_FAIL((int)er, "ur_lora_bgrad: memset failed");
+    return 0;
+  }
+  UR_REQUIRE(workspace && UR_ALIGNED16(workspace) && workspace_bytes >= ur_lora_bgrad_workspace_bytes(a),
+             "ur_lora_bgrad: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)ur_lora_bgrad_workspace_bytes(a));
+  p.X = (const bf16_t*)a->X; p.ldx = a->ldx; p.M = a->M;
+  p.V = (const bf16_t*)a->V; p.ldv = a->ldv;
+  p.P = (bf16_t*)a->P; p.ldp = a->ldp;
+  p.slabs = (float*)workspace; p.total = total; p.alpha = a->alpha;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&lora_bgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM);
+    if (er != hipSuccess) UR_FAIL((int)er, "ur_lora_bgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(er));
+    attr_set = true;
+  }
+  const int nblk = ur_cdiv(a->M, BG_TOK);
+  hipLaunchKernelGGL(lora_bgrad_kernel, dim3(nblk, a->nad), dim3(256), BG_SMEM, st, p);
+  UR_CHECK_LAUNCH("ur_lora_bgrad");
+  const long total4 = total / 4;
+  int blocks = (int)((total4 + 255) / 256);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, (float*)a->G, total4, nblk);
+  UR_CHECK_LAUNCH("ur_lora_bgrad(slab_sum)");
   return 0;
 }

@@ -545,6 +545,31 @@ def rank_of_index(scores, gt_index):
     return rank
 
 
+def lora_bgrad(dy, t, Bt, cols, gB, alpha=1.0, out=None):
+    """One pass over dy: returns tb [M, 16 nad] = alpha * dy_a B_a (Bt: list of B_a^T [16, width_a]) and fills
+    gB [sum width, 16] f32 with dB_a = dy_a^T t_a (adapter a owns columns cols[a] of dy, t holds t_a at columns 16a)."""
+    lib = _lib.load()
+    a = _lora_args(dy, cols, False, None, alpha)
+    for e, u in enumerate(Bt):
+        if u.dtype != BF16 or u.shape[0] != 16 or u.stride(1) != 1 or u.shape[1] != cols[e][1]:
+            raise ValueError("lora_bgrad: Bt[a] must be bf16 [16, width_a]")
+        a.U[e], a.ldu[e] = u.data_ptr(), u.stride(0)
+    if t.dtype != BF16 or t.stride(1) != 1 or t.shape[0] != dy.shape[0] or t.shape[1] < 16 * len(cols):
+        raise ValueError("lora_bgrad: t must be bf16 [M, >= 16 nad]")
+    _need(gB, F32, "gB")
+    if gB.numel() != 16 * sum(w for _, w in cols):
+        raise ValueError("lora_bgrad: gB has the wrong size")
+    if out is None:
+        out = torch.empty((dy.shape[0], 16 * len(cols)), dtype=BF16, device=dy.device)
+    a.V, a.ldv = t.data_ptr(), t.stride(0)
+    a.P, a.ldp = out.data_ptr(), out.stride(0)
+    a.G, a.g_transposed = gB.data_ptr(), 1
+    wsb = lib.ur_lora_bgrad_workspace_bytes(ctypes.byref(a))
+    ws = workspace(wsb, dy.device, "lora").data_ptr() if wsb else 0
+    check(lib.ur_lora_bgrad(ctypes.byref(a), ws, wsb, _stream()), "ur_lora_bgrad")
+    return out
+
+
 def context_mlp1(x, kind, W1, b1):
     """bf16 [n, 2H] = gelu(W1 feat(x) + b1); kind 0: x = f32 timestamps [n]; kind 1: x = f32 (lat, lon) [n,2]."""
     lib = _lib.load()

@@ -376,8 +376,7 @@ class Qwen3LoRAModel(nn.Module):
             cols = [(c0, n) for _, c0, n in b_specs]
             bnames = [b for b, _, _ in b_specs]
             gB = pack.fusedg(bnames) if nb > 1 else pack.g32(bnames[0])            # [sum n, r]: adapter ranges in order
-            hip.lora_reduce(dy, t, gB, cols=cols, transposed=True)
-            tb = hip.lora_project(dy, [hip.transpose_bf16(pack.w16(b)) for b in bnames], cols=cols, alpha=sc)
+            tb = hip.lora_bgrad(dy, t, [hip.transpose_bf16(pack.w16(b)) for b in bnames], cols, gB, alpha=sc)     # dB and tb, dy read once
             gA = pack.fusedg(a_names) if len(a_names) > 1 else pack.g32(a_names[0])
             hip.lora_reduce(xin, tb, gA, nad=len(a_names), alpha=1.0 / (1.0 - pdrop), bits=bits)
             return tb
