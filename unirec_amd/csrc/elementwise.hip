@@ -53,13 +53,23 @@ __device__ __forceinline__ uint4 pk8(const float (&f)[8]) {
 }
 
 // gu [M][2I]: gate = cols [0,I), up = cols [I,2I)
+// read-once / written-for-a-much-later-kernel streams: non-temporal accesses keep them from displacing L2 lines
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream(const bf16_t* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st_stream(bf16_t* p, uint4 v) {
+  u32x4_t t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<u32x4_t*>(p));
+}
 __global__ void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act, long M, int I8, int I) {
   const long total = M * I8, stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const long m = i / I8; const int c = (int)(i - m * I8) * 8;
     float g[8], u[8], o[8];
-    un8(*reinterpret_cast<const uint4*>(gu + m * 2 * I + c), g);
-    un8(*reinterpret_cast<const uint4*>(gu + m * 2 * I + I + c), u);
+    un8(ld_stream(gu + m * 2 * I + c), g);
+    un8(ld_stream(gu + m * 2 * I + I + c), u);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = silu_f(g[e]) * u[e];
     *reinterpret_cast<uint4*>(act + m * I + c) = pk8(o);
@@ -71,9 +81,9 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t*
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const long m = i / I8; const int c = (int)(i - m * I8) * 8;
     float g[8], u[8], d[8], dg[8], du[8];
-    un8(*reinterpret_cast<const uint4*>(gu + m * 2 * I + c), g);
-    un8(*reinterpret_cast<const uint4*>(gu + m * 2 * I + I + c), u);
-    un8(*reinterpret_cast<const uint4*>(dact + m * I + c), d);
+    un8(ld_stream(gu + m * 2 * I + c), g);
+    un8(ld_stream(gu + m * 2 * I + I + c), u);
+    un8(ld_stream(dact + m * I + c), d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float sg = 1.0f / (1.0f + __expf(-g[e]));
@@ -81,8 +91,8 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t*
       du[e] = d[e] * si;
       dg[e] = d[e] * u[e] * (sg * (1.0f + g[e] * (1.0f - sg)));
     }
-    *reinterpret_cast<uint4*>(dgu + m * 2 * I + c) = pk8(dg);
-    *reinterpret_cast<uint4*>(dgu + m * 2 * I + I + c) = pk8(du);
+    st_stream(dgu + m * 2 * I + c, pk8(dg));
+    st_stream(dgu + m * 2 * I + I + c, pk8(du));
   }
 }
 
