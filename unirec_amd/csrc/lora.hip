@@ -46,6 +46,12 @@ __device__ __forceinline__ uint4 drop_apply(uint4 x, uint32_t byte) {
   x.w &= ~pk_sign16((z << 12) & 0x80008000u);
   return x;
 }
+// the activations these kernels stream are read once per kernel: non-temporal loads keep them out of the L2's way
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream(const bf16_t* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ int kc_g(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int f64sw(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
 
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256) void lora_project_kernel(ProjP p) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int k = kc + 32 * s + 8 * g;
-        xf[rb][s] = (k < W) ? *reinterpret_cast<const uint4*>(xrow[rb] + k) : make_uint4(0, 0, 0, 0);
+        xf[rb][s] = (k < W) ? ld_stream(xrow[rb] + k) : make_uint4(0, 0, 0, 0);
       }
       if (MASKED) {
 #pragma unroll
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int m = min(t0 + prow[i], p.M - 1);
-      xr[i] = *reinterpret_cast<const uint4*>(p.X + (long)m * p.ldx + col0 + pcol[i]);
+      xr[i] = ld_stream(p.X + (long)m * p.ldx + col0 + pcol[i]);
       if (MASKED) {
 #pragma unroll
         for (int a = 0; a < NAD; ++a) br[i][a] = p.bits[(long)a * p.bits_stride + (long)m * p.bits_ld + (pcol[i] >> 3)];
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void lora_bgrad_kernel(BgradP p) {
       const bool ok = k < W;
       uf[s2] = ok ? *reinterpret_cast<const uint4*>(urow + k) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-      for (int rb = 0; rb < 8; ++rb) xf[rb][s2] = ok ? *reinterpret_cast<const uint4*>(xrow[rb] + k) : make_uint4(0, 0, 0, 0);
+      for (int rb = 0; rb < 8; ++rb) xf[rb][s2] = ok ? *reinterpret_cast<const uint4*>(xrow[rb] + k) : make_uint4(0, 0, 0, 0);   // (non-temporal measured slower here)
     }
     // (the previous chunk's transposed reads of this tile are complete: lgkmcnt(0) below precedes the MFMAs)
 #pragma unroll
