@@ -659,7 +659,9 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
           const uint4 val = *reinterpret_cast<const uint4*>(smem + row * CROWB + ch * 16);
           bf16_t* dst = Cb + (long)m * p.ldc + n;
           if (wide && (interior || n + 8 <= p.N)) {
-            *reinterpret_cast<uint4*>(dst) = val;
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            const u32x4_t tv = {val.x, val.y, val.z, val.w};
+            __builtin_nontemporal_store(tv, reinterpret_cast<u32x4_t*>(dst));
           } else {
             *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);                       // N % 4 == 0: first half always fits
             if (n + 8 <= p.N) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(val.z, val.w);
