@@ -436,16 +436,24 @@ __global__ __launch_bounds__(256, 2) void lora_bgrad_kernel(BgradP p) {
   }
 }
 
-__global__ void slab_sum_kernel(const float* __restrict__ ws, float* __restrict__ out, long total4, int splits) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long stride = (long)gridDim.x * blockDim.x;
+// out = sum over `splits` slabs of total4 float4 each: 1024 threads = 64 float4 x 16 groups of slabs (a thread per
+// element walking 256 slabs serially took 64 us for 64 K floats)
+__global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict__ ws, float* __restrict__ out, long total4, int splits) {
+  __shared__ float4 red[16][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lane;
   const float4* w4 = reinterpret_cast<const float4*>(ws);
-  for (; i < total4; i += stride) {
-    float4 a = w4[i];
-    for (int z = 1; z < splits; ++z) {
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < total4)
+    for (int z = g; z < splits; z += 16) {
       const float4 b = w4[i + (long)z * total4];
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }
+  red[g][lane] = a;
+  __syncthreads();
+  if (g == 0 && i < total4) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 b = red[k][lane]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
     reinterpret_cast<float4*>(out)[i] = a;
   }
 }
@@ -597,9 +605,7 @@ extern "C" int ur_lora_reduce(const ur_lora_args* a, void* workspace, int64_t wo
   UR_CHECK_LAUNCH("ur_lora_reduce");
   if (splits > 1) {
     const long total4 = total / 4;
-    int blocks = (int)((total4 + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, (float*)a->G, total4, splits);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(1024), 0, st, (const float*)workspace, (float*)a->G, total4, splits);
     UR_CHECK_LAUNCH("ur_lora_reduce(slab_sum)");
   }
   return 0;
@@ -652,9 +658,7 @@ extern "C" int ur_lora_bgrad(const ur_lora_args* a, void* workspace, int64_t wor
   hipLaunchKernelGGL(lora_bgrad_kernel, dim3(nblk, a->nad), dim3(256), BG_SMEM, st, p);
   UR_CHECK_LAUNCH("ur_lora_bgrad");
   const long total4 = total / 4;
-  int blocks = (int)((total4 + 255) / 256);
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(slab_sum_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, (float*)a->G, total4, nblk);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(1024), 0, st, (const float*)workspace, (float*)a->G, total4, nblk);
   UR_CHECK_LAUNCH("ur_lora_bgrad(slab_sum)");
   return 0;
 }
