@@ -181,17 +181,30 @@ __device__ __forceinline__ bf16x8 g_frag(const bf16_t* rowp, int s, int lane, bo
   if (!ok) return z;
   return *reinterpret_cast<const bf16x8*>(rowp + 16 * s + 8 * (lane >> 5));
 }
-// store a transposed accumulator set (lane = row of the output matrix, regs = head_dim) as bf16
+// store a transposed accumulator set (lane = row of the output matrix, regs = head_dim) as bf16.  The two lane halves
+// of a row hold alternating 4-column groups, i.e. 8-byte pieces: one v_permlane32_swap per dword trades the upper
+// half's group k against the lower half's group k+1, after which every lane owns 16 contiguous bytes -- 8 dwordx4
+// stores per row instead of 16 dwordx2 (the store tail is issue-bound).  Called by ALL lanes of the wave (the swaps
+// need the full EXEC mask); `ok` predicates the stores only.
 template <int HD>
-__device__ __forceinline__ void store_T(bf16_t* rowp, const f32x16 (&acc)[Cfg<HD>::NDT], float mul, int lane) {
+__device__ __forceinline__ void store_T(bf16_t* rowp, const f32x16 (&acc)[Cfg<HD>::NDT], float mul, int lane, bool ok) {
   const int h = lane >> 5;
+  const bool wide = __all(!ok || ((reinterpret_cast<uintptr_t>(rowp) & 15) == 0));       // wave-uniform
 #pragma unroll
   for (int dt = 0; dt < Cfg<HD>::NDT; ++dt)
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) {
-      const int d = 32 * dt + 8 * rq + 4 * h;
-      *reinterpret_cast<uint2*>(rowp + d) = make_uint2(pack_bf2(acc[dt][4 * rq] * mul, acc[dt][4 * rq + 1] * mul),
-                                                       pack_bf2(acc[dt][4 * rq + 2] * mul, acc[dt][4 * rq + 3] * mul));
+    for (int rq = 0; rq < 4; rq += 2) {
+      uint2 a = make_uint2(pack_bf2(acc[dt][4 * rq] * mul, acc[dt][4 * rq + 1] * mul), pack_bf2(acc[dt][4 * rq + 2] * mul, acc[dt][4 * rq + 3] * mul));
+      uint2 b = make_uint2(pack_bf2(acc[dt][4 * rq + 4] * mul, acc[dt][4 * rq + 5] * mul), pack_bf2(acc[dt][4 * rq + 6] * mul, acc[dt][4 * rq + 7] * mul));
+      if (wide) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+        // lanes 0-31: [own group k | upper half's group k] = columns 8k .. 8k+7; lanes 32-63: the next eight
+        if (ok) *reinterpret_cast<uint4*>(rowp + 32 * dt + 8 * rq + 8 * h) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+      } else if (ok) {
+        *reinterpret_cast<uint2*>(rowp + 32 * dt + 8 * rq + 4 * h) = a;
+        *reinterpret_cast<uint2*>(rowp + 32 * dt + 8 * rq + 8 + 4 * h) = b;
+      }
     }
 }
 
@@ -416,9 +429,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
     }
     __syncthreads();
   }
+  {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    store_T<HD>(p.o + ((long)b * p.Sq + (qok ? q : 0)) * p.ldo + (long)hq * HD, o, inv, lane, qok);
+  }
   if (qok) {
     const float inv = l > 0.f ? 1.0f / l : 0.f;
-    store_T<HD>(p.o + ((long)b * p.Sq + q) * p.ldo + (long)hq * HD, o, inv, lane);
     if (h == 0) {
       float* st = p.stats + (((long)b * p.nq + hq) * p.Sq + q) * 2;
       st[0] = (m == NEG_INF) ? 0.f : m;
@@ -558,7 +574,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
     }
     __syncthreads();
   }
-  if (qok) store_T<HD>(p.dq + ((long)b * p.Sq + q) * p.lddq + (long)hq * HD, dq, 1.0f, lane);
+  store_T<HD>(p.dq + ((long)b * p.Sq + (qok ? q : 0)) * p.lddq + (long)hq * HD, dq, 1.0f, lane, qok);
 }
 
 // ================================================================================================
@@ -598,10 +614,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
   // the MOST query tiles to sweep) has P = 0 everywhere: dK = dV = 0 without reading Q or dO
   if (CAUSAL && p.kmask != nullptr) {
     if (!__syncthreads_or(kvalid ? 1 : 0)) {
-      if (kok) {
-        store_T<HD>(p.dk + ((long)b * p.Sk + key) * p.lddk + (long)kvh * HD, dk, 0.f, lane);
-        store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 0.f, lane);
-      }
+      store_T<HD>(p.dk + ktok * p.lddk + (long)kvh * HD, dk, 0.f, lane, kok);
+      store_T<HD>(p.dv + ktok * p.lddv + (long)kvh * HD, dv, 0.f, lane, kok);
       return;
     }
   }
@@ -800,10 +814,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     if (it + 1 < ntot) store_tile(smem + ((it + 1) & 1) * STG);
     __syncthreads();
   }
-  if (kok) {
-    store_T<HD>(p.dk + ((long)b * p.Sk + key) * p.lddk + (long)kvh * HD, dk, p.scale, lane);     // dS was kept unscaled
-    store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 1.0f, lane);
-  }
+  store_T<HD>(p.dk + ktok * p.lddk + (long)kvh * HD, dk, p.scale, lane, kok);     // dS was kept unscaled
+  store_T<HD>(p.dv + ktok * p.lddv + (long)kvh * HD, dv, 1.0f, lane, kok);
 }
 
 // ================================================================================================
@@ -871,10 +883,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // the MOST query tiles to sweep) has P = 0 everywhere: dK = dV = 0 without reading Q or dO
   if (CAUSAL && p.kmask != nullptr) {
     if (!__syncthreads_or(kvalid ? 1 : 0)) {
-      if (kok) {
-        store_T<HD>(p.dk + ((long)b * p.Sk + key) * p.lddk + (long)kvh * HD, dk, 0.f, lane);
-        store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 0.f, lane);
-      }
+      store_T<HD>(p.dk + ktok * p.lddk + (long)kvh * HD, dk, 0.f, lane, kok);
+      store_T<HD>(p.dv + ktok * p.lddv + (long)kvh * HD, dv, 0.f, lane, kok);
       return;
     }
   }
@@ -1076,10 +1086,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     __syncthreads();
   }
-  if (kok) {
-    store_T<HD>(p.dk + ((long)b * p.Sk + key) * p.lddk + (long)kvh * HD, dk, p.scale, lane);     // dS was kept unscaled
-    store_T<HD>(p.dv + ((long)b * p.Sk + key) * p.lddv + (long)kvh * HD, dv, 1.0f, lane);
-  }
+  store_T<HD>(p.dk + ktok * p.lddk + (long)kvh * HD, dk, p.scale, lane, kok);     // dS was kept unscaled
+  store_T<HD>(p.dv + ktok * p.lddv + (long)kvh * HD, dv, 1.0f, lane, kok);
 }
 
 // ================================================================================================
