@@ -174,7 +174,7 @@ def run_stage(args):
     from unirec_amd.losses import QFormerLoss, mse_loss
     from unirec_amd.optim import FusedAdamW
     rank, world, local = dp.init_from_env()
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % max(1, torch.cuda.device_count()))      # (modulo: gloo rehearsal of N ranks on one GPU)
     torch.cuda.set_device(device)
     torch.manual_seed(1234)
     g = torch.Generator().manual_seed(1234 + rank)
@@ -251,7 +251,7 @@ def main():
     rank, world, local = dp.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    device = torch.device("cuda", local)
+    device = torch.device("cuda", local % max(1, torch.cuda.device_count()))      # (modulo: gloo rehearsal of N ranks on one GPU)
     torch.cuda.set_device(device)
     model, qf, cfg, dims = build(args, device)
     Qi, F, E, D = dims

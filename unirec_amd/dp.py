@@ -28,7 +28,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # UNIREC_DP_BACKEND=gloo: functional rehearsal of the multi-rank path with several ranks on ONE GPU
+            # (RCCL needs one device per rank); the product default on GPUs is nccl = RCCL over xGMI
+            backend = os.environ.get("UNIREC_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
