@@ -281,8 +281,10 @@ def main():
         opt.step(grad_scale=1.0 / world)
         return loss
 
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()    # world > 1 (or UNIREC_DP_FORCE=1)
+
     def sync():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -296,7 +298,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof, hip.PROFILE = hip.PROFILE, None
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -346,7 +348,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.destroy_process_group()
 
 

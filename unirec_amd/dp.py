@@ -24,7 +24,10 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # UNIREC_DP_FORCE=1: initialise the process group (and run every bucket all-reduce) even with ONE rank, so the RCCL
+    # launch path -- communicator, side stream, event fences -- can be exercised on a one-GPU box
+    force = os.environ.get("UNIREC_DP_FORCE") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -52,7 +55,8 @@ class GradBuckets:
         self.bounds = list(boundaries)
         self.group = group
         self.pending = []
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.enabled = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or os.environ.get("UNIREC_DP_FORCE") == "1")
 
     @property
     def n(self):
