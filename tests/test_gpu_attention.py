@@ -120,6 +120,39 @@ def test_attention_dropout_is_deterministic_and_unbiased():
     assert abs(lhs - rhs) <= 2e-2 * abs(lhs) + 1.0
 
 
+@pytest.mark.parametrize("B,nh,Sq,Sk,p_drop", [(3, 2, 64, 1600, 0.1), (2, 4, 64, 1600, 0.0), (5, 2, 40, 333, 0.2), (1, 1, 20, 257, 0.1),
+                                               (2, 16, 64, 800, 0.1), (40, 16, 33, 256, 0.0)])
+def test_few_query_dkv_kernel_matches_generic_kernel_bitwise(B, nh, Sq, Sk, p_drop, monkeypatch):
+    """The user Q-Former's cross-attention backward (<= 64 queries, >= 256 keys) takes attn_bwd_dkv_fewq_kernel: the
+    same arithmetic in the same order as attn_bwd_dkv_kernel, so dK / dV must agree bit for bit -- with ragged key
+    masks (incl. a fully masked sample: uniform softmax), probability dropout, key counts that are not multiples of
+    32 and both workgroup-per-pair and chunked grids."""
+    q, k, v = _randn((B, Sq, nh, 64), 1, 0.5), _randn((B, Sk, nh, 64), 2, 0.5), _randn((B, Sk, nh, 64), 3)
+    g = torch.Generator(device="cpu").manual_seed(Sk)
+    lens = torch.randint(Sk // 2, Sk + 1, (B,), generator=g)
+    km = (torch.arange(Sk)[None, :] < lens[:, None]).to(torch.uint8)
+    if B > 1:
+        km[1] = 0
+    km = km.to(DEV)
+    dout = _randn((B, Sq, nh, 64), 4)
+    o, ctx = hip.attn_fwd(q, k, v, causal=False, key_mask=km, dropout_p=p_drop, seed=5)
+    monkeypatch.setenv("UR_ATTN_FEWQ", "0")
+    dq0, dk0, dv0 = hip.attn_bwd(ctx, dout)
+    monkeypatch.setenv("UR_ATTN_FEWQ", "1")
+    dq1, dk1, dv1 = hip.attn_bwd(ctx, dout)
+    torch.cuda.synchronize()
+    assert torch.equal(dq0, dq1)
+    assert torch.equal(dk0, dk1), f"dk differs: {(dk0.float() - dk1.float()).abs().max().item()}"
+    assert torch.equal(dv0, dv1), f"dv differs: {(dv0.float() - dv1.float()).abs().max().item()}"
+    assert dk1.float().abs().max() > 0
+    if p_drop == 0.0:      # and against the fp32 reference
+        qf, kf, vf = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
+        _ref(qf, kf, vf, km, False).backward(dout.float())
+        for name, got, want in (("dk", dk1, kf.grad), ("dv", dv1, vf.grad)):
+            err = (got.float() - want).abs().max().item()
+            assert err <= 2e-2 * want.abs().max().item() + 2e-2, f"{name}: max err {err}"
+
+
 @pytest.mark.parametrize("spike_key,gain", [(200, 6.0), (31, 3.0), (449, 12.0), (64, 1.5)])
 def test_deferred_max_rescale_is_exact_when_forced(spike_key, gain):
     """The forward defers the running-maximum update while the maximum grows by less than 2^6: a rare, data-dependent

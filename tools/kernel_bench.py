@@ -48,6 +48,47 @@ def gemm(args):
         print(f"gemm {name:12s} M={M} N={N} K={K}: {t:.3f} ms  {2 * M * N * K / t / 1e9:.1f} TFLOP/s")
 
 
+def dw(args):
+    """Token-reduction (dW) GEMM of the user Q-Former's K|V projection at C3: out[2048,1024] = dKV^T X over 819200
+    tokens; token-major operands (K-strided, as the backward has them) against pre-transposed K-contiguous ones."""
+    Kt, Mo, No = 512 * 1600, 2048, 1024
+    g = torch.Generator().manual_seed(0)
+    dy = torch.randn(Kt, Mo, generator=g).cuda().to(torch.bfloat16)
+    x = torch.randn(Kt, No, generator=g).cuda().to(torch.bfloat16)
+    out = torch.empty(Mo, No, device="cuda")
+    fl = 2.0 * Kt * Mo * No
+    for sp in (4, 8, 16):
+        t = timeit(lambda: hip.gemm(dy, x, r_kcontig=False, s_kcontig=False, out=out, split_k=sp), args.iters)
+        print(f"dW token-major  split {sp:2d}: {t:.3f} ms  {fl / t / 1e9:.1f} TFLOP/s")
+    ref = out.clone()
+    dyT, xT = dy.t().contiguous(), x.t().contiguous()
+    for sp in (8, 16):
+        t = timeit(lambda: hip.gemm(dyT, xT, r_kcontig=True, s_kcontig=True, out=out, split_k=sp), args.iters)
+        print(f"dW transposed   split {sp:2d}: {t:.3f} ms  {fl / t / 1e9:.1f} TFLOP/s   max|diff| vs token-major {float((out - ref).abs().max()):.3e}")
+    t = timeit(lambda: hip.transpose_bf16(dy), args.iters)
+    print(f"transpose [819200,2048] bf16: {t:.3f} ms")
+
+
+def xattn(args):
+    """User Q-Former cross-attention at C3: 64 queries x 1600 keys, B*heads = 512*16, ragged key mask, p = 0.1."""
+    B, nh, Sq, Sk = 512, 16, 64, 1600
+    g = torch.Generator().manual_seed(0)
+    q = (torch.randn(B, Sq, nh, 64, generator=g) * 0.5).cuda().to(torch.bfloat16)
+    kv = (torch.randn(B, Sk, 2, nh, 64, generator=g) * 0.5).cuda().to(torch.bfloat16)
+    lens = torch.randint(Sk // 2, Sk + 1, (B,), generator=g)
+    km = (torch.arange(Sk)[None, :] < lens[:, None]).to(torch.uint8).cuda()
+    dout = torch.randn(B, Sq, nh, 64, generator=g).cuda().to(torch.bfloat16)
+    dkv = torch.empty_like(kv)
+    for pd in (0.1, 0.0):
+        o, ctx = hip.attn_fwd(q, kv[:, :, 0], kv[:, :, 1], causal=False, key_mask=km, dropout_p=pd, seed=3)
+        t = timeit(lambda: hip.attn_fwd(q, kv[:, :, 0], kv[:, :, 1], causal=False, key_mask=km, dropout_p=pd, seed=3), args.iters)
+        print(f"xattn fwd p={pd}: {t:.3f} ms")
+        for sw in ("0", "1"):
+            os.environ["UR_ATTN_FEWQ"] = sw
+            t = timeit(lambda: hip.attn_bwd(ctx, dout, dk=dkv[:, :, 0], dv=dkv[:, :, 1]), args.iters)
+            print(f"xattn bwd (dq + dkv) p={pd} UR_ATTN_FEWQ={sw}: {t:.3f} ms")
+
+
 def lora(args):
     """The rank-16 LoRA side kernels at the C4 shapes (M = B*S tokens): GB/s of the activation they stream."""
     M, r = args.B * args.S, 16
@@ -73,9 +114,9 @@ def lora(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["attn", "gemm", "lora"])
+    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn"])
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--S", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=5)
     a = ap.parse_args()
-    {"attn": attn, "gemm": gemm, "lora": lora}[a.what](a)
+    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn}[a.what](a)

@@ -20,6 +20,8 @@
 //   p = exp2(fma(s, scale*log2e, -m*log2e)); O is rescaled only when some row's max moved.
 // Backward = dQ kernel (same decomposition as forward) + dK/dV kernel (one 32-key block per wave,
 // looping over the query heads of its GQA group): no atomics, bitwise reproducible.
+#include <algorithm>
+#include <cstdlib>
 #include "common.cuh"
 #include "unirec_hip.h"
 
@@ -819,6 +821,150 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 }
 
 // ================================================================================================
+// dK/dV for FEW queries against MANY keys: the user Q-Former's cross-attention (models/qformer.py:169-275 called from
+// training/user_qformer_training.py:47-68 -- 64 learned queries, T = hist*Q_item = 1600 keys, B*heads = 8192 pairs).
+// attn_bwd_dkv_kernel gives every 128-key workgroup its own copy of the (single) Q / dO tile and runs at one wave per
+// SIMD: 106 496 workgroups that each load, wait, do 32 MFMAs per wave and leave -- latency end to end (4.1 ms per
+// layer at C3 for 6.8 GB of K/V/dK/dV traffic).  Here a workgroup keeps the Q / dO tile and the row constants of ONE
+// (batch, head) pair in LDS and its 4 waves walk that pair's 32-key blocks (wave w takes blocks w, w+4, ...), the
+// next block's K / V fragments and key-mask byte in flight under the current block's MFMAs and softmax / dropout
+// arithmetic, two waves per SIMD.  No barrier after the prologue.  Same arithmetic in the same order as
+// attn_bwd_dkv_kernel -> bit-identical results (tests/test_gpu_attention.py).  Non-causal, rep == 1, Sq <= 64.
+template <int HD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_fewq_kernel(AttnP p, int nchunk, int bpc) {
+  using C = Cfg<HD>;
+  static_assert(HD == 64, "register-staged Q / dO tile");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
+  const int chunk = blockIdx.x % nchunk, pair = blockIdx.x / nchunk;
+  const int hq = pair % p.nq, b = pair / p.nq;
+  char* qtile = smem;
+  char* dotile = smem + C::TILE;
+  float* fst = reinterpret_cast<float*>(smem + 2 * C::TILE);      // [128] (m, 1/l) pairs, [64] -delta
+  const long sbase = ((long)b * p.nq + hq) * p.Sq;
+  {
+    Loader<HD, 256> qs, dos;
+    qs.issue(qtile, p.q + (long)b * p.Sq * p.ldq + (long)hq * HD, p.ldq, 0, p.Sq, tid);
+    dos.issue(dotile, p.dout + (long)b * p.Sq * p.lddo + (long)hq * HD, p.lddo, 0, p.Sq, tid);
+    if (tid < 2 * KT) fst[tid] = p.stats[(sbase + min(tid >> 1, p.Sq - 1)) * 2 + (tid & 1)];      // rows past Sq: clamped copies,
+    else if (tid < 3 * KT) fst[tid] = p.delta[sbase + min(tid - 2 * KT, p.Sq - 1)];             // masked by position below
+    qs.commit(qtile, tid);
+    dos.commit(dotile, tid);
+  }
+  __syncthreads();
+
+  const int nblk = (p.Sk + 31) >> 5;
+  const int blk_hi = min(nblk, (chunk + 1) * bpc);
+  const float c2 = p.scale * LOG2E;
+  const bool dropping = p.drop_thr != 0;
+  const uint64_t drop_row0 = (uint64_t)sbase * (uint64_t)p.Sk;       // dropout counter of (b, hq, query 0, key 0)
+  const uint8_t* kmrow = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
+  const bf16_t* kbase = p.k + (long)b * p.Sk * p.ldk + (long)hq * HD;
+  const bf16_t* vbase = p.v + (long)b * p.Sk * p.ldv + (long)hq * HD;
+
+  auto load_kv = [&](int blk, bf16x8 (&kf)[C::NS], bf16x8 (&vf)[C::NS], uint32_t& state) {
+    const int key = blk * 32 + (lane & 31);
+    const bool kok = blk < blk_hi && key < p.Sk;
+    const long krow = kok ? key : 0;
+#pragma unroll
+    for (int st = 0; st < C::NS; ++st) {
+      kf[st] = g_frag(kbase + krow * p.ldk, st, lane, kok);
+      vf[st] = g_frag(vbase + krow * p.ldv, st, lane, kok);
+    }
+    uint32_t m = 1;
+    if (kok && kmrow) m = kmrow[key];
+    state = (kok ? 1u : 0u) | ((kok && m != 0) ? 2u : 0u);          // bit 0: inside Sk, bit 1: allowed by the key mask
+  };
+
+  bf16x8 kf[C::NS], vf[C::NS];
+  uint32_t state;
+  int blk = chunk * bpc + wave;
+  load_kv(blk, kf, vf, state);
+  for (; blk < blk_hi; blk += 4) {
+    bf16x8 kn[C::NS], vn[C::NS];
+    uint32_t state_n;
+    load_kv(blk + 4, kn, vn, state_n);                                // lands under this block's arithmetic
+    const int kblk = blk * 32, key = kblk + (lane & 31);
+    const bool kok = (state & 1u) != 0, kvalid = (state & 2u) != 0;
+    const bool all_valid = __all(kvalid);
+    f32x16 dk[C::NDT], dv[C::NDT];
+#pragma unroll
+    for (int dt = 0; dt < C::NDT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const int qbase = 32 * sub;
+      if (qbase >= p.Sq) break;
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int st = 0; st < C::NS; ++st) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(qtile, 32 * sub, st, lane), kf[st], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dotile, 32 * sub, st, lane), vf[st], dp, 0, 0, 0);
+      }
+      const bool fast = all_valid && !dropping && (qbase + 32 <= p.Sq);
+      if (fast) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int qr = 32 * sub + 8 * rq + 4 * h;
+          const float4 a = *reinterpret_cast<const float4*>(fst + 2 * qr);
+          const float4 bq = *reinterpret_cast<const float4*>(fst + 2 * qr + 4);
+          const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
+          const float ma[4] = {a.x, a.z, bq.x, bq.z}, iv[4] = {a.y, a.w, bq.y, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
+            const float ps = fast_exp2(fmaf(s[r], c2, -ma[e] * LOG2E)) * iv[e];
+            s[r] = ps;
+            dp[r] = ps * (dp[r] + dl[e]);          // dl = -delta
+          }
+        }
+      } else {
+        const int qb0 = opaque(qbase + 4 * h), keyo = opaque(key);
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int qr = 32 * sub + 8 * rq + 4 * h;
+          const float4 a = *reinterpret_cast<const float4*>(fst + 2 * qr);
+          const float4 bq = *reinterpret_cast<const float4*>(fst + 2 * qr + 4);
+          const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
+          const float ma[4] = {a.x, a.z, bq.x, bq.z}, iv[4] = {a.y, a.w, bq.y, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
+            const int qpos = qb0 + e + 8 * rq;
+            const float sc = mask_score<false>(s[r], p.scale, kvalid, kok, keyo, qpos);       // natural-log domain
+            const float ps = (sc == NEG_INF || qpos >= p.Sq) ? 0.f : fast_exp2((sc - ma[e]) * LOG2E) * iv[e];
+            float g = dp[r], pd = ps;
+            if (dropping) {
+              const float dsc = ur_dropout_scale(p.seed, drop_row0 + (uint64_t)qpos * (uint64_t)p.Sk + (uint64_t)keyo, p.drop_thr, p.drop_inv);
+              g *= dsc; pd *= dsc;
+            }
+            s[r] = pd;
+            dp[r] = ps * (g + dl[e]);
+          }
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pf = acc_frag(s, s2), df = acc_frag(dp, s2);
+        bf16x8 tdo[C::NDT], tq[C::NDT];
+        tr_frags<HD>(tdo, dotile, 32 * sub + 16 * s2, lane);
+        tr_frags<HD>(tq, qtile, 32 * sub + 16 * s2, lane);
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tdo[dt], pf, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[dt], df, dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    const long ktok = (long)b * p.Sk + (kok ? key : 0);
+    store_T<HD>(p.dk + ktok * p.lddk + (long)hq * HD, dk, p.scale, lane, kok);     // dS was kept unscaled
+    store_T<HD>(p.dv + ktok * p.lddv + (long)hq * HD, dv, 1.0f, lane, kok);
+#pragma unroll
+    for (int st = 0; st < C::NS; ++st) { kf[st] = kn[st]; vf[st] = vn[st]; }
+    state = state_n;
+  }
+}
+
+// ================================================================================================
 // dK/dV for head_dim 128, 4 waves (the Qwen3 shape): same decomposition as attn_bwd_dkv_kernel, one wave per
 // SIMD with the whole register file, but built for instruction ISSUE, which bounded the first version
 // (10 vector instructions per MFMA, 175 accumulator moves per tile):
@@ -1141,8 +1287,24 @@ int launch_dq(const AttnP& p, hipStream_t st) {
   UR_CHECK_LAUNCH("ur_attn_bwd(dq)");
   return 0;
 }
+// lab / test switch: UR_ATTN_FEWQ=0 sends few-query shapes back to attn_bwd_dkv_kernel (read on every call so one
+// test process can compare the two kernels bit for bit)
+inline bool fewq_enabled() { const char* e = getenv("UR_ATTN_FEWQ"); return !(e && e[0] == '0'); }
+
 template <int HD, bool CAUSAL, int NW>
 int launch_dkv(const AttnP& p, hipStream_t st) {
+  if (HD == 64 && !CAUSAL && NW == 4 && p.rep == 1 && p.Sq <= KT && p.Sk >= 256 && fewq_enabled()) {
+    // few queries, many keys: one workgroup per (batch, head) pair -- or per chunk of its key blocks while the pairs
+    // alone do not fill the chip (>= 8 key blocks, i.e. two per wave, per workgroup)
+    constexpr int SMF = 2 * Cfg<64>::TILE + 3 * KT * (int)sizeof(float);
+    const int nblk = ur_cdiv(p.Sk, 32), pairs = p.nq * p.B;
+    int nchunk = std::max(1, std::min(ur_cdiv(4096, pairs), nblk / 8));
+    const int bpc = ur_cdiv(ur_cdiv(nblk, nchunk), 4) * 4;
+    nchunk = ur_cdiv(nblk, bpc);
+    hipLaunchKernelGGL((attn_bwd_dkv_fewq_kernel<64>), dim3(pairs * nchunk), dim3(256), SMF, st, p, nchunk, bpc);
+    UR_CHECK_LAUNCH("ur_attn_bwd(dkv fewq)");
+    return 0;
+  }
   dim3 grid(ur_cdiv(p.Sk, 32 * NW) * p.nkv * p.B);
   if (HD == 128 && NW == 4 && p.drop_thr == 0) {
     constexpr int SM2 = 2 * (2 * Cfg<128>::TILE + 4 * KT * (int)sizeof(float));
