@@ -120,6 +120,46 @@ def test_attention_dropout_is_deterministic_and_unbiased():
     assert abs(lhs - rhs) <= 2e-2 * abs(lhs) + 1.0
 
 
+@pytest.mark.parametrize("B,nh,Sq,Sk", [(7, 3, 2, 2), (50, 16, 2, 14), (5, 4, 4, 4), (9, 2, 4, 8), (3, 1, 1, 16), (6, 5, 3, 5)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+def test_tiny_attention_kernels(B, nh, Sq, Sk, p_drop, monkeypatch):
+    """<= 4 queries x <= 16 keys (the item Q-Former of the joint step: 2 x 2 and 2 x 14) runs on the DPP-row kernels
+    (4 pairs per wave, one backward kernel): against the fp32 reference without dropout, and against the MFMA kernels
+    (UR_ATTN_TINY=0; same dropout counters, so the same masks) with it.  Pair counts that do not fill a wave, ragged
+    masks and a fully masked sample (uniform softmax) included."""
+    q, k, v = _randn((B, Sq, nh, 64), 1, 0.7), _randn((B, Sk, nh, 64), 2, 0.7), _randn((B, Sk, nh, 64), 3)
+    g = torch.Generator(device="cpu").manual_seed(Sk * 10 + Sq)
+    km = (torch.rand((B, Sk), generator=g) < 0.7).to(torch.uint8)
+    km[:, 0] = 1
+    km[1] = 0
+    km = km.to(DEV)
+    dout = _randn((B, Sq, nh, 64), 4)
+    monkeypatch.setenv("UR_ATTN_TINY", "1")
+    o1, c1 = hip.attn_fwd(q, k, v, causal=False, key_mask=km, dropout_p=p_drop, seed=9)
+    dq1, dk1, dv1 = hip.attn_bwd(c1, dout)
+    monkeypatch.setenv("UR_ATTN_TINY", "0")
+    o0, c0 = hip.attn_fwd(q, k, v, causal=False, key_mask=km, dropout_p=p_drop, seed=9)
+    dq0, dk0, dv0 = hip.attn_bwd(c0, dout)
+    # mixed: MFMA backward from the tiny forward's context (its row statistics must be the same quantities)
+    dqm, dkm, dvm = hip.attn_bwd(c1, dout)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("UR_ATTN_TINY")
+    if p_drop == 0.0:
+        qf, kf, vf = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
+        ref = _ref(qf, kf, vf, km, False)
+        ref.backward(dout.float())
+        want = (ref, qf.grad, kf.grad, vf.grad)
+    else:
+        want = (o0.float(), dq0.float(), dk0.float(), dv0.float())
+    for name, got, w in zip(("o", "dq", "dk", "dv"), (o1, dq1, dk1, dv1), want):
+        err = (got.float() - w).abs().max().item()
+        assert err <= 2e-2 * w.abs().max().item() + 2e-2, f"{name}: max err {err} (scale {w.abs().max().item()})"
+    for name, got, w in zip(("dq", "dk", "dv"), (dqm, dkm, dvm), (dq0, dk0, dv0)):
+        err = (got.float() - w.float()).abs().max().item()
+        assert err <= 2e-2 * w.float().abs().max().item() + 2e-2, f"mixed {name}: max err {err}"
+    assert o1[1].float().sub(v[1].float().mean(dim=0, keepdim=True)).abs().max() < (3e-2 if p_drop == 0.0 else 10.0)   # fully masked sample: uniform
+
+
 @pytest.mark.parametrize("B,nh,Sq,Sk,p_drop", [(3, 2, 64, 1600, 0.1), (2, 4, 64, 1600, 0.0), (5, 2, 40, 333, 0.2), (1, 1, 20, 257, 0.1),
                                                (2, 16, 64, 800, 0.1), (40, 16, 33, 256, 0.0)])
 def test_few_query_dkv_kernel_matches_generic_kernel_bitwise(B, nh, Sq, Sk, p_drop, monkeypatch):

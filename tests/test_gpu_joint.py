@@ -89,8 +89,14 @@ def test_joint_matches_reference(name):
     assert rank.cpu().tolist() == g["ranks"].tolist()
     loss.backward()
     named = dict(qf.named_parameters())
+    # Ill-conditioned gradients: with Q = 2 the layer-0 self-attention softmax runs over two nearly identical keys, and
+    # every item sees the SAME learned queries, so the bf16 rounding of P / o is one coherent draw over the whole batch:
+    # the query / key weight gradients come out 50x smaller than their neighbours (norm 3e-3 against 0.2) and carry
+    # 0.7 - 3 % error for either attention kernel depending on the weight seed (tools/lab/tiny_attn_joint_err.py; 7 %
+    # for this fixture's seed).  Their error is held against 5 % of the query-table gradient's norm instead of their own.
+    ill = 0.05 * float(np.linalg.norm(g["grad/query_embeddings"]))
     for k in cases.item_grad_keys(c, heads=False):
-        assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL * 1.5, "grad/" + k, floor=1e-6)
+        assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL * 1.5, "grad/" + k, floor=1e-6, abs_scale=ill)
     assert named["item_representation_head.weight"].grad is None      # unused heads stay untouched (as in the reference)
 
 

@@ -89,6 +89,25 @@ def xattn(args):
             print(f"xattn bwd (dq + dkv) p={pd} UR_ATTN_FEWQ={sw}: {t:.3f} ms")
 
 
+def gemm_lora(args):
+    """What the LoRA term costs inside the projection GEMMs: plain / + second K range (forward: t B^T, K2 = 16) /
+    + masked rank-16 epilogue (dX under LoRA dropout)."""
+    M, r = args.B * args.S, 16
+    g = torch.Generator().manual_seed(0)
+    for (N, K, nad, name) in [(2048, 1024, 1, "q fwd"), (3072, 1024, 1, "gate fwd"), (1024, 3072, 1, "down fwd"),
+                              (1024, 4096, 3, "dX qkv"), (3072, 1024, 1, "dX down"), (1024, 6144, 2, "dX gate|up")]:
+        R = torch.randn(M, K, generator=g).cuda().to(torch.bfloat16)
+        S_ = (torch.randn(N, K, generator=g) * 0.05).cuda().to(torch.bfloat16)
+        t = torch.randn(M, nad * r, generator=g).cuda().to(torch.bfloat16)
+        Bm = (torch.randn(N, nad * r, generator=g) * 0.05).cuda().to(torch.bfloat16)
+        bits = hip.lora_dropout_bits(1, 0.1, M, N, nad, "cuda")
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        t0 = timeit(lambda: hip.gemm(R, S_, out=out), args.iters)
+        t1 = timeit(lambda: hip.gemm(R, S_, out=out, R2=t, S2=Bm), args.iters)
+        t2 = timeit(lambda: hip.gemm(R, S_, out=out, R2=t, S2=Bm, drop=(bits, 0.1, r)), args.iters)
+        print(f"gemm {name:12s} N={N} K={K}: plain {t0:.3f} ms | + K2={nad * r} range {t1:.3f} ms | + masked epilogue ({nad} adapters) {t2:.3f} ms")
+
+
 def lora(args):
     """The rank-16 LoRA side kernels at the C4 shapes (M = B*S tokens): GB/s of the activation they stream."""
     M, r = args.B * args.S, 16
@@ -114,9 +133,9 @@ def lora(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn"])
+    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn", "gemm_lora"])
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--S", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=5)
     a = ap.parse_args()
-    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn}[a.what](a)
+    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora}[a.what](a)

@@ -1237,6 +1237,212 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ================================================================================================
+// Tiny attention: <= 4 learned queries against <= 16 keys, head_dim 64 -- the item Q-Former inside the joint step
+// (models/qformer.py:169-275 with Q_item = 2: self-attention 2 x 2, cross-attention 2 x 14 fields, over
+// 64 x 50 items x 16 heads = 51 200 (item, head) pairs per launch) and BASELINE config C1 (4 x 4, 4 x 8).
+// The MFMA kernels above give every pair a 32-query x 64-key tile of its own (a wave, an LDS tile, a barrier) and use
+// 2 of its 32 query rows: 246 / 304 / 280 us per forward / dQ / dK-dV launch for ~200 MB of traffic.  Here a 16-lane
+// DPP row owns one pair (4 pairs per wave): lane sl holds elements 4 sl .. 4 sl + 3 of every q / k / v / dO row (8-byte
+// loads, a 128-byte row per DPP row), a score is 4 FMAs + a 4-step DPP row reduction that leaves the total in all 16
+// lanes, so softmax, the mask semantics (additive finfo.min: a fully masked row is uniform) and dropout run on
+// row-uniform registers in f32; the dropout decision of key j is hashed once, by lane j, with the same counter as the
+// MFMA kernels (identical masks) and shared through a ballot.  The backward is ONE kernel (dQ, dK, dV: a pair's
+// gradients never leave its row -- no atomics, no row constants to publish).
+constexpr int TK = 16;
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row, total in every lane: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row_sum16(float x) {
+  x += dpp_mov<0xB1>(x);
+  x += dpp_mov<0x4E>(x);
+  x += dpp_mov<0x141>(x);
+  x += dpp_mov<0x140>(x);
+  return x;
+}
+__device__ __forceinline__ float dot4(uint2 a, uint2 b) {
+  return fmaf(bf_lo(a.x), bf_lo(b.x), fmaf(bf_hi(a.x), bf_hi(b.x), fmaf(bf_lo(a.y), bf_lo(b.y), bf_hi(a.y) * bf_hi(b.y))));
+}
+__device__ __forceinline__ void axpy4(float (&acc)[4], float w, uint2 x) {
+  acc[0] = fmaf(w, bf_lo(x.x), acc[0]); acc[1] = fmaf(w, bf_hi(x.x), acc[1]);
+  acc[2] = fmaf(w, bf_lo(x.y), acc[2]); acc[3] = fmaf(w, bf_hi(x.y), acc[3]);
+}
+struct TinyPair { int b, hq, sl, g; bool ok; long qoff, koff; };
+__device__ __forceinline__ TinyPair tiny_pair(const AttnP& p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  TinyPair t;
+  t.g = lane >> 4; t.sl = lane & 15;
+  const long npairs = (long)p.B * p.nq;
+  const long pr = ((long)blockIdx.x * 4 + wave) * 4 + t.g;
+  t.ok = pr < npairs;
+  const long pc = t.ok ? pr : npairs - 1;          // tail rows compute on a clamped pair (DPP / ballots need every lane)
+  t.b = (int)(pc / p.nq); t.hq = (int)(pc % p.nq);
+  return t;
+}
+// scores -> probabilities of one pair, row-uniform: P[qi][kj] = exp(sc - m) (before dropout and 1/l), m, 1/l and the
+// keep bits (bit kj of keep[qi]; all ones without dropout)
+template <int TQ>
+__device__ __forceinline__ void tiny_probs(const AttnP& p, const TinyPair& t, const uint2 (&qv)[TQ], const uint2 (&kv)[TK],
+                                           float (&P)[TQ][TK], float (&mrow)[TQ], float (&inv)[TQ], uint32_t (&keep)[TQ]) {
+  const bool kval = t.sl < p.Sk && (p.kmask == nullptr || p.kmask[(long)t.b * p.Sk + t.sl] != 0);
+  const uint32_t vbits = (uint32_t)(__ballot(kval) >> (16 * t.g)) & 0xffffu;
+#pragma unroll
+  for (int qi = 0; qi < TQ; ++qi) {
+    mrow[qi] = 0.f; inv[qi] = 0.f; keep[qi] = 0xffffu;
+    if (qi >= p.Sq) continue;
+    float mx = NEG_INF;
+#pragma unroll
+    for (int kj = 0; kj < TK; ++kj) {
+      P[qi][kj] = NEG_INF;
+      if (kj >= p.Sk) continue;
+      const float raw = row_sum16(dot4(qv[qi], kv[kj]));
+      const float sc = ((vbits >> kj) & 1u) ? raw * p.scale : F32_MIN;
+      P[qi][kj] = sc;
+      mx = fmaxf(mx, sc);
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int kj = 0; kj < TK; ++kj) {
+      const float e = (kj < p.Sk) ? fast_exp2((P[qi][kj] - mx) * LOG2E) : 0.f;
+      P[qi][kj] = e;
+      l += e;
+    }
+    mrow[qi] = mx; inv[qi] = 1.0f / l;             // l >= 1: the maximum itself contributes exp(0)
+    if (p.drop_thr != 0) {
+      const uint64_t idx = (((uint64_t)((long)t.b * p.nq + t.hq) * p.Sq + (uint64_t)qi) * (uint64_t)p.Sk) + (uint64_t)t.sl;
+      const bool kp = ur_dropout_scale(p.seed, idx, p.drop_thr, 1.0f) != 0.f;
+      keep[qi] = (uint32_t)(__ballot(kp) >> (16 * t.g)) & 0xffffu;
+    }
+  }
+}
+template <int TQ>
+__device__ __forceinline__ void tiny_load(const AttnP& p, const TinyPair& t, uint2 (&qv)[TQ], uint2 (&kv)[TK], uint2 (&vv)[TK]) {
+  const long e0 = (long)t.hq * 64 + 4 * t.sl;
+#pragma unroll
+  for (int qi = 0; qi < TQ; ++qi)
+    qv[qi] = (qi < p.Sq) ? *reinterpret_cast<const uint2*>(p.q + ((long)t.b * p.Sq + qi) * p.ldq + e0) : make_uint2(0, 0);
+#pragma unroll
+  for (int kj = 0; kj < TK; ++kj) {
+    const bool in = kj < p.Sk;
+    kv[kj] = in ? *reinterpret_cast<const uint2*>(p.k + ((long)t.b * p.Sk + kj) * p.ldk + e0) : make_uint2(0, 0);
+    vv[kj] = in ? *reinterpret_cast<const uint2*>(p.v + ((long)t.b * p.Sk + kj) * p.ldv + e0) : make_uint2(0, 0);
+  }
+}
+
+template <int TQ>
+__global__ __launch_bounds__(256) void attn_tiny_fwd_kernel(AttnP p) {
+  const TinyPair t = tiny_pair(p);
+  uint2 qv[TQ], kv[TK], vv[TK];
+  tiny_load<TQ>(p, t, qv, kv, vv);
+  float P[TQ][TK], mrow[TQ], inv[TQ];
+  uint32_t keep[TQ];
+  tiny_probs<TQ>(p, t, qv, kv, P, mrow, inv, keep);
+  const long e0 = (long)t.hq * 64 + 4 * t.sl;
+#pragma unroll
+  for (int qi = 0; qi < TQ; ++qi) {
+    if (qi >= p.Sq) continue;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kj = 0; kj < TK; ++kj) {
+      if (kj >= p.Sk) continue;
+      const float w = ((keep[qi] >> kj) & 1u) ? P[qi][kj] * p.drop_inv : 0.f;
+      axpy4(acc, w, vv[kj]);
+    }
+    if (t.ok) {
+      const float s = inv[qi];
+      *reinterpret_cast<uint2*>(p.o + ((long)t.b * p.Sq + qi) * p.ldo + e0) = make_uint2(pack_bf2(acc[0] * s, acc[1] * s), pack_bf2(acc[2] * s, acc[3] * s));
+      if (t.sl == 0) {
+        float* st = p.stats + (((long)t.b * p.nq + t.hq) * p.Sq + qi) * 2;
+        st[0] = mrow[qi]; st[1] = s;
+      }
+    }
+  }
+}
+
+template <int TQ>
+__global__ __launch_bounds__(256) void attn_tiny_bwd_kernel(AttnP p) {
+  const TinyPair t = tiny_pair(p);
+  uint2 qv[TQ], kv[TK], vv[TK], dov[TQ];
+  tiny_load<TQ>(p, t, qv, kv, vv);
+  const long e0 = (long)t.hq * 64 + 4 * t.sl;
+#pragma unroll
+  for (int qi = 0; qi < TQ; ++qi)
+    dov[qi] = (qi < p.Sq) ? *reinterpret_cast<const uint2*>(p.dout + ((long)t.b * p.Sq + qi) * p.lddo + e0) : make_uint2(0, 0);
+  float P[TQ][TK], mrow[TQ], inv[TQ];
+  uint32_t keep[TQ];
+  tiny_probs<TQ>(p, t, qv, kv, P, mrow, inv, keep);
+  // normalised probabilities with dropout, and delta[qi] = sum_d dO * O
+  float delta[TQ];
+#pragma unroll
+  for (int qi = 0; qi < TQ; ++qi) {
+    delta[qi] = 0.f;
+    if (qi >= p.Sq) continue;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kj = 0; kj < TK; ++kj) {
+      if (kj >= p.Sk) continue;
+      P[qi][kj] *= inv[qi];                                              // p / l
+      const float w = ((keep[qi] >> kj) & 1u) ? P[qi][kj] * p.drop_inv : 0.f;
+      axpy4(acc, w, vv[kj]);
+    }
+    const uint2 d = dov[qi];
+    delta[qi] = row_sum16(fmaf(bf_lo(d.x), acc[0], fmaf(bf_hi(d.x), acc[1], fmaf(bf_lo(d.y), acc[2], bf_hi(d.y) * acc[3]))));
+  }
+  float dq[TQ][4];
+#pragma unroll
+  for (int qi = 0; qi < TQ; ++qi) { dq[qi][0] = dq[qi][1] = dq[qi][2] = dq[qi][3] = 0.f; }
+#pragma unroll
+  for (int kj = 0; kj < TK; ++kj) {
+    if (kj >= p.Sk) continue;
+    float dk[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qi = 0; qi < TQ; ++qi) {
+      if (qi >= p.Sq) continue;
+      const float dsc = ((keep[qi] >> kj) & 1u) ? p.drop_inv : 0.f;
+      const float dP = row_sum16(dot4(dov[qi], vv[kj]));
+      const float pd = P[qi][kj] * dsc;
+      const float dS = P[qi][kj] * (dP * dsc - delta[qi]) * p.scale;
+      axpy4(dv, pd, dov[qi]);
+      axpy4(dk, dS, qv[qi]);
+      axpy4(dq[qi], dS, kv[kj]);
+    }
+    if (t.ok) {
+      *reinterpret_cast<uint2*>(p.dk + ((long)t.b * p.Sk + kj) * p.lddk + e0) = make_uint2(pack_bf2(dk[0], dk[1]), pack_bf2(dk[2], dk[3]));
+      *reinterpret_cast<uint2*>(p.dv + ((long)t.b * p.Sk + kj) * p.lddv + e0) = make_uint2(pack_bf2(dv[0], dv[1]), pack_bf2(dv[2], dv[3]));
+    }
+  }
+#pragma unroll
+  for (int qi = 0; qi < TQ; ++qi)
+    if (qi < p.Sq && t.ok)
+      *reinterpret_cast<uint2*>(p.dq + ((long)t.b * p.Sq + qi) * p.lddq + e0) = make_uint2(pack_bf2(dq[qi][0], dq[qi][1]), pack_bf2(dq[qi][2], dq[qi][3]));
+}
+
+// lab / test switch (read on every call): UR_ATTN_TINY=0 keeps tiny shapes on the MFMA kernels (f / b: tiny forward /
+// backward only)
+inline bool tiny_enabled(bool bwd) {
+  const char* e = getenv("UR_ATTN_TINY");
+  if (!e) return true;
+  return e[0] == '1' || (e[0] == 'f' && !bwd) || (e[0] == 'b' && bwd);
+}
+inline bool tiny_shape(const AttnP& p, int hd, bool causal, bool bwd) {
+  return hd == 64 && !causal && p.rep == 1 && p.Sq <= 4 && p.Sk <= TK && tiny_enabled(bwd);
+}
+int launch_tiny(const AttnP& p, bool bwd, hipStream_t st) {
+  const long npairs = (long)p.B * p.nq;
+  dim3 grid((unsigned)((npairs + 15) / 16));
+  if (!bwd) {
+    if (p.Sq <= 2) hipLaunchKernelGGL((attn_tiny_fwd_kernel<2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_tiny_fwd_kernel<4>), grid, dim3(256), 0, st, p);
+    UR_CHECK_LAUNCH("ur_attn_fwd(tiny)");
+  } else {
+    if (p.Sq <= 2) hipLaunchKernelGGL((attn_tiny_bwd_kernel<2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((attn_tiny_bwd_kernel<4>), grid, dim3(256), 0, st, p);
+    UR_CHECK_LAUNCH("ur_attn_bwd(tiny)");
+  }
+  return 0;
+}
+
+// ================================================================================================
 template <int HD> constexpr int fwd_smem() { return 4 * Cfg<HD>::TILE + MAX_KTILES * 16; }
 template <int HD> constexpr int dkv_smem() { return 2 * (2 * Cfg<HD>::TILE + 3 * KT * (int)sizeof(float)); }
 
@@ -1346,6 +1552,7 @@ extern "C" int ur_attn_fwd(const ur_attn_args* a, void* stream) {
   if (rc) return rc;
   if (a->B == 0) return 0;
   UR_REQUIRE(a->o && UR_ALIGNED16(a->o) && (a->ldo % 4) == 0 && a->ldo >= (int64_t)a->nq * a->head_dim, "ur_attn_fwd: bad output");
+  if (tiny_shape(p, a->head_dim, a->causal != 0, false)) return launch_tiny(p, false, (hipStream_t)stream);
   return do_fwd(p, a->head_dim, a->causal != 0, (hipStream_t)stream);
 }
 
@@ -1361,6 +1568,7 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
   p.dout = (const bf16_t*)g->dout; p.dq = (bf16_t*)g->dq; p.dk = (bf16_t*)g->dk; p.dv = (bf16_t*)g->dv; p.delta = g->delta;
   p.lddo = g->lddo; p.lddq = g->lddq; p.lddk = g->lddk; p.lddv = g->lddv;
   hipStream_t st = (hipStream_t)stream;
+  if (tiny_shape(p, a->head_dim, a->causal != 0, true)) return launch_tiny(p, true, st);      // dQ, dK, dV in one kernel
   // the dQ kernel also computes the row constants (delta, -LSE/scale) and leaves them in `delta` for dK/dV
   rc = do_dq(p, a->head_dim, a->causal != 0, st);
   if (rc) return rc;
