@@ -44,13 +44,15 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU oracle leg and print its JSON")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--user-tokens", action="store_true",
+                    help="C5 / U4: also run the User Q-Former over hist*32 cached item tokens and inject its 64 query tokens")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--lora-dropout", type=float, default=0.1, help="LoRA adapter dropout (reference lora_dropout=0.1)")
     return ap.parse_args()
 
 
 # ---- synthetic inputs ----------------------------------------------------------
-def make_batch(B, hist, S, pool, F, E, D, Qi, vocab, first_special, seed, device):
+def make_batch(B, hist, S, pool, F, E, D, Qi, vocab, first_special, seed, device, n_user=0):
     g = torch.Generator(device="cpu").manual_seed(seed)
     x = torch.randn(B, hist, F, E, generator=g)
     x = x / x.norm(dim=-1, keepdim=True)
@@ -64,18 +66,26 @@ def make_batch(B, hist, S, pool, F, E, D, Qi, vocab, first_special, seed, device
     ids = torch.randint(0, vocab, (B, S), generator=g)
     am = torch.ones(B, S, dtype=torch.long)
     npad = (torch.rand(B, generator=g) * 0.2 * S).long()
-    stride = max(1, (S - int(npad.max()) - 8) // (hist * Qi))
+    nsp = hist * Qi + n_user                                     # history specials, then the user-query specials (U4)
+    stride = max(1, (S - int(npad.max()) - 8) // nsp)
     for b in range(B):
         am[b, :npad[b]] = 0                                      # left padding (~10 % of positions)
-        pos = npad[b] + 4 + torch.arange(hist * Qi) * stride
-        ids[b, pos] = first_special + torch.arange(hist * Qi)    # each special token exactly once
+        pos = npad[b] + 4 + torch.arange(nsp) * stride
+        ids[b, pos] = first_special + torch.arange(nsp)          # each special token exactly once
     posv = torch.randn(B, D, generator=g)
     posv = posv / posv.norm(dim=-1, keepdim=True)
     neg = torch.randn(B, pool - 1, D, generator=g)
     neg = neg / neg.norm(dim=-1, keepdim=True)
-    return dict(input_ids=ids.to(device), attention_mask=am.to(device), history_field_embeddings=x.to(device),
-                history_attention_mask=hmask.to(device), positive_item_embeddings=posv.to(device),
-                negative_item_embeddings=neg.to(device), negative_masks=None)
+    out = dict(input_ids=ids.to(device), attention_mask=am.to(device), history_field_embeddings=x.to(device),
+               history_attention_mask=hmask.to(device), positive_item_embeddings=posv.to(device),
+               negative_item_embeddings=neg.to(device), negative_masks=None, user_sequence_tokens=None, user_attention_mask=None)
+    if n_user > 0:       # C3-shaped user sequence: hist x 32 cached item query tokens, ragged with the history length
+        T = hist * 32
+        ut = (torch.randn(B, T, D, generator=g) * 0.8).to(torch.bfloat16)
+        um = (torch.arange(T)[None, :] < (hlen * 32)[:, None]).float()
+        out["user_sequence_tokens"] = (ut * um[..., None].to(torch.bfloat16)).to(device)
+        out["user_attention_mask"] = um.to(device)
+    return out
 
 
 def build(args, device):
@@ -88,8 +98,12 @@ def build(args, device):
     qf = QFormerForItemRepresentation(hidden_size=D, num_hidden_layers=12, num_attention_heads=16, intermediate_size=4096,
                                       num_query_tokens=Qi, field_embedding_dim=E, num_fields=F, dropout=p)
     cfg = Qwen3Config(num_hidden_layers=args.layers, lora_dropout=0.0 if args.no_dropout else args.lora_dropout)    # reference: :121-131
+    uq = None
+    if args.user_tokens:
+        from unirec_amd.user_qformer import UserQFormer
+        uq = UserQFormer(dropout=0.0 if args.no_dropout else 0.1)
     model = MultiModalQwenEmbedding(qformer_model=qf, use_lora=True, qwen_config=cfg, num_history_items=args.hist,
-                                    num_query_tokens_per_item=Qi)
+                                    num_query_tokens_per_item=Qi, user_qformer=uq)
     model.base_model.reset_parameters(lora_b_std=0.01)           # exercise the LoRA path
     model = model.to(device).train()
     return model, qf, cfg, (Qi, F, E, D)
@@ -193,12 +207,13 @@ def run_stage(args):
         loss_fn = QFormerLoss()
         pack = m._ensure_pack(device)
         opt = FusedAdamW([pack], lr=1e-4)
+        bk = dp.GradBuckets(pack.grad, [0, pack.numel])
         def step():          # training/item_qformer_training.py:117-131: anchor with grad, pos/neg without
             out = m(xa, ma)
             with torch.no_grad():
                 pr = m(xp, mp)["item_representation"]; nr = m(xn, mn)["item_representation"]
             loss, _, _ = loss_fn(out, {"field_embeddings": xa}, pr, nr, ma)
-            loss.backward(); opt.step(grad_scale=1.0 / world)
+            loss.backward(); bk.ready_all(); bk.wait(); opt.step(grad_scale=1.0 / world)
             return loss
         unit, metric = "items/sec", "items/sec item Q-Former triplet step (C2: L12 Q32 H768 F14, 3 fwd + 1 bwd + AdamW)"
         flops = 2 * 8.0e12 / 256 * B / 2          # 8.0 TFLOP per 256-item triplet step
@@ -214,20 +229,31 @@ def run_stage(args):
         tgt = (torch.randn(B, 32, 1024, generator=g) * 0.8).to(device)
         pack = m._ensure_pack(device)
         opt = FusedAdamW([pack], lr=1e-4)
+        bk = dp.GradBuckets(pack.grad, [0, pack.numel])
         def step():          # training/user_qformer_training.py:203-214
             loss = mse_loss(m(x, mask), tgt)
-            loss.backward(); opt.step(grad_scale=1.0 / world)
+            loss.backward(); bk.ready_all(); bk.wait(); opt.step(grad_scale=1.0 / world)
             return loss
         unit, metric = "user-sequences/sec", f"user-sequences/sec user Q-Former step (C3: L4 Q64 H1024, T={T}, fwd+bwd+AdamW)"
         flops = 55.6e12 / 512 * B * (T / 1600.0)
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+
+    def sync():
+        if dist_on:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
-    torch.cuda.synchronize()
+    sync()
     dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
     if rank == 0:
         print(json.dumps({"metric": metric, "value": round(world * B * args.steps / dt, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
@@ -235,6 +261,8 @@ def run_stage(args):
                           "config": {"workload": args.workload, "per_gpu_batch": B, "dropout": "off" if args.no_dropout else "on"},
                           "step_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1), "loss": round(float(loss), 5),
                           "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}), flush=True)
+    if dist_on:
+        torch.distributed.destroy_process_group()
 
 
 def main():
@@ -256,12 +284,19 @@ def main():
     model, qf, cfg, dims = build(args, device)
     Qi, F, E, D = dims
     B = args.batch
-    batch = make_batch(B, args.hist, args.seq, args.pool, F, E, D, Qi, cfg.vocab_size - args.hist * Qi, model.first_special_id,
-                       1234 + rank, device)
+    n_user = model.num_user_query_tokens
+    batch = make_batch(B, args.hist, args.seq, args.pool, F, E, D, Qi, model.first_special_id, model.first_special_id,
+                       1234 + rank, device, n_user=n_user)
     loss_fn = InfoNCELoss(0.07)
     qw = model.base_model
     qpack, lpack = qf._ensure_pack(device), qw._ensure_pack(device)
-    opt = FusedAdamW([qpack, lpack], lr=1e-4, weight_decay=0.01)
+    packs = [qpack, lpack]
+    ubk = None
+    if model.user_qformer is not None:
+        upack = model.user_qformer._ensure_pack(device)
+        packs.append(upack)
+        ubk = dp.GradBuckets(upack.grad, [0, upack.numel])      # the user Q-Former's gradients: one bucket after the backward
+    opt = FusedAdamW(packs, lr=1e-4, weight_decay=0.01)
 
     # ---- gradient buckets in backward-completion order (LoRA 27..0, Q-Former 11..0, query table) ----
     lgrp, qgrp = 7, 3
@@ -274,9 +309,12 @@ def main():
     qf.qformer.grad_ready_hook = lambda i: qbk.ready(0) if i == -1 else (qbk.ready(q_first[i]) if i in q_first else None)
 
     def step():
-        user = model(batch["input_ids"], batch["attention_mask"], batch["history_field_embeddings"], batch["history_attention_mask"])
+        user = model(batch["input_ids"], batch["attention_mask"], batch["history_field_embeddings"], batch["history_attention_mask"],
+                     batch["user_sequence_tokens"], batch["user_attention_mask"])
         loss = loss_fn(user, batch["positive_item_embeddings"], batch["negative_item_embeddings"], batch["negative_masks"])
         loss.backward()
+        if ubk is not None:
+            ubk.ready_all(); ubk.wait()
         lbk.wait(); qbk.wait()
         opt.step(grad_scale=1.0 / world)
         return loss
@@ -338,7 +376,8 @@ def main():
                "unit": "user-sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"C4 joint step: item Q-Former(L12,H1024,Q2,F14) on {B}x{args.hist} items -> inject -> "
+               "config": {"workload": ("C5-shaped joint step with the User Q-Former's 64 tokens (U4): " if n_user else "C4 joint step: ") +
+                                      f"item Q-Former(L12,H1024,Q2,F14) on {B}x{args.hist} items -> inject -> "
                                       f"Qwen3-0.6B-shaped({cfg.num_hidden_layers}L)+LoRA r16 -> mean-pool -> InfoNCE pool {args.pool}; "
                                       f"fwd+bwd+allreduce+AdamW", "per_gpu_batch": B, "global_batch": B * world, "seq_len": args.seq,
                           "hist": args.hist, "pool": args.pool, "dropout": 0.0 if args.no_dropout else 0.2, "lora_dropout": 0.0 if args.no_dropout else args.lora_dropout,
