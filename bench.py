@@ -99,7 +99,7 @@ def build(args, device):
                                       num_query_tokens=Qi, field_embedding_dim=E, num_fields=F, dropout=p)
     cfg = Qwen3Config(num_hidden_layers=args.layers, lora_dropout=0.0 if args.no_dropout else args.lora_dropout)    # reference: :121-131
     uq = None
-    if args.user_tokens:
+    if getattr(args, "user_tokens", False):
         from unirec_amd.user_qformer import UserQFormer
         uq = UserQFormer(dropout=0.0 if args.no_dropout else 0.1)
     model = MultiModalQwenEmbedding(qformer_model=qf, use_lora=True, qwen_config=cfg, num_history_items=args.hist,

@@ -107,11 +107,15 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
 
 
 # ---- LoRA adapter products (rank 16): include/unirec_hip.h, csrc/lora.hip ---------------------------
-def lora_dropout_bits(seed, p, M, W, nad, device):
+def lora_bits_ld(W):
+    return int(_lib.load().ur_lora_bits_ld(int(W)))
+
+
+def lora_dropout_bits(seed, p, M, W, nad, device, out=None):
     """Dropped-flag bit planes uint8 [nad, M, ur_lora_bits_ld(W)] of nad adapters that share an [M, W] input."""
     lib = _lib.load()
     ld = int(lib.ur_lora_bits_ld(int(W)))
-    bits = torch.empty((nad, M, ld), dtype=torch.uint8, device=device)
+    bits = torch.empty((nad, M, ld), dtype=torch.uint8, device=device) if out is None else out
     check(lib.ur_lora_dropout_bits(int(seed), float(p), int(M), int(W), int(nad), bits.data_ptr(), ld, bits.stride(0), _stream()),
           "ur_lora_dropout_bits")
     return bits

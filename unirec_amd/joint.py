@@ -83,6 +83,10 @@ class MultiModalQwenEmbedding(nn.Module):
         if attention_mask is not None:
             attention_mask = attention_mask.to(dev)
         item_tokens = None
+        if self.use_lora and self.training and input_ids.is_cuda:
+            # this step's LoRA dropout bit planes do not depend on any activation: generate them on a side stream under the
+            # Q-Former forward(s) below
+            self.base_model.prefetch_lora_bits(input_ids.shape[0] * input_ids.shape[1], dev)
         if history_field_embeddings is not None and history_attention_mask is not None:
             hfe = history_field_embeddings.to(dev)
             ham = history_attention_mask.to(dev)

@@ -129,6 +129,8 @@ class Qwen3LoRAModel(nn.Module):
         self.grad_ready_hook = None
         self.lora_seed = 0x5EED        # base seed of the LoRA dropout masks (set per rank / per run by the trainer)
         self._lora_step = 0            # forward calls with dropout so far: every step draws new masks
+        self._bits_stream = None       # side stream + planes of prefetch_lora_bits
+        self._bits_pre = None
         self.keep_norm_outputs = True   # keep the two RMSNorm outputs per layer for the backward (memory for time); False recomputes them
         self.reset_parameters()
 
@@ -255,7 +257,36 @@ class Qwen3LoRAModel(nn.Module):
         planes from it (hip.lora_dropout_bits) and feed the unpacked masks to the oracle."""
         return (int(self.lora_seed) * 0x9E3779B1 + int(step) * 1000003 + layer * 8 + group) & 0x7FFFFFFFFFFFFFFF
 
-    def _lora_down(self, xin, a_names, pack, sc, seed, p):
+    def _bits_groups(self):
+        """(input width, adapters sharing it) of the four adapter groups of a layer: q|k|v, o, gate|up, down."""
+        c = self.config
+        return ((c.hidden_size, 3), (c.num_attention_heads * c.head_dim, 1), (c.hidden_size, 2), (c.intermediate_size, 1))
+
+    def prefetch_lora_bits(self, M, device):
+        """Generate the NEXT forward's LoRA dropout bit planes (all layers, all adapter groups) on a side stream.  The planes
+        are pure functions of (seed, step, layer, group) -- nothing on the main stream feeds them -- so the caller starts
+        this before the item Q-Former's forward, whose small launches leave most of the chip idle, and the 8 ms of mask
+        arithmetic per step disappear under it.  The planes are allocated on the caller's stream (the caching allocator
+        keys blocks by stream) and written on the side stream after it has caught up with the caller's stream."""
+        p = self._drop_p()
+        self._bits_pre = None
+        if p <= 0.0 or self.config.lora_r != 16 or not torch.is_grad_enabled():
+            return
+        main = torch.cuda.current_stream(device)
+        if self._bits_stream is None:
+            self._bits_stream = torch.cuda.Stream(device=device)
+        side, step = self._bits_stream, self._lora_step
+        planes = {(i, g): torch.empty((nad, M, hip.lora_bits_ld(W)), dtype=torch.uint8, device=device)
+                  for i in range(self.config.num_hidden_layers) for g, (W, nad) in enumerate(self._bits_groups())}
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for (i, g), buf in planes.items():
+                W, nad = self._bits_groups()[g]
+                hip.lora_dropout_bits(self.lora_dropout_seed(step, i, g), p, M, W, nad, device, out=buf)
+            ev = side.record_event()
+        self._bits_pre = {"step": step, "M": M, "planes": planes, "event": ev}
+
+    def _lora_down(self, xin, a_names, pack, sc, seed, p, pre=None):
         """(t, bits): t[M, nb*r] = s * dropout_j(x) A_j^T for the nb adapters that share the input x (one dropped-flag
         bit plane per adapter, generated once here and kept for the backward)."""
         if self.config.lora_r != 16:
@@ -263,7 +294,9 @@ class Qwen3LoRAModel(nn.Module):
                 raise hip._lib.UniRecHipError("LoRA dropout is implemented for rank 16 (the reference's r) only")
             A = pack.fused16(a_names) if len(a_names) > 1 else pack.w16(a_names[0])
             return hip.gemm(xin, A, alpha=sc), None
-        bits = hip.lora_dropout_bits(seed, p, xin.shape[0], xin.shape[1], len(a_names), xin.device) if p > 0.0 else None
+        bits = pre
+        if bits is None and p > 0.0:
+            bits = hip.lora_dropout_bits(seed, p, xin.shape[0], xin.shape[1], len(a_names), xin.device)
         t = hip.lora_project(xin, [pack.w16(n) for n in a_names], alpha=sc / (1.0 - p), bits=bits)
         return t, bits
 
@@ -289,6 +322,13 @@ class Qwen3LoRAModel(nn.Module):
             self._lora_step += 1
         saved = {"B": B, "S": S, "T": T, "ids": input_ids, "first": first_special_id, "mask": mask_u8, "layers": [],
                  "pdrop": pdrop, "step": step}
+        pre, self._bits_pre = self._bits_pre, None
+        if pre is not None and pdrop > 0.0 and pre["step"] == step and pre["M"] == M and pack is not None:
+            torch.cuda.current_stream(dev).wait_event(pre["event"])      # planes prefetched on the side stream
+            pre = pre["planes"]
+        else:
+            pre = None
+        bp = (lambda i, g: pre[(i, g)]) if pre is not None else (lambda i, g: None)
         for i, fl in enumerate(fz["layers"]):
             lp = f"layers.{i}."
             L = {"x": x}
@@ -296,7 +336,7 @@ class Qwen3LoRAModel(nn.Module):
             qkv = torch.empty((M, NQ + 2 * NKV), dtype=BF16, device=dev)
             if pack is not None:
                 t_qkv, L["bits_qkv"] = self._lora_down(h, [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"], pack, sc,
-                                                       self.lora_dropout_seed(step, i, 0), pdrop)     # [M,3r] = s * dropout(h) A^T
+                                                       self.lora_dropout_seed(step, i, 0), pdrop, bp(i, 0))     # [M,3r] = s * dropout(h) A^T
                 col = 0
                 for j, (p, n) in enumerate((("q", NQ), ("k", NKV), ("v", NKV))):
                     hip.gemm(h, fl["qkv"][col:col + n], out=qkv[:, col:col + n], R2=t_qkv[:, j * r:(j + 1) * r],
@@ -310,7 +350,7 @@ class Qwen3LoRAModel(nn.Module):
             att, actx = hip.attn_fwd(q_r.view(B, S, nq, hd), k_r.view(B, S, nkv, hd), v4, causal=True, key_mask=mask_u8)
             att2 = att.view(M, NQ)
             if pack is not None:
-                t_o, L["bits_o"] = self._lora_down(att2, [lp + "self_attn.o_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 1), pdrop)
+                t_o, L["bits_o"] = self._lora_down(att2, [lp + "self_attn.o_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 1), pdrop, bp(i, 1))
                 x2 = hip.gemm(att2, fl["o"], residual=x, R2=t_o, S2=pack.w16(lp + "self_attn.o_proj.lora_B.weight"))
                 L["t_o"] = t_o
             else:
@@ -319,7 +359,7 @@ class Qwen3LoRAModel(nn.Module):
             gu = torch.empty((M, 2 * I), dtype=BF16, device=dev)
             if pack is not None:
                 t_gu, L["bits_gu"] = self._lora_down(h2, [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"], pack, sc,
-                                                     self.lora_dropout_seed(step, i, 2), pdrop)
+                                                     self.lora_dropout_seed(step, i, 2), pdrop, bp(i, 2))
                 for j, p in enumerate(("gate", "up")):
                     hip.gemm(h2, fl["gu"][j * I:(j + 1) * I], out=gu[:, j * I:(j + 1) * I], R2=t_gu[:, j * r:(j + 1) * r],
                              S2=pack.w16(lp + f"mlp.{p}_proj.lora_B.weight"))
@@ -328,7 +368,7 @@ class Qwen3LoRAModel(nn.Module):
                 hip.gemm(h2, fl["gu"], out=gu)
             act = hip.swiglu_fwd(gu, I)
             if pack is not None:
-                t_d, L["bits_d"] = self._lora_down(act, [lp + "mlp.down_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 3), pdrop)
+                t_d, L["bits_d"] = self._lora_down(act, [lp + "mlp.down_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 3), pdrop, bp(i, 3))
                 x3 = hip.gemm(act, fl["d"], residual=x2, R2=t_d, S2=pack.w16(lp + "mlp.down_proj.lora_B.weight"))
                 L["t_d"] = t_d
             else:
