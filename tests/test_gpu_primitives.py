@@ -220,6 +220,33 @@ def test_layernorm_broadcast_rows_and_dropout():
     assert torch.allclose(dy.float()[~dropped], dz.float()[~dropped] / (1 - p), rtol=2e-2, atol=1e-3)
 
 
+@pytest.mark.parametrize("p", [0.1, 0.2, 0.5])
+def test_dropout_counter_hash_statistics(p):
+    """The counter-based dropout generator (common.cuh ur_hash2: keyed 32-bit murmur finaliser): drop rate, independence
+    of neighbouring elements (along a row and across rows), and independence of the streams of neighbouring seeds and of
+    seeds that differ only in their high word -- all within 5 sigma on 2^21 decisions."""
+    M, H = 2048, 1024
+    ones = torch.ones((M, H), device=DEV, dtype=torch.bfloat16)
+    gamma, beta = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
+
+    def mask(seed):
+        _, z0, _, _ = hip.layernorm_fwd(ones, gamma, beta, 1e-12, p_pre=p, seed_pre=seed)      # no residual: z0 = dropout(ones)
+        return (z0.float() == 0)
+    n = M * H
+    sig1 = (p * (1 - p) / n) ** 0.5
+    m0 = mask(1000)
+    assert abs(m0.float().mean().item() - p) < 5 * sig1
+    # joint drop probability of two independent decisions is p^2
+    sig2 = (p * p * (1 - p * p) / n) ** 0.5
+    for other in (torch.roll(m0, 1, dims=1), torch.roll(m0, 1, dims=0), torch.roll(m0, 7, dims=1), mask(1001), mask(1002), mask(1000 + (1 << 32)),
+                  mask(1000 ^ 0x55555555)):
+        both = (m0 & other).float().mean().item()
+        assert abs(both - p * p) < 5 * sig2 + 1e-4, (both, p * p)
+    # per-row and per-column drop rates show no structure
+    assert (m0.float().mean(dim=1) - p).abs().max().item() < 6 * (p * (1 - p) / H) ** 0.5
+    assert (m0.float().mean(dim=0) - p).abs().max().item() < 6 * (p * (1 - p) / M) ** 0.5
+
+
 def test_batch_reduce_and_colsum():
     nb, rows, H = 37, 4, 64
     x = _bf(_randn((nb * rows, H), 1))

@@ -113,12 +113,20 @@ __device__ __forceinline__ float group_max(float v) {
 
 // ---- counter-based RNG for dropout (mask is a pure function of (seed, element index), so the
 // backward regenerates it instead of storing it; independent of grid shape and rank count) ------
+// 32-bit decision word of element idx: a keyed murmur3 finaliser over the low counter word -- three 32-bit multiplies per
+// element where the splitmix64 round it replaces cost three 64-bit ones (ten quarter-rate v_mul per probability: the
+// user Q-Former's attention kernels spent half their time there).  The seed enters three times (xor into the counter,
+// add after the first multiply, xor between the two mixing rounds), so the streams of two seeds are neither shifted nor
+// xor-permuted copies of each other; the high counter word (element index >= 2^32) moves the additive key.
 __device__ __forceinline__ uint32_t ur_hash2(uint64_t seed, uint64_t idx) {
-  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32);
+  const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+  const uint32_t k2 = (s0 * 0x7FEB352Du) ^ ((s1 << 13) | (s1 >> 19)) ^ 0x5851F42Du;      // seed only: scalar unit
+  uint32_t h = ((uint32_t)idx ^ s0) * 0x9E3779B1u + ((uint32_t)(idx >> 32) + s1);
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= k2;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
 }
 // Full 64-bit mix of the same generator: four independent 16-bit fields per element (LoRA dropout:
 // one field per adapter that shares an input; keep iff field >= p * 65536).
