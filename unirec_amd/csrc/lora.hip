@@ -54,6 +54,12 @@ __device__ __forceinline__ uint4 ld_stream(const bf16_t* p) {
 }
 __device__ __forceinline__ int kc_g(int r) { return (r >> 1) & 7; }
 __device__ __forceinline__ int f64sw(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
+// 16-byte-chunk swizzle of a [tokens][64 columns] tile (128-byte rows) that is conflict-free for BOTH accesses of
+// lora_bgrad: ds_write_b128 of one column chunk by 8 consecutive token rows (8-lane groups, banks mod 128 B: the 8 rows
+// need 8 distinct chunk positions -> low 3 bits of the row), and ds_read_b64_tr_b16 of a 32-byte chunk pair by rows
+// {0..3, 8..11} + 4 (32-lane groups, banks mod 256 B: rows of one parity need distinct pair positions -> bit 3 of the row
+// moves the pair index by 2).  The f64sw form left the writes 4-way conflicted (PMC: 66 % of the kernel's LDS cycles).
+__device__ __forceinline__ int sw16(int r) { return (r & 7) ^ ((r & 8) >> 1); }
 
 // ---- dropped-flag bit planes ---------------------------------------------------------------------
 // thread <-> (row m, group q of 32 columns): one 32-bit word per adapter plane.  Every element draws a 15-bit
@@ -331,6 +337,9 @@ struct BgradP {
 // tb accumulators, parks the same fragments row-major in its private LDS tile and reads them back transposed
 // (ds_read_b64_tr_b16) as the operands of dB^T[16 x 64] += t^T[16 x 128] dy[128 x 64]; the four waves' partials are
 // summed through LDS and leave as this block's slab.  dy is read once where ur_lora_project + ur_lora_reduce read it twice.
+#ifndef UR_BG_ABLATE
+#define UR_BG_ABLATE 0      // lab (tools/lab/bgrad_ablate.sh; results WRONG by construction): 1 = no dB phase, 2 = loads + tb MFMAs only, 3 = no cross-wave exchange / barriers
+#endif
 constexpr int BG_TOK = 512, BG_WTOK = 128;
 constexpr int BG_XT = BG_WTOK * 128;                 // a wave's X tile: 128 tokens x 64 columns bf16
 constexpr int BG_SMEM = 4 * BG_XT + 4 * 16 * 64 * 4; // + cross-wave reduction of the [16 x 64] f32 partials
@@ -381,19 +390,34 @@ __global__ __launch_bounds__(256, 2) void lora_bgrad_kernel(BgradP p) {
     for (int s2 = 0; s2 < 2; ++s2) {
       const int k = c0 + 32 * s2 + 8 * g;
       const bool ok = k < W;
+#if UR_BG_ABLATE >= 4
+      uf[s2] = *reinterpret_cast<const uint4*>(urow + k);
+#pragma unroll
+      for (int rb = 0; rb < 8; ++rb) xf[rb][s2] = *reinterpret_cast<const uint4*>(xrow[rb] + k);
+#else
       uf[s2] = ok ? *reinterpret_cast<const uint4*>(urow + k) : make_uint4(0, 0, 0, 0);
 #pragma unroll
       for (int rb = 0; rb < 8; ++rb) xf[rb][s2] = ok ? *reinterpret_cast<const uint4*>(xrow[rb] + k) : make_uint4(0, 0, 0, 0);   // (non-temporal measured slower here)
+#endif
     }
     // (the previous chunk's transposed reads of this tile are complete: lgkmcnt(0) below precedes the MFMAs)
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
       for (int rb = 0; rb < 8; ++rb) {
+#if UR_BG_ABLATE == 5
+        tb[rb][0] += __uint_as_float((xf[rb][s2].x ^ xf[rb][s2].y ^ xf[rb][s2].z ^ xf[rb][s2].w ^ uf[s2].x) & 0x3f800000u);
+#else
         tb[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, uf[s2]), __builtin_bit_cast(bf16x8, xf[rb][s2]), tb[rb], 0, 0, 0);
+#endif
         const int row = 16 * rb + l15, ch = 4 * s2 + g;
-        *reinterpret_cast<uint4*>(xt + row * 128 + ((((ch >> 1) ^ f64sw(row)) << 5) | ((ch & 1) << 4))) = xf[rb][s2];
+#if UR_BG_ABLATE < 2
+        *reinterpret_cast<uint4*>(xt + row * 128 + ((ch ^ sw16(row)) << 4)) = xf[rb][s2];
+#endif
       }
+#if UR_BG_ABLATE == 1 || UR_BG_ABLATE == 2 || UR_BG_ABLATE >= 4
+    continue;
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own writes have landed (private tile: no barrier)
     f32x4 db[4];
 #pragma unroll
@@ -404,13 +428,20 @@ __global__ __launch_bounds__(256, 2) void lora_bgrad_kernel(BgradP p) {
 #pragma unroll
       for (int cb = 0; cb < 4; cb += 2) {
         bf16x8 f[2];
-        const uint32_t a0 = lds_off(xt) + ka * 128 + ((cb ^ f64sw(ka)) << 5) + pp * 8;
-        const uint32_t a1 = lds_off(xt) + ka * 128 + (((cb + 1) ^ f64sw(ka)) << 5) + pp * 8;
-        tr_pair(f, a0, a0 + 4 * 128, a1, a1 + 4 * 128);
+        // 8-byte piece pp of the 32-byte chunk pair cb: 16-byte chunk 2 cb + (pp >> 1), swizzled per row; row ka + 4 flips
+        // bit 2 of the swizzle
+        const int swk = sw16(ka), c0 = 2 * cb + (pp >> 1), c1 = c0 + 2;
+        const uint32_t base = lds_off(xt) + ka * 128 + ((pp & 1) << 3);
+        const uint32_t a0 = base + ((c0 ^ swk) << 4), b0 = base + 4 * 128 + ((c0 ^ swk ^ 4) << 4);
+        const uint32_t a1 = base + ((c1 ^ swk) << 4), b1 = base + 4 * 128 + ((c1 ^ swk ^ 4) << 4);
+        tr_pair(f, a0, b0, a1, b1);
         db[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT[k], f[0], db[cb], 0, 0, 0);            // D[j = 4g+e][w = l15]
         db[cb + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT[k], f[1], db[cb + 1], 0, 0, 0);
       }
     }
+#if UR_BG_ABLATE == 3
+    if (c0 + 64 < W) { if (db[0][0] + db[1][0] + db[2][0] + db[3][0] == 123.456f) slab[0] = 1.f; continue; }
+#endif
     // cross-wave sum: red[wave][w (64)][j (16)]
 #pragma unroll
     for (int cb = 0; cb < 4; ++cb)
