@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 1
+#define UR_ABI_VERSION 2
 
 int ur_version(void);
 const char* ur_last_error(void);
@@ -67,6 +67,14 @@ typedef struct {
    * drop_bits_ld = ur_lora_bits_ld(N) bytes, plane stride drop_bits_stride bytes). */
   const void* drop_bits; int64_t drop_bits_ld; int64_t drop_bits_stride;
   int32_t drop_rank; float drop_p;
+  /* SwiGLU backward as the epilogue of the down-projection's dX GEMM (Qwen3MLP: down(act_fn(gate(x)) * up(x)),
+   * transformers modeling_qwen3.py:81-91).  swiglu_gu != NULL: the GEMM result v[m][n] (n < N = swiglu_I, f32, never
+   * rounded or stored) is d(act); with g = gu[m][n], u = gu[m][swiglu_I + n] the epilogue writes
+   *   dgu[m][n] = v * u * silu'(g)      dgu[m][swiglu_I + n] = v * silu(g)
+   * and C is not written (pass any valid pointer).  bf16 output, no split_k, no residual / gelu modes. */
+  const void* swiglu_gu; int64_t swiglu_ldgu;
+  void* swiglu_dgu; int64_t swiglu_lddgu;
+  int32_t swiglu_I;
 } ur_gemm_args;
 int64_t ur_gemm_workspace_bytes(const ur_gemm_args* a);
 int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, void* stream);

@@ -220,6 +220,29 @@ def test_layernorm_broadcast_rows_and_dropout():
     assert torch.allclose(dy.float()[~dropped], dz.float()[~dropped] / (1 - p), rtol=2e-2, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,I,K", [(300, 256, 128), (16384, 1024, 64), (1000, 516, 72)])
+def test_gemm_swiglu_backward_epilogue(M, I, K):
+    """ur_gemm with swiglu_gu: the down-projection's dX GEMM hands d(act) to the SwiGLU backward in its epilogue (dgate | dup
+    leave, d(act) is never stored) -- against fp32 torch and against the two-kernel path (GEMM, then ur_swiglu_bwd); both
+    tile configurations, interior and edge tiles, 16- and 8-byte pieces."""
+    dy, w = _bf(_randn((M, K), 1)), _bf(_randn((I, K), 2, 0.2))
+    gu = _bf(_randn((M, 2 * I), 3))
+    dgu = torch.full((M, 2 * I), float("nan"), device=DEV, dtype=torch.bfloat16)
+    out = hip.gemm(dy, w, swiglu_bwd=(gu, dgu))
+    assert out.data_ptr() == dgu.data_ptr()
+    dact = dy.float() @ w.float().t()
+    g, u = gu.float()[:, :I], gu.float()[:, I:]
+    sg = torch.sigmoid(g)
+    want = torch.cat([dact * u * (sg * (1 + g * (1 - sg))), dact * g * sg], dim=1)
+    assert torch.isfinite(dgu.float()).all()
+    err = (dgu.float() - want).norm() / want.norm()
+    assert err < 6e-3, err
+    if I % 8 == 0:       # (ur_swiglu_bwd's own constraint)
+        two = hip.swiglu_bwd(hip.gemm(dy, w), gu, I)
+        assert (two.float() - want).norm() / want.norm() < 1e-2
+        assert (dgu.float() - two.float()).norm() / want.norm() < 1e-2
+
+
 @pytest.mark.parametrize("p", [0.1, 0.2, 0.5])
 def test_dropout_counter_hash_statistics(p):
     """The counter-based dropout generator (common.cuh ur_hash2: keyed 32-bit murmur finaliser): drop rate, independence

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UNIREC_HIP_LIB selects another build of the SAME library (kernel A/B experiments); there is still no fallback.
 LIB_PATH = os.environ.get("UNIREC_HIP_LIB") or os.path.join(_HERE, "lib", "libunirec_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int, c_i64, c_u64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
@@ -28,7 +28,9 @@ class GemmArgs(ctypes.Structure):
                 ("gelu_grad_aux", c_void_p), ("ldaux", c_i64),
                 ("split_k", c_int),
                 ("drop_bits", c_void_p), ("drop_bits_ld", c_i64), ("drop_bits_stride", c_i64),
-                ("drop_rank", c_int), ("drop_p", c_float)]
+                ("drop_rank", c_int), ("drop_p", c_float),
+                ("swiglu_gu", c_void_p), ("swiglu_ldgu", c_i64), ("swiglu_dgu", c_void_p), ("swiglu_lddgu", c_i64),
+                ("swiglu_I", c_int)]
 
 
 class LoraArgs(ctypes.Structure):

@@ -68,6 +68,8 @@ struct GemmP {
   int gm, gn;
   // LoRA dropout (ur_gemm_args.drop_*): masked rank-r LoRA epilogue driven by the adapters' dropped-flag bit planes
   const uint8_t* drop_bits; long drop_bits_ld, drop_bits_stride; int drop_rank; float drop_inv_keep;
+  // SwiGLU backward epilogue (ur_gemm_args.swiglu_*): the result is d(act); dgate / dup leave instead of C
+  const bf16_t* sw_gu; long sw_ldgu; bf16_t* sw_dgu; long sw_lddgu; int sw_I;
 };
 
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
@@ -208,7 +210,9 @@ __device__ __forceinline__ void lds_frags(bf16x8* f, const char* tile, int idx0,
 }
 
 // BM x BN block tile, NWM x NWN waves; each wave owns (BM/NWM) rows x (BN/NWN) columns of C.
-template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN>
+// SWIGLU: the SwiGLU backward epilogue (ur_gemm_args.swiglu_*) as its own instantiation, so the ordinary kernels' code
+// and register allocation do not change with it.
+template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN, bool SWIGLU = false>
 __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NWM * NWN * 64;
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     }
   } else {
     bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
-    const bool rich = p.res || p.aux || p.gelu_out;                  // uniform (a bias alone stays on the plain path)
+    const bool rich = SWIGLU || p.res || p.aux || p.gelu_out;        // uniform (a bias alone stays on the plain path)
     __syncthreads();                                                   // every wave is done with the ring
     if (!rich) {
       constexpr int CROWB = BN * 2 + 16;            // padded LDS row of the bf16 C tile
@@ -673,7 +677,9 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
       const bool wide8 = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                          (!p.res || (((p.ldres & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0))) &&
                          (!p.aux || (((p.ldaux & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.aux) & 15) == 0))) &&
-                         (!p.gelu_out || (((p.ldg & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.gelu_out) & 15) == 0)));
+                         (!p.gelu_out || (((p.ldg & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.gelu_out) & 15) == 0))) &&
+                         (!SWIGLU || (((p.sw_ldgu & 7) == 0) && ((p.sw_lddgu & 7) == 0) && ((p.sw_I & 7) == 0) &&
+                                       ((reinterpret_cast<uintptr_t>(p.sw_gu) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.sw_dgu) & 15) == 0)));
       // pieces of 8 columns (16 bytes) when everything is 16-byte addressable, else of 4 columns (N, ld % 4 == 0 always)
       const int cw = wide8 ? 8 : 4, cpr = (BN / 2) / cw, ch = tid % cpr, rstep = NT / cpr;
       auto ldp = [&](const bf16_t* q, uint32_t (&w)[4]) {
@@ -721,7 +727,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
         // four rows per trip: their residual / aux pieces go out together (one wait instead of one per row)
 #pragma unroll 1
         for (int r0 = tid / cpr; r0 < BM; r0 += 4 * rstep) {
-          uint32_t rw[4][4], aw[4][4];
+          uint32_t rw[4][4], aw[4][4], gw[4][4], uw[4][4];
           bool ok[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -731,6 +737,12 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
             aw[k][0] = aw[k][1] = aw[k][2] = aw[k][3] = 0;
             if (p.res && ok[k]) ldp(p.res + (long)m * p.ldres + n, rw[k]);
             if (p.aux && ok[k]) ldp(p.aux + (long)m * p.ldaux + n, aw[k]);
+            gw[k][0] = gw[k][1] = gw[k][2] = gw[k][3] = 0;
+            uw[k][0] = uw[k][1] = uw[k][2] = uw[k][3] = 0;
+            if (SWIGLU && ok[k]) {
+              ldp(p.sw_gu + (long)m * p.sw_ldgu + n, gw[k]);
+              ldp(p.sw_gu + (long)m * p.sw_ldgu + p.sw_I + n, uw[k]);
+            }
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -748,6 +760,26 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
             if (p.aux) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[2 * e] *= gelu_erf_grad_f(bf_lo(aw[k][e])); v[2 * e + 1] *= gelu_erf_grad_f(bf_hi(aw[k][e])); }
+            }
+            if (SWIGLU) {
+              // d(act) = v (f32, unrounded): dgate = v u silu'(g), dup = v silu(g)   (elementwise.hip: swiglu_bwd_kernel)
+              uint32_t og[4], ou[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float dgv[2], duv[2];
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                  const float gg = hh ? bf_hi(gw[k][e]) : bf_lo(gw[k][e]), uu = hh ? bf_hi(uw[k][e]) : bf_lo(uw[k][e]);
+                  const float d = v[2 * e + hh];
+                  const float sg = 1.0f / (1.0f + __expf(-gg));
+                  duv[hh] = d * (gg * sg);
+                  dgv[hh] = d * uu * (sg * (1.0f + gg * (1.0f - sg)));
+                }
+                og[e] = pack_bf2(dgv[0], dgv[1]); ou[e] = pack_bf2(duv[0], duv[1]);
+              }
+              stp(p.sw_dgu + (long)m * p.sw_lddgu + n, og);
+              stp(p.sw_dgu + (long)m * p.sw_lddgu + p.sw_I + n, ou);
+              continue;
             }
             uint32_t o[4];
 #pragma unroll
@@ -785,7 +817,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
   }
 }
 
-template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN>
+template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN, bool SWIGLU = false>
 int launch_cfg(GemmP p, int splits, hipStream_t st) {
   constexpr int S_BYTES = SK ? Tile<BN>::KC_BYTES : Tile<BN>::KS_BYTES;
   constexpr int R_BYTES = RK ? Tile<BM>::KC_BYTES : Tile<BM>::KS_BYTES;
@@ -793,14 +825,14 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
   constexpr int SMEM = OUTF32 ? RING : (RING > CTILE ? RING : CTILE);
   static bool attr_set = false;   // idempotent; a race only repeats the call
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN, SWIGLU>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) UR_FAIL((int)e, "ur_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     attr_set = true;
   }
   p.gm = ur_cdiv(p.M, BM); p.gn = ur_cdiv(p.N, BN);
   dim3 grid(p.gm * p.gn, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN>), grid, dim3(NWM * NWN * 64), SMEM, st, p);
+  hipLaunchKernelGGL((gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN, SWIGLU>), grid, dim3(NWM * NWN * 64), SMEM, st, p);
   UR_CHECK_LAUNCH("ur_gemm");
   return 0;
 }
@@ -810,6 +842,12 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
 template <bool RK, bool SK, bool OUTF32>
 int launch(const GemmP& p, int splits, hipStream_t st) {
   const long big_wgs = (long)ur_cdiv(p.M, 256) * ur_cdiv(p.N, 256) * splits;
+  if constexpr (RK && SK && !OUTF32) {
+    if (p.sw_gu) {       // SwiGLU backward epilogue: K-contiguous bf16 launches only (ur_gemm checks)
+      if (p.M >= 256 && p.N >= 256 && big_wgs >= 256) return launch_cfg<true, true, false, 256, 256, 2, 4, true>(p, splits, st);
+      return launch_cfg<true, true, false, 128, 128, 2, 2, true>(p, splits, st);
+    }
+  }
   if (p.M >= 256 && p.N >= 256 && big_wgs >= 256) return launch_cfg<RK, SK, OUTF32, 256, 256, 2, 4>(p, splits, st);
   return launch_cfg<RK, SK, OUTF32, 128, 128, 2, 2>(p, splits, st);
 }
@@ -866,6 +904,14 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
     UR_REQUIRE(!a->gelu_grad_aux || ((a->ldaux % 4) == 0 && (((uintptr_t)a->gelu_grad_aux) & 7) == 0), "ur_gemm: aux misaligned");
   }
   UR_REQUIRE(!a->bias || UR_ALIGNED16(a->bias), "ur_gemm: bias must be 16-byte aligned");
+  if (a->swiglu_gu) {
+    UR_REQUIRE(!a->c_f32 && splits <= 1 && !a->residual && !a->gelu_out && !a->gelu_grad_aux && !a->bias && a->r_kcontig && a->s_kcontig,
+               "ur_gemm: the SwiGLU backward epilogue needs K-contiguous operands, bf16 output, no split_k / bias / residual / gelu modes");
+    UR_REQUIRE(a->swiglu_dgu && a->swiglu_I == a->N && (a->swiglu_I % 4) == 0 && (a->swiglu_ldgu % 4) == 0 && (a->swiglu_lddgu % 4) == 0 &&
+               a->swiglu_ldgu >= 2 * (int64_t)a->swiglu_I && a->swiglu_lddgu >= 2 * (int64_t)a->swiglu_I &&
+               (((uintptr_t)a->swiglu_gu) & 7) == 0 && (((uintptr_t)a->swiglu_dgu) & 7) == 0,
+               "ur_gemm: SwiGLU backward epilogue: N must equal swiglu_I, gu / dgu rows of >= 2 I elements, 8-byte aligned");
+  }
   if (a->drop_bits) {
     UR_REQUIRE(a->K2 > 0 && a->drop_rank >= 8 && a->drop_rank <= 32 && (a->drop_rank % 8) == 0 && (a->K2 % a->drop_rank) == 0 &&
                a->K2 / a->drop_rank <= 4 && a->r_kcontig && a->s_kcontig && splits_ok(a) && !a->c_f32,
@@ -883,6 +929,8 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
   p.drop_bits = (const uint8_t*)a->drop_bits; p.drop_bits_ld = a->drop_bits_ld; p.drop_bits_stride = a->drop_bits_stride;
   p.drop_rank = a->drop_rank;
   p.drop_inv_keep = a->drop_bits ? 1.0f / (1.0f - a->drop_p) : 1.0f;
+  p.sw_gu = (const bf16_t*)a->swiglu_gu; p.sw_ldgu = a->swiglu_ldgu; p.sw_dgu = (bf16_t*)a->swiglu_dgu; p.sw_lddgu = a->swiglu_lddgu;
+  p.sw_I = a->swiglu_I;
   p.slab_stride = 0;
   if (splits > 1) {
     int tiles = ur_cdiv(a->K, BK);

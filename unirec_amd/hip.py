@@ -51,10 +51,12 @@ def workspace(nbytes, device, tag="default"):
 
 # ------------------------------------------------------------------------------------------------
 def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=None, out_f32=False, alpha=1.0,
-         bias=None, residual=None, gelu_out=None, gelu_grad_aux=None, R2=None, S2=None, split_k=1, drop=None):
+         bias=None, residual=None, gelu_out=None, gelu_grad_aux=None, R2=None, S2=None, split_k=1, drop=None,
+         swiglu_bwd=None):
     """C[M,N] = alpha*(R(m,k) S(n,k) + R2 S2) + epilogue.  R/S are 2-D bf16 (row stride = stride(0)).
     drop = (bits, p, rank): masked LoRA epilogue (bits = hip.lora_dropout_bits planes of the adapters' shared input),
-    see ur_gemm_args in include/unirec_hip.h."""
+    swiglu_bwd = (gu, dgu): the result is d(act) of SwiGLU; dgate | dup are written to dgu [M, 2N] and no C is produced
+    (returns dgu).  See ur_gemm_args in include/unirec_hip.h."""
     lib = _lib.load()
     for t, n in ((R, "R"), (S, "S")):
         if t.dtype != BF16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
@@ -68,6 +70,12 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
     Ks = S.shape[1] if s_kcontig else S.shape[0]
     if Ks != K:
         raise ValueError(f"gemm: K mismatch R:{K} S:{Ks}")
+    if swiglu_bwd is not None:
+        gu_, dgu_ = swiglu_bwd
+        for t, n in ((gu_, "gu"), (dgu_, "dgu")):
+            if t.dtype != BF16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.shape[0] != M or t.shape[1] != 2 * N:
+                raise ValueError(f"gemm: swiglu_bwd {n} must be a bf16 [M, 2N] device tensor with unit inner stride")
+        out = dgu_            # C is not written in this mode; any valid bf16 pointer with ldc >= N
     if out is None:
         out = torch.empty((M, N), dtype=F32 if out_f32 else BF16, device=R.device)
     a = GemmArgs()
@@ -87,6 +95,9 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
     if gelu_grad_aux is not None:
         a.gelu_grad_aux, a.ldaux = gelu_grad_aux.data_ptr(), gelu_grad_aux.stride(0)
     a.split_k = int(split_k)
+    if swiglu_bwd is not None:
+        a.swiglu_gu, a.swiglu_ldgu = gu_.data_ptr(), gu_.stride(0)
+        a.swiglu_dgu, a.swiglu_lddgu, a.swiglu_I = dgu_.data_ptr(), dgu_.stride(0), N
     if drop is not None:
         bits, pdrop, rank = drop
         a.drop_bits, a.drop_bits_ld, a.drop_bits_stride = bits.data_ptr(), bits.stride(1), bits.stride(0)

@@ -421,12 +421,13 @@ class Qwen3LoRAModel(nn.Module):
             hip.lora_reduce(xin, tb, gA, nad=len(a_names), alpha=1.0 / (1.0 - pdrop), bits=bits)
             return tb
 
-        def dx_gemm(dy, wT, tb, a_names, bits):
+        def dx_gemm(dy, wT, tb, a_names, bits, swiglu=None):
             """dx = dy W + sum_j mask_j * (tb_j A_j): the adapters' part joins the main reduction when there is no
-            dropout, and is a masked rank-r epilogue (ur_gemm drop_bits) when there is."""
+            dropout, and is a masked rank-r epilogue (ur_gemm drop_bits) when there is.  swiglu = (gu, dgu): dx is d(act)
+            and leaves the GEMM as dgate | dup (SwiGLU backward in the epilogue: d(act) is never stored)."""
             A = pack.fused16(a_names) if len(a_names) > 1 else pack.w16(a_names[0])
             drop = (bits, pdrop, r) if bits is not None else None
-            return hip.gemm(dy, wT, R2=tb, S2=hip.transpose_bf16(A), drop=drop)
+            return hip.gemm(dy, wT, R2=tb, S2=hip.transpose_bf16(A), drop=drop, swiglu_bwd=swiglu)
 
         for i in reversed(range(len(fz["layers"]))):
             fl, L = fz["layers"][i], saved["layers"][i]
@@ -434,12 +435,12 @@ class Qwen3LoRAModel(nn.Module):
             x, x2, gu, qkv = L["x"], L["x2"], L["gu"], L["qkv"]
             # ---- MLP: x3 = x2 + down(silu(gate) * up)
             act = L["act"]
+            dgu = torch.empty_like(gu)
             if pack is not None:
                 tb = lora_grads(dx, L["t_d"], act, [lp + "mlp.down_proj.lora_A.weight"], [(lp + "mlp.down_proj.lora_B.weight", 0, D)], L["bits_d"])
-                dact = dx_gemm(dx, fl["dT"], tb, [lp + "mlp.down_proj.lora_A.weight"], L["bits_d"])
+                dx_gemm(dx, fl["dT"], tb, [lp + "mlp.down_proj.lora_A.weight"], L["bits_d"], swiglu=(gu, dgu))
             else:
-                dact = hip.gemm(dx, fl["dT"])
-            dgu = hip.swiglu_bwd(dact, gu, I)
+                hip.gemm(dx, fl["dT"], swiglu_bwd=(gu, dgu))
             h2 = L["h2"] if "h2" in L else hip.rmsnorm_fwd(x2, fl["ln2"], eps)[0]          # kept, or recomputed
             if pack is not None:
                 a_names = [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"]
