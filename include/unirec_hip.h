@@ -75,6 +75,11 @@ typedef struct {
   const void* swiglu_gu; int64_t swiglu_ldgu;
   void* swiglu_dgu; int64_t swiglu_lddgu;
   int32_t swiglu_I;
+  /* SwiGLU forward as the epilogue of the up-projection GEMM (the gate projection has run): swiglu_gate != NULL:
+   * C[m][n] = bf16(v) is up(x) as usual, and additionally  swiglu_act[m][n] = silu(gate[m][n]) * C[m][n]  (from the
+   * ROUNDED C, the value the backward reads).  bf16 output, no split_k, no residual / gelu modes. */
+  const void* swiglu_gate; int64_t swiglu_ldgate;
+  void* swiglu_act; int64_t swiglu_ldact;
 } ur_gemm_args;
 int64_t ur_gemm_workspace_bytes(const ur_gemm_args* a);
 int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, void* stream);

@@ -243,6 +243,29 @@ def test_gemm_swiglu_backward_epilogue(M, I, K):
         assert (dgu.float() - two.float()).norm() / want.norm() < 1e-2
 
 
+@pytest.mark.parametrize("M,I,K", [(300, 256, 128), (16384, 1024, 64), (1000, 516, 72)])
+def test_gemm_swiglu_forward_epilogue(M, I, K):
+    """ur_gemm with swiglu_gate: the up projection's epilogue reads the gate tile and writes act = silu(gate) * up beside up;
+    identical to the two-kernel path bit for bit (the product uses the ROUNDED up in both), gate | up as column halves of
+    one buffer (strided views) like the decoder calls it."""
+    x, w = _bf(_randn((M, K), 1)), _bf(_randn((I, K), 2, 0.2))
+    act = torch.full((M, I), float("nan"), device=DEV, dtype=torch.bfloat16)
+    if I % 8 == 0:
+        gu = torch.empty((M, 2 * I), device=DEV, dtype=torch.bfloat16)
+        gu[:, :I] = _bf(_randn((M, I), 3))
+        gate, upv = gu[:, :I], gu[:, I:]
+    else:               # (column halves of one buffer would leave the up half 8-byte aligned only: separate tensors)
+        gate, upv = _bf(_randn((M, I), 3)), torch.empty((M, I), device=DEV, dtype=torch.bfloat16)
+    hip.gemm(x, w, out=upv, swiglu_fwd=(gate, act))
+    up = hip.gemm(x, w)
+    assert torch.equal(upv, up)
+    want = torch.nn.functional.silu(gate.float()) * up.float()
+    assert torch.isfinite(act.float()).all()
+    assert (act.float() - want).norm() / want.norm() < 4e-3
+    if I % 8 == 0:
+        assert torch.equal(act, hip.swiglu_fwd(gu.contiguous(), I))
+
+
 @pytest.mark.parametrize("p", [0.1, 0.2, 0.5])
 def test_dropout_counter_hash_statistics(p):
     """The counter-based dropout generator (common.cuh ur_hash2: keyed 32-bit murmur finaliser): drop rate, independence

@@ -30,7 +30,8 @@ class GemmArgs(ctypes.Structure):
                 ("drop_bits", c_void_p), ("drop_bits_ld", c_i64), ("drop_bits_stride", c_i64),
                 ("drop_rank", c_int), ("drop_p", c_float),
                 ("swiglu_gu", c_void_p), ("swiglu_ldgu", c_i64), ("swiglu_dgu", c_void_p), ("swiglu_lddgu", c_i64),
-                ("swiglu_I", c_int)]
+                ("swiglu_I", c_int),
+                ("swiglu_gate", c_void_p), ("swiglu_ldgate", c_i64), ("swiglu_act", c_void_p), ("swiglu_ldact", c_i64)]
 
 
 class LoraArgs(ctypes.Structure):

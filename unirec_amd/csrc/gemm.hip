@@ -69,7 +69,8 @@ struct GemmP {
   // LoRA dropout (ur_gemm_args.drop_*): masked rank-r LoRA epilogue driven by the adapters' dropped-flag bit planes
   const uint8_t* drop_bits; long drop_bits_ld, drop_bits_stride; int drop_rank; float drop_inv_keep;
   // SwiGLU backward epilogue (ur_gemm_args.swiglu_*): the result is d(act); dgate / dup leave instead of C
-  const bf16_t* sw_gu; long sw_ldgu; bf16_t* sw_dgu; long sw_lddgu; int sw_I;
+  // (forward epilogue, sw_mode 2: sw_gu = gate, sw_dgu = act)
+  const bf16_t* sw_gu; long sw_ldgu; bf16_t* sw_dgu; long sw_lddgu; int sw_I; int sw_mode;
 };
 
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
@@ -210,9 +211,9 @@ __device__ __forceinline__ void lds_frags(bf16x8* f, const char* tile, int idx0,
 }
 
 // BM x BN block tile, NWM x NWN waves; each wave owns (BM/NWM) rows x (BN/NWN) columns of C.
-// SWIGLU: the SwiGLU backward epilogue (ur_gemm_args.swiglu_*) as its own instantiation, so the ordinary kernels' code
-// and register allocation do not change with it.
-template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN, bool SWIGLU = false>
+// EPI: 1 = SwiGLU backward epilogue (ur_gemm_args.swiglu_gu), 2 = SwiGLU forward epilogue (ur_gemm_args.swiglu_gate), each its
+// own instantiation, so the ordinary kernels' code and register allocation do not change with them.
+template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN, int EPI = 0>
 __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NWM * NWN * 64;
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     }
   } else {
     bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
-    const bool rich = SWIGLU || p.res || p.aux || p.gelu_out;        // uniform (a bias alone stays on the plain path)
+    const bool rich = EPI != 0 || p.res || p.aux || p.gelu_out;        // uniform (a bias alone stays on the plain path)
     __syncthreads();                                                   // every wave is done with the ring
     if (!rich) {
       constexpr int CROWB = BN * 2 + 16;            // padded LDS row of the bf16 C tile
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
                          (!p.res || (((p.ldres & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0))) &&
                          (!p.aux || (((p.ldaux & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.aux) & 15) == 0))) &&
                          (!p.gelu_out || (((p.ldg & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.gelu_out) & 15) == 0))) &&
-                         (!SWIGLU || (((p.sw_ldgu & 7) == 0) && ((p.sw_lddgu & 7) == 0) && ((p.sw_I & 7) == 0) &&
+                         (EPI == 0 || (((p.sw_ldgu & 7) == 0) && ((p.sw_lddgu & 7) == 0) && ((p.sw_I & 7) == 0) &&
                                        ((reinterpret_cast<uintptr_t>(p.sw_gu) & 15) == 0) && ((reinterpret_cast<uintptr_t>(p.sw_dgu) & 15) == 0)));
       // pieces of 8 columns (16 bytes) when everything is 16-byte addressable, else of 4 columns (N, ld % 4 == 0 always)
       const int cw = wide8 ? 8 : 4, cpr = (BN / 2) / cw, ch = tid % cpr, rstep = NT / cpr;
@@ -739,10 +740,11 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
             if (p.aux && ok[k]) ldp(p.aux + (long)m * p.ldaux + n, aw[k]);
             gw[k][0] = gw[k][1] = gw[k][2] = gw[k][3] = 0;
             uw[k][0] = uw[k][1] = uw[k][2] = uw[k][3] = 0;
-            if (SWIGLU && ok[k]) {
+            if (EPI == 1 && ok[k]) {
               ldp(p.sw_gu + (long)m * p.sw_ldgu + n, gw[k]);
               ldp(p.sw_gu + (long)m * p.sw_ldgu + p.sw_I + n, uw[k]);
             }
+            if (EPI == 2 && ok[k]) ldp(p.sw_gu + (long)m * p.sw_ldgu + n, gw[k]);       // gate
           }
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -761,7 +763,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) { v[2 * e] *= gelu_erf_grad_f(bf_lo(aw[k][e])); v[2 * e + 1] *= gelu_erf_grad_f(bf_hi(aw[k][e])); }
             }
-            if (SWIGLU) {
+            if (EPI == 1) {
               // d(act) = v (f32, unrounded): dgate = v u silu'(g), dup = v silu(g)   (elementwise.hip: swiglu_bwd_kernel)
               uint32_t og[4], ou[4];
 #pragma unroll
@@ -785,6 +787,13 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
             stp(Cb + (long)m * p.ldc + n, o);
+            if (EPI == 2) {
+              // act = silu(gate) * up, from the bf16-ROUNDED up the backward will read (elementwise.hip: swiglu_fwd_kernel)
+              uint32_t oa[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) oa[e] = pack_bf2(silu_f(bf_lo(gw[k][e])) * bf_lo(o[e]), silu_f(bf_hi(gw[k][e])) * bf_hi(o[e]));
+              stp(p.sw_dgu + (long)m * p.sw_lddgu + n, oa);
+            }
             if (p.gelu_out) {
               // GELU of the bf16-ROUNDED pre-activation, so backward's gelu'(u) sees the same u
               uint32_t gq[4];
@@ -817,7 +826,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
   }
 }
 
-template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN, bool SWIGLU = false>
+template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN, int EPI = 0>
 int launch_cfg(GemmP p, int splits, hipStream_t st) {
   constexpr int S_BYTES = SK ? Tile<BN>::KC_BYTES : Tile<BN>::KS_BYTES;
   constexpr int R_BYTES = RK ? Tile<BM>::KC_BYTES : Tile<BM>::KS_BYTES;
@@ -825,14 +834,14 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
   constexpr int SMEM = OUTF32 ? RING : (RING > CTILE ? RING : CTILE);
   static bool attr_set = false;   // idempotent; a race only repeats the call
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN, SWIGLU>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) UR_FAIL((int)e, "ur_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
     attr_set = true;
   }
   p.gm = ur_cdiv(p.M, BM); p.gn = ur_cdiv(p.N, BN);
   dim3 grid(p.gm * p.gn, 1, splits);
-  hipLaunchKernelGGL((gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN, SWIGLU>), grid, dim3(NWM * NWN * 64), SMEM, st, p);
+  hipLaunchKernelGGL((gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN, EPI>), grid, dim3(NWM * NWN * 64), SMEM, st, p);
   UR_CHECK_LAUNCH("ur_gemm");
   return 0;
 }
@@ -843,9 +852,13 @@ template <bool RK, bool SK, bool OUTF32>
 int launch(const GemmP& p, int splits, hipStream_t st) {
   const long big_wgs = (long)ur_cdiv(p.M, 256) * ur_cdiv(p.N, 256) * splits;
   if constexpr (RK && SK && !OUTF32) {
-    if (p.sw_gu) {       // SwiGLU backward epilogue: K-contiguous bf16 launches only (ur_gemm checks)
-      if (p.M >= 256 && p.N >= 256 && big_wgs >= 256) return launch_cfg<true, true, false, 256, 256, 2, 4, true>(p, splits, st);
-      return launch_cfg<true, true, false, 128, 128, 2, 2, true>(p, splits, st);
+    if (p.sw_gu && p.sw_mode == 1) {       // SwiGLU backward epilogue: K-contiguous bf16 launches only (ur_gemm checks)
+      if (p.M >= 256 && p.N >= 256 && big_wgs >= 256) return launch_cfg<true, true, false, 256, 256, 2, 4, 1>(p, splits, st);
+      return launch_cfg<true, true, false, 128, 128, 2, 2, 1>(p, splits, st);
+    }
+    if (p.sw_gu && p.sw_mode == 2) {       // SwiGLU forward epilogue
+      if (p.M >= 256 && p.N >= 256 && big_wgs >= 256) return launch_cfg<true, true, false, 256, 256, 2, 4, 2>(p, splits, st);
+      return launch_cfg<true, true, false, 128, 128, 2, 2, 2>(p, splits, st);
     }
   }
   if (p.M >= 256 && p.N >= 256 && big_wgs >= 256) return launch_cfg<RK, SK, OUTF32, 256, 256, 2, 4>(p, splits, st);
@@ -904,6 +917,13 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
     UR_REQUIRE(!a->gelu_grad_aux || ((a->ldaux % 4) == 0 && (((uintptr_t)a->gelu_grad_aux) & 7) == 0), "ur_gemm: aux misaligned");
   }
   UR_REQUIRE(!a->bias || UR_ALIGNED16(a->bias), "ur_gemm: bias must be 16-byte aligned");
+  if (a->swiglu_gate) {
+    UR_REQUIRE(!a->swiglu_gu && !a->c_f32 && splits <= 1 && !a->residual && !a->gelu_out && !a->gelu_grad_aux && a->r_kcontig && a->s_kcontig,
+               "ur_gemm: the SwiGLU forward epilogue needs K-contiguous operands, bf16 output, no split_k / residual / gelu modes");
+    UR_REQUIRE(a->swiglu_act && (a->swiglu_ldgate % 4) == 0 && (a->swiglu_ldact % 4) == 0 && a->swiglu_ldgate >= a->N && a->swiglu_ldact >= a->N &&
+               (((uintptr_t)a->swiglu_gate) & 7) == 0 && (((uintptr_t)a->swiglu_act) & 7) == 0,
+               "ur_gemm: SwiGLU forward epilogue: gate / act rows of >= N elements, 8-byte aligned");
+  }
   if (a->swiglu_gu) {
     UR_REQUIRE(!a->c_f32 && splits <= 1 && !a->residual && !a->gelu_out && !a->gelu_grad_aux && !a->bias && a->r_kcontig && a->s_kcontig,
                "ur_gemm: the SwiGLU backward epilogue needs K-contiguous operands, bf16 output, no split_k / bias / residual / gelu modes");
@@ -930,7 +950,11 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
   p.drop_rank = a->drop_rank;
   p.drop_inv_keep = a->drop_bits ? 1.0f / (1.0f - a->drop_p) : 1.0f;
   p.sw_gu = (const bf16_t*)a->swiglu_gu; p.sw_ldgu = a->swiglu_ldgu; p.sw_dgu = (bf16_t*)a->swiglu_dgu; p.sw_lddgu = a->swiglu_lddgu;
-  p.sw_I = a->swiglu_I;
+  p.sw_I = a->swiglu_I; p.sw_mode = a->swiglu_gu ? 1 : 0;
+  if (a->swiglu_gate) {
+    p.sw_gu = (const bf16_t*)a->swiglu_gate; p.sw_ldgu = a->swiglu_ldgate; p.sw_dgu = (bf16_t*)a->swiglu_act; p.sw_lddgu = a->swiglu_ldact;
+    p.sw_I = 0; p.sw_mode = 2;
+  }
   p.slab_stride = 0;
   if (splits > 1) {
     int tiles = ur_cdiv(a->K, BK);

@@ -52,11 +52,12 @@ def workspace(nbytes, device, tag="default"):
 # ------------------------------------------------------------------------------------------------
 def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=None, out_f32=False, alpha=1.0,
          bias=None, residual=None, gelu_out=None, gelu_grad_aux=None, R2=None, S2=None, split_k=1, drop=None,
-         swiglu_bwd=None):
+         swiglu_bwd=None, swiglu_fwd=None):
     """C[M,N] = alpha*(R(m,k) S(n,k) + R2 S2) + epilogue.  R/S are 2-D bf16 (row stride = stride(0)).
     drop = (bits, p, rank): masked LoRA epilogue (bits = hip.lora_dropout_bits planes of the adapters' shared input),
     swiglu_bwd = (gu, dgu): the result is d(act) of SwiGLU; dgate | dup are written to dgu [M, 2N] and no C is produced
-    (returns dgu).  See ur_gemm_args in include/unirec_hip.h."""
+    (returns dgu).  swiglu_fwd = (gate, act): C is up(x) as usual and act[M, N] = silu(gate) * C is written beside it.
+    See ur_gemm_args in include/unirec_hip.h."""
     lib = _lib.load()
     for t, n in ((R, "R"), (S, "S")):
         if t.dtype != BF16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
@@ -98,6 +99,12 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
     if swiglu_bwd is not None:
         a.swiglu_gu, a.swiglu_ldgu = gu_.data_ptr(), gu_.stride(0)
         a.swiglu_dgu, a.swiglu_lddgu, a.swiglu_I = dgu_.data_ptr(), dgu_.stride(0), N
+    if swiglu_fwd is not None:
+        gate_, act_ = swiglu_fwd
+        for t, n in ((gate_, "gate"), (act_, "act")):
+            if t.dtype != BF16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.shape[0] != M or t.shape[1] != N:
+                raise ValueError(f"gemm: swiglu_fwd {n} must be a bf16 [M, N] device tensor with unit inner stride")
+        a.swiglu_gate, a.swiglu_ldgate, a.swiglu_act, a.swiglu_ldact = gate_.data_ptr(), gate_.stride(0), act_.data_ptr(), act_.stride(0)
     if drop is not None:
         bits, pdrop, rank = drop
         a.drop_bits, a.drop_bits_ld, a.drop_bits_stride = bits.data_ptr(), bits.stride(1), bits.stride(0)
