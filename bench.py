@@ -349,11 +349,13 @@ def main():
         # ---- roofline of the dominant kernel: forward projection GEMM gemm_kernel<RK=1,SK=1,bf16> -----
         tot_ms, tot_fl, n = 0.0, 0.0, 0
         all_ms, all_fl = 0.0, 0.0
-        for (e0, e1, rk, sk, f32, M, N, K, split) in prof:
+        for (e0, e1, rk, sk, f32, M, N, K, split, epi) in prof:
             ms = e0.elapsed_time(e1)
             all_ms += ms; all_fl += 2.0 * M * N * K
-            # exactly the launches ur_gemm dispatches to gemm_kernel<RK=1,SK=1,bf16,256,256,2,4> (gemm.hip: launch())
-            if rk and sk and not f32 and M >= 256 and N >= 256 and (-(-M // 256)) * (-(-N // 256)) * max(split, 1) >= 256:
+            # exactly the launches ur_gemm dispatches to gemm_kernel<RK=1,SK=1,bf16,256,256,2,4,EPI=0> (gemm.hip: launch()); the
+            # down-projection dX launches that carry the SwiGLU backward in their epilogue are another instantiation (EPI=1: an
+            # HBM-bound elementwise pass rides on them) and are counted under all_gemm only
+            if epi == 0 and rk and sk and not f32 and M >= 256 and N >= 256 and (-(-M // 256)) * (-(-N // 256)) * max(split, 1) >= 256:
                 tot_ms += ms; tot_fl += 2.0 * M * N * K; n += 1
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         # HBM bytes of one launch from the separate rocprofv3 --pmc passes (profiles/r1_gemm_pmc.json); bench.py itself

@@ -118,7 +118,8 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
         e0.record()
         check(lib.ur_gemm(ctypes.byref(a), ws, wsb, _stream()), "ur_gemm")
         e1.record()
-        PROFILE.append((e0, e1, int(r_kcontig), int(s_kcontig), int(out.dtype == F32), M, N, K + int(a.K2), int(split_k)))
+        PROFILE.append((e0, e1, int(r_kcontig), int(s_kcontig), int(out.dtype == F32), M, N, K + int(a.K2), int(split_k),
+                        1 if swiglu_bwd is not None else (2 if swiglu_fwd is not None else 0)))
         return out
     check(lib.ur_gemm(ctypes.byref(a), ws, wsb, _stream()), "ur_gemm")
     return out
