@@ -145,6 +145,10 @@ def load():
         raise UniRecHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C unirec_amd/csrc`).  The UniRec MI355X path has no CPU fallback.")
+    # torch first: its bundled HIP runtime must be the process's only one.  The library's libamdhip64 dependency then resolves
+    # to the already-loaded copy; loaded the other way round (build() before anything imported torch) the process ends up with
+    # two runtimes and the library's launches fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here == header/library mismatch: fail loudly
