@@ -108,7 +108,7 @@ struct ProjP {
 // X fragments are the MFMA column operand straight from global memory (lane: token lane&15, 8 consecutive
 // columns); the U chunk is staged once per block through a 2-slot LDS ring (GEMM K-contiguous image).
 template <int NAD, bool MASKED>
-__global__ __launch_bounds__(256) void lora_project_kernel(ProjP p) {
+__global__ __launch_bounds__(256, 4) void lora_project_kernel(ProjP p) {
   constexpr int RB = 2, KC = 128;
   constexpr int SUB = NAD * 16 * 128;              // one 64-column sub-tile of the U chunk: rows x 128 B
   constexpr int STAGE = 2 * SUB;
