@@ -45,7 +45,12 @@ def gemm(args):
         S_ = (torch.randn(N, K, generator=g) if sk else torch.randn(K, N, generator=g)).cuda().to(torch.bfloat16) * 0.05
         out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
         t = timeit(lambda: hip.gemm(R, S_, r_kcontig=rk, s_kcontig=sk, out=out), args.iters)
-        print(f"gemm {name:12s} M={M} N={N} K={K}: {t:.3f} ms  {2 * M * N * K / t / 1e9:.1f} TFLOP/s")
+        line = f"gemm {name:12s} M={M} N={N} K={K}: {t:.3f} ms  {2 * M * N * K / t / 1e9:.1f} TFLOP/s"
+        if args.lib:       # reference point only (the product never calls it): the vendor library GEMM torch dispatches to
+            Sm = S_ if sk else S_.t()
+            tl = timeit(lambda: torch.matmul(R, Sm.t(), out=out), args.iters)
+            line += f"   | torch.matmul (hipBLASLt / rocBLAS): {tl:.3f} ms  {2 * M * N * K / tl / 1e9:.1f} TFLOP/s"
+        print(line)
 
 
 def dw(args):
@@ -137,5 +142,6 @@ if __name__ == "__main__":
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--S", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--lib", action="store_true", help="gemm: also time torch.matmul on the same operands (reference point)")
     a = ap.parse_args()
     {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora}[a.what](a)
