@@ -20,6 +20,7 @@
 // tile t+2 is issued under tile t's 64 MFMAs per wave (one barrier per tile, between its two k-halves).
 // K-contiguous tiles are read with ds_read_b128, K-strided tiles with ds_read_b64_tr_b16 (hardware
 // transpose); both images are bank-conflict-free.
+#include <cstdlib>
 #include <type_traits>
 #include "common.cuh"
 #include "unirec_hip.h"
@@ -66,6 +67,7 @@ struct GemmP {
   bf16_t* gelu_out; long ldg; const bf16_t* aux; long ldaux;
   int ksplit_len; long slab_stride;
   int gm, gn;
+  int gcw;    // column-chunk width (tiles) of the per-XCD tile order; 0 = plain row-major runs
   // LoRA dropout (ur_gemm_args.drop_*): masked rank-r LoRA epilogue driven by the adapters' dropped-flag bit planes
   const uint8_t* drop_bits; long drop_bits_ld, drop_bits_stride; int drop_rank; float drop_inv_keep;
   // SwiGLU backward epilogue (ur_gemm_args.swiglu_*): the result is d(act); dgate / dup leave instead of C
@@ -242,7 +244,16 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     int q = nwg >> 3, r = nwg & 7, x = id & 7;
     id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
   }
-  const int bm = id / p.gn, bn = id - bm * p.gn;
+  int bm = id / p.gn, bn = id - bm * p.gn;
+  if (p.gcw > 0) {
+    // each XCD owns gm/8 whole tile rows (host checks divisibility): walk them in column chunks of gcw tiles, so a
+    // chunk's S panels (gcw * BN * K * 2 bytes) are what the XCD's L2 has to hold while the R panels stream past
+    const int run = nwg >> 3, rows_x = run / p.gn, x = blockIdx.x & 7;
+    const int j = id - x * run, per = rows_x * p.gcw;
+    const int ch = j / per, rem = j - ch * per;
+    bm = x * rows_x + rem / p.gcw;
+    bn = ch * p.gcw + rem % p.gcw;
+  }
   const int m0 = bm * BM, n0 = bn * BN;
   const int z = blockIdx.z;
   UR_STAMP(0);
@@ -840,6 +851,16 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
     attr_set = true;
   }
   p.gm = ur_cdiv(p.M, BM); p.gn = ur_cdiv(p.N, BN);
+  {
+    // UR_GEMM_CW = n (lab): walk each XCD's tiles in column chunks of n tiles.  With K = 1024 a tile's S panel is 512 KiB: an
+    // XCD's 32 concurrent tiles over 12 column tiles keep 6 MiB of S panels in play against a 4 MiB L2 and every tile
+    // re-fetches its panel from the Infinity Cache; chunks of 4 halve the fabric reads of the N = 3072 launches (FETCH_SIZE
+    // 2.24 -> 1.20 GB for gate_proj, profiles/r1_gemm_pmc.json) -- and cost 1 % of the joint step in alternating same-box
+    // runs (118.8 vs 117.5 seq/s), so the plain row-major runs stay the default.
+    static const int env_cw = [] { const char* e = getenv("UR_GEMM_CW"); return e ? atoi(e) : 0; }();
+    p.gcw = 0;
+    if (env_cw > 0 && BM == 256 && (p.gm % 8) == 0 && p.gn > env_cw && (p.gn % env_cw) == 0) p.gcw = env_cw;
+  }
   dim3 grid(p.gm * p.gn, 1, splits);
   hipLaunchKernelGGL((gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN, EPI>), grid, dim3(NWM * NWN * 64), SMEM, st, p);
   UR_CHECK_LAUNCH("ur_gemm");
