@@ -172,6 +172,8 @@ ALL = {
     # shrunken C3: cross every layer, Q=64, ragged T
     "user_t96": dict(kind="user", seed=21, B=3, T=96, cfg=dict(H=128, L=2, nh=2, I=256, Q=64, E=128, n_pred=4)),
     "user_t8": dict(kind="user", seed=22, B=2, T=8, cfg=dict(H=128, L=2, nh=2, I=256, Q=64, E=192, n_pred=2)),
+    # >= 256 keys: the cross-attention backward takes the few-query dK/dV kernel (attn_bwd_dkv_fewq_kernel)
+    "user_t320": dict(kind="user", seed=23, B=3, T=320, cfg=dict(H=128, L=2, nh=2, I=256, Q=64, E=128, n_pred=4)),
     # Qwen3 decoder alone, right padding (no fully-masked query rows) and left padding
     "qwen_right": dict(kind="qwen", seed=31, B=3, S=40, pad_side="right", qwen=_TINYQ),
     "qwen_left": dict(kind="qwen", seed=32, B=3, S=40, pad_side="left", qwen=_TINYQ),

@@ -247,7 +247,10 @@ def gen_qwen_only(case):
 
 def main():
     os.makedirs(HERE, exist_ok=True)
+    only = set(sys.argv[1:])          # optional: regenerate the named cases only
     for name, case in cases.ALL.items():
+        if only and name not in only:
+            continue
         kind = case["kind"]
         res = {"item": gen_item, "user": gen_user, "joint": gen_joint, "qwen": gen_qwen_only}[kind](case)
         path = os.path.join(HERE, name + ".npz")
