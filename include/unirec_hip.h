@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 2
+#define UR_ABI_VERSION 3
 
 int ur_version(void);
 const char* ur_last_error(void);
@@ -188,6 +188,14 @@ typedef struct {
   const void* dout; void* dq; void* dk; void* dv;
   int64_t lddo, lddq, lddk, lddv;
   float* delta;
+  /* q-norm + RoPE backward fused into the dQ kernel (Qwen3Attention: q = rope(q_norm(q_proj(x))), modeling_qwen3.py:59-64,
+   * 107-170,244-252; causal, head_dim 128).  rope_q_raw != NULL: q in ur_attn_args was produced from the raw projection
+   * rope_q_raw [B*Sq, >= nq*hd] (row stride rope_ldraw) with norm weight rope_q_weight [hd] (f32), eps rope_eps and the
+   * cos / sin tables [Sq, hd/2] (f32, position = row index inside the sequence); the kernel then writes the gradient of
+   * the RAW projection to rope_dq_raw (row stride rope_lddraw) and dq is not written (may be NULL). */
+  const void* rope_q_raw; int64_t rope_ldraw;
+  const float* rope_q_weight; const float* rope_cos; const float* rope_sin; float rope_eps;
+  void* rope_dq_raw; int64_t rope_lddraw;
 } ur_attn_bwd_args;
 int ur_attn_fwd(const ur_attn_args* a, void* stream);
 int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, void* stream);

@@ -193,6 +193,49 @@ def test_few_query_dkv_kernel_matches_generic_kernel_bitwise(B, nh, Sq, Sk, p_dr
             assert err <= 2e-2 * want.abs().max().item() + 2e-2, f"{name}: max err {err}"
 
 
+@pytest.mark.parametrize("S,mask_kind", [(130, "none"), (512, "left"), (200, "rand")])
+def test_dq_kernel_carries_qnorm_rope_backward(S, mask_kind):
+    """ur_attn_bwd with rope_q_raw: the dQ kernel un-rotates, applies the norm weight and the RMS-norm backward in its store
+    and writes the gradient of the RAW q projection; against the two-kernel path (dQ, then ur_qknorm_rope_bwd) on the same
+    inputs -- same arithmetic from the same bf16-rounded dq, so equal up to the order of two 128-term row sums."""
+    B, nq, nkv, hd, eps = 2, 4, 2, 128, 1e-6
+    NQ, NKV = nq * hd, nkv * hd
+    M = B * S
+    qkv = _randn((M, NQ + 2 * NKV), S).contiguous()
+    g = torch.Generator(device="cpu").manual_seed(S)
+    qw = (1.0 + 0.1 * torch.randn(hd, generator=g)).to(DEV)
+    kw = (1.0 + 0.1 * torch.randn(hd, generator=g)).to(DEV)
+    cos, sin = hip.rope_table(S, hd, 1e6, DEV)
+    q_r, k_r = hip.qknorm_rope_fwd(qkv, qw, kw, cos, sin, S, nq, nkv, hd, eps)
+    km = None
+    if mask_kind != "none":
+        km = torch.ones((B, S), dtype=torch.uint8)
+        if mask_kind == "left":
+            km[1, :70] = 0
+        else:
+            km = (torch.rand((B, S), generator=g) < 0.8).to(torch.uint8); km[:, 0] = 1
+        km = km.to(DEV)
+    v4 = qkv[:, NQ + NKV:].view(B, S, nkv, hd)
+    o, ctx = hip.attn_fwd(q_r.view(B, S, nq, hd), k_r.view(B, S, nkv, hd), v4, causal=True, key_mask=km)
+    dout = _randn((B, S, nq, hd), S + 3)
+    # two kernels
+    d0 = torch.zeros_like(qkv)
+    dq_r = torch.empty((M, NQ), dtype=torch.bfloat16, device=DEV); dk_r = torch.empty((M, NKV), dtype=torch.bfloat16, device=DEV)
+    hip.attn_bwd(ctx, dout, dq=dq_r.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd), dv=d0[:, NQ + NKV:].view(B, S, nkv, hd))
+    hip.qknorm_rope_bwd(dq_r, dk_r, qkv, qw, kw, cos, sin, d0, S, nq, nkv, hd, eps)
+    # fused q part + k-only stand-alone kernel
+    d1 = torch.zeros_like(qkv)
+    dk2 = torch.empty_like(dk_r)
+    hip.attn_bwd(ctx, dout, dk=dk2.view(B, S, nkv, hd), dv=d1[:, NQ + NKV:].view(B, S, nkv, hd), rope_q=(qkv[:, :NQ], qw, cos, sin, eps, d1[:, :NQ]))
+    hip.qknorm_rope_bwd(dk2, dk2, qkv[:, NQ:], qw, kw, cos, sin, d1[:, NQ:], S, 0, nkv, hd, eps)
+    torch.cuda.synchronize()
+    assert torch.equal(dk_r, dk2) and torch.equal(d0[:, NQ:], d1[:, NQ:])          # k and v parts: identical kernels / inputs
+    a, bq = d0[:, :NQ].float(), d1[:, :NQ].float()
+    assert torch.isfinite(bq).all() and a.abs().max() > 0
+    assert (a - bq).abs().max() <= 2e-2 * a.abs().max()                            # elementwise: a bf16 ulp or two
+    assert (a - bq).norm() / a.norm() < 3e-3
+
+
 @pytest.mark.parametrize("spike_key,gain", [(200, 6.0), (31, 3.0), (449, 12.0), (64, 1.5)])
 def test_deferred_max_rescale_is_exact_when_forced(spike_key, gain):
     """The forward defers the running-maximum update while the maximum grows by less than 2^6: a rare, data-dependent

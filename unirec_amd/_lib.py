@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UNIREC_HIP_LIB selects another build of the SAME library (kernel A/B experiments); there is still no fallback.
 LIB_PATH = os.environ.get("UNIREC_HIP_LIB") or os.path.join(_HERE, "lib", "libunirec_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_void_p, c_int, c_i64, c_u64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
@@ -59,7 +59,9 @@ class AttnArgs(ctypes.Structure):
 class AttnBwdArgs(ctypes.Structure):
     """Mirror of ur_attn_bwd_args."""
     _fields_ = [("dout", c_void_p), ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
-                ("lddo", c_i64), ("lddq", c_i64), ("lddk", c_i64), ("lddv", c_i64), ("delta", c_void_p)]
+                ("lddo", c_i64), ("lddq", c_i64), ("lddk", c_i64), ("lddv", c_i64), ("delta", c_void_p),
+                ("rope_q_raw", c_void_p), ("rope_ldraw", c_i64), ("rope_q_weight", c_void_p), ("rope_cos", c_void_p),
+                ("rope_sin", c_void_p), ("rope_eps", c_float), ("rope_dq_raw", c_void_p), ("rope_lddraw", c_i64)]
 
 
 # name -> (restype, argtypes).  Every symbol include/unirec_hip.h declares must appear here

@@ -58,6 +58,10 @@ struct AttnP {
   // backward
   const bf16_t* dout; bf16_t* dq; bf16_t* dk; bf16_t* dv; const float* delta;
   long lddo, lddq, lddk, lddv;
+  // q-norm + RoPE backward fused into the dQ kernel's store (head_dim 128, ur_attn_bwd_args.rope_*): dq leaves as the
+  // gradient of the RAW q projection
+  const bf16_t* rp_raw; long rp_ldraw; const float* rp_w; const float* rp_cos; const float* rp_sin; float rp_eps;
+  bf16_t* rp_draw; long rp_lddraw;
 };
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -575,6 +579,65 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
       vs.commit(nk + C::TILE, tid);
     }
     __syncthreads();
+  }
+  if (HD == 128 && p.rp_raw != nullptr) {
+    // Qwen3Attention: q = rope(q_norm(q_raw)) (modeling_qwen3.py:59-64,107-170,244-252).  dq above is the gradient of the
+    // ROTATED, NORMED q; the lane holds half of its row (d = 32 dt + acc_row(r, h)), and the rotate-half partner d +- 64 is
+    // the same register of tile dt +- 2, so the whole chain back to the raw projection -- un-rotate, norm weight, RMS-norm
+    // backward with its two row sums (registers + one cross-half shuffle each) -- is lane-local.  Same arithmetic as
+    // qknorm_rope_kernel<128, true>; the 2 + 2 activation passes of writing dq and reading it back are gone.
+    const long qrow = (long)b * p.Sq + (qok ? q : 0);
+    const bf16_t* xr = p.rp_raw + qrow * p.rp_ldraw + (long)hq * HD;
+    const int pos = qok ? q : 0;
+    const float* cr = p.rp_cos + (long)pos * (HD / 2);
+    const float* sr = p.rp_sin + (long)pos * (HD / 2);
+    uint2 xp[4][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        xp[dt][rq] = *reinterpret_cast<const uint2*>(xr + 32 * dt + 8 * rq + 4 * h);
+        const float x0 = bf_lo(xp[dt][rq].x), x1 = bf_hi(xp[dt][rq].x), x2 = bf_lo(xp[dt][rq].y), x3 = bf_hi(xp[dt][rq].y);
+        ss += x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
+      }
+    ss += __shfl_xor(ss, 32, 64);
+    const float rs = rsqrtf(ss / (float)HD + p.rp_eps);
+    float t = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int j = 32 * dt + 8 * rq + 4 * h;              // d of the first-half element; its partner is d + 64
+        const float4 c4 = *reinterpret_cast<const float4*>(cr + j), s4 = *reinterpret_cast<const float4*>(sr + j);
+        const float4 wa = *reinterpret_cast<const float4*>(p.rp_w + j), wb = *reinterpret_cast<const float4*>(p.rp_w + j + 64);
+        const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+        const float wA[4] = {wa.x, wa.y, wa.z, wa.w}, wB[4] = {wb.x, wb.y, wb.z, wb.w};
+        const float xA[4] = {bf_lo(xp[dt][rq].x), bf_hi(xp[dt][rq].x), bf_lo(xp[dt][rq].y), bf_hi(xp[dt][rq].y)};
+        const float xB[4] = {bf_lo(xp[dt + 2][rq].x), bf_hi(xp[dt + 2][rq].x), bf_lo(xp[dt + 2][rq].y), bf_hi(xp[dt + 2][rq].y)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rq + e;
+          // the standalone kernel reads dq back as bf16: round here too, so both paths see the same upstream gradient
+          const float dA = bf2f(f2bf(dq[dt][r])), dB = bf2f(f2bf(dq[dt + 2][r]));
+          const float gA = (dA * cc[e] + dB * sn[e]) * wA[e];            // d <  64: dy c + dy[d+64] s
+          const float gB = (dB * cc[e] - dA * sn[e]) * wB[e];            // d >= 64: dy c - dy[d-64] s
+          t += gA * (xA[e] * rs) + gB * (xB[e] * rs);
+          dq[dt][r] = gA; dq[dt + 2][r] = gB;
+        }
+      }
+    t += __shfl_xor(t, 32, 64);
+    t /= (float)HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float xv[4] = {bf_lo(xp[dt][rq].x), bf_hi(xp[dt][rq].x), bf_lo(xp[dt][rq].y), bf_hi(xp[dt][rq].y)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dq[dt][4 * rq + e] = rs * (dq[dt][4 * rq + e] - xv[e] * rs * t);
+      }
+    store_T<HD>(p.rp_draw + qrow * p.rp_lddraw + (long)hq * HD, dq, 1.0f, lane, qok);
+    return;
   }
   store_T<HD>(p.dq + ((long)b * p.Sq + (qok ? q : 0)) * p.lddq + (long)hq * HD, dq, 1.0f, lane, qok);
 }
@@ -1561,12 +1624,21 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
   int rc = fill(p, a);
   if (rc) return rc;
   if (a->B == 0) return 0;
-  UR_REQUIRE(g && g->dout && g->dq && g->dk && g->dv && g->delta && a->o, "ur_attn_bwd: null argument");
+  UR_REQUIRE(g && g->dout && (g->dq || g->rope_q_raw) && g->dk && g->dv && g->delta && a->o, "ur_attn_bwd: null argument");
+  if (g->rope_q_raw) {
+    UR_REQUIRE(a->head_dim == 128 && a->causal && a->Sq == a->Sk, "ur_attn_bwd: the fused q-norm / RoPE backward is built for the causal head_dim-128 shape");
+    UR_REQUIRE(g->rope_q_weight && g->rope_cos && g->rope_sin && g->rope_dq_raw && UR_ALIGNED16(g->rope_q_raw) && UR_ALIGNED16(g->rope_dq_raw) &&
+               UR_ALIGNED16(g->rope_q_weight) && UR_ALIGNED16(g->rope_cos) && UR_ALIGNED16(g->rope_sin) && (g->rope_ldraw % 8) == 0 &&
+               (g->rope_lddraw % 8) == 0 && g->rope_ldraw >= (int64_t)a->nq * a->head_dim && g->rope_lddraw >= (int64_t)a->nq * a->head_dim,
+               "ur_attn_bwd: bad q-norm / RoPE operands (16-byte aligned, row strides %% 8 == 0)");
+  }
   UR_REQUIRE(UR_ALIGNED16(g->dout) && UR_ALIGNED16(a->o) && (g->lddo % 8) == 0 && (a->ldo % 8) == 0, "ur_attn_bwd: dout/o need 16-byte aligned rows");
-  UR_REQUIRE((g->lddq % 4) == 0 && (g->lddk % 4) == 0 && (g->lddv % 4) == 0 && ((uintptr_t)g->dq & 7) == 0 && ((uintptr_t)g->dk & 7) == 0 &&
+  UR_REQUIRE((g->dq == nullptr || (g->lddq % 4) == 0) && (g->lddk % 4) == 0 && (g->lddv % 4) == 0 && ((uintptr_t)g->dq & 7) == 0 && ((uintptr_t)g->dk & 7) == 0 &&
              ((uintptr_t)g->dv & 7) == 0, "ur_attn_bwd: gradient outputs need 8-byte aligned rows");
   p.dout = (const bf16_t*)g->dout; p.dq = (bf16_t*)g->dq; p.dk = (bf16_t*)g->dk; p.dv = (bf16_t*)g->dv; p.delta = g->delta;
   p.lddo = g->lddo; p.lddq = g->lddq; p.lddk = g->lddk; p.lddv = g->lddv;
+  p.rp_raw = (const bf16_t*)g->rope_q_raw; p.rp_ldraw = g->rope_ldraw; p.rp_w = g->rope_q_weight; p.rp_cos = g->rope_cos; p.rp_sin = g->rope_sin;
+  p.rp_eps = g->rope_eps; p.rp_draw = (bf16_t*)g->rope_dq_raw; p.rp_lddraw = g->rope_lddraw;
   hipStream_t st = (hipStream_t)stream;
   if (tiny_shape(p, a->head_dim, a->causal != 0, true)) return launch_tiny(p, true, st);      // dQ, dK, dV in one kernel
   // the dQ kernel also computes the row constants (delta, -LSE/scale) and leaves them in `delta` for dK/dV

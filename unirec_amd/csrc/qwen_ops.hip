@@ -256,7 +256,7 @@ extern "C" int ur_rope_table(float* cos_out, float* sin_out, int32_t S, int32_t 
 static int qk_common_check(const void* raw, int64_t ldraw, const float* qw, const float* kw, const float* c, const float* s,
                            int64_t M, int32_t S, int32_t nq, int32_t nkv, int32_t hd, const char* who) {
   UR_REQUIRE(hd == 64 || hd == 128, "%s: head_dim must be 64 or 128", who);
-  UR_REQUIRE(raw && qw && kw && c && s && M >= 0 && S > 0 && nq > 0 && nkv > 0, "%s: null / bad argument", who);
+  UR_REQUIRE(raw && qw && kw && c && s && M >= 0 && S > 0 && nq >= 0 && nkv > 0, "%s: null / bad argument", who);   // (nq == 0: the k heads alone)
   UR_REQUIRE((ldraw % 8) == 0 && ldraw >= (int64_t)(nq + 2 * nkv) * hd && UR_ALIGNED16(raw) && UR_ALIGNED16(qw) && UR_ALIGNED16(kw) &&
              UR_ALIGNED16(c) && UR_ALIGNED16(s), "%s: alignment / stride", who);
   return 0;

@@ -315,11 +315,13 @@ def attn_fwd(q, k, v, *, causal, key_mask=None, scale=None, dropout_p=0.0, seed=
     return out, ctx
 
 
-def attn_bwd(ctx, dout, dq=None, dk=None, dv=None):
-    """dout [B,Sq,nq,hd] -> (dq, dk, dv); outputs may be strided views into a fused gradient buffer."""
+def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None):
+    """dout [B,Sq,nq,hd] -> (dq, dk, dv); outputs may be strided views into a fused gradient buffer.
+    rope_q = (q_raw [M, >= nq*hd] view, q_norm_weight f32 [hd], cos, sin, eps, dq_raw [M, >= nq*hd] view): the dQ kernel carries
+    the q-norm + RoPE backward and writes the gradient of the RAW q projection into dq_raw; no dq is produced (returns None)."""
     lib = _lib.load()
     q, k, v, _ = ctx.keep
-    if dq is None:
+    if dq is None and rope_q is None:
         dq = torch.empty(q.shape, dtype=BF16, device=q.device)
     if dk is None:
         dk = torch.empty(k.shape, dtype=BF16, device=q.device)
@@ -328,8 +330,13 @@ def attn_bwd(ctx, dout, dq=None, dk=None, dv=None):
     a = ctx.args
     delta = torch.empty((2, a.B, a.nq, a.Sq), dtype=F32, device=q.device)   # row constants: -rowsum(dO*O), -LSE/scale
     g = AttnBwdArgs()
-    g.dout, g.dq, g.dk, g.dv = dout.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
-    g.lddo, g.lddq, g.lddk, g.lddv = _tok_stride(dout), _tok_stride(dq), _tok_stride(dk), _tok_stride(dv)
+    g.dout, g.dq, g.dk, g.dv = dout.data_ptr(), (0 if dq is None else dq.data_ptr()), dk.data_ptr(), dv.data_ptr()
+    g.lddo, g.lddq, g.lddk, g.lddv = _tok_stride(dout), (0 if dq is None else _tok_stride(dq)), _tok_stride(dk), _tok_stride(dv)
+    if rope_q is not None:
+        q_raw, qw, cos, sin, eps, dq_raw = rope_q
+        g.rope_q_raw, g.rope_ldraw, g.rope_q_weight = q_raw.data_ptr(), q_raw.stride(0), qw.data_ptr()
+        g.rope_cos, g.rope_sin, g.rope_eps = cos.data_ptr(), sin.data_ptr(), float(eps)
+        g.rope_dq_raw, g.rope_lddraw = dq_raw.data_ptr(), dq_raw.stride(0)
     g.delta = delta.data_ptr()
     check(lib.ur_attn_bwd(ctypes.byref(a), ctypes.byref(g), _stream()), "ur_attn_bwd")
     return dq, dk, dv

@@ -470,11 +470,21 @@ class Qwen3LoRAModel(nn.Module):
             else:
                 datt = hip.gemm(dx2, fl["oT"])
             dqkv = torch.empty_like(qkv)
-            dq_r = torch.empty((M, NQ), dtype=BF16, device=dev)
             dk_r = torch.empty((M, NKV), dtype=BF16, device=dev)
-            hip.attn_bwd(L["actx"], datt.view(B, S, nq, hd), dq=dq_r.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd),
-                         dv=dqkv[:, NQ + NKV:].view(B, S, nkv, hd))
-            hip.qknorm_rope_bwd(dq_r, dk_r, qkv, fl["qn"], fl["kn"], cos, sin, dqkv, S, nq, nkv, hd, eps)
+            if hd == 128 and os.environ.get("UNIREC_ROPE_BWD_FUSED", "0") == "1":
+                # UNIREC_ROPE_BWD_FUSED=1: the dQ kernel carries the q-norm + RoPE backward of the q heads (its lanes own whole
+                # rows) and writes straight into dqkv; the stand-alone kernel is left with the k heads (nq = 0, operands offset
+                # to the k columns).  Parity-tested; measured neutral on the joint step (115.7 vs 115.9 seq/s, alternating
+                # same-box runs: the ~1000 vector instructions per wave in the dQ kernel's store cost what the 4 saved
+                # activation passes return), so the separate launch stays the default.
+                hip.attn_bwd(L["actx"], datt.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd), dv=dqkv[:, NQ + NKV:].view(B, S, nkv, hd),
+                             rope_q=(qkv[:, :NQ], fl["qn"], cos, sin, eps, dqkv[:, :NQ]))
+                hip.qknorm_rope_bwd(dk_r, dk_r, qkv[:, NQ:], fl["qn"], fl["kn"], cos, sin, dqkv[:, NQ:], S, 0, nkv, hd, eps)
+            else:
+                dq_r = torch.empty((M, NQ), dtype=BF16, device=dev)
+                hip.attn_bwd(L["actx"], datt.view(B, S, nq, hd), dq=dq_r.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd),
+                             dv=dqkv[:, NQ + NKV:].view(B, S, nkv, hd))
+                hip.qknorm_rope_bwd(dq_r, dk_r, qkv, fl["qn"], fl["kn"], cos, sin, dqkv, S, nq, nkv, hd, eps)
             h = L["h"] if "h" in L else hip.rmsnorm_fwd(x, fl["ln1"], eps)[0]              # kept, or recomputed
             if pack is not None:
                 a_names = [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"]
