@@ -889,12 +889,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 // attn_bwd_dkv_kernel gives every 128-key workgroup its own copy of the (single) Q / dO tile and runs at one wave per
 // SIMD: 106 496 workgroups that each load, wait, do 32 MFMAs per wave and leave -- latency end to end (4.1 ms per
 // layer at C3 for 6.8 GB of K/V/dK/dV traffic).  Here a workgroup keeps the Q / dO tile and the row constants of ONE
-// (batch, head) pair in LDS and its 4 waves walk that pair's 32-key blocks (wave w takes blocks w, w+4, ...), the
-// next block's K / V fragments and key-mask byte in flight under the current block's MFMAs and softmax / dropout
-// arithmetic, two waves per SIMD.  No barrier after the prologue.  Same arithmetic in the same order as
+// (batch, head) pair in LDS and its 4 waves walk that pair's 32-key blocks (wave w takes blocks w, w+4, ...), two waves
+// per SIMD covering each other's K / V load latency (an explicit register prefetch of the next block measured 3 % slower:
+// 256 VGPRs + spills).  No barrier after the prologue.  Same arithmetic in the same order as
 // attn_bwd_dkv_kernel -> bit-identical results (tests/test_gpu_attention.py).  Non-causal, rep == 1, Sq <= 64.
+#ifndef UR_FEWQ_PREFETCH
+#define UR_FEWQ_PREFETCH 0      // 1 = register prefetch of the next key block: 256 VGPRs + 5 spills, measured 3 % slower than relying on the second wave of the SIMD
+#endif
+#ifndef UR_FEWQ_WAVES
+#define UR_FEWQ_WAVES 2         // lab: waves per SIMD the kernel is compiled for
+#endif
 template <int HD>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_fewq_kernel(AttnP p, int nchunk, int bpc) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAVES, UR_FEWQ_WAVES))) void attn_bwd_dkv_fewq_kernel(AttnP p, int nchunk, int bpc) {
   using C = Cfg<HD>;
   static_assert(HD == 64, "register-staged Q / dO tile");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -942,11 +948,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   bf16x8 kf[C::NS], vf[C::NS];
   uint32_t state;
   int blk = chunk * bpc + wave;
+#if UR_FEWQ_PREFETCH
   load_kv(blk, kf, vf, state);
+#endif
   for (; blk < blk_hi; blk += 4) {
+#if UR_FEWQ_PREFETCH
     bf16x8 kn[C::NS], vn[C::NS];
     uint32_t state_n;
     load_kv(blk + 4, kn, vn, state_n);                                // lands under this block's arithmetic
+#else
+    load_kv(blk, kf, vf, state);
+#endif
     const int kblk = blk * 32, key = kblk + (lane & 31);
     const bool kok = (state & 1u) != 0, kvalid = (state & 2u) != 0;
     const bool all_valid = __all(kvalid);
@@ -1021,9 +1033,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const long ktok = (long)b * p.Sk + (kok ? key : 0);
     store_T<HD>(p.dk + ktok * p.lddk + (long)hq * HD, dk, p.scale, lane, kok);     // dS was kept unscaled
     store_T<HD>(p.dv + ktok * p.lddv + (long)hq * HD, dv, 1.0f, lane, kok);
+#if UR_FEWQ_PREFETCH
 #pragma unroll
     for (int st = 0; st < C::NS; ++st) { kf[st] = kn[st]; vf[st] = vn[st]; }
     state = state_n;
+#endif
   }
 }
 
