@@ -1055,8 +1055,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
 // Split transposed reads for the one-wave-per-SIMD dK/dV kernel: tr_issue4 starts the 8 reads of one batch
 // (4 fragments), tr_landed<N> waits until at most N younger LDS reads are outstanding and ties the batch's
 // registers to that wait.  Between the two the registers hold no data yet: this is only sound while the
-// allocator leaves them alone (it parked them in AGPRs at 426 registers; at <= 380 it does not -- the
-// build check in tests/test_cabi.py greps the ISA for exactly that).
+// allocator leaves them alone (it parked them in AGPRs at 426 registers; at <= 380 it does not -- the kernel's
+// parity tests in tests/test_gpu_attention.py are what catches a build where it does).
 __device__ __forceinline__ void tr_issue4(bf16x4 (&lo)[4], bf16x4 (&hi)[4], const uint32_t (&a)[4], const uint32_t (&b)[4]) {
   asm volatile(
       "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\t"
