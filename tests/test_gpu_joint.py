@@ -138,6 +138,28 @@ def test_joint_with_lora_matches_oracle(name):
     assert named["layers.0.self_attn.q_proj.weight"].grad is None      # base weights are frozen
 
 
+def test_merged_projection_launches_are_bit_identical(monkeypatch):
+    """q|k|v and gate|up leave as ONE GEMM launch each, their LoRA term as a block-diagonal second K range (exact zeros off the
+    diagonal): the pooled output and every LoRA gradient must equal the per-adapter launches bit for bit."""
+    import unirec_amd.qwen3 as qmod
+    from unirec_amd.joint import InfoNCELoss
+    case = cases.ALL[JOINT[0]]
+    ids, am, hfe, ham, pos, neg, nmask = cases.joint_inputs(case)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    res = []
+    for merged in (True, False):
+        monkeypatch.setattr(qmod, "_MERGE_PROJ", merged)
+        m, qf = _build_joint(case, use_lora=True, lora_seed=case["seed"] + 2)
+        user = m(t(ids), t(am), t(hfe), t(ham))
+        InfoNCELoss()(user, t(pos), t(neg), t(nmask)).backward()
+        grads = {k: p.grad.detach().clone() for k, p in m.base_model.named_parameters() if p.grad is not None}
+        res.append((user.detach().clone(), grads))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 0
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
 @pytest.mark.parametrize("name", JOINT[:1])
 def test_joint_with_lora_dropout_matches_oracle(name):
     """LoRA dropout (reference :121-131, lora_dropout=0.1; peft: one nn.Dropout per adapter on the adapter's

@@ -94,6 +94,25 @@ def xattn(args):
             print(f"xattn bwd (dq + dkv) p={pd} UR_ATTN_FEWQ={sw}: {t:.3f} ms")
 
 
+def gemm_merge(args):
+    """One projection launch over q|k|v (N = 4096) or gate|up (N = 6144) against the separate launches the decoder issues
+    today (one per LoRA adapter): what merging them behind a block-diagonal second K range would buy."""
+    M, K = args.B * args.S, 1024
+    g = torch.Generator().manual_seed(0)
+    R = torch.randn(M, K, generator=g).cuda().to(torch.bfloat16)
+    for name, parts in (("q|k|v", (2048, 1024, 1024)), ("gate|up", (3072, 3072))):
+        N = sum(parts)
+        W = (torch.randn(N, K, generator=g) * 0.05).cuda().to(torch.bfloat16)
+        out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        def separate():
+            c = 0
+            for n in parts:
+                hip.gemm(R, W[c:c + n], out=out[:, c:c + n]); c += n
+        t1 = timeit(separate, args.iters)
+        t2 = timeit(lambda: hip.gemm(R, W, out=out), args.iters)
+        print(f"gemm {name:8s} N={N}: separate launches {t1:.3f} ms | one launch {t2:.3f} ms  ({2 * M * N * K / t2 / 1e9:.0f} TFLOP/s)")
+
+
 def gemm_lora(args):
     """What the LoRA term costs inside the projection GEMMs: plain / + second K range (forward: t B^T, K2 = 16) /
     + masked rank-16 epilogue (dX under LoRA dropout)."""
@@ -138,10 +157,10 @@ def lora(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn", "gemm_lora"])
+    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn", "gemm_lora", "gemm_merge"])
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--S", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--lib", action="store_true", help="gemm: also time torch.matmul on the same operands (reference point)")
     a = ap.parse_args()
-    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora}[a.what](a)
+    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora, "gemm_merge": gemm_merge}[a.what](a)
