@@ -98,6 +98,7 @@ class _TokenTable(nn.Module):
 # Measured neutral on the joint step (115.1 vs 115.5 seq/s on one box, alternating runs: the epilogue's extra gate read and act
 # write are not overlapped with MFMA work at one workgroup per CU, and the stand-alone kernel already streams at 5.4 TB/s), so
 # the separate launch stays the default; the backward fusion (swiglu_gu), which removes 6 of 15 activation passes, is always on.
+# (Needs the per-adapter launches: it has no effect unless UNIREC_MERGE_PROJ=0 as well.)
 _FUSE_SWIGLU_FWD = os.environ.get("UNIREC_SWIGLU_FWD_FUSED", "0") == "1"
 
 
