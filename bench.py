@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU oracle leg and print its JSON")
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-budget", type=float, default=100.0, help="seconds of oracle work the cpu_baseline leg may start (warm-up 1 + best of 3 inside it)")
     ap.add_argument("--user-tokens", action="store_true",
                     help="C5 / U4: also run the User Q-Former over hist*32 cached item tokens and inject its 64 query tokens")
     ap.add_argument("--no-dropout", action="store_true")
@@ -129,16 +130,37 @@ def flops_per_step(args, B, cfg, dims):
     return qf_fwd * 3 + qwen
 
 
-def cpu_baseline(args, cfg, dims):
-    """Oracle joint step (fwd+bwd, fp32) on the host cores, B=1 sequence of the same workload."""
-    from oracle import qformer_ref as R, qwen3_ref as Q, weights as W
-    Qi, F, E, D = dims
+def _cpu_threads(args):
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
     threads = max(1, min(args.cpu_threads, avail))     # more threads than this thrash on the small fp32 ops
     torch.set_num_threads(threads)
+    return threads
+
+
+def _best_of(step, budget_s, runs=3):
+    """warm-up 1 + best of 3, inside a time budget (a run that would overshoot the budget is not started)."""
+    t_start = time.time()
+    t0 = time.time(); step(); warm = time.time() - t0
+    times = []
+    for _ in range(runs):
+        if times and time.time() - t_start + min(times) > budget_s:
+            break
+        if not times and time.time() - t_start + warm > budget_s:
+            break
+        t0 = time.time(); step(); times.append(time.time() - t0)
+    if not times:
+        return warm, f"1 run (cold, {warm:.1f} s; the budget of {budget_s:.0f} s left no room for timed repeats)"
+    return min(times), f"warm-up 1 + best of {len(times)} ({min(times):.2f} s; warm-up {warm:.1f} s)"
+
+
+def cpu_baseline(args, cfg, dims):
+    """Oracle joint step (fwd+bwd, fp32) on the host cores, B=1 sequence of the same workload."""
+    from oracle import qformer_ref as R, qwen3_ref as Q, weights as W
+    Qi, F, E, D = dims
+    threads = _cpu_threads(args)
     qcfg = R.QFormerCfg(D, 12, 16, 4096, Qi, E, 2)
     wc = Q.Qwen3Cfg(hidden_size=D, num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
                     num_key_value_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim, intermediate_size=cfg.intermediate_size,
@@ -155,32 +177,78 @@ def cpu_baseline(args, cfg, dims):
     b = make_batch(1, args.hist, args.seq, args.pool, F, E, D, Qi, first, first, 7, "cpu")
 
     def step():
+        for t in list(PQ.values()) + list(PW.values()):
+            t.grad = None
         out = R.item_qformer_forward(PQ, qcfg, b["history_field_embeddings"].view(args.hist, F, E), b["history_attention_mask"].view(args.hist, F))
         toks = out["query_outputs"].view(1, args.hist, Qi, D)
         u = Q.joint_forward(PW, wc, b["input_ids"], b["attention_mask"], toks, first)
         loss = Q.infonce_loss(u, b["positive_item_embeddings"], b["negative_item_embeddings"])
         loss.backward()
-    t0 = time.time()
-    step()
-    dt = time.time() - t0
+    dt, how = _best_of(step, args.cpu_budget)
     return {"value": round(1.0 / dt, 5), "unit": "user-sequences/sec", "cores": threads, "kind": "port",
             "sample": f"1 user-sequence (hist={args.hist}, S={args.seq}, pool={args.pool}, {cfg.num_hidden_layers} layers), "
-                      f"oracle fp32 fwd+bwd, 1 run, {dt:.1f} s"}
+                      f"oracle fp32 fwd+bwd, {how}"}
+
+
+def cpu_baseline_stage(args):
+    """Oracle item (C2) / user (C3) Q-Former step, fwd+bwd fp32 on the host cores, on a reduced batch of the same shapes
+    (C3 at B=32; C2 at B=64), dropout off (the oracle has no dropout path; its cost is negligible on the CPU)."""
+    from oracle import qformer_ref as R
+    threads = _cpu_threads(args)
+    g = torch.Generator().manual_seed(0)
+    if args.workload == "item":
+        B, F = 64, 14
+        cfg = R.QFormerCfg(768, 12, 12, 3072, 32, 1024, 2)
+        P = {k: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for k, s in R.item_qformer_shapes(cfg, F).items()}
+
+        def fields(n):
+            x = torch.randn(n, F, 1024, generator=g); x = x / x.norm(dim=-1, keepdim=True)
+            mk = (torch.rand(n, F, generator=g) < 0.8).long(); mk[:, 0] = 1
+            return x * mk[..., None], mk
+        (xa, ma), (xpn, mpn) = fields(B), fields(2 * B)
+
+        def step():      # training/item_qformer_training.py:117-131: anchor with grad, positives / negatives without
+            for t in P.values():
+                t.grad = None
+            out = R.item_qformer_forward(P, cfg, xa, ma)
+            with torch.no_grad():
+                rep = R.item_qformer_forward(P, cfg, xpn, mpn)["item_representation"]
+            R.qformer_loss(out, xa, ma, rep[:B], rep[B:])[0].backward()
+        unit, what = "items/sec", f"{B} items (C2 shapes L12 Q32 H768 F14; anchor fwd+bwd + positives|negatives no-grad fwd)"
+    else:
+        B, T = 16, args.hist * 32
+        cfg = R.QFormerCfg(1024, 4, 16, 4096, 64, 1024, 1)
+        P = {k: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for k, s in R.user_qformer_shapes(cfg, 32).items()}
+        x = torch.randn(B, T, 1024, generator=g) * 0.8
+        lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+        mask = (torch.arange(T)[None, :] < lens[:, None]).float()
+        x = x * mask[..., None]
+        tgt = torch.randn(B, 32, 1024, generator=g) * 0.8
+
+        def step():      # training/user_qformer_training.py:203-214
+            for t in P.values():
+                t.grad = None
+            torch.nn.functional.mse_loss(R.user_qformer_forward(P, cfg, x, mask, 32)[0], tgt).backward()
+        unit, what = "user-sequences/sec", f"{B} user sequences (C3 shapes L4 Q64 H1024, T={T})"
+    dt, how = _best_of(step, args.cpu_budget)
+    return {"value": round(B / dt, 3), "unit": unit, "cores": threads, "kind": "port", "sample": f"{what}, oracle fp32, {how}"}
 
 
 def cpu_baseline_subprocess(args):
     """Run the oracle leg in a child process with a hard time bound (a GPU-initialised process must not
     exec; a child is fine) so the default bench always finishes within minutes."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--hist", str(args.hist), "--seq", str(args.seq),
-           "--pool", str(args.pool), "--layers", str(args.layers), "--cpu-threads", str(args.cpu_threads)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload, "--hist", str(args.hist),
+           "--seq", str(args.seq), "--pool", str(args.pool), "--layers", str(args.layers), "--cpu-threads", str(args.cpu_threads),
+           "--cpu-budget", str(args.cpu_budget)]
+    unit = {"item": "items/sec"}.get(args.workload, "user-sequences/sec")
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env={**os.environ, "HIP_VISIBLE_DEVICES": ""})
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_budget + 150, env={**os.environ, "HIP_VISIBLE_DEVICES": ""})
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:       # timeout / failure: report it, never hide it
-        return {"value": None, "unit": "user-sequences/sec", "cores": args.cpu_threads, "kind": "port",
-                "sample": f"oracle leg did not finish within 240 s ({type(e).__name__})"}
+        return {"value": None, "unit": unit, "cores": args.cpu_threads, "kind": "port",
+                "sample": f"oracle leg did not finish within {args.cpu_budget + 150} s ({type(e).__name__})"}
 
 
 # ---- per-stage workloads (BASELINE configs[1], configs[2]); reported with their own metric names ----
@@ -188,7 +256,9 @@ def run_stage(args):
     from unirec_amd import dp
     from unirec_amd.losses import QFormerLoss, mse_loss
     from unirec_amd.optim import FusedAdamW
+    from unirec_amd import hip
     rank, world, local = dp.init_from_env()
+    _check_world(args, world)
     device = torch.device("cuda", local % max(1, torch.cuda.device_count()))      # (modulo: gloo rehearsal of N ranks on one GPU)
     torch.cuda.set_device(device)
     torch.manual_seed(1234)
@@ -206,7 +276,8 @@ def run_stage(args):
             return (x * mk[..., None]).to(device), mk.to(device)
         (xa, ma), (xp, mp), (xn, mn) = fields(), fields(), fields()
         xpn, mpn = torch.cat([xp, xn]), torch.cat([mp, mn])
-        loss_fn = QFormerLoss()
+        loss_fn = QFormerLoss(data_parallel=True)       # the masked MSE divides by the all-reduced sum of the mask
+        dp.set_rank_seeds(rank, m)
         pack = m._ensure_pack(device)
         opt = FusedAdamW([pack], lr=1e-4)
         bk = dp.GradBuckets(pack.grad, [0, pack.numel])
@@ -229,6 +300,7 @@ def run_stage(args):
         mask = (torch.arange(T)[None, :] < lens[:, None]).float().to(device)
         x = x * mask[..., None].to(torch.bfloat16)
         tgt = (torch.randn(B, 32, 1024, generator=g) * 0.8).to(device)
+        dp.set_rank_seeds(rank, m)
         pack = m._ensure_pack(device)
         opt = FusedAdamW([pack], lr=1e-4)
         bk = dp.GradBuckets(pack.grad, [0, pack.numel])
@@ -247,40 +319,80 @@ def run_stage(args):
     for _ in range(args.warmup):
         step()
     sync()
+    hip.PROFILE = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     sync()
     dt = time.perf_counter() - t0
+    prof, hip.PROFILE = hip.PROFILE, None
     if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
-        print(json.dumps({"metric": metric, "value": round(world * B * args.steps / dt, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                          "config": {"workload": args.workload, "per_gpu_batch": B, "dropout": "off" if args.no_dropout else "on"},
-                          "step_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1), "loss": round(float(loss), 5),
-                          "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1)}), flush=True)
+        # roofline of the dominant kernel family of the stage: every MFMA GEMM launch of the timed region (projections,
+        # dX, token-reduction dW), HIP events on the launching stream
+        g_ms = sum(e0.elapsed_time(e1) for (e0, e1, *_r) in prof)
+        g_fl = sum(2.0 * M * N * K for (_e0, _e1, _rk, _sk, _f32, M, N, K, _sp, _epi) in prof)
+        ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
+                "kernel": "gemm_kernel<...> (all MFMA GEMM launches of the stage)", "launches": len(prof),
+                "avg_launch_ms": round(g_ms / max(len(prof), 1), 4), "gemm_ms_per_step": round(g_ms / args.steps, 2),
+                "step_frac_of_peak": round(flops / (dt / args.steps) / 2.5e15, 4)}
+        out = {"metric": metric, "value": round(world * B * args.steps / dt, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": args.workload, "per_gpu_batch": B, "global_batch": B * world, "dropout": "off" if args.no_dropout else "on",
+                          "parallelism": f"dp{world}"},
+               "step_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1), "loss": round(float(loss), 5),
+               "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "comm": _comm_info(world)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_subprocess(args)
+        print(json.dumps(out), flush=True)
     if dist_on:
         torch.distributed.destroy_process_group()
 
 
+def _check_world(args, world):
+    """--gpus N must be the number of ranks that actually run (a silent 1-rank run would report a 1-GPU number as N)."""
+    if world != args.gpus and os.environ.get("UNIREC_DP_FORCE") != "1":
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with\n  python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {args.gpus} ...\n"
+                         f"(or plain `python bench.py --gpus {args.gpus}`, which starts the ranks itself)")
+
+
+def _comm_info(world):
+    """What the gradient all-reduce actually ran on: backend and number of ranks of the initialised process group."""
+    d = torch.distributed
+    if d.is_available() and d.is_initialized():
+        be = d.get_backend()
+        return {"backend": "rccl (torch.distributed nccl)" if be == "nccl" else be, "ranks": d.get_world_size()}
+    return {"backend": None, "ranks": 1}
+
+
 def main():
     args = parse()
-    if args.workload != "joint":
-        return run_stage(args)
     if args.cpu_baseline_only:
+        if args.workload != "joint":
+            print(json.dumps(cpu_baseline_stage(args)), flush=True)
+            return
         from unirec_amd.qwen3 import Qwen3Config
         print(json.dumps(cpu_baseline(args, Qwen3Config(num_hidden_layers=args.layers), (2, 14, 1024, 1024))), flush=True)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process has not touched the GPU (no HIP call so far) -- start the N ranks
+        # as CHILD processes under torch.distributed.run, relay their output (rank 0 prints the JSON line) and leave with
+        # the launcher's exit code.  Never re-exec: the parent just waits.
+        from unirec_amd import dp
+        raise SystemExit(dp.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
+    if args.workload != "joint":
+        return run_stage(args)
     from unirec_amd import dp, hip
     from unirec_amd.joint import InfoNCELoss
     from unirec_amd.optim import FusedAdamW
     rank, world, local = dp.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    _check_world(args, world)
     device = torch.device("cuda", local % max(1, torch.cuda.device_count()))      # (modulo: gloo rehearsal of N ranks on one GPU)
     torch.cuda.set_device(device)
     model, qf, cfg, dims = build(args, device)
@@ -291,6 +403,7 @@ def main():
                        1234 + rank, device, n_user=n_user)
     loss_fn = InfoNCELoss(0.07)
     qw = model.base_model
+    dp.set_rank_seeds(rank, model)                 # per-rank dropout / LoRA-dropout mask streams (rank 0 keeps the base seeds)
     qpack, lpack = qf._ensure_pack(device), qw._ensure_pack(device)
     packs = [qpack, lpack]
     ubk = None
@@ -387,7 +500,7 @@ def main():
                           "hist": args.hist, "pool": args.pool, "dropout": 0.0 if args.no_dropout else 0.2, "lora_dropout": 0.0 if args.no_dropout else args.lora_dropout,
                           "parallelism": f"dp{world}", "random_init": True},
                "step_tflops_per_gpu": round(fl / (dt / args.steps) / 1e12, 1), "loss": round(lossv, 4),
-               "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof}
+               "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "comm": _comm_info(world)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,70 @@
+"""One rank of the 2-rank PRODUCT-path data-parallel test (tests/test_gpu_dp_product.py starts two of these as child
+processes, both on cuda:0, backend gloo -- RCCL needs one device per rank; the code path above the backend is the one
+bench.py runs: HIP forward/backward, bucket hooks, sum all-reduce of the flat gradient pack, fused AdamW with 1/world).
+Usage: python tests/dp_product_worker.py <outdir> <global_batch> [dropout]   (RANK / WORLD_SIZE / MASTER_* from the env)"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+
+def make_global(Bg, F, E, seed=11):
+    g = torch.Generator().manual_seed(seed)
+
+    def fields():
+        x = torch.randn(Bg, F, E, generator=g)
+        x = x / x.norm(dim=-1, keepdim=True)
+        mk = (torch.rand(Bg, F, generator=g) < 0.7).long()
+        mk[:, 0] = 1
+        return x * mk[..., None], mk
+    return fields(), fields(), fields()
+
+
+def build(dropout):
+    from unirec_amd.qformer_utils import QFormerForItemRepresentation
+    torch.manual_seed(5)
+    return QFormerForItemRepresentation(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024,
+                                        num_query_tokens=4, field_embedding_dim=256, num_fields=8, dropout=dropout)
+
+
+def run(outdir, Bg, dropout):
+    from unirec_amd import dp
+    from unirec_amd.losses import QFormerLoss
+    from unirec_amd.optim import FusedAdamW
+    rank, world, _ = dp.init_from_env()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    m = build(dropout).to(dev).train()
+    dp.set_rank_seeds(rank, m)
+    (xa, ma), (xp, mp_), (xn, mn) = make_global(Bg, 8, 256)
+    lo, hi = dp.shard_range(Bg, rank, world)
+    xa, ma, xp, mp_, xn, mn = [t[lo:hi].to(dev) for t in (xa, ma, xp, mp_, xn, mn)]
+    pack = m._ensure_pack(dev)
+    opt = FusedAdamW([pack], lr=1e-3, weight_decay=0.01)
+    bounds = dp.layer_boundaries(pack, [f"qformer.encoder.layer.{i}." for i in range(2)], 1)
+    bk = dp.GradBuckets(pack.grad, bounds)
+    first = {i: 1 + i for i in range(2)}
+    m.qformer.grad_ready_hook = lambda i: bk.ready(0) if i == -1 else (bk.ready(first[i]) if i in first else None)
+    loss_fn = QFormerLoss(data_parallel=True)
+    out = m(xa, ma)
+    with torch.no_grad():
+        pr, nr = m(xp, mp_)["item_representation"], m(xn, mn)["item_representation"]
+    loss, recon, _ = loss_fn(out, {"field_embeddings": xa}, pr, nr, ma)
+    loss.backward()
+    bk.ready(bk.n - 1)            # heads: written last by the loss-side backward nodes, first in the autograd order
+    bk.wait()
+    torch.cuda.synchronize()
+    grad = (pack.grad / world).cpu()
+    opt.step(grad_scale=1.0 / world)
+    torch.cuda.synchronize()
+    torch.save({"grad": grad, "master": pack.master.cpu(), "loss": float(loss), "seed": int(m.qformer.seed), "n": hi - lo,
+                "enabled": bk.enabled, "world": world}, os.path.join(outdir, f"rank{rank}.pt"))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    run(sys.argv[1], int(sys.argv[2]), float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)

@@ -109,3 +109,36 @@ def test_two_rank_gloo_allreduce_matches_unsharded_gradient(tmp_path):
         o = pack.offsets[n]
         want = torch.zeros(P[n].numel()) if P[n].grad is None else P[n].grad.reshape(-1)
         assert torch.allclose(g0[o:o + P[n].numel()], want, rtol=1e-4, atol=1e-7), n
+
+
+def test_shard_range_keeps_the_remainder():
+    got = [dp.shard_range(10, r, 4) for r in range(4)]
+    assert got == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def test_rank_seeds_are_distinct_and_rank0_keeps_the_base():
+    seeds = [dp.rank_seed(0x5EED, r) for r in range(8)]
+    assert seeds[0] == 0x5EED and len(set(seeds)) == 8 and all(0 <= s < 2 ** 46 for s in seeds)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.seed, self.lora_seed = 0x5EED, 0x5EED
+    a, b = M(), M()
+    dp.set_rank_seeds(0, a)
+    dp.set_rank_seeds(3, b)
+    assert (a.seed, a.lora_seed) == (0x5EED, 0x5EED) and b.seed != 0x5EED and b.lora_seed != 0x5EED
+
+
+def test_bench_gpus_flag_must_match_the_world(monkeypatch):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class A:
+        gpus = 4
+    monkeypatch.delenv("UNIREC_DP_FORCE", raising=False)
+    with pytest.raises(SystemExit):
+        bench._check_world(A, 1)
+    bench._check_world(A, 4)

@@ -41,9 +41,66 @@ def init_from_env(backend=None):
 
 
 def shard_range(n_global, rank, world):
-    """Rank r takes samples [r*B_local, (r+1)*B_local) of the global minibatch."""
-    per = n_global // world
-    return rank * per, (rank + 1) * per
+    """Rank r takes a contiguous slice of the global minibatch; the n_global % world remainder goes one
+    sample each to the first ranks, so no sample is dropped."""
+    per, rem = divmod(n_global, world)
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def rank_seed(base, rank):
+    """Dropout base seed of one rank: splitmix64 of (base, rank), so the ranks' mask streams are unrelated (rank 0 keeps
+    `base`: a 1-rank run is bit-identical to a run without data parallelism)."""
+    if rank == 0:
+        return int(base)
+    z = (int(base) + (int(rank) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return (z ^ (z >> 31)) & 0x3FFFFFFFFFFF          # 46 bits: the per-site arithmetic on top stays below 2^63
+
+
+def set_rank_seeds(rank, *modules):
+    """Give every dropout site of the models a per-rank seed (the masks of a sample must not repeat on another rank).
+    Touches the attributes the modules read their seeds from: `.seed` (Q-Former backbones), `.lora_seed` (Qwen3 LoRA)."""
+    for m in modules:
+        if m is None:
+            continue
+        for sub in m.modules():
+            if hasattr(sub, "lora_seed"):
+                sub.lora_seed = rank_seed(sub.lora_seed, rank)
+            if hasattr(sub, "seed") and isinstance(getattr(sub, "seed"), int):
+                sub.seed = rank_seed(sub.seed, rank)
+
+
+def world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def allreduce_sum_(t, group=None):
+    """In-place sum all-reduce of a small tensor (loss denominators such as the item loss's sum of mask); no-op for one rank."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def launch_ranks(n, script, argv, extra_env=None):
+    """Start `n` ranks of `script` on this node as CHILD processes (python -m torch.distributed.run, rendezvous on
+    127.0.0.1) and return the launcher's exit code.  Must be called before the calling process touches the GPU: the
+    parent only waits and relays, it never re-execs itself."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
 
 
 class GradBuckets:

@@ -15,8 +15,18 @@ F32 = torch.float32
 
 class _QFormerLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rec, item_rep, x, mask, pos, neg, recon_w, cont_w, margin):
+    def forward(ctx, rec, item_rep, x, mask, pos, neg, recon_w, cont_w, margin, data_parallel):
         sums = hip.recon_stats(rec, x, mask)
+        if data_parallel:
+            # the masked MSE divides by the GLOBAL number of valid fields.  sums[1] = sum(mask) all-reduced
+            # and divided by the world size: the local loss is then world * (local numerator / global denominator), so
+            # the mean over ranks -- what the sum all-reduce of gradients with its 1/world realises -- is the
+            # single-process loss over the global batch.
+            from . import dp
+            w = dp.world_size()
+            if w > 1:
+                den = dp.allreduce_sum_(sums[1:2].clone())
+                sums = torch.cat([sums[0:1], den / w, sums[2:]])
         tl, d_item = hip.triplet_margin(item_rep, pos, neg, margin, cont_w, need_grad=True)
         ctx.saved = (rec, x, mask, sums, d_item, recon_w)
         # scalar combine on device (3 floats): plumbing, not compute
@@ -27,19 +37,23 @@ class _QFormerLossFn(torch.autograd.Function):
     def backward(ctx, g, g_recon, g_cont):
         rec, x, mask, sums, d_item, recon_w = ctx.saved
         d_rec = hip.recon_grad(rec, x, mask, sums, recon_w)
-        return d_rec * g, d_item * g, None, None, None, None, None, None, None
+        return d_rec * g, d_item * g, None, None, None, None, None, None, None, None
 
 
 class QFormerLoss(nn.Module):
-    def __init__(self, reconstruction_weight=1.0, contrastive_weight=0.5, margin=0.5):
+    def __init__(self, reconstruction_weight=1.0, contrastive_weight=0.5, margin=0.5, data_parallel=False):
+        """data_parallel=True (new; the reference is single-process): under an initialised torch.distributed group the
+        reconstruction term divides by the all-reduced sum of the mask, so N ranks on N shards reproduce the
+        single-process loss and gradient over the global batch."""
         super().__init__()
         self.recon_w, self.cont_w, self.margin = reconstruction_weight, contrastive_weight, margin
+        self.data_parallel = bool(data_parallel)
 
     def forward(self, model_output, input_embeddings, pos_rep, neg_rep, attention_mask):
         x = input_embeddings["field_embeddings"].contiguous().to(F32)
         return _QFormerLossFn.apply(model_output["reconstructed_fields"].contiguous(), model_output["item_representation"].contiguous(),
                                     x, attention_mask.contiguous().to(F32), pos_rep.detach().contiguous().to(F32),
-                                    neg_rep.detach().contiguous().to(F32), float(self.recon_w), float(self.cont_w), float(self.margin))
+                                    neg_rep.detach().contiguous().to(F32), float(self.recon_w), float(self.cont_w), float(self.margin), self.data_parallel)
 
 
 class _MSEFn(torch.autograd.Function):
