@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-budget", type=float, default=100.0, help="seconds of oracle work the cpu_baseline leg may start (warm-up 1 + best of 3 inside it)")
     ap.add_argument("--user-tokens", action="store_true",
                     help="C5 / U4: also run the User Q-Former over hist*32 cached item tokens and inject its 64 query tokens")
+    ap.add_argument("--micro-batches", type=int, default=1,
+                    help="split the per-GPU batch into this many micro-batches inside one optimizer step (gradient accumulation; "
+                         "C5: --batch 64 --micro-batches 2 keeps S=4096 within 288 GB)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--lora-dropout", type=float, default=0.1, help="LoRA adapter dropout (reference lora_dropout=0.1)")
     return ap.parse_args()
@@ -282,6 +285,7 @@ def run_stage(args):
         opt = FusedAdamW([pack], lr=1e-4)
         bk = dp.GradBuckets(pack.grad, [0, pack.numel])
         def step():          # training/item_qformer_training.py:117-131: anchor with grad, pos/neg without
+            opt.zero_grad()
             out = m(xa, ma)
             with torch.no_grad():         # samples are independent: positives and negatives share ONE no-grad forward of 2B items
                 rep = m(xpn, mpn)["item_representation"]; pr, nr = rep[:B], rep[B:]
@@ -305,6 +309,7 @@ def run_stage(args):
         opt = FusedAdamW([pack], lr=1e-4)
         bk = dp.GradBuckets(pack.grad, [0, pack.numel])
         def step():          # training/user_qformer_training.py:203-214
+            opt.zero_grad()
             loss = mse_loss(m(x, mask), tgt)
             loss.backward(); bk.ready_all(); bk.wait(); opt.step(grad_scale=1.0 / world)
             return loss
@@ -423,16 +428,36 @@ def main():
     q_first = {k * qgrp: 1 + k for k in range(12 // qgrp)}       # bucket 0 = query table + embedding LN, last = heads (unused here)
     qf.qformer.grad_ready_hook = lambda i: qbk.ready(0) if i == -1 else (qbk.ready(q_first[i]) if i in q_first else None)
 
+    nmb = max(1, args.micro_batches)
+    if B % nmb:
+        raise SystemExit(f"--batch {B} is not a multiple of --micro-batches {nmb}")
+    mb = B // nmb
+
     def step():
-        user = model(batch["input_ids"], batch["attention_mask"], batch["history_field_embeddings"], batch["history_attention_mask"],
-                     batch["user_sequence_tokens"], batch["user_attention_mask"])
-        loss = loss_fn(user, batch["positive_item_embeddings"], batch["negative_item_embeddings"], batch["negative_masks"])
-        loss.backward()
+        opt.zero_grad()
+        total = None
+        for k in range(nmb):
+            sl = slice(k * mb, (k + 1) * mb)
+            last = k == nmb - 1
+            for bk in (lbk, qbk, ubk):
+                if bk is not None:
+                    bk.begin_micro_batch(last)
+            ut, um = batch["user_sequence_tokens"], batch["user_attention_mask"]
+            user = model(batch["input_ids"][sl], batch["attention_mask"][sl], batch["history_field_embeddings"][sl],
+                         batch["history_attention_mask"][sl], None if ut is None else ut[sl], None if um is None else um[sl])
+            nm = batch["negative_masks"]
+            loss = loss_fn(user, batch["positive_item_embeddings"][sl], batch["negative_item_embeddings"][sl], None if nm is None else nm[sl])
+            if nmb > 1:
+                loss = loss / nmb               # mean over the whole batch = mean of the micro-batch means
+            loss.backward()
+            if ubk is not None:
+                ubk.ready_all()
+            total = loss.detach() if total is None else total + loss.detach()
         if ubk is not None:
-            ubk.ready_all(); ubk.wait()
+            ubk.wait()
         lbk.wait(); qbk.wait()
         opt.step(grad_scale=1.0 / world)
-        return loss
+        return total
 
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()    # world > 1 (or UNIREC_DP_FORCE=1)
 
@@ -498,7 +523,7 @@ def main():
                                       f"Qwen3-0.6B-shaped({cfg.num_hidden_layers}L)+LoRA r16 -> mean-pool -> InfoNCE pool {args.pool}; "
                                       f"fwd+bwd+allreduce+AdamW", "per_gpu_batch": B, "global_batch": B * world, "seq_len": args.seq,
                           "hist": args.hist, "pool": args.pool, "dropout": 0.0 if args.no_dropout else 0.2, "lora_dropout": 0.0 if args.no_dropout else args.lora_dropout,
-                          "parallelism": f"dp{world}", "random_init": True},
+                          "micro_batches": nmb, "parallelism": f"dp{world}", "random_init": True},
                "step_tflops_per_gpu": round(fl / (dt / args.steps) / 1e12, 1), "loss": round(lossv, 4),
                "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "comm": _comm_info(world)}
         if world == 1 and not args.no_cpu_baseline:

@@ -183,3 +183,21 @@ ALL = {
     "joint_left": dict(kind="joint", seed=42, B=3, S=48, hist=3, N=7, D=256, first_special_id=90, pad_side="left",
                        cfg=dict(H=256, L=2, nh=4, I=512, Q=2, F=5, E=192), qwen=_TINYQ),
 }
+
+
+# ------------------------------------------------------------------ mid-size cases (round 2) --
+# One reference-generated fixture per family at sizes where the 256x256 8-phase GEMM, the multi-tile causal
+# head_dim-128 attention and the few-query dK/dV kernel actually run (tests/golden/make_golden_r2.py).
+_MIDQ = dict(D=1024, L=4, nq=16, nkv=8, hd=128, I=3072, vocab=64)
+MID = {
+    # Qwen3-0.6B-shaped decoder slice: 4 layers, D=1024, 16 q / 8 kv heads of 128, S=512, left padding, sdpa semantics
+    "qwen_mid": dict(kind="qwen_mid", seed=51, B=4, S=512, pad_side="left", qwen=_MIDQ),
+    # the reference's DEFAULT UserQFormer (L4 Q64 H1024 I4096, 32 predicted tokens) over T=1600 keys (C3's shape), B=2
+    "user_mid": dict(kind="user_mid", seed=52, B=2, T=1600, cfg=dict(H=1024, L=4, nh=16, I=4096, Q=64, E=1024, n_pred=32)),
+}
+MID_STRIDE = 16
+
+
+def mid_sample(x):
+    """Fixture-size rule of the mid-size cases: [B,S,D] activations keep every MID_STRIDE-th position."""
+    return np.ascontiguousarray(np.asarray(x)[:, ::MID_STRIDE])

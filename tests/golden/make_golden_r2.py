@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Round-2 golden vectors, produced by running the REFERENCE's own Python on CPU (build container only; same shim as
+make_golden.py, which this script imports):
+
+  qwen_mid.npz        installed transformers Qwen3Model, 4 layers D=1024 hd=128 S=512 B=4, left padding, sdpa:
+                      pooled output, strided last_hidden_state and gradient w.r.t. inputs_embeds
+  user_mid.npz        the reference's default UserQFormer over T=1600 keys, B=2: prediction, MSE loss, gradients
+  use_real.npz        models/user_sequence_encoder.py UserSequenceEncoder._get_item_query_tokens_batch /
+                      encode_user_sequence with a real (small) reference item Q-Former behind it
+  state_dict_shapes.json   key -> shape of the reference modules' state_dict (item default / Q=8 duplicate / C1 / C2,
+                      UserQFormer default): the checkpoint-compatibility contract of SURVEY 8(b)
+
+Usage:  python tests/golden/make_golden_r2.py [qwen_mid user_mid use_real shapes]
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+import numpy as np
+import torch
+
+from tests.golden import make_golden as mg          # installs the shim and imports the reference modules
+from tests.golden import cases
+from tests.golden import data_cases as dc
+from oracle import weights as W
+from oracle import data_ref as D
+from oracle.qformer_ref import QFormerCfg, item_qformer_shapes, user_qformer_shapes
+
+USE_CFG = dict(H=dc.CTX_H, L=2, nh=2, I=256, Q=dc.QI, E=dc.E, seed=61)      # the item Q-Former behind UserSequenceEncoder
+
+
+def gen_qwen_mid(case):
+    qc = cases.qwen_cfg(case)
+    x, am = cases.qwen_inputs(case)
+    base = mg.build_hf_qwen3(qc, case["seed"] + 1, "sdpa")
+    xt = torch.from_numpy(x).requires_grad_(True)
+    h = base(inputs_embeds=xt, attention_mask=torch.from_numpy(am), output_hidden_states=True)
+    last = h.hidden_states[-1]
+    pooled = last.mean(dim=1)
+    pooled.pow(2).sum().backward()
+    g = xt.grad.numpy()
+    return {"sdpa/pooled": pooled.detach().numpy(), "sdpa/last_hidden_state_s": cases.mid_sample(last.detach().numpy()),
+            "sdpa/grad_inputs_embeds_s": cases.mid_sample(g),
+            "sdpa/grad_inputs_embeds_norm": np.array(np.linalg.norm(g.astype(np.float64)))}
+
+
+def gen_user_mid(case):
+    return mg.gen_user(case)
+
+
+def gen_use_real():
+    import models.user_sequence_encoder as ruse
+    from models.mwne import TimestampEncoder as RefTime, GeoCoordinateEncoder as RefGeo
+    from models.qformer_utils import QFormerForItemRepresentation as RefItem
+    c = USE_CFG
+    samples, item_dict = dc.item_samples()
+    fields = sorted({k for s in samples for k in s if k != "item_id"})
+    m = RefItem(hidden_size=c["H"], num_hidden_layers=c["L"], num_attention_heads=c["nh"], intermediate_size=c["I"],
+                num_query_tokens=c["Q"], field_embedding_dim=c["E"], num_fields=len(fields), dropout=0.0)
+    mg.load_generated(m, item_qformer_shapes(QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 2), len(fields)), c["seed"])
+    H = c["H"]
+    te, ge = RefTime(H), RefGeo(H)
+    te.load_state_dict({k: torch.from_numpy(v) for k, v in W.fill_state_dict(D.context_mlp_shapes(H, 9), dc.CTX_SEED).items()})
+    ge.load_state_dict({k: torch.from_numpy(v) for k, v in W.fill_state_dict(D.context_mlp_shapes(H, 3), dc.CTX_SEED + 1).items()})
+    use = ruse.UserSequenceEncoder.__new__(ruse.UserSequenceEncoder)
+    use.device = torch.device("cpu")
+    use.item_encoder = dc.FakeItemEncoder()
+    use.item_qformer = m.eval()
+    use.item_qformer_fields = fields
+    use.embedding_dim = H
+    use.timestamp_encoder, use.geo_encoder = te, ge
+    use.positional_encoder = ruse.PositionalEncoding(d_model=H).eval()          # dropout off for the fixture
+    events = [dict(e, item_data=item_dict[e["item_id"]]) for e in dc.user_events()[0]]
+    with torch.no_grad():
+        toks = use._get_item_query_tokens_batch([e["item_data"] for e in events])
+        seq = use.encode_user_sequence(events)
+    return {"item_query_tokens": toks.numpy(), "encoded_user_sequence": seq.numpy(),
+            "fields": np.array(fields)}
+
+
+def gen_shapes():
+    from models.qformer_utils import QFormerForItemRepresentation as RefItem
+    out = {}
+
+    def shapes(m):
+        return {k: list(v.shape) for k, v in m.state_dict().items()}
+    out["item_default_F14"] = shapes(RefItem(num_fields=14))
+    out["item_qformer_model_default_F14"] = shapes(mg.RefItemQFormer(num_fields=14))
+    out["item_c1"] = shapes(mg.RefItemQFormer(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024,
+                                              num_query_tokens=4, field_embedding_dim=256, num_fields=8))
+    out["item_c2"] = shapes(RefItem(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                                    num_query_tokens=32, field_embedding_dim=1024, num_fields=14))
+    out["user_default"] = shapes(mg.RefUserQFormer())
+    return out
+
+
+def main():
+    only = set(sys.argv[1:])
+    want = lambda n: not only or n in only
+    for name in ("qwen_mid", "user_mid"):
+        if want(name):
+            case = cases.MID[name]
+            res = {"qwen_mid": gen_qwen_mid, "user_mid": gen_user_mid}[name](case)
+            path = os.path.join(HERE, name + ".npz")
+            np.savez_compressed(path, **{k: np.asarray(v) for k, v in res.items()})
+            print(f"{name}: {len(res)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+    if want("use_real"):
+        res = gen_use_real()
+        path = os.path.join(HERE, "use_real.npz")
+        np.savez_compressed(path, **res)
+        print(f"use_real: {os.path.getsize(path) / 1024:.1f} KiB", {k: v.shape for k, v in res.items()})
+    if want("shapes"):
+        with open(os.path.join(HERE, "state_dict_shapes.json"), "w") as f:
+            json.dump(gen_shapes(), f, indent=0, sort_keys=True)
+        print("state_dict_shapes.json written")
+
+
+if __name__ == "__main__":
+    main()

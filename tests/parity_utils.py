@@ -37,9 +37,10 @@ def assert_close(got, want, tol, what, floor=0.0, abs_scale=0.0):
         got = got.detach().float().cpu().numpy()
     e = rel_err(got, want)
     wn = float(np.linalg.norm(np.asarray(want, dtype=np.float64)))
-    print(f"  {what}: rel_err={e:.3e} (tol {tol:.1e})")
+    branch = "rel" if e <= tol else ("floor" if wn <= floor else ("abs_scale" if e * wn <= tol * abs_scale else "FAIL"))
+    print(f"  {what}: rel_err={e:.3e} (tol {tol:.1e}) passed-by={branch}")
     assert np.isfinite(got).all(), f"{what}: non-finite values"
-    assert e <= tol or wn <= floor or e * wn <= tol * abs_scale, f"{what}: rel err {e:.3e} > {tol:.1e}"
+    assert branch != "FAIL", f"{what}: rel err {e:.3e} > {tol:.1e}"
 
 
 def load_generated(module, shapes, seed, device="cuda"):

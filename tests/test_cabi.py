@@ -54,3 +54,19 @@ def test_product_path_has_no_oracle_import():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
+
+
+def test_live_and_dead_parameter_split_matches_the_reference_probe():
+    """dead = word/position embeddings + the per-layer TEXT FFN; attention.output / crossattention.output
+    are live (a substring match once froze them by accident)."""
+    import torch
+    from unirec_amd.qformer import _dead
+    from unirec_amd.qformer_utils import QFormerForItemRepresentation
+    with torch.device("meta"):
+        m = QFormerForItemRepresentation(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024,
+                                         num_query_tokens=4, field_embedding_dim=256, num_fields=8)
+    live = {n for n, _ in m.live_named_parameters()}
+    named = dict(m.named_parameters())
+    assert all(_dead(n) == (n not in live) for n in named)
+    # C1 live / dead parameter counts probed on the reference: 1 976 360 / 8 996 864
+    assert sum(named[n].numel() for n in live) == 1976360 and sum(p.numel() for n, p in named.items() if n not in live) == 8996864

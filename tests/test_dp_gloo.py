@@ -142,3 +142,21 @@ def test_bench_gpus_flag_must_match_the_world(monkeypatch):
     with pytest.raises(SystemExit):
         bench._check_world(A, 1)
     bench._check_world(A, 4)
+
+
+def test_micro_batch_accumulation_adds_the_stash_before_the_bucket_leaves():
+    """Gradient accumulation inside one optimizer step: backward OVERWRITES the flat buffer, non-final micro-batches stash
+    their buckets, the final one folds the stash back in bucket by bucket."""
+    flat = torch.zeros(24)
+    bk = dp.GradBuckets(flat, [0, 8, 16, 24])
+    bk.begin_micro_batch(last=False)
+    flat.copy_(torch.arange(24.0))
+    for i in reversed(range(bk.n)):
+        bk.ready(i)
+    bk.begin_micro_batch(last=True)
+    flat.copy_(torch.ones(24))                   # the second backward overwrites
+    bk.ready(2)
+    assert torch.equal(flat[16:], torch.arange(16.0, 24.0) + 1) and torch.equal(flat[:16], torch.ones(16))
+    bk.ready(1); bk.ready(0); bk.wait()
+    assert torch.equal(flat, torch.arange(24.0) + 1)
+    assert float(bk.stash.abs().sum()) == 0.0    # ready for the next step

@@ -95,8 +95,10 @@ def test_joint_matches_reference(name):
     # 0.7 - 3 % error for either attention kernel depending on the weight seed (tools/lab/tiny_attn_joint_err.py; 7 %
     # for this fixture's seed).  Their error is held against 5 % of the query-table gradient's norm instead of their own.
     ill = 0.05 * float(np.linalg.norm(g["grad/query_embeddings"]))
+    ILL_KEYS = ("qformer.encoder.layer.0.attention.self.query.weight", "qformer.encoder.layer.0.attention.self.key.bias")
     for k in cases.item_grad_keys(c, heads=False):
-        assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL * 1.5, "grad/" + k, floor=1e-6, abs_scale=ill)
+        assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL * 1.5, "grad/" + k, floor=1e-6,
+                     abs_scale=ill if k in ILL_KEYS else 0.0)
     assert named["item_representation_head.weight"].grad is None      # unused heads stay untouched (as in the reference)
 
 

@@ -427,3 +427,102 @@ def test_lora_kernels_on_column_ranges(M):
     hip.lora_reduce(x, t[:, :2 * r], gA, nad=2)
     want = t[:, :2 * r].float().t() @ x.float()
     assert (gA - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-2
+
+
+def test_fused_adamw_skips_untouched_tensors_like_torch_and_resumes():
+    """ADVICE r1: torch.optim.AdamW leaves parameters with grad=None alone (no decay, no moment update, own step count);
+    FusedAdamW must do the same for tensors no backward published, and its state must round-trip for resume."""
+    from unirec_amd.optim import FusedAdamW
+    from unirec_amd.packing import ParamPack
+    torch.manual_seed(0)
+    names = ["a.weight", "a.bias", "head.weight", "head.bias", "b.weight"]
+    shapes = [(64, 32), (64,), (16, 64), (16,), (8, 8)]
+    ps = [(n, torch.nn.Parameter(torch.randn(s))) for n, s in zip(names, shapes)]
+    ref = [torch.nn.Parameter(p.detach().clone().to(DEV)) for _, p in ps]
+    pack = ParamPack(ps, DEV)
+    opt = FusedAdamW([pack], lr=1e-2, weight_decay=0.1)
+    topt = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1)
+    plan = [["a.weight", "a.bias", "b.weight"], names, ["head.weight", "head.bias"], ["a.weight", "b.weight"], names]
+    for it, live in enumerate(plan):
+        opt.zero_grad(); topt.zero_grad(set_to_none=True)
+        for n, r in zip(names, ref):
+            if n in live:
+                g = torch.randn_like(r)
+                pack.g32(n).copy_(g)
+                r.grad = g.clone()
+        pack.publish_grads(live)
+        assert all((pack.params[n].grad is None) == (n not in live) for n in names)
+        opt.step(); topt.step()
+        for n, r in zip(names, ref):
+            torch.testing.assert_close(pack.w32(n), r.detach(), rtol=2e-6, atol=2e-7, msg=f"step {it}: {n}")
+        if it == 2:            # resume: a fresh optimizer loaded from the state continues identically
+            sd = opt.state_dict()
+            opt = FusedAdamW([pack], lr=1.0, weight_decay=0.0)
+            opt.load_state_dict(sd)
+    assert opt.steps[0]["head.weight"] == 3 and opt.steps[0]["a.weight"] == 4 and opt.steps[0]["a.bias"] == 3
+
+
+def test_load_base_weights_keeps_the_added_special_rows():
+    """a real Qwen3 checkpoint has the BASE vocabulary; loading it after the table was extended must fill the
+    first rows, keep the special rows and refresh the frozen bf16 copies."""
+    from unirec_amd.joint import MultiModalQwenEmbedding
+    from unirec_amd.qformer_model import QFormerForItemRepresentation
+    from unirec_amd.qwen3 import Qwen3Config, Qwen3LoRAModel
+    cfg = Qwen3Config(vocab_size=100, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=128)
+    qf = QFormerForItemRepresentation(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                                      num_query_tokens=2, field_embedding_dim=64, num_fields=5, dropout=0.0)
+    m = MultiModalQwenEmbedding(qformer_model=qf, use_lora=True, qwen_config=cfg, num_history_items=3, num_query_tokens_per_item=2).to(DEV).eval()
+    assert m.base_model.embed_tokens.weight.shape[0] == 106
+    ids = torch.randint(0, 100, (2, 16), device=DEV)
+    with torch.no_grad():
+        before = m.base_model.forward_pooled(ids)                  # builds the frozen bf16 copies
+    torch.manual_seed(1)
+    donor = Qwen3LoRAModel(Qwen3Config(vocab_size=100, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                                       num_key_value_heads=2, head_dim=128), use_lora=False)
+    sd = {"model." + k: v for k, v in donor.state_dict().items()}
+    with pytest.raises(RuntimeError):
+        m.base_model.load_state_dict({k[6:]: v for k, v in sd.items()}, strict=False)       # the documented failure mode
+    special = m.base_model.embed_tokens.weight[100:].detach().clone()
+    missing, unexpected = m.load_base_weights(sd)
+    assert not missing and not unexpected
+    assert torch.equal(m.base_model.embed_tokens.weight[:100].cpu(), donor.embed_tokens.weight.detach())
+    assert torch.equal(m.base_model.embed_tokens.weight[100:], special)
+    with torch.no_grad():
+        after = m.base_model.forward_pooled(ids)
+    assert not torch.equal(before, after)                          # stale frozen copies would give `before` again
+    donor = donor.to(DEV).eval()
+    with torch.no_grad():
+        want = donor.forward_pooled(ids)
+    # LoRA B is zero-initialised: the adapter contributes nothing, so the loaded model reproduces the donor
+    torch.testing.assert_close(after, want, rtol=2e-2, atol=2e-3)
+
+
+def test_lora_dropout_planes_of_different_sites_are_unrelated():
+    """the masks of different (layer, adapter group, step) must be independent draws -- not XOR-permuted
+    copies of one stream (v_proj's plane used to equal gate_proj's, and layer i+1 was layer i with its 32-column groups
+    swapped).  Two independent Bernoulli(0.9) keep masks agree on 0.9^2 + 0.1^2 = 0.82 of the positions."""
+    from unirec_amd.qwen3 import Qwen3Config, Qwen3LoRAModel
+    m = Qwen3LoRAModel(Qwen3Config(num_hidden_layers=2, vocab_size=64), use_lora=True)
+    M, W, p = 512, 1024, 0.1
+
+    def keep(step, layer, group, nad):
+        bits = hip.lora_dropout_bits(m.lora_dropout_seed(step, layer, group), p, M, W, nad, DEV)
+        return hip.lora_bits_to_keep(bits, W).float()
+    a = keep(0, 0, 0, 3)            # q|k|v planes of layer 0
+    g = keep(0, 0, 2, 2)            # gate|up planes of layer 0
+    b = keep(0, 1, 0, 3)            # q|k|v planes of layer 1
+    c = keep(1, 0, 0, 3)            # next step
+    assert abs(a.mean().item() - 0.9) < 5e-3
+
+    def agree(x, y):
+        return (x == y).float().mean().item()
+    ind = 0.82
+    assert abs(agree(a[2], g[0]) - ind) < 0.01            # v_proj vs gate_proj (same M, same W): were identical
+    assert abs(agree(a[0], b[0]) - ind) < 0.01 and abs(agree(a[0], c[0]) - ind) < 0.01 and abs(agree(a[0], a[1]) - ind) < 0.01
+    # layer 1 against layer 0 with neighbouring 32-column groups swapped, and with any single XOR of the group index
+    a0, b0 = a[0].view(M, W // 32, 32), b[0].view(M, W // 32, 32)
+    for x in (1, 2, 3, 4, 8, 16, 31):
+        perm = torch.arange(W // 32, device=DEV) ^ x
+        assert abs(agree(a0[:, perm], b0) - ind) < 0.01, x
+    assert torch.equal(keep(0, 0, 0, 3), a)               # and a pure function of (seed, step, layer, group)

@@ -1,0 +1,283 @@
+"""GPU parity, round 2: mid-size reference fixtures (the 256x256 8-phase GEMM, multi-tile causal head_dim-128 attention
+and the few-query dK/dV kernel meet reference-produced vectors), the gradients w.r.t. the decoder's input embeddings
+(golden `grad_inputs_embeds`), the real UserSequenceEncoder boundary, and full-size C2 / C3 / C5 steps through
+size-independent properties."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import data_ref as D  # noqa: E402
+from oracle import qformer_ref as R  # noqa: E402
+from oracle import qwen3_ref as Q  # noqa: E402
+from oracle import weights as W  # noqa: E402
+from tests.golden import cases  # noqa: E402
+from tests.golden import data_cases as dc  # noqa: E402
+from tests.parity_utils import GRAD_REL, OUT_REL, assert_close, load_generated, load_golden  # noqa: E402
+from tests.test_gpu_joint import _qwen_cfg  # noqa: E402
+
+DEV = "cuda"
+QWEN_SMALL = [n for n, c in cases.ALL.items() if c["kind"] == "qwen"]
+
+
+def _decoder_with_inputs_as_injected_tokens(case):
+    """The product decoder consumes token ids; to differentiate w.r.t. `inputs_embeds` every position carries its own
+    special id and the embeddings ride in as the injected tokens (the J2 path), whose gradient the backward returns."""
+    from unirec_amd.qwen3 import Qwen3LoRAModel
+    qc = cases.qwen_cfg(case)
+    m = Qwen3LoRAModel(_qwen_cfg(qc, False), use_lora=False)
+    m = load_generated(m, Q.qwen3_shapes(qc, lora=False), case["seed"] + 1)
+    x, am = cases.qwen_inputs(case)
+    B, S, Dm = x.shape
+    m.resize_token_embeddings(qc.vocab_size + S)
+    m = m.to(DEV).train()
+    ids = (qc.vocab_size + torch.arange(S, device=DEV)).expand(B, S).contiguous()
+    tok = torch.from_numpy(x).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    pooled = m.forward_pooled(ids, torch.from_numpy(am).to(DEV), tok, qc.vocab_size)
+    return pooled, tok, x
+
+
+@pytest.mark.parametrize("name", QWEN_SMALL)
+def test_decoder_input_gradient_matches_transformers(name):
+    case = cases.ALL[name]
+    g = load_golden(name)
+    pooled, tok, _ = _decoder_with_inputs_as_injected_tokens(case)
+    assert_close(pooled, g["sdpa/last_hidden_state"].mean(axis=1), OUT_REL, "pooled")
+    pooled.pow(2).sum().backward()
+    assert_close(tok.grad.float(), g["sdpa/grad_inputs_embeds"], GRAD_REL, "grad_inputs_embeds")
+
+
+def test_qwen3_mid_size_matches_transformers():
+    """4 layers of the 0.6B shape at B*S = 2048 tokens: 256x256 GEMM tiles, 8 causal key tiles per head, GQA 16/8."""
+    case = cases.MID["qwen_mid"]
+    g = load_golden("qwen_mid")
+    pooled, tok, x = _decoder_with_inputs_as_injected_tokens(case)
+    assert_close(pooled, g["sdpa/pooled"], OUT_REL, "pooled")
+    pooled.pow(2).sum().backward()
+    got = tok.grad.float().cpu().numpy()
+    assert_close(cases.mid_sample(got), g["sdpa/grad_inputs_embeds_s"], GRAD_REL, "grad_inputs_embeds (every 16th position)")
+    gn = float(np.linalg.norm(got.astype(np.float64)))
+    assert abs(gn - float(g["sdpa/grad_inputs_embeds_norm"])) <= GRAD_REL * gn
+
+
+def test_user_qformer_mid_size_matches_reference():
+    """The reference's default UserQFormer (L4 Q64 H1024 I4096) over T = 1600 keys: C3's shapes at B = 2."""
+    from unirec_amd.user_qformer import UserQFormer
+    case = cases.MID["user_mid"]
+    c = case["cfg"]
+    g = load_golden("user_mid")
+    cfg = R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 1)
+    m = UserQFormer(dropout=0.0)
+    m = load_generated(m, R.user_qformer_shapes(cfg, c["n_pred"]), case["seed"]).train()
+    x, mask, tgt = cases.user_inputs(case)
+    pred = m(torch.from_numpy(x).to(DEV), torch.from_numpy(mask).to(DEV))
+    assert_close(pred, g["predicted_item_tokens"], OUT_REL, "predicted_item_tokens")
+    loss = ((pred - torch.from_numpy(tgt).to(DEV)) ** 2).mean()
+    assert_close(loss, g["loss"], OUT_REL, "loss")
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k in cases.user_grad_keys(c):
+        assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL, "grad/" + k, floor=1e-6)
+
+
+# ---- the UserSequenceEncoder boundary (models/user_sequence_encoder.py:36-142) ----------------------------------------
+USE_CFG = dict(H=dc.CTX_H, L=2, nh=2, I=256, Q=dc.QI, E=dc.E, seed=61)      # = tests/golden/make_golden_r2.py:USE_CFG
+
+
+def _write_item_checkpoint(path, fields, config_as):
+    """A checkpoint in the format training/item_qformer_training.py:178-186 writes: {'model_state_dict','config','field_names'}."""
+    from unirec_amd.qformer_utils import QFormerForItemRepresentation
+    c = USE_CFG
+    m = QFormerForItemRepresentation(hidden_size=c["H"], num_hidden_layers=c["L"], num_attention_heads=c["nh"], intermediate_size=c["I"],
+                                     num_query_tokens=c["Q"], field_embedding_dim=c["E"], num_fields=len(fields), dropout=0.2)
+    gen = W.fill_state_dict(R.item_qformer_shapes(R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 2), len(fields)), c["seed"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in gen.items()}, strict=False)
+    cfg = m.config if config_as == "object" else dict(m.config.__dict__)
+    torch.save({"model_state_dict": m.state_dict(), "config": cfg, "field_names": fields}, path)
+
+
+@pytest.mark.parametrize("config_as", ["object", "dict"])
+def test_user_sequence_encoder_drop_in(tmp_path, config_as):
+    from unirec_amd.user_sequence_encoder import UserSequenceEncoder
+    g = load_golden("use_real")
+    samples, item_dict = dc.item_samples()
+    fields = [str(f) for f in g["fields"]]
+    ck = tmp_path / "best_qformer_model.pth"
+    _write_item_checkpoint(str(ck), fields, config_as)
+    cfgp = tmp_path / "triplet_config.yaml"
+    cfgp.write_text("FIELD_MAPPING:\n" + "".join(f"  {f}: [{i}, 0, text]\n" for i, f in enumerate(fields)) + "MODALITY_IDS:\n  text: 0\n")
+    enc = UserSequenceEncoder(item_qformer_checkpoint_path=str(ck), item_encoder_config_path=str(cfgp), item_encoder=dc.FakeItemEncoder())
+    H = USE_CFG["H"]
+    assert enc.embedding_dim == H and enc.item_qformer_fields == fields and not enc.item_qformer.training
+    assert enc.item_qformer.config.num_hidden_layers == USE_CFG["L"] and enc.item_qformer.num_query_tokens == dc.QI
+    enc.timestamp_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in W.fill_state_dict(D.context_mlp_shapes(H, 9), dc.CTX_SEED).items()})
+    enc.geo_encoder.load_state_dict({k: torch.from_numpy(v) for k, v in W.fill_state_dict(D.context_mlp_shapes(H, 3), dc.CTX_SEED + 1).items()})
+    enc.timestamp_encoder.to(DEV); enc.geo_encoder.to(DEV)
+    events = [dict(e, item_data=item_dict[e["item_id"]]) for e in dc.user_events()[0]]
+    toks = enc._get_item_query_tokens_batch([e["item_data"] for e in events])
+    assert toks.dtype == torch.float32 and tuple(toks.shape) == (5, dc.QI, H)
+    assert_close(toks, g["item_query_tokens"], OUT_REL, "_get_item_query_tokens_batch")
+    enc.positional_encoder.eval()                      # the fixture was generated with the positional dropout off
+    seq = enc.encode_user_sequence(events)
+    assert tuple(seq.shape) == (5 * dc.QI, H)          # the reference's own shape check (:187-189)
+    assert_close(seq, g["encoded_user_sequence"], OUT_REL, "encode_user_sequence")
+    enc.positional_encoder.train()                     # reference default: dropout(0.1) active
+    seq2 = enc.encode_user_sequence(events)
+    zeros = float((seq2 == 0).float().mean())
+    assert 0.03 < zeros < 0.25, zeros
+    assert tuple(enc.encode_user_sequence([]).shape) == (0, dc.QI, H)
+
+
+def test_user_sequence_encoder_without_encoders_raises(tmp_path):
+    from unirec_amd.item_encoder_pure_value import ModalityEncodersUnavailable
+    from unirec_amd.user_sequence_encoder import UserSequenceEncoder
+    fields = ["title", "price"]
+    ck = tmp_path / "ck.pth"
+    _write_item_checkpoint(str(ck), fields, "object")
+    cfgp = tmp_path / "cfg.yaml"
+    cfgp.write_text("FIELD_MAPPING:\n  title: [0, 0, text]\n  price: [1, 3, number]\nMODALITY_IDS:\n  text: 0\n  number: 3\n")
+    enc = UserSequenceEncoder(str(ck), str(cfgp))
+    with pytest.raises(ModalityEncodersUnavailable):
+        enc._get_item_query_tokens_batch([{"item_id": "a", "title": "x", "price": 1.0}])
+
+
+# ---- full-size configurations through size-independent properties -------------------------------------------------------
+def _grads(m):
+    return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+def _worst_rel(ga, gb, g):
+    worst = 0.0
+    for k in g:
+        s = ga[k].float() + gb[k].float()
+        worst = max(worst, ((s - g[k].float()).norm() / (g[k].float().norm() + 1e-20)).item())
+    return worst
+
+
+def test_c2_full_size_item_step_properties():
+    """C2: item Q-Former L12 Q32 H768 nh12 I3072 F14 E1024, B=256, the triplet step's loss (models/qformer_utils.py:17-60,
+    training/item_qformer_training.py:117-131): determinism, shard invariance of the forward, additivity of gradients."""
+    from unirec_amd.losses import QFormerLoss
+    from unirec_amd.qformer_utils import QFormerForItemRepresentation
+    torch.manual_seed(3)
+    B = 256
+    m = QFormerForItemRepresentation(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                                     num_query_tokens=32, field_embedding_dim=1024, num_fields=14, dropout=0.0).to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 14, 1024, generator=g); x = x / x.norm(dim=-1, keepdim=True)
+    mk = (torch.rand(B, 14, generator=g) < 0.8).long(); mk[:, 0] = 1
+    x, mk = (x * mk[..., None]).to(DEV), mk.to(DEV)
+    pr, nr = (torch.randn(B, 1024, generator=g) * 0.05).to(DEV), (torch.randn(B, 1024, generator=g) * 0.05).to(DEV)
+    loss_fn = QFormerLoss()
+
+    def step(sl, recon_only=False):
+        for p in m.parameters():
+            p.grad = None
+        out = m(x[sl], mk[sl])
+        loss, recon, cont = loss_fn(out, {"field_embeddings": x[sl]}, pr[sl], nr[sl], mk[sl])
+        (cont if recon_only else loss).backward()
+        return out, loss.detach().clone(), _grads(m)
+    full = slice(0, B)
+    out, loss, gr = step(full)
+    assert all(torch.isfinite(v).all() for v in out.values()) and torch.isfinite(loss)
+    out2, loss2, gr2 = step(full)
+    assert torch.equal(loss, loss2) and all(torch.equal(out[k], out2[k]) for k in out)
+    assert [k for k in gr if not torch.equal(gr[k], gr2[k])] == []                       # run-to-run bitwise determinism
+    assert len(gr) == len([n for n, p in m.named_parameters() if p.requires_grad])       # every live tensor receives a gradient
+    with torch.no_grad():
+        o = m(x[64:128], mk[64:128])
+    for k in out:
+        assert torch.equal(o[k], out[k][64:128]), k                                      # shard invariance, bit for bit
+    # additivity on the per-sample-mean triplet term (the masked MSE has a batch-global denominator: covered by the DP test)
+    _, _, g_all = step(full, recon_only=True)
+    _, _, ga = step(slice(0, 128), recon_only=True)
+    _, _, gb = step(slice(128, 256), recon_only=True)
+    ga = {k: v * 0.5 for k, v in ga.items()}
+    gb = {k: v * 0.5 for k, v in gb.items()}
+    assert _worst_rel(ga, gb, g_all) < 2e-2
+
+
+def test_c3_full_size_user_step_properties():
+    """C3: UserQFormer L4 Q64 H1024 over T = 1600 cached item tokens, B = 512, ragged (training/user_qformer_training.py:21-68)."""
+    from unirec_amd.losses import mse_loss
+    from unirec_amd.user_qformer import UserQFormer
+    torch.manual_seed(4)
+    B, T = 512, 1600
+    m = UserQFormer(dropout=0.0).to(DEV).train()
+    g = torch.Generator().manual_seed(6)
+    lens = torch.randint(T // 2, T + 1, (B,), generator=g)
+    lens[0], lens[1] = T, 1
+    mask = (torch.arange(T)[None, :] < lens[:, None]).float().to(DEV)
+    x = torch.empty(B, T, 1024, dtype=torch.bfloat16, device=DEV)
+    for i in range(0, B, 64):
+        x[i:i + 64] = (torch.randn(64, T, 1024, generator=g) * 0.8).to(torch.bfloat16).to(DEV)
+    x = x * mask[..., None].to(torch.bfloat16)
+    tgt = (torch.randn(B, 32, 1024, generator=g) * 0.8).to(DEV)
+
+    def step(sl, scale=1.0):
+        for p in m.parameters():
+            p.grad = None
+        pred = m(x[sl], mask[sl])
+        loss = mse_loss(pred, tgt[sl]) * scale
+        loss.backward()
+        return pred.detach().clone(), loss.detach().clone(), _grads(m)
+    pred, loss, gr = step(slice(0, B))
+    assert tuple(pred.shape) == (B, 32, 1024) and torch.isfinite(pred).all() and torch.isfinite(loss)
+    pred2, loss2, gr2 = step(slice(0, B))
+    assert torch.equal(pred, pred2) and torch.equal(loss, loss2) and all(torch.equal(gr[k], gr2[k]) for k in gr)
+    with torch.no_grad():
+        p0 = m(x[:64], mask[:64])
+    assert torch.equal(p0, pred[:64])                                # shard invariance incl. the 1-key and full-length rows
+    _, la, ga = step(slice(0, 256), 0.5)
+    _, lb, gb = step(slice(256, 512), 0.5)
+    assert abs((la + lb).item() - loss.item()) <= 1e-5 * abs(loss.item())
+    assert _worst_rel(ga, gb, gr) < 2e-2
+    # padded keys are inert: garbage behind a sample's length changes nothing
+    x2 = x.clone()
+    x2[1, 1:] = 7.0
+    with torch.no_grad():
+        assert torch.equal(m(x2[:64], mask[:64]), p0)
+
+
+def test_c5_shaped_step_properties():
+    """C5: hist = 100, S = 4096, pool 10000, the User Q-Former's 64 tokens injected (U4), 28 layers -- at B = 16 per
+    launch (the full B = 64 is the micro-batched / recomputed step of bench.py): determinism, shard invariance, exact
+    ranks and top-K over the 10000-candidate pool."""
+    import bench
+    from unirec_amd import hip
+    from unirec_amd.joint import InfoNCELoss, mrr_ranks
+    args = argparse.Namespace(layers=28, hist=100, seq=4096, pool=10000, no_dropout=True, lora_dropout=0.0, user_tokens=True)
+    model, qf, cfg, (Qi, F, E, Dm) = bench.build(args, torch.device(DEV))
+    B = 16
+    b = bench.make_batch(B, args.hist, args.seq, args.pool, F, E, Dm, Qi, model.first_special_id, model.first_special_id, 99, DEV,
+                         n_user=model.num_user_query_tokens)
+    model.train()
+
+    def fwd(sl):
+        return model(b["input_ids"][sl], b["attention_mask"][sl], b["history_field_embeddings"][sl], b["history_attention_mask"][sl],
+                     b["user_sequence_tokens"][sl], b["user_attention_mask"][sl])
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        u = fwd(slice(0, B))
+        loss = InfoNCELoss()(u, b["positive_item_embeddings"], b["negative_item_embeddings"])
+        loss.backward()
+        return u.detach().clone(), loss.detach().clone(), _grads(model)
+    u, loss, gr = step()
+    assert torch.isfinite(u).all() and torch.isfinite(loss)
+    u2, loss2, gr2 = step()
+    assert torch.equal(u, u2) and torch.equal(loss, loss2) and all(torch.equal(gr[k], gr2[k]) for k in gr)
+    assert any(k.startswith("user_qformer.") for k in gr) and any(k.startswith("qformer_model.") for k in gr) and any(".lora_" in k for k in gr)
+    with torch.no_grad():
+        assert torch.equal(fwd(slice(4, 8)), u[4:8])
+    scores, rank = mrr_ranks(u, b["positive_item_embeddings"], b["negative_item_embeddings"])
+    assert tuple(scores.shape) == (B, 10000)
+    assert torch.equal(rank.long(), 1 + (scores[:, 1:] > scores[:, :1]).sum(1))
+    idx, val = hip.topk(scores, 10)
+    order = torch.sort(scores, dim=1, descending=True, stable=True)
+    assert torch.equal(idx.long(), order.indices[:, :10]) and torch.equal(val, order.values[:, :10])

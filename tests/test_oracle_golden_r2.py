@@ -1,0 +1,141 @@
+"""CPU: round-2 reference fixtures (tests/golden/make_golden_r2.py) against the oracle and the host side of the product:
+mid-size Qwen3 / user Q-Former vectors, the real UserSequenceEncoder path, the state_dict key/shape contract and the
+ItemEncoder surface."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data_ref as D
+from oracle import qformer_ref as R
+from oracle import qwen3_ref as Q
+from oracle import weights as W
+from tests.golden import cases
+from tests.golden import data_cases as dc
+from tests.test_oracle_golden import _check_grads, _close, _load, _params
+
+torch.set_num_threads(min(8, os.cpu_count() or 1))
+USE_CFG = dict(H=dc.CTX_H, L=2, nh=2, I=256, Q=dc.QI, E=dc.E, seed=61)      # = tests/golden/make_golden_r2.py:USE_CFG
+
+
+def test_qwen3_mid_size(golden_dir):
+    case = cases.MID["qwen_mid"]
+    g = _load(golden_dir, "qwen_mid")
+    qc = cases.qwen_cfg(case)
+    P = _params(Q.qwen3_shapes(qc, lora=False), case["seed"] + 1, requires_grad=False)
+    x, am = cases.qwen_inputs(case)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    h = Q.qwen3_forward(P, qc, xt, torch.from_numpy(am), fully_masked="zero")
+    pooled = h.mean(dim=1)
+    pooled.pow(2).sum().backward()
+    _close(pooled.detach().numpy(), g["sdpa/pooled"], rtol=1e-3, atol=1e-4, what="pooled")
+    _close(cases.mid_sample(h.detach().numpy()), g["sdpa/last_hidden_state_s"], rtol=1e-3, atol=2e-4, what="last_hidden_state")
+    _close(cases.mid_sample(xt.grad.numpy()), g["sdpa/grad_inputs_embeds_s"], rtol=2e-3, atol=1e-7, what="grad_inputs_embeds")
+    gn = float(np.linalg.norm(xt.grad.numpy().astype(np.float64)))
+    assert abs(gn - float(g["sdpa/grad_inputs_embeds_norm"])) <= 1e-3 * gn
+
+
+def test_user_qformer_mid_size(golden_dir):
+    case = cases.MID["user_mid"]
+    c = case["cfg"]
+    g = _load(golden_dir, "user_mid")
+    cfg = R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 1)
+    P = _params(R.user_qformer_shapes(cfg, c["n_pred"]), case["seed"])
+    x, mask, tgt = cases.user_inputs(case)
+    pred, _ = R.user_qformer_forward(P, cfg, torch.from_numpy(x), torch.from_numpy(mask), c["n_pred"])
+    _close(pred.detach().numpy(), g["predicted_item_tokens"], rtol=1e-3, atol=1e-4, what="pred")
+    loss = ((pred - torch.from_numpy(tgt)) ** 2).mean()
+    _close(loss.detach(), g["loss"], what="loss")
+    loss.backward()
+    _check_grads(P, g, cases.user_grad_keys(c))
+
+
+def test_user_sequence_encoder_real_path_oracle(golden_dir):
+    """models/user_sequence_encoder.py:72-142 with a real item Q-Former behind it: field vectors -> np.any mask -> item
+    Q-Former (eval) -> + time/geo context -> flatten -> + sinusoidal PE."""
+    g = _load(golden_dir, "use_real")
+    c = USE_CFG
+    samples, item_dict = dc.item_samples()
+    fields = sorted({k for s in samples for k in s if k != "item_id"})
+    assert list(g["fields"]) == fields
+    events = dc.user_events()[0]
+    batch = [item_dict[e["item_id"]] for e in events]
+    enc = dc.FakeItemEncoder().encode_batch_by_field(batch, fields)
+    x = np.stack([enc[f] for f in fields], axis=1)
+    mask = np.any(x != 0, axis=-1).astype(np.int64)
+    cfg = R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 2)
+    P = _params(R.item_qformer_shapes(cfg, len(fields)), c["seed"], requires_grad=False)
+    toks = R.item_qformer_forward(P, cfg, torch.from_numpy(x), torch.from_numpy(mask))["query_outputs"]
+    _close(toks.numpy(), g["item_query_tokens"], what="item_query_tokens")
+    H = c["H"]
+    tw = W.fill_state_dict(D.context_mlp_shapes(H, 9), dc.CTX_SEED)
+    gw = W.fill_state_dict(D.context_mlp_shapes(H, 3), dc.CTX_SEED + 1)
+    ts = [e["timestamp"] for e in events]
+    co = [e["coordinates"] for e in events]
+    ctx = D.context_mlp(D.timestamp_features(ts), tw) + D.context_mlp(D.geo_features(co), gw)
+    seq = R.assemble_user_sequence(toks, torch.from_numpy(np.asarray(ctx, dtype=np.float32)))
+    _close(seq.numpy(), g["encoded_user_sequence"], rtol=1e-3, atol=1e-4, what="encoded_user_sequence")
+
+
+SHAPE_CASES = {
+    "item_default_F14": ("qformer_utils", dict(num_fields=14)),
+    "item_qformer_model_default_F14": ("qformer_model", dict(num_fields=14)),
+    "item_c1": ("qformer_model", dict(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024,
+                                      num_query_tokens=4, field_embedding_dim=256, num_fields=8)),
+    "item_c2": ("qformer_utils", dict(hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                                      num_query_tokens=32, field_embedding_dim=1024, num_fields=14)),
+    "user_default": ("user_qformer", dict()),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SHAPE_CASES))
+def test_state_dict_keys_and_shapes_equal_the_reference(golden_dir, name):
+    """checkpoints must load both ways -- every key and shape of the reference module's state_dict
+    (dead tensors and the position_ids buffer included), nothing more."""
+    import importlib
+    want = json.load(open(os.path.join(golden_dir, "state_dict_shapes.json")))[name]
+    modname, kw = SHAPE_CASES[name]
+    mod = importlib.import_module("unirec_amd." + modname)
+    cls = mod.UserQFormer if modname == "user_qformer" else mod.QFormerForItemRepresentation
+    with torch.device("meta"):
+        m = cls(**kw)
+    got = {k: list(v.shape) for k, v in m.state_dict().items()}
+    assert sorted(got) == sorted(want), (sorted(set(want) - set(got))[:5], sorted(set(got) - set(want))[:5])
+    assert got == want
+
+
+def test_item_encoder_surface(tmp_path):
+    from unirec_amd.item_encoder_pure_value import ItemEncoder, ModalityEncodersUnavailable
+    cfgp = tmp_path / "triplet_config.yaml"
+    cfgp.write_text("FIELD_MAPPING:\n  title: [0, 0, text]\n  brand: [1, 1, category]\n  main_image: [2, 2, image]\n  price: [3, 3, number]\n"
+                    "MODALITY_IDS:\n  text: 0\n  category: 1\n  image: 2\n  number: 3\n")
+    enc = ItemEncoder(config_path=str(cfgp))
+    assert enc.embedding_dim == 1024 and list(enc.field_mapping) == ["title", "brand", "main_image", "price"]
+    assert enc.encode_batch_by_field([], ["title"])["title"].size == 0
+    with pytest.raises(ModalityEncodersUnavailable):
+        enc.encode_batch_by_field([{"item_id": "a", "title": "x"}], ["title"])
+    out = enc.encode_batch_by_field([{"item_id": "a"}], ["not_a_field"])          # unknown field: zeros, as the reference
+    assert out["not_a_field"].shape == (1, 1024) and not out["not_a_field"].any()
+
+    class Backend:
+        def encode_text_batch(self, xs):
+            return np.stack([np.full(1024, len(x), dtype=np.float32) for x in xs])
+
+        def encode_image_batch(self, xs):
+            return np.zeros((len(xs), 1024), dtype=np.float32)
+
+        def encode_number_batch(self, xs):
+            return np.stack([np.full(1024, float(x or 0), dtype=np.float32) for x in xs])
+    enc = ItemEncoder(config_path=str(cfgp), backend=Backend())
+    samples = [{"item_id": "a", "title": "abc", "price": 2.5}, {"item_id": "b", "title": "", "brand": "zz"}]
+    out = enc.encode_batch_by_field(samples, ["title", "brand", "price", "main_image"])
+    assert out["title"][:, 0].tolist() == [3.0, 0.0] and out["brand"][:, 0].tolist() == [0.0, 2.0] and out["price"][:, 0].tolist() == [2.5, 0.0]
+    rows = enc.encode_batch(samples)
+    assert len(rows) == 2 and set(rows[0]) == set(enc.field_mapping)
+    cache = {"a": {"title": np.ones(1024, dtype=np.float32)}}
+    enc = ItemEncoder(config_path=str(cfgp), field_cache=cache)
+    out = enc.encode_batch_by_field(samples, ["title"])
+    assert out["title"][0].sum() == 1024 and not out["title"][1].any()
+    assert enc.get_embedding_dimensions() == {k: 1024 for k in enc.field_mapping}

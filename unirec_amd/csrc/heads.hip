@@ -38,10 +38,11 @@ __global__ __launch_bounds__(256) void fproj_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ Wf, bf16_t* __restrict__ drec,
                                                         float* __restrict__ part, int B, int Q, int F, int E) {
   __shared__ float w[MAXF * MAXQ];
-  __shared__ float acc[MAXF * MAXQ + MAXF];
+  __shared__ float accw[4][MAXF * MAXQ + MAXF];      // one accumulator set per wave, summed in wave order: bitwise reproducible
   const int nacc = F * Q + F;
+  float* acc = accw[threadIdx.x >> 6];
   for (int i = threadIdx.x; i < F * Q; i += 256) w[i] = Wf[i];
-  for (int i = threadIdx.x; i < nacc; i += 256) acc[i] = 0.f;
+  for (int i = threadIdx.x; i < nacc; i += 256) { accw[0][i] = 0.f; accw[1][i] = 0.f; accw[2][i] = 0.f; accw[3][i] = 0.f; }
   __syncthreads();
   const long total = (long)B * E;
   for (long i0 = (long)blockIdx.x * 256; i0 < total; i0 += (long)gridDim.x * 256) {
@@ -56,17 +57,17 @@ __global__ __launch_bounds__(256) void fproj_bwd_kernel(const float* __restrict_
       for (int f = 0; f < F; ++f) {
         s += w[f * Q + q] * g[f];
         const float c = wave_sum(g[f] * r);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&acc[f * Q + q], c);     // LDS atomics, 4 waves
+        if ((threadIdx.x & 63) == 0) acc[f * Q + q] += c;
       }
       if (ok) drec[(b * Q + q) * E + e] = f2bf(s);
     }
     for (int f = 0; f < F; ++f) {
       const float c = wave_sum(g[f]);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&acc[F * Q + f], c);
+      if ((threadIdx.x & 63) == 0) acc[F * Q + f] += c;
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < nacc; i += 256) part[(long)blockIdx.x * nacc + i] = acc[i];
+  for (int i = threadIdx.x; i < nacc; i += 256) part[(long)blockIdx.x * nacc + i] = (accw[0][i] + accw[1][i]) + (accw[2][i] + accw[3][i]);
 }
 __global__ void part_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ o0, int n0,
                                    float* __restrict__ o1) {

@@ -72,11 +72,15 @@ __global__ void lora_bits_kernel(uint64_t seed, uint32_t thr15, int M, int W, in
   const int q = (int)(gid - m * ng);
   if (m >= M) return;
   const uint32_t thr_pk = thr15 * 0x10001u;
+  // seed-only key (scalar unit), entered between the two mixing rounds as ur_hash2 does: the streams of two seeds are
+  // neither shifted nor XOR-permuted copies of each other even when the seeds differ in a few low bits only
+  const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
+  const uint32_t k2 = fmix32((s_lo * 0x7FEB352Du) ^ ((s_hi << 13) | (s_hi >> 19)) ^ 0x5851F42Du);
   for (int a = 0; a < nad; ++a) {
     uint32_t out = 0;
     if (q * 32 < W) {
       const uint64_t ctr = (((uint64_t)m * (uint64_t)ng + (uint64_t)q) << 2) + (uint64_t)a;
-      const uint32_t h = fmix32(((uint32_t)ctr ^ (uint32_t)seed) + fmix32((uint32_t)(ctr >> 32) + (uint32_t)(seed >> 32) + 0x9E3779B9u));
+      const uint32_t h = fmix32((((uint32_t)ctr ^ s_lo) + fmix32((uint32_t)(ctr >> 32) + s_hi + 0x9E3779B9u)) ^ k2) + k2;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         uint32_t v = 0;

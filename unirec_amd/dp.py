@@ -112,6 +112,8 @@ class GradBuckets:
         self.bounds = list(boundaries)
         self.group = group
         self.pending = []
+        self.stash = None          # micro-batch accumulation: gradients of the earlier micro-batches of this step
+        self.hold = False          # True while a non-final micro-batch runs its backward: hooks accumulate, nothing is sent
         self.enabled = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(group) > 1 or os.environ.get("UNIREC_DP_FORCE") == "1")
 
@@ -120,12 +122,27 @@ class GradBuckets:
         return len(self.bounds) - 1
 
     def ready(self, i):
-        """All gradients of bucket i have been written on the current stream: start its all-reduce."""
-        if not self.enabled:
-            return
+        """All gradients of bucket i have been written on the current stream: fold in the stashed gradients of the earlier
+        micro-batches (if any) and start the bucket's all-reduce -- or, on a non-final micro-batch, only stash."""
         lo, hi = self.bounds[i], self.bounds[i + 1]
-        if hi > lo:
+        if hi <= lo:
+            return
+        if self.hold:
+            if self.stash is None:
+                self.stash = torch.zeros_like(self.flat)
+            self.stash[lo:hi].add_(self.flat[lo:hi])
+            return
+        if self.stash is not None:
+            self.flat[lo:hi].add_(self.stash[lo:hi])
+            self.stash[lo:hi].zero_()
+        if self.enabled:
             self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def begin_micro_batch(self, last):
+        """Gradient accumulation over micro-batches inside ONE optimizer step (every backward OVERWRITES the flat gradient
+        buffer): non-final micro-batches add their buckets to a stash as the backward completes them; the final one adds
+        the stash back bucket by bucket, right before that bucket's all-reduce, so the overlap with the backward stays."""
+        self.hold = not last
 
     def ready_all(self):
         for i in reversed(range(self.n)):

@@ -65,14 +65,26 @@ class MultiModalQwenEmbedding(nn.Module):
         if qformer_model is not None and qformer_model.config.hidden_size != self.hidden_size:
             raise ValueError("No projector: Q-Former hidden size must equal the LLM hidden size (:109)")
         base_vocab = cfg.vocab_size
-        self.tokenizer = tokenizer or HistoryTokenTable(base_vocab, num_history_items, num_query_tokens_per_item)
         self.history_tokens = [f"<|history_item_{i}_query_{j}|>" for i in range(num_history_items)
                                for j in range(num_query_tokens_per_item)]
+        self.user_tokens = [f"<|user_query_{k}|>" for k in range(self.num_user_query_tokens)]
+        if tokenizer is None:
+            tokenizer = HistoryTokenTable(base_vocab, num_history_items, num_query_tokens_per_item)
+        elif hasattr(tokenizer, "add_special_tokens"):
+            # a real tokenizer: extend it exactly as the reference does (:106-118); ids of the added tokens are consecutive
+            if getattr(tokenizer, "pad_token", None) is None and getattr(tokenizer, "eos_token", None) is not None:
+                tokenizer.pad_token = tokenizer.eos_token
+            tokenizer.add_special_tokens({"additional_special_tokens": self.history_tokens + self.user_tokens})
+        self.tokenizer = tokenizer
         # ids of the added special tokens are consecutive (tokenizer.add_special_tokens order, :106-119)
         self.first_special_id = int(self.tokenizer.convert_tokens_to_ids(self.history_tokens[0]))
-        self.user_tokens = [f"<|user_query_{k}|>" for k in range(self.num_user_query_tokens)]
         self.first_user_special_id = self.first_special_id + len(self.history_tokens)
-        self.base_model.resize_token_embeddings(max(base_vocab, self.first_user_special_id + len(self.user_tokens)))
+        need = self.first_user_special_id + len(self.user_tokens)
+        try:
+            need = max(need, len(self.tokenizer))          # :119 resize_token_embeddings(len(tokenizer))
+        except TypeError:
+            pass
+        self.base_model.resize_token_embeddings(max(base_vocab, need))
         if user_qformer is not None and user_qformer.config.hidden_size != self.hidden_size:
             raise ValueError("No projector: User Q-Former hidden size must equal the LLM hidden size")
 
@@ -101,6 +113,13 @@ class MultiModalQwenEmbedding(nn.Module):
                 item_tokens = torch.zeros((u16.shape[0], len(self.history_tokens), self.hidden_size), dtype=BF16, device=dev)
             item_tokens = torch.cat([item_tokens, u16], dim=1)      # special ids are consecutive: history block, then user block
         return self.base_model.forward_pooled(input_ids, attention_mask, item_tokens, self.first_special_id)
+
+    def load_base_weights(self, state_dict, strict=True):
+        """Load a Qwen3 checkpoint (the state_dict of the ``AutoModel`` the reference builds at :98-103) into the frozen
+        backbone AFTER the vocabulary was extended: ``embed_tokens.weight`` of the checkpoint has the base vocabulary only,
+        its rows are copied and the added special-token rows are kept (load first, resize afterwards in the reference,
+        :99-119 -- same result).  Returns (missing, unexpected) like ``load_state_dict``."""
+        return self.base_model.load_base_weights(state_dict, strict=strict)
 
     def save_pretrained(self, save_directory):
         os.makedirs(save_directory, exist_ok=True)

@@ -1,9 +1,15 @@
-"""Fused AdamW over flat parameter packs (one HIP kernel launch per pack per step).
+"""Fused AdamW over flat parameter packs (one HIP kernel launch per contiguous run of live tensors; one per pack when
+every tensor received a gradient).
 
 Semantics = torch.optim.AdamW (decoupled weight decay), the optimizer of all three reference loops
 (training/item_qformer_training.py:108, training/user_qformer_training.py:196, HF Trainer default at
-train_item_individual_token_joint.py:755-773).  ``grad_scale`` folds the 1/world_size of a summed
-all-reduce into the update.
+train_item_individual_token_joint.py:755-773), including what it does with parameters a backward did not reach:
+``grad is None`` => the parameter is skipped entirely -- no weight decay, no moment update, its own step count does not
+advance (the item Q-Former's heads and ``UserQFormer.prediction_head`` in the joint step).  Which tensors are live is
+what the backward published since the last ``zero_grad()`` (packing.ParamPack.live).  Gradients are OVERWRITTEN, not
+accumulated, by every backward: call ``zero_grad()`` once per step as the reference loops do, so a tensor touched in one
+step and untouched in the next is not re-stepped with a stale gradient.  ``grad_scale`` folds the 1/world_size of a
+summed all-reduce into the update.  ``state_dict`` / ``load_state_dict`` carry the moments and step counts (resume).
 """
 import torch
 
@@ -16,14 +22,38 @@ class FusedAdamW:
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.state = [(torch.zeros_like(p.master), torch.zeros_like(p.master)) for p in self.packs]
+        self.steps = [{n: 0 for n in p.names} for p in self.packs]          # per-tensor step counts (bias correction)
 
     def zero_grad(self, set_to_none=True):
-        # gradients are overwritten by every backward (packing.ParamPack.publish_grads); nothing to clear
-        return None
+        for p in self.packs:
+            p.clear_grads(set_to_none)
 
     def step(self, grad_scale=1.0):
         self.step_count += 1
-        for pack, (m, v) in zip(self.packs, self.state):
-            hip.adamw_step(pack.master, pack.grad, m, v, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                           self.step_count, grad_scale)
+        for pack, (m, v), steps in zip(self.packs, self.state, self.steps):
+            if not pack.live:
+                continue
+            for n in pack.live:
+                steps[n] += 1
+            for lo, hi, t in pack.live_ranges(key=steps.__getitem__):
+                hip.adamw_step(pack.master[lo:hi], pack.grad[lo:hi], m[lo:hi], v[lo:hi], self.lr, self.betas[0], self.betas[1],
+                               self.eps, self.weight_decay, t, grad_scale)
             pack.mark_dirty()
+
+    # ---- resume -----------------------------------------------------------------------------------------------------
+    def state_dict(self):
+        return {"step_count": self.step_count, "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                "packs": [{"names": list(p.names), "offsets": dict(p.offsets), "steps": dict(s), "exp_avg": m.detach().clone(),
+                           "exp_avg_sq": v.detach().clone()} for p, (m, v), s in zip(self.packs, self.state, self.steps)]}
+
+    def load_state_dict(self, sd):
+        if len(sd["packs"]) != len(self.packs):
+            raise ValueError(f"optimizer state holds {len(sd['packs'])} packs, this optimizer {len(self.packs)}")
+        for p, (m, v), s, rec in zip(self.packs, self.state, self.steps, sd["packs"]):
+            if list(rec["names"]) != list(p.names) or dict(rec["offsets"]) != dict(p.offsets):
+                raise ValueError("optimizer state does not match the parameter pack layout")
+            m.copy_(rec["exp_avg"].to(m.device))
+            v.copy_(rec["exp_avg_sq"].to(v.device))
+            s.update(rec["steps"])
+        self.step_count = int(sd["step_count"])
+        self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]

@@ -41,6 +41,7 @@ class ParamPack:
             p.data = v
         self._shadow_key = None
         self.dirty = True
+        self.live = set()          # names whose gradient entry a backward has written since the last clear_grads()
 
     def _view(self, flat, name, shape=None):
         o = self.offsets[name]
@@ -112,10 +113,45 @@ class ParamPack:
         grad=None exactly as in the reference).  Gradients are OVERWRITTEN per backward (the reference
         always zero_grads first: training/item_qformer_training.py:129); a param holding a foreign
         gradient tensor gets the new value accumulated (cold path)."""
-        for n in (self.names if names is None else names):
+        names = self.names if names is None else names
+        self.live.update(names)
+        for n in names:
             p = self.params[n]
             g = self.g32(n)
             if p.grad is None:
                 p.grad = g
             elif p.grad.data_ptr() != g.data_ptr():
                 p.grad.add_(g)
+
+    def clear_grads(self, set_to_none=True):
+        """optimizer.zero_grad(): forget which entries are live; param.grad -> None (or zeroed views)."""
+        for n in self.live:
+            p = self.params[n]
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+        self.live = set()
+
+    def span(self, name):
+        """[lo, hi) of one tensor in the flat buffers, padding up to the next tensor included."""
+        lo = self.offsets[name]
+        cnt = 1
+        for d in self.shapes[name]:
+            cnt *= d
+        return lo, lo + (cnt + ALIGN - 1) // ALIGN * ALIGN
+
+    def live_ranges(self, key=None):
+        """Maximal contiguous [lo, hi) runs of live tensors (in pack order); `key(name)` splits runs whose tensors must
+        not share a launch (different optimizer step counts)."""
+        runs = []
+        for n in self.names:
+            if n not in self.live:
+                continue
+            lo, hi = self.span(n)
+            k = None if key is None else key(n)
+            if runs and runs[-1][1] == lo and runs[-1][2] == k:
+                runs[-1][1] = hi
+            else:
+                runs.append([lo, hi, k])
+        return [(lo, hi, k) for lo, hi, k in runs]

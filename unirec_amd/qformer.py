@@ -15,6 +15,7 @@ invert_attention_mask; BertSelfAttention :169-275; BertSelfOutput :285-289; Bert
 :402-484; BertEncoder loop :517-566; BertModel.forward :804-972.
 """
 import math
+import re
 from types import SimpleNamespace
 
 import torch
@@ -111,9 +112,14 @@ class _EncoderParams(nn.Module):
         self.layer = nn.ModuleList([_LayerParams(config, i) for i in range(config.num_hidden_layers)])
 
 
+_DEAD_RE = re.compile(r"(^|\.)layer\.\d+\.(intermediate\.dense|output\.dense|output\.LayerNorm)\.")
+
+
 def _dead(name):
-    return (".intermediate.dense." in name or ".output.dense." in name or ".output.LayerNorm." in name
-            or "word_embeddings" in name or "position_embeddings" in name)
+    """Reference tensors the query-only path never touches: the text FFN directly under a layer
+    (``layer.N.intermediate`` / ``layer.N.output`` -- NOT ``attention.output`` / ``crossattention.output``, which are live)
+    and the word / position embedding tables."""
+    return bool(_DEAD_RE.search(name)) or "word_embeddings" in name or "position_embeddings" in name
 
 
 def _split_k_for(out_rows, out_cols, red):
@@ -272,6 +278,10 @@ class BertModel(nn.Module):
         else:
             qe_src = qe
         self._ensure_pack(query_embeds.device)
+        if not torch.is_grad_enabled():
+            # inference (token caches, evaluators, the no-grad positive / negative forward of the item step): no layer's
+            # activations are kept, the peak is one layer instead of all of them
+            return self._forward_impl(qe_src.detach(), enc.detach(), mask_u8, B, keep=False)[0]
         return _EncoderFn.apply(self, qe_src, enc, mask_u8, B, qe_param_name)
 
     # ---- implementation (sequence of HIP calls) --------------------------------------------------
@@ -283,7 +293,7 @@ class BertModel(nn.Module):
     def _seed(self, layer, site):
         return (self.seed * 1000003 + self._step * 8191 + layer * 64 + site) & 0x7FFFFFFFFFFFFFFF
 
-    def _forward_impl(self, query_embeds, enc, mask_u8, B):
+    def _forward_impl(self, query_embeds, enc, mask_u8, B, keep=True):
         cfg = self.config
         pack = self._ensure_pack(query_embeds.device)
         pre = self._names()
@@ -348,9 +358,10 @@ class BertModel(nn.Module):
             x3, z3, m3, r3 = hip.layernorm_fwd(y3, pack.w32(f2 + "LayerNorm.weight"), pack.w32(f2 + "LayerNorm.bias"), eps,
                                                residual=xc, p_pre=p_h, seed_pre=s_h3)
             L["ffn"] = (xc, u, hbuf, z3, m3, r3, s_h3)
-            S["layers"].append(L)
+            if keep:
+                S["layers"].append(L)
             x = x3
-        return x.view(B, Qn, H), S
+        return x.view(B, Qn, H), (S if keep else None)
 
     def _backward_impl(self, S, dout, enc_needs_grad, qe_param_name=None):
         cfg = self.config

@@ -178,6 +178,41 @@ class Qwen3LoRAModel(nn.Module):
         self.config.vocab_size = new_size
         self._frozen = None
 
+    def load_base_weights(self, state_dict, strict=True):
+        """Frozen base weights from a Qwen3Model / Qwen3-Embedding state_dict (HF key names, optional ``model.`` or
+        ``base_model.model.`` prefix).  A checkpoint vocabulary smaller than the (resized) table fills the first rows and
+        leaves the added special-token rows alone -- ``load_state_dict(strict=False)`` cannot do that: it raises on the
+        shape mismatch.  LoRA tensors in the dict are loaded too.  strict: every base tensor must be present."""
+        sd = {}
+        for k, v in state_dict.items():
+            for pre in ("base_model.model.", "model."):
+                if k.startswith(pre):
+                    k = k[len(pre):]
+            sd[k] = v
+        own = dict(self.named_parameters())
+        missing, unexpected = [], [k for k in sd if k not in own and k != "lm_head.weight"]
+        with torch.no_grad():
+            for k, p in own.items():
+                if k not in sd:
+                    if ".lora_" not in k:
+                        missing.append(k)
+                    continue
+                v = sd[k]
+                if k == "embed_tokens.weight" and v.shape[0] != p.shape[0]:
+                    if v.shape[0] > p.shape[0] or v.shape[1] != p.shape[1]:
+                        raise RuntimeError(f"embed_tokens.weight: checkpoint {tuple(v.shape)} does not fit the table {tuple(p.shape)}")
+                    p[:v.shape[0]].copy_(v.to(p.device, p.dtype))
+                    continue
+                if tuple(v.shape) != tuple(p.shape):
+                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {tuple(p.shape)}")
+                p.copy_(v.to(p.device, p.dtype))
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_base_weights: missing {missing[:5]}{'...' if len(missing) > 5 else ''}, unexpected {unexpected[:5]}")
+        self._frozen = None
+        if self._pack is not None:
+            self._pack.mark_dirty()
+        return missing, unexpected
+
     # ---- parameter plumbing ---------------------------------------------------------------------
     def lora_named_parameters(self):
         named = dict(self.named_parameters())
@@ -205,7 +240,9 @@ class Qwen3LoRAModel(nn.Module):
 
     def _ensure_frozen(self, device):
         """bf16 operands of the frozen base weights, fused per layer: [q|k|v], o, [gate|up], down."""
-        key = (str(device), self.embed_tokens.weight.data_ptr(), self.embed_tokens.weight._version)
+        # keyed on EVERY frozen tensor (storage + in-place version): loading any of them after a forward has run must not
+        # leave stale bf16 / transposed copies behind
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for n, p in self.named_parameters() if ".lora_" not in n)
         if self._frozen is not None and self._frozen["key"] == key:
             return self._frozen
         fz = {"key": key, "layers": []}
@@ -254,7 +291,11 @@ class Qwen3LoRAModel(nn.Module):
             item_tokens16 = torch.zeros((B, 0, self.config.hidden_size), dtype=BF16, device=input_ids.device)
         # the LoRA gradients are side effects of this node's backward: an anchor input keeps the node
         # alive even when the injected tokens do not require grad (frozen / absent Q-Former)
-        anchor = torch.zeros(1, device=input_ids.device, requires_grad=True) if (torch.is_grad_enabled() and self.use_lora) else None
+        if not torch.is_grad_enabled():
+            # inference (MRREvaluator, CatalogEvaluator, token caches): nothing is kept for a backward, so the peak is one
+            # layer's activations instead of all of them (178 GB at B=64, S=2048 in training)
+            return self._forward_impl(item_tokens16.detach(), input_ids.contiguous(), mask_u8, int(first_special_id), keep=False)[0]
+        anchor = torch.zeros(1, device=input_ids.device, requires_grad=True) if self.use_lora else None
         return _JointFn.apply(self, item_tokens16, input_ids.contiguous(), mask_u8, int(first_special_id), anchor)
 
     # ---- implementation ---------------------------------------------------------------------------
@@ -269,7 +310,12 @@ class Qwen3LoRAModel(nn.Module):
         """Seed of the dropout masks of one adapter group (the adapters that share an input: 0 = q|k|v, 1 = o,
         2 = gate|up, 3 = down) -- a pure function of (base seed, step, layer, group); tests regenerate the bit
         planes from it (hip.lora_dropout_bits) and feed the unpacked masks to the oracle."""
-        return (int(self.lora_seed) * 0x9E3779B1 + int(step) * 1000003 + layer * 8 + group) & 0x7FFFFFFFFFFFFFFF
+        # splitmix64 of the combined index: the seeds of neighbouring (step, layer, group) differ in every bit, not in a
+        # few low ones (the mask streams of two adapter groups must be unrelated, as peft's per-module nn.Dropout are)
+        z = (int(self.lora_seed) * 0x9E3779B97F4A7C15 + int(step) * 0xD1B54A32D192ED03 + (layer * 8 + group + 1) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        return (z ^ (z >> 31)) & 0x7FFFFFFFFFFFFFFF
 
     def _bits_groups(self):
         """(input width, adapters sharing it) of the four adapter groups of a layer: q|k|v, o, gate|up, down."""
@@ -337,7 +383,7 @@ class Qwen3LoRAModel(nn.Module):
         t = hip.lora_project(xin, [pack.w16(n) for n in a_names], alpha=sc / (1.0 - p), bits=bits)
         return t, bits
 
-    def _forward_impl(self, item_tokens16, input_ids, mask_u8, first_special_id):
+    def _forward_impl(self, item_tokens16, input_ids, mask_u8, first_special_id, keep=True):
         c = self.config
         dev = input_ids.device
         fz = self._ensure_frozen(dev)
@@ -426,10 +472,13 @@ class Qwen3LoRAModel(nn.Module):
             L.update(rstd1=rstd1, qkv=qkv, actx=actx, att=att2, x2=x2, rstd2=rstd2, gu=gu, act=act)
             if self.keep_norm_outputs:       # 2 x [M,D] bf16 per layer (15 GB at C4) instead of two RMSNorm recomputes
                 L.update(h=h, h2=h2)
-            saved["layers"].append(L)
+            if keep:
+                saved["layers"].append(L)
             x = x3
         last, rstd_f = hip.rmsnorm_fwd(x, fz["norm"], eps)
         pooled, _ = hip.mean_pool_fwd(last.view(B, S, D))
+        if not keep:
+            return pooled, None
         saved["xf"], saved["rstd_f"] = x, rstd_f
         return pooled, saved
 
