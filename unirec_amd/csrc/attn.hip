@@ -21,6 +21,7 @@
 // Backward = dQ kernel (same decomposition as forward) + dK/dV kernel (one 32-key block per wave,
 // looping over the query heads of its GQA group): no atomics, bitwise reproducible.
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include "common.cuh"
 #include "unirec_hip.h"
@@ -1073,6 +1074,78 @@ __device__ __forceinline__ void tr_landed(bf16x4 (&lo)[4], bf16x4 (&hi)[4]) {
                : "n"(N));
 }
 
+// ---- hand-ordered LDS streams of the dK/dV fast path (one wave per SIMD: nobody else hides an LDS latency, so every read
+// is issued up to 14 LDS operations ahead of its use and every use waits with a COUNTED lgkmcnt for exactly its own data;
+// the asm forms are invisible to hipcc's waitcnt pass, which would otherwise drain the in-flight LDS-DMA of the next tile
+// in front of the first LDS load that follows it).  Between issue and landed the destination registers hold no data yet.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+template <int OQ, int ODO>
+__device__ __forceinline__ void rf_issue(bf16x8& qa, bf16x8& da, uint32_t addr) {
+  asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4" : "=&v"(qa), "=&v"(da) : "v"(addr), "n"(OQ), "n"(ODO));
+}
+template <int N>
+__device__ __forceinline__ void rf_landed(bf16x8& qa, bf16x8& da) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(qa), "+v"(da) : "n"(N));
+}
+template <int OFF>
+__device__ __forceinline__ void tr_issue1(bf16x4& lo, bf16x4& hi, uint32_t a, uint32_t b) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4" : "=&v"(lo), "=&v"(hi) : "v"(a), "v"(b), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void tr_landed1(bf16x4& lo, bf16x4& hi) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(lo), "+v"(hi) : "n"(N));
+}
+
+// single-instruction f32 multiply: hipcc's SLP vectoriser packs neighbouring f32 multiplies of the softmax into v_pk_mul_f32,
+// which does not hide in an MFMA gap at one wave per SIMD (tools/lab/mfma_gap_lab.hip: +17 cycles per MFMA)
+__device__ __forceinline__ float mul1(float a, float b) {
+  float r;
+  asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// pin: the MFMA intrinsics are pure values, which hipcc is free to sink past sched_barriers (it bunched 12 of stream 2's
+// MFMAs behind the softmax fillers); an empty volatile asm that "rewrites" the accumulator just produced keeps every
+// MFMA between the two volatile asm statements (landed / next issue) it was written between
+__device__ __forceinline__ void pin(f32x16& a) { asm volatile("" : "+v"(a)); }
+__device__ __forceinline__ void pin(f32x16& a, f32x16& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+
+// MFMA with the accumulator held in AccVGPRs for the whole kernel (inline asm: under -amdgpu-mfma-vgpr-form hipcc keeps every
+// accumulator in arch VGPRs and, with dK^T / dV^T (128 registers) + K / V fragments (64) + S / dP of two halves (64) alone at the
+// 256-register limit, parked dK / dV in AccVGPRs anyway and copied 16 registers in and 16 out around MFMAs).  Volatile: keeps its
+// place between the counted LDS waits.  The leading s_nop (two wait states) covers what hipcc would put between a vector write of an
+// operand (a landed LDS fragment, a packed bf16 conversion) and the MFMA that reads it.
+__device__ __forceinline__ void mfma_acc_nop(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// the same without the wait states: ONLY where both operands were written long before (LDS fragments behind a counted
+// lgkmcnt, bf16 conversions at least one MFMA earlier) -- measured (tools/lab/mfma_gap_lab.hip): an s_nop between the
+// lgkmcnt wait and the MFMA costs 4-8 cycles per MFMA at one wave per SIMD
+__device__ __forceinline__ void mfma_acc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+#ifndef UR_DKV2_V2
+#define UR_DKV2_V2 1         // 0 (lab): the four hard-fenced phases of round 1 instead of the three counted streams
+#endif
+#ifndef UR_DKV2_STAMPS
+#define UR_DKV2_STAMPS 0     // lab builds only: lane 0 of wave 0 of the first 256 workgroups logs the cycle counter at 8 points of tiles 4..11 (ur_lab_attn_stamps)
+#endif
+#if UR_DKV2_STAMPS
+__device__ long long g_attn_stamps[256 * 8 * 8];
+#ifndef UR_STAMP_BLK0
+#define UR_STAMP_BLK0 0      // first stamped workgroup (0: the launch's first wave of workgroups; 4096: mid-kernel, clocks settled)
+#endif
+#define UR_STAMP_ON (threadIdx.x == 0 && blockIdx.x >= UR_STAMP_BLK0 && blockIdx.x < UR_STAMP_BLK0 + 256 && it >= 4 && it < 12)
+#define UR_ASTAMP(k) do { if (UR_STAMP_ON) g_attn_stamps[((blockIdx.x - UR_STAMP_BLK0) * 8 + (it - 4)) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define UR_ASTAMP(k) do { } while (0)
+#endif
+#ifndef UR_DKV2_ABLATE
+#define UR_DKV2_ABLATE 0     // lab (tools/lab/dkv2_ablate.sh; timing only, results wrong): 1 no tile reload, 2 no softmax, 3 no dV/dK phases, 4 no S/dP phases, 5 diagonal tiles on the fast path; three-stream path: 6 no MFMAs, 7 no LDS reads, 8 no fillers, 9 no LDS-DMA
+#endif
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv2_kernel(AttnP p) {
   constexpr int HD = 128, NW = 4;
@@ -1128,22 +1201,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   // row constants travel by LDS-DMA too (one dword per lane): ns[64] | nd[64] | (m, 1/l)[64]; rows past Sq are
   // clamped copies (masked by position in the general path; an interior tile has none)
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // row constants: four 256-byte pieces, one per wave (ns | nd | (m, 1/l) of rows 0-31 | of rows 32-63)
+  auto load_consts = [&](char* buf, long sbase, int q0) {
+    char* fb = buf + 2 * C::TILE + 256 * wave_u;
+    const int rd = min(q0 + lane, p.Sq - 1);
+    const int rs = min(q0 + 32 * (wave_u & 1) + (lane >> 1), p.Sq - 1);
+    const float* src = wave_u == 0 ? p.delta + nrows + sbase + rd : (wave_u == 1 ? p.delta + sbase + rd : p.stats + (sbase + rs) * 2 + (lane & 1));
+    __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)fb, 4, 0, 0);
+  };
   auto load_tile = [&](int it, char* buf) {
     const bf16_t* qb; const bf16_t* dob; long sbase; int q0;
     tile_ptrs(it, qb, dob, sbase, q0);
     qs.issue(buf, qb, p.ldq, q0, p.Sq, tid);
     dos.issue(buf + C::TILE, dob, p.lddo, q0, p.Sq, tid);
-    if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
-      typedef __attribute__((address_space(3))) void lds_void;
-      typedef const __attribute__((address_space(1))) void gbl_void;
-      char* fb = buf + 2 * C::TILE;
-      const int rd = min(q0 + lane, p.Sq - 1);
-      const int r0 = min(q0 + (lane >> 1), p.Sq - 1), r1 = min(q0 + 32 + (lane >> 1), p.Sq - 1);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(p.delta + nrows + sbase + rd), (lds_void*)fb, 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(p.delta + sbase + rd), (lds_void*)(fb + 256), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(p.stats + (sbase + r0) * 2 + (lane & 1)), (lds_void*)(fb + 512), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((gbl_void*)(p.stats + (sbase + r1) * 2 + (lane & 1)), (lds_void*)(fb + 768), 4, 0, 0);
-    }
+    load_consts(buf, sbase, q0);
   };
 
   // lane-constant LDS byte offsets (relative to a tile): row fragments of rows (lane&31) for the 8 k-steps, and the
@@ -1175,7 +1249,154 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // latency on every tile.  Phases 3-4 only read LDS through the inline-asm transposed reads.
     const bf16_t* qb_; const bf16_t* dob_; long sbase_; int q0;
     tile_ptrs(it, qb_, dob_, sbase_, q0);
-    const bool tile_fast = all_valid && (q0 + KT <= p.Sq) && (!CAUSAL || q0 >= kblk + 31);
+    bool tile_fast = all_valid && (q0 + KT <= p.Sq) && (!CAUSAL || q0 >= kblk + 31 || UR_DKV2_ABLATE == 5);
+#if UR_DKV2_V2
+    // the fast path issues the next tile's LDS-DMA itself, as whole-row pieces: the next tile must be full too
+    const bf16_t* nqb; const bf16_t* ndob; long nsb; int nq0;
+    tile_ptrs(it + 1 < ntot ? it + 1 : it, nqb, ndob, nsb, nq0);
+    tile_fast = tile_fast && (nq0 + KT <= p.Sq);
+#endif
+    UR_ASTAMP(0);
+#if UR_DKV2_STAMPS
+    if (UR_STAMP_ON) g_attn_stamps[((blockIdx.x - UR_STAMP_BLK0) * 8 + (it - 4)) * 8 + 1] = (long long)wall_clock64();   // 100 MHz constant clock
+#endif
+#if UR_DKV2_V2
+    if (kblk < p.Sk && tile_fast) {
+      // ---------------- fast path, three counted streams (64 MFMAs per 64-query tile) ----------------
+      const uint32_t bufb = lds_off(qtile);
+      // initial accumulators (plain LDS loads, BEFORE this tile issues any LDS-DMA): rows 8g + 4h + 0..3 of the 32-row
+      // half -> registers 4g .. 4g+3
+      auto init16 = [&](f32x16& a, const float* src) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 v = *reinterpret_cast<const float4*>(src + 8 * g + 4 * h);
+          a[4 * g] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
+        }
+      };
+      f32x16 sa, dpa, sb, dpb;
+      const float c2v = c2;       // one VGPR copy: mul1's operands are vector registers
+      init16(sa, fst); init16(dpa, fst + 64); init16(sb, fst + 32); init16(dpb, fst + 96);
+      __builtin_amdgcn_sched_barrier(0);
+      // next tile: wave-uniform row bases; its 8 + 1 LDS-DMA pieces ride in the MFMA gaps of stream 1
+      // (no next tile: the same tile is copied again into the idle buffer -- unconditional pieces keep stream 1 one
+      // straight-line block; a ragged next tile never gets here, see tile_fast)
+      char* nbuf = smem + ((it + 1) & 1) * STG;
+      auto dma_piece = [&](auto J) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < 4) {
+          const char* ub = reinterpret_cast<const char*>(nqb + (long)(nq0 + 16 * j) * p.ldq);
+          __builtin_amdgcn_global_load_lds((gbl_void*)(ub + qs.voff), (lds_void*)(nbuf + (j * 4 + wave_u) * 1024), 16, 0, 0);
+        } else if constexpr (j < 8) {
+          const char* ub = reinterpret_cast<const char*>(ndob + (long)(nq0 + 16 * (j - 4)) * p.lddo);
+          __builtin_amdgcn_global_load_lds((gbl_void*)(ub + dos.voff), (lds_void*)(nbuf + C::TILE + ((j - 4) * 4 + wave_u) * 1024), 16, 0, 0);
+        } else {
+          const float* cb = wave_u == 0 ? p.delta + nrows + nsb + nq0 : (wave_u == 1 ? p.delta + nsb + nq0 : p.stats + (nsb + nq0 + 32 * (wave_u & 1)) * 2);
+          __builtin_amdgcn_global_load_lds((gbl_void*)(cb + lane), (lds_void*)(nbuf + 2 * C::TILE + 256 * wave_u), 4, 0, 0);
+        }
+      };
+      // ---- streams 1 + 2: S', dP' of the two 32-query halves = 16 k-steps of {2 row fragments, 2 MFMAs}, fragments
+      //      issued RD k-steps ahead; softmax of half a rides under half b's MFMAs
+      constexpr int RD = 6;
+      bf16x8 qa[RD + 1], da[RD + 1];
+      uint32_t ra[C::NS];
+#pragma unroll
+      for (int st = 0; st < C::NS; ++st) ra[st] = bufb + rfo[st];
+      auto rissue = [&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if (UR_DKV2_ABLATE != 7 && UR_DKV2_ABLATE != 10) rf_issue<8192 * (k >> 3), C::TILE + 8192 * (k >> 3)>(qa[k % (RD + 1)], da[k % (RD + 1)], ra[k & 7]);
+      };
+      auto soft1 = [&](f32x16& sv, f32x16& dpv, int r) {
+        const float pr = fast_exp2(sv[r] * c2);
+        sv[r] = pr;
+        dpv[r] = pr * dpv[r];
+      };
+      static_for<0, RD>([&](auto K) { rissue(K); });
+      bf16x8 p0a, d0a, p1a, d1a, p0b, d0b, p1b, d1b;
+      static_for<0, 16>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if constexpr (k + RD < 16) rissue(std::integral_constant<int, k + RD>{});
+        constexpr int younger = (k + RD < 16) ? RD : (15 - k);
+        if (UR_DKV2_ABLATE != 7 && UR_DKV2_ABLATE != 10) rf_landed<2 * younger>(qa[k % (RD + 1)], da[k % (RD + 1)]);
+        if constexpr (UR_DKV2_ABLATE == 6) {
+          if constexpr (k < 8) { dma_piece(std::integral_constant<int, k>{}); if constexpr (k == 7) dma_piece(std::integral_constant<int, 8>{}); }
+          else { soft1(sa, dpa, 2 * (k - 8)); soft1(sa, dpa, 2 * (k - 8) + 1); if constexpr (k == 12) { p0a = acc_frag(sa, 0); d0a = acc_frag(dpa, 0); } }
+        } else if constexpr (k < 8) {
+          sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[k % (RD + 1)], kf[k & 7], sa, 0, 0, 0);
+          dpa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[k % (RD + 1)], vf[k & 7], dpa, 0, 0, 0);
+          pin(sa, dpa);
+          if constexpr (UR_DKV2_ABLATE != 9) { dma_piece(std::integral_constant<int, k>{}); if constexpr (k == 7) dma_piece(std::integral_constant<int, 8>{}); }
+        } else {
+          sb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[k % (RD + 1)], kf[k & 7], sb, 0, 0, 0);
+          dpb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da[k % (RD + 1)], vf[k & 7], dpb, 0, 0, 0);
+          pin(sb, dpb);
+          if constexpr (UR_DKV2_ABLATE != 8 && UR_DKV2_ABLATE != 10) {      // softmax of half a, staged: scale (k) | exp2 (k+1) | dS (k+2)
+            constexpr int e = 2 * (k - 8);
+            sa[e] = mul1(sa[e], c2v); sa[e + 1] = mul1(sa[e + 1], c2v);
+            if constexpr (k >= 9) { sa[e - 2] = fast_exp2(sa[e - 2]); sa[e - 1] = fast_exp2(sa[e - 1]); }
+            if constexpr (k >= 10) { dpa[e - 4] = mul1(sa[e - 4], dpa[e - 4]); dpa[e - 3] = mul1(sa[e - 3], dpa[e - 3]); }
+          }
+          if constexpr (k == 14) { p0a = acc_frag(sa, 0); d0a = acc_frag(dpa, 0); }       // elements 0..7 are complete after k = 13
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      UR_ASTAMP(2);
+      // ---- stream 3: dV^T += dO^T P, dK^T += Q^T dS = 32 units of {one transposed fragment (2 reads), 1 MFMA}, fragments
+      //      issued RT units ahead; softmax / bf16 conversion of half b ride in the first half of the stream
+      constexpr int RT = 7;
+      bf16x4 tl[RT + 1], th[RT + 1];
+      uint32_t ta[4], tb[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { ta[dt] = bufb + tao[dt]; tb[dt] = bufb + tbo[dt]; }
+      auto tissue = [&](auto U) {
+        constexpr int u = decltype(U)::value;
+        constexpr int bt = u >> 2, dt = u & 3;
+        constexpr int off = ((bt & 1) ? 0 : C::TILE) + 256 * (16 * (bt >> 1));      // even batches: dO tile, odd: Q tile; 16 query rows per pair
+        if (UR_DKV2_ABLATE != 7 && UR_DKV2_ABLATE != 10) tr_issue1<off>(tl[u % (RT + 1)], th[u % (RT + 1)], ta[dt], tb[dt]);
+      };
+      static_for<0, RT>([&](auto U) { tissue(U); });
+      // Per unit: wait for its own fragment (6 younger units stay in flight) | MFMA | issue unit u + RT | vector fillers.
+      // Issue budget of a 32x32x16 gap at one wave per SIMD (mfma_gap_lab): 32 cycles = MFMA 8 + two transposed reads ~14 +
+      // ~10 of vector work -- so the 72 vector instructions of half b's softmax + the bf16 conversions are spread over the
+      // whole stream, at most three per unit, each a different stage of a different element (no instruction waits on the
+      // one in front of it): element e is scaled in unit e + 3, exponentiated in unit e + 4, multiplied into dS in unit e + 5
+      // (e < 8), and three units later for e >= 8 (units 11 .. 21); conversions follow in units 10-13 and 22-25.
+      static_for<0, 32>([&](auto U) {
+        constexpr int u = decltype(U)::value;
+        constexpr int bt = u >> 2, dt = u & 3;
+        constexpr int younger = (31 - u < RT - 1) ? (31 - u) : (RT - 1);
+        if (UR_DKV2_ABLATE != 7 && UR_DKV2_ABLATE != 10) tr_landed1<2 * younger>(tl[u % (RT + 1)], th[u % (RT + 1)]);
+        const bf16x8 af = cat4(tl[u % (RT + 1)], th[u % (RT + 1)]);
+        if constexpr (UR_DKV2_ABLATE == 6) { sb[u & 15] += __builtin_bit_cast(float, (int)af[0] | ((int)af[4] << 16)); }
+        else if constexpr (bt == 0) mfma_acc(dv[dt], af, p0a);
+        else if constexpr (bt == 1) mfma_acc(dk[dt], af, d0a);
+        else if constexpr (bt == 2) mfma_acc(dv[dt], af, p1a);
+        else if constexpr (bt == 3) mfma_acc(dk[dt], af, d1a);
+        else if constexpr (bt == 4) mfma_acc(dv[dt], af, p0b);
+        else if constexpr (bt == 5) mfma_acc(dk[dt], af, d0b);
+        else if constexpr (bt == 6) mfma_acc(dv[dt], af, p1b);
+        else mfma_acc(dk[dt], af, d1b);
+        if constexpr (u + RT < 32) tissue(std::integral_constant<int, u + RT>{});
+        if constexpr (UR_DKV2_ABLATE != 8 && UR_DKV2_ABLATE != 10) {
+          // tail of half a (its elements 12..15), then half b
+          if constexpr (u == 0) { sa[14] = fast_exp2(sa[14]); sa[15] = fast_exp2(sa[15]); }
+          if constexpr (u == 1) { dpa[12] = mul1(sa[12], dpa[12]); dpa[13] = mul1(sa[13], dpa[13]); }
+          if constexpr (u == 2) { dpa[14] = mul1(sa[14], dpa[14]); dpa[15] = mul1(sa[15], dpa[15]); }
+          constexpr int sh = 3;                                         // half b starts in unit 3
+          if constexpr (u >= sh && u < sh + 16) sb[u - sh] = mul1(sb[u - sh], c2v);
+          if constexpr (u >= sh + 1 && u < sh + 17) sb[u - sh - 1] = fast_exp2(sb[u - sh - 1]);
+          if constexpr (u >= sh + 2 && u < sh + 18) dpb[u - sh - 2] = mul1(sb[u - sh - 2], dpb[u - sh - 2]);
+        }
+        if constexpr (u == 3) p1a = acc_frag(sa, 1);
+        if constexpr (u == 4) d1a = acc_frag(dpa, 1);
+        if constexpr (u == 13) p0b = acc_frag(sb, 0);                  // elements 0..7 of half b are complete after unit 12
+        if constexpr (u == 14) d0b = acc_frag(dpb, 0);
+        if constexpr (u == 21) p1b = acc_frag(sb, 1);                  // elements 8..15 after unit 20
+        if constexpr (u == 22) d1b = acc_frag(dpb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      UR_ASTAMP(6);
+    } else
+#else
     if (kblk < p.Sk && tile_fast) {
       const uint32_t qbase = lds_off(qtile), dobase = lds_off(dotile);
       // initial accumulators: rows 8g + 4h + 0..3 of the 32-row half -> registers 4g .. 4g+3
@@ -1243,22 +1464,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat4(l1[dt], h1[dt]), d1, dk[dt], 0, 0, 0);
       };
+#if UR_DKV2_ABLATE == 4
+      sa = dk[0]; dpa = dv[0]; sb = dk[1]; dpb = dv[1];
+#else
       // phase 1: S', dP' of half a
       s_dp(sa, dpa, 0);
       __builtin_amdgcn_sched_barrier(0);
+      UR_ASTAMP(1);
       // phase 2: S', dP' of half b; softmax of half a
       s_dp(sb, dpb, 1);
+#endif
+      UR_ASTAMP(2);
+#if UR_DKV2_ABLATE != 2
       soft(sa, dpa);
+#endif
       __builtin_amdgcn_sched_barrier(0);
+      UR_ASTAMP(3);
+#if UR_DKV2_ABLATE != 1
       if (it + 1 < ntot) load_tile(it + 1, smem + ((it + 1) & 1) * STG);
+#endif
       __builtin_amdgcn_sched_barrier(0);
+      UR_ASTAMP(4);
+#if UR_DKV2_ABLATE == 3
+      dk[0][0] += sa[0] + dpa[1] + sb[2] + dpb[3];
+#else
       // phase 3: dV, dK of half a; softmax of half b
       dvdk_half(sa, dpa, 0);
+#if UR_DKV2_ABLATE != 2
       soft(sb, dpb);
+#endif
       __builtin_amdgcn_sched_barrier(0);
+      UR_ASTAMP(5);
       // phase 4: dV, dK of half b
       dvdk_half(sb, dpb, 32);
-    } else if (kblk < p.Sk) {
+#endif
+      UR_ASTAMP(6);
+    } else
+#endif
+    if (kblk < p.Sk) {
       const int hq = kvh * p.rep + it / ntq;
       (void)hq;
 #pragma unroll
@@ -1298,8 +1541,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           tr_frags<HD>(tq, qtile, 32 * sub + 16 * s2, lane);
 #pragma unroll
           for (int dt = 0; dt < C::NDT; ++dt) {
+#if UR_DKV2_V2
+            mfma_acc_nop(dv[dt], tdo[dt], pf);      // dK^T / dV^T stay in AccVGPRs on every path (a builtin here would copy 128 registers in and out)
+            mfma_acc_nop(dk[dt], tq[dt], df);
+#else
             dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tdo[dt], pf, dv[dt], 0, 0, 0);
             dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tq[dt], df, dk[dt], 0, 0, 0);
+#endif
           }
         }
       }
@@ -1308,6 +1556,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (it + 1 < ntot) load_tile(it + 1, smem + ((it + 1) & 1) * STG);     // waves past Sk still take part in the staging
     }
     __syncthreads();
+    UR_ASTAMP(7);
   }
   store_T<HD>(p.dk + ktok * p.lddk + (long)kvh * HD, dk, p.scale, lane, kok);     // dS was kept unscaled
   store_T<HD>(p.dv + ktok * p.lddv + (long)kvh * HD, dv, 1.0f, lane, kok);
@@ -1622,6 +1871,12 @@ int do_dq(const AttnP& p, int hd, bool causal, hipStream_t st) { UR_ATTN_DISPATC
 int do_dkv(const AttnP& p, int hd, bool causal, hipStream_t st) { UR_ATTN_DISPATCH(hd, causal, pick_nw(p.Sk), launch_dkv, p, st); }
 
 }  // namespace
+
+#if UR_DKV2_STAMPS
+extern "C" int ur_lab_attn_stamps(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), sizeof(long long) * n);
+}
+#endif
 
 extern "C" int ur_attn_fwd(const ur_attn_args* a, void* stream) {
   AttnP p;
