@@ -1281,14 +1281,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // (no next tile: the same tile is copied again into the idle buffer -- unconditional pieces keep stream 1 one
       // straight-line block; a ragged next tile never gets here, see tile_fast)
       char* nbuf = smem + ((it + 1) & 1) * STG;
+      // per-lane source pointers of piece 0, formed once per tile; a piece then costs one 64-bit add of a scalar step
+      const char* qrow = reinterpret_cast<const char*>(nqb + (long)nq0 * p.ldq) + qs.voff;
+      const char* dorow = reinterpret_cast<const char*>(ndob + (long)nq0 * p.lddo) + dos.voff;
+      const long qstep = 32L * p.ldq, dostep = 32L * p.lddo;           // bytes per 16 rows
+      char* nbw = nbuf + wave_u * 1024;
       auto dma_piece = [&](auto J) {
         constexpr int j = decltype(J)::value;
         if constexpr (j < 4) {
-          const char* ub = reinterpret_cast<const char*>(nqb + (long)(nq0 + 16 * j) * p.ldq);
-          __builtin_amdgcn_global_load_lds((gbl_void*)(ub + qs.voff), (lds_void*)(nbuf + (j * 4 + wave_u) * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void*)(qrow + j * qstep), (lds_void*)(nbw + j * 4096), 16, 0, 0);
         } else if constexpr (j < 8) {
-          const char* ub = reinterpret_cast<const char*>(ndob + (long)(nq0 + 16 * (j - 4)) * p.lddo);
-          __builtin_amdgcn_global_load_lds((gbl_void*)(ub + dos.voff), (lds_void*)(nbuf + C::TILE + ((j - 4) * 4 + wave_u) * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((gbl_void*)(dorow + (j - 4) * dostep), (lds_void*)(nbw + C::TILE + (j - 4) * 4096), 16, 0, 0);
         } else {
           const float* cb = wave_u == 0 ? p.delta + nrows + nsb + nq0 : (wave_u == 1 ? p.delta + nsb + nq0 : p.stats + (nsb + nq0 + 32 * (wave_u & 1)) * 2);
           __builtin_amdgcn_global_load_lds((gbl_void*)(cb + lane), (lds_void*)(nbuf + 2 * C::TILE + 256 * wave_u), 4, 0, 0);
