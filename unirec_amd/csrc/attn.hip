@@ -1110,6 +1110,9 @@ __device__ __forceinline__ float mul1(float a, float b) {
 // MFMAs behind the softmax fillers); an empty volatile asm that "rewrites" the accumulator just produced keeps every
 // MFMA between the two volatile asm statements (landed / next issue) it was written between
 __device__ __forceinline__ void pin(f32x16& a) { asm volatile("" : "+v"(a)); }
+// ... and a converted bf16 fragment: materialised HERE (hipcc otherwise sinks the conversions to just in front of the asm
+// MFMA that reads them, where nothing pads the vector-write -> MFMA-read hazard: the first MFMA of a batch read stale registers)
+__device__ __forceinline__ void pin(bf16x8& a) { asm volatile("" : "+v"(a)); }
 __device__ __forceinline__ void pin(f32x16& a, f32x16& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 
 // MFMA with the accumulator held in AccVGPRs for the whole kernel (inline asm: under -amdgpu-mfma-vgpr-form hipcc keeps every
@@ -1251,10 +1254,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     tile_ptrs(it, qb_, dob_, sbase_, q0);
     bool tile_fast = all_valid && (q0 + KT <= p.Sq) && (!CAUSAL || q0 >= kblk + 31 || UR_DKV2_ABLATE == 5);
 #if UR_DKV2_V2
-    // the fast path issues the next tile's LDS-DMA itself, as whole-row pieces: the next tile must be full too
+    // the fast path issues the next tile's LDS-DMA itself, as whole-row pieces: the next tile must be full too.  Tiles on
+    // the causal diagonal take the same three streams with the mask applied to P (two more vector instructions per
+    // element) instead of the general path (position compares, row constants from LDS: ~2x a fast tile)
     const bf16_t* nqb; const bf16_t* ndob; long nsb; int nq0;
     tile_ptrs(it + 1 < ntot ? it + 1 : it, nqb, ndob, nsb, nq0);
-    tile_fast = tile_fast && (nq0 + KT <= p.Sq);
+    const bool tile_diag = CAUSAL && q0 < kblk + 31;
+    tile_fast = all_valid && (q0 + KT <= p.Sq) && (nq0 + KT <= p.Sq);
 #endif
     UR_ASTAMP(0);
 #if UR_DKV2_STAMPS
@@ -1262,8 +1268,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
 #if UR_DKV2_V2
     if (kblk < p.Sk && tile_fast) {
+     auto fast_body = [&](auto DIAG_) {
+      constexpr bool DIAG = decltype(DIAG_)::value;
       // ---------------- fast path, three counted streams (64 MFMAs per 64-query tile) ----------------
       const uint32_t bufb = lds_off(qtile);
+      // causal diagonal: P[query row e of half x][key] = 0 where key > q0 + 32 x + acc_row(e, h)
+      const int dkh = key - q0 - 4 * h;
+      auto cmask = [&](float v, int e, int half) { return (dkh - 32 * half <= (e & 3) + 8 * (e >> 2)) ? v : 0.f; };
       // initial accumulators (plain LDS loads, BEFORE this tile issues any LDS-DMA): rows 8g + 4h + 0..3 of the 32-row
       // half -> registers 4g .. 4g+3
       auto init16 = [&](f32x16& a, const float* src) {
@@ -1335,10 +1346,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if constexpr (UR_DKV2_ABLATE != 8 && UR_DKV2_ABLATE != 10) {      // softmax of half a, staged: scale (k) | exp2 (k+1) | dS (k+2)
             constexpr int e = 2 * (k - 8);
             sa[e] = mul1(sa[e], c2v); sa[e + 1] = mul1(sa[e + 1], c2v);
-            if constexpr (k >= 9) { sa[e - 2] = fast_exp2(sa[e - 2]); sa[e - 1] = fast_exp2(sa[e - 1]); }
+            if constexpr (k >= 9) {
+              sa[e - 2] = fast_exp2(sa[e - 2]); sa[e - 1] = fast_exp2(sa[e - 1]);
+              if constexpr (DIAG) { sa[e - 2] = cmask(sa[e - 2], e - 2, 0); sa[e - 1] = cmask(sa[e - 1], e - 1, 0); }
+            }
             if constexpr (k >= 10) { dpa[e - 4] = mul1(sa[e - 4], dpa[e - 4]); dpa[e - 3] = mul1(sa[e - 3], dpa[e - 3]); }
           }
-          if constexpr (k == 14) { p0a = acc_frag(sa, 0); d0a = acc_frag(dpa, 0); }       // elements 0..7 are complete after k = 13
+          if constexpr (k == 14) { p0a = acc_frag(sa, 0); d0a = acc_frag(dpa, 0); pin(p0a); pin(d0a); }       // elements 0..7 are complete after k = 13
         }
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -1370,34 +1384,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (UR_DKV2_ABLATE != 7 && UR_DKV2_ABLATE != 10) tr_landed1<2 * younger>(tl[u % (RT + 1)], th[u % (RT + 1)]);
         const bf16x8 af = cat4(tl[u % (RT + 1)], th[u % (RT + 1)]);
         if constexpr (UR_DKV2_ABLATE == 6) { sb[u & 15] += __builtin_bit_cast(float, (int)af[0] | ((int)af[4] << 16)); }
-        else if constexpr (bt == 0) mfma_acc(dv[dt], af, p0a);
-        else if constexpr (bt == 1) mfma_acc(dk[dt], af, d0a);
-        else if constexpr (bt == 2) mfma_acc(dv[dt], af, p1a);
-        else if constexpr (bt == 3) mfma_acc(dk[dt], af, d1a);
-        else if constexpr (bt == 4) mfma_acc(dv[dt], af, p0b);
-        else if constexpr (bt == 5) mfma_acc(dk[dt], af, d0b);
-        else if constexpr (bt == 6) mfma_acc(dv[dt], af, p1b);
-        else mfma_acc(dk[dt], af, d1b);
+        else {
+          auto mm = [&](f32x16& acc, const bf16x8& bfrag) {
+            if constexpr (dt == 0) mfma_acc_nop(acc, af, bfrag); else mfma_acc(acc, af, bfrag);     // first read of a fragment
+          };
+          if constexpr (bt == 0) mm(dv[dt], p0a);
+          else if constexpr (bt == 1) mm(dk[dt], d0a);
+          else if constexpr (bt == 2) mm(dv[dt], p1a);
+          else if constexpr (bt == 3) mm(dk[dt], d1a);
+          else if constexpr (bt == 4) mm(dv[dt], p0b);
+          else if constexpr (bt == 5) mm(dk[dt], d0b);
+          else if constexpr (bt == 6) mm(dv[dt], p1b);
+          else mm(dk[dt], d1b);
+        }
         if constexpr (u + RT < 32) tissue(std::integral_constant<int, u + RT>{});
         if constexpr (UR_DKV2_ABLATE != 8 && UR_DKV2_ABLATE != 10) {
           // tail of half a (its elements 12..15), then half b
-          if constexpr (u == 0) { sa[14] = fast_exp2(sa[14]); sa[15] = fast_exp2(sa[15]); }
+          if constexpr (u == 0) {
+            sa[14] = fast_exp2(sa[14]); sa[15] = fast_exp2(sa[15]);
+            if constexpr (DIAG) { sa[14] = cmask(sa[14], 14, 0); sa[15] = cmask(sa[15], 15, 0); }
+          }
           if constexpr (u == 1) { dpa[12] = mul1(sa[12], dpa[12]); dpa[13] = mul1(sa[13], dpa[13]); }
           if constexpr (u == 2) { dpa[14] = mul1(sa[14], dpa[14]); dpa[15] = mul1(sa[15], dpa[15]); }
           constexpr int sh = 3;                                         // half b starts in unit 3
           if constexpr (u >= sh && u < sh + 16) sb[u - sh] = mul1(sb[u - sh], c2v);
-          if constexpr (u >= sh + 1 && u < sh + 17) sb[u - sh - 1] = fast_exp2(sb[u - sh - 1]);
+          if constexpr (u >= sh + 1 && u < sh + 17) {
+            sb[u - sh - 1] = fast_exp2(sb[u - sh - 1]);
+            if constexpr (DIAG) sb[u - sh - 1] = cmask(sb[u - sh - 1], u - sh - 1, 1);
+          }
           if constexpr (u >= sh + 2 && u < sh + 18) dpb[u - sh - 2] = mul1(sb[u - sh - 2], dpb[u - sh - 2]);
         }
-        if constexpr (u == 3) p1a = acc_frag(sa, 1);
-        if constexpr (u == 4) d1a = acc_frag(dpa, 1);
-        if constexpr (u == 13) p0b = acc_frag(sb, 0);                  // elements 0..7 of half b are complete after unit 12
-        if constexpr (u == 14) d0b = acc_frag(dpb, 0);
-        if constexpr (u == 21) p1b = acc_frag(sb, 1);                  // elements 8..15 after unit 20
-        if constexpr (u == 22) d1b = acc_frag(dpb, 1);
+        if constexpr (u == 3) { p1a = acc_frag(sa, 1); pin(p1a); }
+        if constexpr (u == 4) { d1a = acc_frag(dpa, 1); pin(d1a); }
+        if constexpr (u == 13) { p0b = acc_frag(sb, 0); pin(p0b); }                  // elements 0..7 of half b are complete after unit 12
+        if constexpr (u == 14) { d0b = acc_frag(dpb, 0); pin(d0b); }
+        if constexpr (u == 21) { p1b = acc_frag(sb, 1); pin(p1b); }                  // elements 8..15 after unit 20
+        if constexpr (u == 22) { d1b = acc_frag(dpb, 1); pin(d1b); }
         __builtin_amdgcn_sched_barrier(0);
       });
       UR_ASTAMP(6);
+     };
+     if (tile_diag) fast_body(std::true_type{}); else fast_body(std::false_type{});
     } else
 #else
     if (kblk < p.Sk && tile_fast) {
