@@ -113,6 +113,30 @@ def gemm_merge(args):
         print(f"gemm {name:8s} N={N}: separate launches {t1:.3f} ms | one launch {t2:.3f} ms  ({2 * M * N * K / t2 / 1e9:.0f} TFLOP/s)")
 
 
+STEP_SHAPES = [(4096, 1024, True, "q|k|v fwd"), (1024, 2048, True, "o_proj fwd"), (6144, 1024, True, "gate|up fwd"), (1024, 3072, True, "down fwd"),
+               (1024, 4096, False, "dX q|k|v"), (2048, 1024, False, "dX o_proj"), (1024, 6144, False, "dX gate|up")]
+
+
+def gemm_step(args):
+    """The K-contiguous 256x256 projection launches the C4 step actually issues (merged q|k|v and gate|up), ONE launch each
+    in a fixed order after one warm-up round -- for the rocprofv3 --pmc passes (tools/gemm_pmc.py maps dispatch order to shape).
+    dX launches read the frozen weights' transposed copies, i.e. they are K-contiguous [N,K] operands as well."""
+    M = args.B * args.S
+    g = torch.Generator().manual_seed(0)
+    ops = []
+    for (N, K, fwd, name) in STEP_SHAPES:
+        R = torch.randn(M, K, generator=g).cuda().to(torch.bfloat16)
+        W = (torch.randn(N, K, generator=g) * 0.05).cuda().to(torch.bfloat16)
+        ops.append((R, W, torch.empty(M, N, dtype=torch.bfloat16, device="cuda"), name, N, K))
+    for rnd in range(2):          # round 0 = warm-up, round 1 = the measured dispatches (the last 7 gemm_kernel dispatches)
+        for (R, W, out, name, N, K) in ops:
+            hip.gemm(R, W, out=out)
+        torch.cuda.synchronize()
+    for (R, W, out, name, N, K) in ops:
+        t = timeit(lambda: hip.gemm(R, W, out=out), args.iters)
+        print(f"gemm {name:12s} M={M} N={N} K={K}: {t:.3f} ms  {2 * M * N * K / t / 1e9:.1f} TFLOP/s")
+
+
 def gemm_lora(args):
     """What the LoRA term costs inside the projection GEMMs: plain / + second K range (forward: t B^T, K2 = 16) /
     + masked rank-16 epilogue (dX under LoRA dropout)."""
@@ -157,10 +181,10 @@ def lora(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn", "gemm_lora", "gemm_merge"])
+    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn", "gemm_lora", "gemm_merge", "gemm_step"])
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--S", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--lib", action="store_true", help="gemm: also time torch.matmul on the same operands (reference point)")
     a = ap.parse_args()
-    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora, "gemm_merge": gemm_merge}[a.what](a)
+    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora, "gemm_merge": gemm_merge, "gemm_step": gemm_step}[a.what](a)

@@ -857,9 +857,14 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
     // re-fetches its panel from the Infinity Cache; chunks of 4 halve the fabric reads of the N = 3072 launches (FETCH_SIZE
     // 2.24 -> 1.20 GB for gate_proj, profiles/r1_gemm_pmc.json) -- and cost 1 % of the joint step in alternating same-box
     // runs (118.8 vs 117.5 seq/s), so the plain row-major runs stay the default.
-    static const int env_cw = [] { const char* e = getenv("UR_GEMM_CW"); return e ? atoi(e) : 0; }();
+    // Round 2, merged launches (q|k|v: 16 column tiles, gate|up: 24; profiles/r2_gemm_pmc.json): the fabric reads reach
+    // 2.4 / 5.9 GB per launch (x8.7 / x21 of A + W, ~4 TB/s) and chunks of 4 are 2.1 / 3.6 % faster in isolation
+    // (tools/kernel_bench.py gemm_step), while launches of <= 12 column tiles still lose 1-3 %: chunks of 4 are the default
+    // from 16 column tiles on (UR_GEMM_CW = n forces n everywhere it divides, UR_GEMM_CW = 0 switches the order off).
+    static const int env_cw = [] { const char* e = getenv("UR_GEMM_CW"); return e ? atoi(e) : -1; }();
     p.gcw = 0;
-    if (env_cw > 0 && BM == 256 && (p.gm % 8) == 0 && p.gn > env_cw && (p.gn % env_cw) == 0) p.gcw = env_cw;
+    const int cw = env_cw >= 0 ? env_cw : ((p.gn >= 16 && p.K <= 2048) ? 4 : 0);
+    if (cw > 0 && BM == 256 && (p.gm % 8) == 0 && p.gn > cw && (p.gn % cw) == 0) p.gcw = cw;
   }
   dim3 grid(p.gm * p.gn, 1, splits);
   hipLaunchKernelGGL((gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN, EPI>), grid, dim3(NWM * NWN * 64), SMEM, st, p);
@@ -882,7 +887,8 @@ int launch(const GemmP& p, int splits, hipStream_t st) {
       return launch_cfg<true, true, false, 128, 128, 2, 2, 2>(p, splits, st);
     }
   }
-  if (p.M >= 256 && p.N >= 256 && big_wgs >= 256) return launch_cfg<RK, SK, OUTF32, 256, 256, 2, 4>(p, splits, st);
+  static const bool force128 = [] { const char* e = getenv("UR_GEMM_FORCE128"); return e && e[0] == '1'; }();      // lab: 128x128 tiles (2 workgroups per CU) everywhere
+  if (p.M >= 256 && p.N >= 256 && big_wgs >= 256 && !force128) return launch_cfg<RK, SK, OUTF32, 256, 256, 2, 4>(p, splits, st);
   return launch_cfg<RK, SK, OUTF32, 128, 128, 2, 2>(p, splits, st);
 }
 
