@@ -1833,7 +1833,7 @@ int fill(AttnP& p, const ur_attn_args* a) {
 
 template <int HD, bool CAUSAL, int NW>
 int launch_fwd(const AttnP& p, hipStream_t st) {
-  static bool once = false;
+  static std::atomic<bool> once{false};   // init-once flag: the call it guards is idempotent, the flag itself is race-free
   if (!once) { int rc = set_smem(&attn_fwd_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_fwd"); if (rc) return rc; once = true; }
   dim3 grid(ur_cdiv(p.Sq, 32 * NW) * p.nq * p.B);
   hipLaunchKernelGGL((attn_fwd_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), fwd_smem<HD>(), st, p);
@@ -1842,7 +1842,7 @@ int launch_fwd(const AttnP& p, hipStream_t st) {
 }
 template <int HD, bool CAUSAL, int NW>
 int launch_dq(const AttnP& p, hipStream_t st) {
-  static bool once = false;
+  static std::atomic<bool> once{false};   // init-once flag: the call it guards is idempotent, the flag itself is race-free
   if (!once) { int rc = set_smem(&attn_bwd_dq_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_bwd(dq)"); if (rc) return rc; once = true; }
   dim3 grid(ur_cdiv(p.Sq, 32 * NW) * p.nq * p.B);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), fwd_smem<HD>(), st, p);
@@ -1870,13 +1870,13 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
   dim3 grid(ur_cdiv(p.Sk, 32 * NW) * p.nkv * p.B);
   if (HD == 128 && NW == 4 && p.drop_thr == 0) {
     constexpr int SM2 = 2 * (2 * Cfg<128>::TILE + 4 * KT * (int)sizeof(float));
-    static bool once2 = false;
+    static std::atomic<bool> once2{false};
     if (!once2) { int rc = set_smem(&attn_bwd_dkv2_kernel<CAUSAL>, SM2, "ur_attn_bwd(dkv2)"); if (rc) return rc; once2 = true; }
     hipLaunchKernelGGL((attn_bwd_dkv2_kernel<CAUSAL>), grid, dim3(256), SM2, st, p);
     UR_CHECK_LAUNCH("ur_attn_bwd(dkv2)");
     return 0;
   }
-  static bool once = false;
+  static std::atomic<bool> once{false};   // init-once flag: the call it guards is idempotent, the flag itself is race-free
   if (!once) { int rc = set_smem(&attn_bwd_dkv_kernel<HD, CAUSAL, NW>, dkv_smem<HD>(), "ur_attn_bwd(dkv)"); if (rc) return rc; once = true; }
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), dkv_smem<HD>(), st, p);
   UR_CHECK_LAUNCH("ur_attn_bwd(dkv)");

@@ -215,7 +215,7 @@ extern "C" int ur_catalog_scores(const float* user, const float* catalog, float*
   rpb = (rpb + 3) / 4 * 4;
   blocks_x = (N + rpb - 1) / rpb;
   const size_t smem = (size_t)CU_USERS * D * sizeof(float);
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_scores_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CU_USERS * 2048 * 4);
     if (e != hipSuccess) UR_FAIL((int)e, "ur_catalog_scores: hipFuncSetAttribute failed: %s", hipGetErrorString(e));

@@ -215,8 +215,21 @@ __device__ __forceinline__ void lds_frags(bf16x8* f, const char* tile, int idx0,
 // BM x BN block tile, NWM x NWN waves; each wave owns (BM/NWM) rows x (BN/NWN) columns of C.
 // EPI: 1 = SwiGLU backward epilogue (ur_gemm_args.swiglu_gu), 2 = SwiGLU forward epilogue (ur_gemm_args.swiglu_gate), each its
 // own instantiation, so the ordinary kernels' code and register allocation do not change with them.
+// MFMA with the accumulator tile in AccVGPRs (inline asm) for the 256x256 kernel: under -amdgpu-mfma-vgpr-form hipcc keeps all
+// 128 accumulator registers of a wave in arch VGPRs, which leaves the 8-phase loop exactly at the 256-register limit (and made
+// every attempt to wrap the body in a tile loop spill).  With "+a" they live in the other half of the unified file.
+#ifndef UR_GEMM_ACC_AGPR
+#define UR_GEMM_ACC_AGPR 0      // lab: at two waves per SIMD the unified file gives a wave 256 registers in TOTAL, so 128 AccVGPRs leave 128 arch VGPRs and the loop spills (468 B scratch): off
+#endif
+template <bool ACC_A>
+__device__ __forceinline__ void mfma16(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  if constexpr (ACC_A) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+  else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+
 template <bool RK, bool SK, bool OUTF32, int BM, int BN, int NWM, int NWN, int EPI = 0>
 __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
+  constexpr bool ACC_A = UR_GEMM_ACC_AGPR && BM == 256 && BN == 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = NWM * NWN * 64;
   constexpr int S_BYTES = SK ? Tile<BN>::KC_BYTES : Tile<BN>::KS_BYTES;
@@ -301,7 +314,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int j = 0; j < MI; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sf[i], rf[j], acc[i][j], 0, 0, 0);
+        mfma16<ACC_A>(acc[i][j], sf[i], rf[j]);
   };
 
   // Software pipeline, ONE barrier per 64-deep tile, placed between its two halves.  Fragment register
@@ -364,7 +377,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
 #if UR_GEMM_ABLATE == 2
       for (int i = 0; i < NI; ++i) acc[i][j][0] += (float)(csf[i][0] ^ rj[0]);       // lab build: no MFMAs
 #else
-      for (int i = 0; i < NI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(csf[i], rj, acc[i][j], 0, 0, 0);
+      for (int i = 0; i < NI; ++i) mfma16<ACC_A>(acc[i][j], csf[i], rj);
 #endif
       __builtin_amdgcn_sched_barrier(0);
       if (!LF) { loads(j); __builtin_amdgcn_sched_barrier(0); }
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
           for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
-              acc[2 * sh + ii][4 * rh + jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S[ii][h], R[jj][h], acc[2 * sh + ii][4 * rh + jj], 0, 0, 0);
+              mfma16<ACC_A>(acc[2 * sh + ii][4 * rh + jj], S[ii][h], R[jj][h]);
         __builtin_amdgcn_s_setprio(0);
       };
       // the two LDS-DMA pieces of this wave for half `hf` (rows 128 hf ..) of an operand tile whose k position is in `ub`
@@ -578,6 +591,9 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   }
 
   UR_STAMP(4);
+  // the asm MFMAs' results are read below by instructions hipcc schedules without knowing an MFMA wrote them: let the
+  // last one retire (16x16x32: 8 passes) before anything touches the accumulators
+  if constexpr (ACC_A) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   // ---- LoRA dropout, backward to the adapter input: C(m,n) += sum_a keep_a(m,n)/(1-p) * tb_a(m,:) . A_a(:,n).
   // Each adapter's rank-r product of a 16x16 sub-tile is ONE MFMA (k = r <= 32, zero-padded) into a scratch
   // accumulator; the keep flags come from the adapters' dropped-flag bit planes (lora.hip: 8 bytes cover the
@@ -843,7 +859,7 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
   constexpr int R_BYTES = RK ? Tile<BM>::KC_BYTES : Tile<BM>::KS_BYTES;
   constexpr int RING = NSTAGE * (S_BYTES + R_BYTES), CTILE = BM * (BN * 2 + 16);      // bf16 tile == f32 half tile rows
   constexpr int SMEM = OUTF32 ? RING : (RING > CTILE ? RING : CTILE);
-  static bool attr_set = false;   // idempotent; a race only repeats the call
+  static std::atomic<bool> attr_set{false};   // idempotent; a race only repeats the call
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);

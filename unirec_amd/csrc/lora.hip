@@ -683,7 +683,7 @@ extern "C" int ur_lora_bgrad(const ur_lora_args* a, void* workspace, int64_t wor
   p.V = (const bf16_t*)a->V; p.ldv = a->ldv;
   p.P = (bf16_t*)a->P; p.ldp = a->ldp;
   p.slabs = (float*)workspace; p.total = total; p.alpha = a->alpha;
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) {
     hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&lora_bgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM);
     if (er != hipSuccess) UR_FAIL((int)er, "ur_lora_bgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(er));
