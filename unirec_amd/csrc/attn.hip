@@ -1154,6 +1154,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int HD = 128, NW = 4;
   using C = Cfg<HD>;
   constexpr int STG = 2 * C::TILE + 4 * KT * (int)sizeof(float);
+  // NB tile buffers, the LDS-DMA runs AH = NB - 1 tiles ahead.  Three buffers (tile t+2 issued at the top of tile t) measured
+  // the same as two (stamps: the ~400 cycles at the barrier are arrival skew, not the DMA): two stay.
+  constexpr int NB = 2, AH = NB - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const BlockMap bm = block_map<false>((p.Sk + 32 * NW - 1) / (32 * NW), 1, p.nkv, p.B);
@@ -1194,6 +1197,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   Loader<HD, NW * 64> qs, dos;
   qs.init(p.ldq, tid); dos.init(p.lddo, tid);
+  auto tile_ptrs2 = [&](int hr, int tq, const bf16_t*& qb, const bf16_t*& dob, long& sbase, int& q0) {
+    const int hq = kvh * p.rep + hr;
+    qb = p.q + (long)b * p.Sq * p.ldq + (long)hq * HD;
+    dob = p.dout + (long)b * p.Sq * p.lddo + (long)hq * HD;
+    sbase = ((long)b * p.nq + hq) * p.Sq;
+    q0 = qstart + tq * KT;
+  };
   auto tile_ptrs = [&](int it, const bf16_t*& qb, const bf16_t*& dob, long& sbase, int& q0) {
     const int hr = it / ntq, tq = it - hr * ntq;
     const int hq = kvh * p.rep + hr;
@@ -1240,25 +1250,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 
   if (ntot > 0) load_tile(0, smem);
+  if (AH == 2 && ntot > 1) load_tile(1, smem + STG);
   __syncthreads();
 
+  // (head of the group, query tile) of tile `it` and of the tile whose DMA it issues, advanced incrementally: the two
+  // scalar divisions per tile were ~100 instructions of the loop top
+  int hr_c = 0, tq_c = 0, hr_n = ntq > 0 ? AH / ntq : 0, tq_n = ntq > 0 ? AH % ntq : 0, buf_c = 0;
   for (int it = 0; it < ntot; ++it) {
-    const char* qtile = smem + (it & 1) * STG;
+    const char* qtile = smem + buf_c * STG;
     const char* dotile = qtile + C::TILE;
     const float* fst = reinterpret_cast<const float*>(qtile + 2 * C::TILE);
     // The next tile's LDS-DMA is issued only AFTER the last compiler-visible LDS load of this tile (the row
     // fragments and row constants of phases 1-2): hipcc puts s_waitcnt vmcnt(0) in front of the first plain LDS
     // load that follows an LDS-DMA (it cannot tell the two buffers apart), which would expose the whole DMA
     // latency on every tile.  Phases 3-4 only read LDS through the inline-asm transposed reads.
-    const bf16_t* qb_; const bf16_t* dob_; long sbase_; int q0;
-    tile_ptrs(it, qb_, dob_, sbase_, q0);
+    const int q0 = qstart + tq_c * KT;
     bool tile_fast = all_valid && (q0 + KT <= p.Sq) && (!CAUSAL || q0 >= kblk + 31 || UR_DKV2_ABLATE == 5);
 #if UR_DKV2_V2
     // the fast path issues the next tile's LDS-DMA itself, as whole-row pieces: the next tile must be full too.  Tiles on
     // the causal diagonal take the same three streams with the mask applied to P (two more vector instructions per
     // element) instead of the general path (position compares, row constants from LDS: ~2x a fast tile)
     const bf16_t* nqb; const bf16_t* ndob; long nsb; int nq0;
-    tile_ptrs(it + 1 < ntot ? it + 1 : it, nqb, ndob, nsb, nq0);
+    // the tile whose DMA this iteration issues (none left: this tile again, into the idle buffer)
+    if (it + AH < ntot) tile_ptrs2(hr_n, tq_n, nqb, ndob, nsb, nq0); else tile_ptrs2(hr_c, tq_c, nqb, ndob, nsb, nq0);
     const bool tile_diag = CAUSAL && q0 < kblk + 31;
     tile_fast = all_valid && (q0 + KT <= p.Sq) && (nq0 + KT <= p.Sq);
 #endif
@@ -1291,7 +1305,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // next tile: wave-uniform row bases; its 8 + 1 LDS-DMA pieces ride in the MFMA gaps of stream 1
       // (no next tile: the same tile is copied again into the idle buffer -- unconditional pieces keep stream 1 one
       // straight-line block; a ragged next tile never gets here, see tile_fast)
-      char* nbuf = smem + ((it + 1) & 1) * STG;
+      char* nbuf = smem + ((buf_c + AH) % NB) * STG;
       // per-lane source pointers of piece 0, formed once per tile; a piece then costs one 64-bit add of a scalar step
       const char* qrow = reinterpret_cast<const char*>(nqb + (long)nq0 * p.ldq) + qs.voff;
       const char* dorow = reinterpret_cast<const char*>(ndob + (long)nq0 * p.lddo) + dos.voff;
@@ -1532,8 +1546,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else
 #endif
     if (kblk < p.Sk) {
-      const int hq = kvh * p.rep + it / ntq;
-      (void)hq;
+
 #pragma unroll
       for (int sub = 0; sub < 2; ++sub) {
         const int qbase = q0 + 32 * sub;
@@ -1581,12 +1594,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
         }
       }
-      if (it + 1 < ntot) load_tile(it + 1, smem + ((it + 1) & 1) * STG);
+      if (it + AH < ntot) load_tile(it + AH, smem + ((it + AH) % NB) * STG);
     } else {
-      if (it + 1 < ntot) load_tile(it + 1, smem + ((it + 1) & 1) * STG);     // waves past Sk still take part in the staging
+      if (it + AH < ntot) load_tile(it + AH, smem + ((it + AH) % NB) * STG);     // waves past Sk still take part in the staging
     }
     __syncthreads();
     UR_ASTAMP(7);
+    if (++tq_c == ntq) { tq_c = 0; ++hr_c; }
+    if (++tq_n == ntq) { tq_n = 0; ++hr_n; }
+    buf_c = (buf_c + 1 == NB) ? 0 : buf_c + 1;
   }
   store_T<HD>(p.dk + ktok * p.lddk + (long)kvh * HD, dk, p.scale, lane, kok);     // dS was kept unscaled
   store_T<HD>(p.dv + ktok * p.lddv + (long)kvh * HD, dv, 1.0f, lane, kok);
@@ -1869,7 +1885,7 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
   }
   dim3 grid(ur_cdiv(p.Sk, 32 * NW) * p.nkv * p.B);
   if (HD == 128 && NW == 4 && p.drop_thr == 0) {
-    constexpr int SM2 = 2 * (2 * Cfg<128>::TILE + 4 * KT * (int)sizeof(float));
+    constexpr int SM2 = 2 * (2 * Cfg<128>::TILE + 4 * KT * (int)sizeof(float));      // = NB buffers of attn_bwd_dkv2_kernel
     static std::atomic<bool> once2{false};
     if (!once2) { int rc = set_smem(&attn_bwd_dkv2_kernel<CAUSAL>, SM2, "ur_attn_bwd(dkv2)"); if (rc) return rc; once2 = true; }
     hipLaunchKernelGGL((attn_bwd_dkv2_kernel<CAUSAL>), grid, dim3(256), SM2, st, p);
