@@ -497,14 +497,17 @@ def main():
             if epi == 0 and rk and sk and not f32 and M >= 256 and N >= 256 and (-(-M // 256)) * (-(-N // 256)) * max(split, 1) >= 256:
                 tot_ms += ms; tot_fl += 2.0 * M * N * K; n += 1
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
-        # HBM bytes of one launch from the separate rocprofv3 --pmc passes (profiles/r1_gemm_pmc.json); bench.py itself
-        # cannot collect PMC counters.  Reported for the gate_proj-shaped launch (M=131072,N=3072,K=1024).
+        # HBM-side bytes of one launch from the separate rocprofv3 --pmc passes (profiles/r2_gemm_pmc.json: FETCH_SIZE x2 +
+        # WRITE_SIZE, the MI355X_MICROARCH corrections); bench.py itself cannot collect PMC counters.  Reported for the
+        # largest launch of the family, the merged gate|up forward (M=131072, N=6144, K=1024).
         traffic, tnote = None, "no PMC summary found"
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_gemm_pmc.json")))["launches"]["gate_proj fwd"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_gemm_pmc.json")))["launches"]["gate|up fwd"]
             if B * args.seq == pm["M"]:
                 traffic = pm["hbm_bytes"]
-                tnote = f"gate_proj launch: PMC HBM bytes {pm['hbm_bytes']} vs algorithmic {pm['algorithmic_bytes']} (x{pm['ratio']}); profiles/r1_gemm_pmc.json"
+                tnote = (f"gate|up forward launch (N=6144, K=1024): fabric reads {pm['fabric_read_bytes']} (x{pm['read_ratio']} of A+W; FETCH_SIZE "
+                         f"counts Infinity-Cache hits too) + writes {pm['write_bytes']} vs algorithmic {pm['algorithmic_bytes']} (x{pm['ratio']}); "
+                         f"profiles/r2_gemm_pmc.json")
         except Exception:
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),

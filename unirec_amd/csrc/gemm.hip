@@ -68,6 +68,7 @@ struct GemmP {
   int ksplit_len; long slab_stride;
   int gm, gn;
   int gcw;    // column-chunk width (tiles) of the per-XCD tile order; 0 = plain row-major runs
+  int stagger;   // cycles between the start groups of the launch's first wave of workgroups (0 = all start together)
   // LoRA dropout (ur_gemm_args.drop_*): masked rank-r LoRA epilogue driven by the adapters' dropped-flag bit planes
   const uint8_t* drop_bits; long drop_bits_ld, drop_bits_stride; int drop_rank; float drop_inv_keep;
   // SwiGLU backward epilogue (ur_gemm_args.swiglu_*): the result is d(act); dgate / dup leave instead of C
@@ -269,6 +270,14 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   }
   const int m0 = bm * BM, n0 = bn * BN;
   const int z = blockIdx.z;
+  // De-phase the CUs: every tile of a launch takes the same time, so the 256 workgroups of a round reach their epilogues
+  // together and 32 MiB of C leave for HBM at once (an epilogue of ~10 k cycles, most of it write back-pressure) while HBM
+  // idles during the main loops.  The launch's FIRST wave of workgroups starts in 8 groups `stagger` cycles apart; the
+  // offsets then persist from round to round.
+  if (p.stagger > 0 && blockIdx.x < 256 && blockIdx.z == 0) {
+    const long long until = (long long)__builtin_readcyclecounter() + (long long)((blockIdx.x >> 3) & 7) * p.stagger;
+    while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(16);
+  }
   UR_STAMP(0);
 
   int kbeg = z * p.ksplit_len;
@@ -875,12 +884,17 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
     // runs (118.8 vs 117.5 seq/s), so the plain row-major runs stay the default.
     // Round 2, merged launches (q|k|v: 16 column tiles, gate|up: 24; profiles/r2_gemm_pmc.json): the fabric reads reach
     // 2.4 / 5.9 GB per launch (x8.7 / x21 of A + W, ~4 TB/s) and chunks of 4 are 2.1 / 3.6 % faster in isolation
-    // (tools/kernel_bench.py gemm_step), while launches of <= 12 column tiles still lose 1-3 %: chunks of 4 are the default
-    // from 16 column tiles on (UR_GEMM_CW = n forces n everywhere it divides, UR_GEMM_CW = 0 switches the order off).
+    // (tools/kernel_bench.py gemm_step), while launches of <= 12 column tiles still lose 1-3 %.  Inside the joint step,
+    // alternating same-box runs: chunks of 4 on the two wide launches only 516.6 vs 517.0 ms (nothing), chunks of 4 wherever
+    // they divide 551.8 vs 545.8 ms (+1.1 %) -- the plain order stays the default (UR_GEMM_CW = n: lab).
     static const int env_cw = [] { const char* e = getenv("UR_GEMM_CW"); return e ? atoi(e) : -1; }();
     p.gcw = 0;
-    const int cw = env_cw >= 0 ? env_cw : ((p.gn >= 16 && p.K <= 2048) ? 4 : 0);
+    const int cw = env_cw >= 0 ? env_cw : 0;
     if (cw > 0 && BM == 256 && (p.gm % 8) == 0 && p.gn > cw && (p.gn % cw) == 0) p.gcw = cw;
+  }
+  {
+    static const int env_st = [] { const char* e = getenv("UR_GEMM_STAGGER"); return e ? atoi(e) : 0; }();     // lab
+    p.stagger = (BM == 256 && p.gm * p.gn >= 1024) ? env_st : 0;
   }
   dim3 grid(p.gm * p.gn, 1, splits);
   hipLaunchKernelGGL((gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN, EPI>), grid, dim3(NWM * NWN * 64), SMEM, st, p);
