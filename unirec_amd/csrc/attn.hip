@@ -1130,6 +1130,9 @@ __device__ __forceinline__ void mfma_acc(f32x16& acc, const bf16x8& a, const bf1
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
+#ifndef UR_DKV2_REGSTAGE
+#define UR_DKV2_REGSTAGE 0   // 1 (lab): register-staged next tile instead of LDS-DMA pieces -- 33 more live registers: 144 B of scratch, kernel 2x slower
+#endif
 #ifndef UR_DKV2_V2
 #define UR_DKV2_V2 1         // 0 (lab): the four hard-fenced phases of round 1 instead of the three counted streams
 #endif
@@ -1311,6 +1314,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const char* dorow = reinterpret_cast<const char*>(ndob + (long)nq0 * p.lddo) + dos.voff;
       const long qstep = 32L * p.ldq, dostep = 32L * p.lddo;           // bytes per 16 rows
       char* nbw = nbuf + wave_u * 1024;
+#if UR_DKV2_REGSTAGE
+      // register-staged next tile: 8 global_load_dwordx4 + 1 dword per lane issued in stream 1's gaps (a few cycles of issue
+      // each, against ~60 for an LDS-DMA piece), written to LDS behind stream 3.  Same lane <-> (row, chunk) map as the DMA:
+      // the swizzle sits on the source address, the LDS side is linear.
+      uint4 stg[8]; float stc = 0.f;
+      auto dma_piece = [&](auto J) {
+        constexpr int j = decltype(J)::value;
+        if constexpr (j < 4) stg[j] = *reinterpret_cast<const uint4*>(qrow + j * qstep);
+        else if constexpr (j < 8) stg[j] = *reinterpret_cast<const uint4*>(dorow + (j - 4) * dostep);
+        else {
+          const float* cb = wave_u == 0 ? p.delta + nrows + nsb + nq0 : (wave_u == 1 ? p.delta + nsb + nq0 : p.stats + (nsb + nq0 + 32 * (wave_u & 1)) * 2);
+          stc = cb[lane];
+        }
+      };
+      auto stage_commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          *reinterpret_cast<uint4*>(nbw + j * 4096 + lane * 16) = stg[j];
+          *reinterpret_cast<uint4*>(nbw + C::TILE + j * 4096 + lane * 16) = stg[4 + j];
+        }
+        *reinterpret_cast<float*>(nbuf + 2 * C::TILE + 256 * wave_u + lane * 4) = stc;
+      };
+#else
+      auto stage_commit = [&]() {};
       auto dma_piece = [&](auto J) {
         constexpr int j = decltype(J)::value;
         if constexpr (j < 4) {
@@ -1322,6 +1349,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           __builtin_amdgcn_global_load_lds((gbl_void*)(cb + lane), (lds_void*)(nbuf + 2 * C::TILE + 256 * wave_u), 4, 0, 0);
         }
       };
+#endif
       // ---- streams 1 + 2: S', dP' of the two 32-query halves = 16 k-steps of {2 row fragments, 2 MFMAs}, fragments
       //      issued RD k-steps ahead; softmax of half a rides under half b's MFMAs
       constexpr int RD = 6;
@@ -1436,6 +1464,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if constexpr (u == 22) { d1b = acc_frag(dpb, 1); pin(d1b); }
         __builtin_amdgcn_sched_barrier(0);
       });
+      stage_commit();
       UR_ASTAMP(6);
      };
      if (tile_diag) fast_body(std::true_type{}); else fast_body(std::false_type{});
