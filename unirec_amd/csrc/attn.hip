@@ -354,9 +354,19 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
       auto soft_pv = [&](const int sub, f32x16& s) {
         const int kbase = k0 + 32 * sub;
         const uint32_t v32 = (uint32_t)(kbits.valid >> (32 * sub)), i32 = (uint32_t)(kbits.inr >> (32 * sub));
-        const bool fast = (v32 == 0xffffffffu) && (!CAUSAL || kbase + 31 <= qblk) && !dropping;
+        // interior sub-tile (every key valid and below the diagonal), or -- `diag` -- every key valid ON the causal diagonal:
+        // the same mask-free softmax after one position compare per element (the general path below costs ~7 vector
+        // instructions per element for the key-state bits; every 32-query block crosses the diagonal once)
+        const bool allv = (v32 == 0xffffffffu) && !dropping;
+        const bool diag = CAUSAL && allv && kbase + 31 > qblk;
+        const bool fast = allv;
         float mx = NEG_INF;
         if (fast) {
+          if (diag) {
+            const int dqk = opaque(q - kbase - 4 * h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = ((r & 3) + 8 * (r >> 2) <= dqk) ? s[r] : NEG_INF;
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
           mx *= p.scale;
@@ -547,8 +557,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(vtile, 32 * sub, st, lane), dof[st], dp, 0, 0, 0);
         }
         const uint32_t v32 = (uint32_t)(kbits.valid >> (32 * sub)), i32 = (uint32_t)(kbits.inr >> (32 * sub));
-        const bool fast = (v32 == 0xffffffffu) && (!CAUSAL || kbase + 31 <= qblk) && !dropping;
+        const bool fast = (v32 == 0xffffffffu) && !dropping;          // incl. the causal diagonal (one compare per element)
         if (fast) {
+          if (CAUSAL && kbase + 31 > qblk) {
+            const int dqk = opaque(q - kbase - 4 * h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = ((r & 3) + 8 * (r >> 2) <= dqk) ? s[r] : NEG_INF;
+          }
 #pragma unroll
           for (int r = 0; r < 16; ++r) s[r] = fast_exp2(fmaf(s[r], c2, -mc)) * invs * (dp[r] - dlt);
         } else {
