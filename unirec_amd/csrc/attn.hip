@@ -1190,24 +1190,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     kf[s] = g_frag(p.k + ktok * p.ldk + (long)kvh * HD, s, lane, kok);
     vf[s] = g_frag(p.v + ktok * p.ldv + (long)kvh * HD, s, lane, kok);
   }
-  const bool kvalid = kok && (p.kmask == nullptr || p.kmask[(long)b * p.Sk + key] != 0);
-  const bool all_valid = __all(kvalid);
   const float c2 = p.scale * LOG2E;
   const long nrows = (long)p.B * p.nq * p.Sq;
 
   f32x16 dk[C::NDT], dv[C::NDT];
 #pragma unroll
   for (int dt = 0; dt < C::NDT; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
-
-  // causal (SDPA) semantics: a key block without a single valid key (the left padding of a prompt: the blocks with
-  // the MOST query tiles to sweep) has P = 0 everywhere: dK = dV = 0 without reading Q or dO
-  if (CAUSAL && p.kmask != nullptr) {
-    if (!__syncthreads_or(kvalid ? 1 : 0)) {
-      store_T<HD>(p.dk + ktok * p.lddk + (long)kvh * HD, dk, 0.f, lane, kok);
-      store_T<HD>(p.dv + ktok * p.lddv + (long)kvh * HD, dv, 0.f, lane, kok);
-      return;
-    }
-  }
 
   const int qstart = CAUSAL ? ((bm.x * (32 * NW)) / KT) * KT : 0;
   const int ntq = (p.Sq - qstart + KT - 1) / KT;
@@ -1269,6 +1257,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   if (ntot > 0) load_tile(0, smem);
   if (AH == 2 && ntot > 1) load_tile(1, smem + STG);
+  // the key-state byte is read AFTER the first tile's LDS-DMA is on its way: the wait for it (vmcnt is in order) then covers
+  // the K / V fragments, the mask byte and the first tile in ONE memory latency instead of two per workgroup
+  const bool kvalid = kok && (p.kmask == nullptr || p.kmask[(long)b * p.Sk + key] != 0);
+  const bool all_valid = __all(kvalid);
+  // causal (SDPA) semantics: a key block without a single valid key (the left padding of a prompt: the blocks with
+  // the MOST query tiles to sweep) has P = 0 everywhere: dK = dV = 0 without reading Q or dO (the barrier inside
+  // __syncthreads_or drains this wave's LDS-DMA pieces before the workgroup gives its LDS back)
+  if (CAUSAL && p.kmask != nullptr) {
+    if (!__syncthreads_or(kvalid ? 1 : 0)) {
+      store_T<HD>(p.dk + ktok * p.lddk + (long)kvh * HD, dk, 0.f, lane, kok);
+      store_T<HD>(p.dv + ktok * p.lddv + (long)kvh * HD, dv, 0.f, lane, kok);
+      return;
+    }
+  }
   __syncthreads();
 
   // (head of the group, query tile) of tile `it` and of the tile whose DMA it issues, advanced incrementally: the two
