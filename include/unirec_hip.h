@@ -320,6 +320,12 @@ int ur_cast_bf16_to_f32(const void* src, float* dst, int64_t n, void* stream);
 /* dst [cols,rows] = src [rows,cols]^T (bf16).  Used for the per-step LoRA A^T operands so that the
  * dX GEMMs against the frozen Qwen3 weights run on K-contiguous operands. */
 int ur_transpose_bf16(const void* src, void* dst, int32_t rows, int32_t cols, void* stream);
+/* n small bf16 transposes in one launch.  desc (device memory, 8-byte aligned): n records of 32 bytes
+   {const void* src; void* dst; int32 rows, cols, tile0, ntx}: dst[c][r] = src[r][c]; tile0 = index of the matrix's first
+   32x32 tile in the launch (ascending, desc[0].tile0 = 0), ntx = ceil(cols / 32); total_tiles = sum of all tiles.
+   Replaces the per-adapter A^T / B^T operand copies of the LoRA backward (peft keeps A, B as nn.Linear weights;
+   train_item_individual_token_joint.py:121-131). */
+int ur_transpose_bf16_batched(const void* desc, int32_t n, int32_t total_tiles, void* stream);
 /* out = a + b (bf16, n % 8 == 0). */
 int ur_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 /* dx = dy * gelu'(u) (erf GELU, nn.GELU() of the user head, training/user_qformer_training.py:40). */

@@ -526,3 +526,15 @@ def test_lora_dropout_planes_of_different_sites_are_unrelated():
         perm = torch.arange(W // 32, device=DEV) ^ x
         assert abs(agree(a0[:, perm], b0) - ind) < 0.01, x
     assert torch.equal(keep(0, 0, 0, 3), a)               # and a pure function of (seed, step, layer, group)
+
+
+def test_batched_transpose_matches_per_matrix_transposes():
+    g = torch.Generator().manual_seed(3)
+    shapes = [(16, 1024), (48, 1024), (2048, 16), (33, 70), (1, 5), (3072, 16), (32, 32)]
+    srcs = [torch.randn(s, generator=g).to(DEV).to(torch.bfloat16) for s in shapes]
+    bt = hip.BatchedTranspose(srcs)
+    outs = bt.run()
+    for s_, o in zip(srcs, outs):
+        assert tuple(o.shape) == (s_.shape[1], s_.shape[0]) and torch.equal(o, s_.t().contiguous())
+    srcs[3].mul_(2)                      # sources are live views: a second run picks the new values up
+    assert torch.equal(bt.run()[3], srcs[3].t().contiguous())

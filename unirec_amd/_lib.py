@@ -123,6 +123,7 @@ SIGNATURES = {
     "ur_cast_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_cast_bf16_to_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ur_transpose_bf16_batched": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ur_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "ur_swiglu_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -124,6 +124,29 @@ __global__ void transpose_kernel(const bf16_t* __restrict__ src, bf16_t* __restr
   }
 }
 
+// many small transposes in ONE launch: desc[i] = {src, dst, rows, cols, first 32x32 tile, tiles per row}; a workgroup
+// finds its matrix by bisection over the first-tile column (the LoRA A^T / B^T operands of a whole backward: 308 matrices)
+struct TransposeDesc { const bf16_t* src; bf16_t* dst; int rows, cols, tile0, ntx; };
+__global__ void transpose_batched_kernel(const TransposeDesc* __restrict__ desc, int n) {
+  __shared__ bf16_t t[32][33];
+  int lo = 0, hi = n - 1;
+  const int blk = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (desc[mid].tile0 <= blk) lo = mid; else hi = mid - 1; }
+  const TransposeDesc d = desc[lo];
+  const int tl = blk - d.tile0;
+  const int c0 = (tl % d.ntx) * 32, r0 = (tl / d.ntx) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    t[i][tx] = (r < d.rows && c < d.cols) ? d.src[(long)r * d.cols + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < d.cols && r < d.rows) d.dst[(long)c * d.rows + r] = t[tx][i];
+  }
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
                              float gscale) {
@@ -195,6 +218,13 @@ extern "C" int ur_transpose_bf16(const void* src, void* dst, int32_t rows, int32
   hipLaunchKernelGGL(transpose_kernel, dim3(ur_cdiv(cols, 32), ur_cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
                      (bf16_t*)dst, rows, cols);
   UR_CHECK_LAUNCH("ur_transpose_bf16");
+  return 0;
+}
+extern "C" int ur_transpose_bf16_batched(const void* desc, int32_t n, int32_t total_tiles, void* stream) {
+  UR_REQUIRE(desc && n > 0 && total_tiles > 0 && (((uintptr_t)desc) & 7) == 0, "ur_transpose_bf16_batched: bad argument");
+  static_assert(sizeof(TransposeDesc) == 32, "descriptor layout: two pointers + four int32 (unirec_hip.h)");
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const TransposeDesc*)desc, n);
+  UR_CHECK_LAUNCH("ur_transpose_bf16_batched");
   return 0;
 }
 extern "C" int ur_swiglu_fwd(const void* gu, void* act, int32_t M, int32_t I, void* stream) {

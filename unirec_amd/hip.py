@@ -360,6 +360,36 @@ def cast_bf16_to_f32(src, dst=None):
     return dst
 
 
+class BatchedTranspose:
+    """Many small bf16 transposes as ONE launch (ur_transpose_bf16_batched).  Built once over persistent source tensors
+    (views of a parameter pack's bf16 shadow); run() refreshes every destination; out[i] is the transposed view."""
+
+    def __init__(self, sources):
+        import numpy as np
+        dev = sources[0].device
+        total = sum(t.numel() for t in sources)
+        self.buf = torch.empty(total, dtype=BF16, device=dev)
+        self.out, rec, off, tile = [], np.zeros((len(sources), 4), dtype=np.int64), 0, 0
+        for i, t in enumerate(sources):
+            if t.dim() != 2 or not t.is_contiguous() or t.dtype != BF16:
+                raise ValueError("BatchedTranspose: contiguous 2-D bf16 sources only")
+            rows, cols = t.shape
+            d = self.buf[off:off + rows * cols].view(cols, rows)
+            off += rows * cols
+            self.out.append(d)
+            ntx = (cols + 31) // 32
+            rec[i] = (t.data_ptr(), d.data_ptr(), rows | (cols << 32), tile | (ntx << 32))
+            tile += ntx * ((rows + 31) // 32)
+        self.sources = sources                       # keeps the storages alive
+        self.n, self.tiles = len(sources), tile
+        self.desc = torch.from_numpy(rec).to(dev)
+        self.key = tuple(t.data_ptr() for t in sources)
+
+    def run(self):
+        check(_lib.load().ur_transpose_bf16_batched(self.desc.data_ptr(), self.n, self.tiles, _stream()), "ur_transpose_bf16_batched")
+        return self.out
+
+
 def transpose_bf16(src, dst=None):
     lib = _lib.load()
     _need(src, BF16, "src")

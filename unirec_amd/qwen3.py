@@ -369,6 +369,28 @@ class Qwen3LoRAModel(nn.Module):
         torch._foreach_copy_(self._bcomb["dst"], self._bcomb["src"])
         return self._bcomb["qkv"], self._bcomb["gu"]
 
+    def _lora_transposes(self, pack):
+        """A^T (per adapter group) and B^T (per adapter) of every layer for the backward, refreshed by ONE launch per
+        backward (308 separate 5 us launches before).  The table is built once per pack: the sources are views of the pack's
+        persistent bf16 shadow."""
+        bt = getattr(self, "_lt", None)
+        if bt is None or bt[0] is not pack:
+            names, srcs = [], []
+            for i in range(self.config.num_hidden_layers):
+                lp = f"layers.{i}."
+                for grp in (("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj"), ("self_attn.o_proj",),
+                            ("mlp.gate_proj", "mlp.up_proj"), ("mlp.down_proj",)):
+                    an = tuple(lp + g + ".lora_A.weight" for g in grp)
+                    names.append(an)
+                    srcs.append(pack.fused16(list(an)) if len(an) > 1 else pack.w16(an[0]))
+                    for g in grp:
+                        names.append(lp + g + ".lora_B.weight")
+                        srcs.append(pack.w16(lp + g + ".lora_B.weight"))
+            bt = (pack, names, hip.BatchedTranspose(srcs))
+            self._lt = bt
+        outs = bt[2].run()
+        return dict(zip(bt[1], outs))
+
     def _lora_down(self, xin, a_names, pack, sc, seed, p, pre=None):
         """(t, bits): t[M, nb*r] = s * dropout_j(x) A_j^T for the nb adapters that share the input x (one dropped-flag
         bit plane per adapter, generated once here and kept for the backward)."""
@@ -498,6 +520,7 @@ class Qwen3LoRAModel(nn.Module):
         touched = []
 
         pdrop, step = saved["pdrop"], saved["step"]
+        lt = self._lora_transposes(pack) if (pack is not None and r == 16) else None      # name(s) -> transposed bf16 operand
 
         def lora_grads(dy, t, xin, a_names, b_specs, bits):
             """dB_p = dy_p^T t_p ; tb = s * dy B ; dA_p = tb_p^T dropout_p(x).  Returns tb [M, len(b)*r] (bf16)."""
@@ -515,7 +538,7 @@ class Qwen3LoRAModel(nn.Module):
             cols = [(c0, n) for _, c0, n in b_specs]
             bnames = [b for b, _, _ in b_specs]
             gB = pack.fusedg(bnames) if nb > 1 else pack.g32(bnames[0])            # [sum n, r]: adapter ranges in order
-            tb = hip.lora_bgrad(dy, t, [hip.transpose_bf16(pack.w16(b)) for b in bnames], cols, gB, alpha=sc)     # dB and tb, dy read once
+            tb = hip.lora_bgrad(dy, t, [lt[b] for b in bnames], cols, gB, alpha=sc)     # dB and tb, dy read once
             gA = pack.fusedg(a_names) if len(a_names) > 1 else pack.g32(a_names[0])
             hip.lora_reduce(xin, tb, gA, nad=len(a_names), alpha=1.0 / (1.0 - pdrop), bits=bits)
             return tb
@@ -524,9 +547,12 @@ class Qwen3LoRAModel(nn.Module):
             """dx = dy W + sum_j mask_j * (tb_j A_j): the adapters' part joins the main reduction when there is no
             dropout, and is a masked rank-r epilogue (ur_gemm drop_bits) when there is.  swiglu = (gu, dgu): dx is d(act)
             and leaves the GEMM as dgate | dup (SwiGLU backward in the epilogue: d(act) is never stored)."""
-            A = pack.fused16(a_names) if len(a_names) > 1 else pack.w16(a_names[0])
+            if lt is not None:
+                AT = lt[tuple(a_names)]
+            else:
+                AT = hip.transpose_bf16(pack.fused16(a_names) if len(a_names) > 1 else pack.w16(a_names[0]))
             drop = (bits, pdrop, r) if bits is not None else None
-            return hip.gemm(dy, wT, R2=tb, S2=hip.transpose_bf16(A), drop=drop, swiglu_bwd=swiglu)
+            return hip.gemm(dy, wT, R2=tb, S2=AT, drop=drop, swiglu_bwd=swiglu)
 
         for i in reversed(range(len(fz["layers"]))):
             fl, L = fz["layers"][i], saved["layers"][i]
