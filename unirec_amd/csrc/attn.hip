@@ -171,6 +171,24 @@ __device__ __forceinline__ void tr_frags(bf16x8 (&f)[Cfg<HD>::NDT], const char* 
   }
   tr_read(f, a, b);
 }
+// split form of tr_frags: issue the 8 reads of one 4-fragment batch now, wait for them later (tr_landed<N>: at most N younger LDS
+// reads still outstanding); between the two the registers hold no data yet
+__device__ __forceinline__ void tr_issue4(bf16x4 (&lo)[4], bf16x4 (&hi)[4], const uint32_t (&a)[4], const uint32_t (&b)[4]) {
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\t"
+      "ds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
+      "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\t"
+      "ds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15"
+      : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
+      : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]));
+}
+template <int N>
+__device__ __forceinline__ void tr_landed(bf16x4 (&lo)[4], bf16x4 (&hi)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3])
+               : "n"(N));
+}
+
 // accumulator registers 8*s2 .. 8*s2+7 -> bf16 B-operand fragment of k-step s2
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s2) {
   bf16x8 r;
@@ -1073,21 +1091,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
 // registers to that wait.  Between the two the registers hold no data yet: this is only sound while the
 // allocator leaves them alone (it parked them in AGPRs at 426 registers; at <= 380 it does not -- the kernel's
 // parity tests in tests/test_gpu_attention.py are what catches a build where it does).
-__device__ __forceinline__ void tr_issue4(bf16x4 (&lo)[4], bf16x4 (&hi)[4], const uint32_t (&a)[4], const uint32_t (&b)[4]) {
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9\n\t"
-      "ds_read_b64_tr_b16 %2, %10\n\tds_read_b64_tr_b16 %3, %11\n\t"
-      "ds_read_b64_tr_b16 %4, %12\n\tds_read_b64_tr_b16 %5, %13\n\t"
-      "ds_read_b64_tr_b16 %6, %14\n\tds_read_b64_tr_b16 %7, %15"
-      : "=&v"(lo[0]), "=&v"(hi[0]), "=&v"(lo[1]), "=&v"(hi[1]), "=&v"(lo[2]), "=&v"(hi[2]), "=&v"(lo[3]), "=&v"(hi[3])
-      : "v"(a[0]), "v"(b[0]), "v"(a[1]), "v"(b[1]), "v"(a[2]), "v"(b[2]), "v"(a[3]), "v"(b[3]));
-}
-template <int N>
-__device__ __forceinline__ void tr_landed(bf16x4 (&lo)[4], bf16x4 (&hi)[4]) {
-  asm volatile("s_waitcnt lgkmcnt(%8)"
-               : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]), "+v"(hi[3])
-               : "n"(N));
-}
 
 // ---- hand-ordered LDS streams of the dK/dV fast path (one wave per SIMD: nobody else hides an LDS latency, so every read
 // is issued up to 14 LDS operations ahead of its use and every use waits with a COUNTED lgkmcnt for exactly its own data;
