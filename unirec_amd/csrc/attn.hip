@@ -189,6 +189,39 @@ __device__ __forceinline__ void tr_landed(bf16x4 (&lo)[4], bf16x4 (&hi)[4]) {
                : "n"(N));
 }
 
+// head_dim 128 with the lane-constant part of the swizzled offsets hoisted out of the tile loop (LaneOff, 16 registers):
+// a row fragment then costs one add (tile base + offset) and a transposed batch four, against ~5 / ~24 vector
+// instructions of swizzle arithmetic per call (the swizzle repeats every 16 rows, so a 32- or 16-row step is an immediate)
+struct LaneOff128 {
+  uint32_t rf[8], ta[4], tb[4];
+  __device__ __forceinline__ void init(int lane) {
+    using C = Cfg<128>;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int st = 0; st < 8; ++st) rf[st] = C::off(lane & 31, 2 * st + h);
+    const int g16 = (lane >> 4) & 1, i = lane & 15;
+    const int row = 4 * h + (i >> 2), sub8 = 8 * (i & 1);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int ch = 4 * dt + 2 * g16 + ((i & 3) >> 1);
+      ta[dt] = C::off(row, ch) + sub8;
+      tb[dt] = C::off(row + 8, ch) + sub8;
+    }
+  }
+};
+template <int R0>
+__device__ __forceinline__ bf16x8 row_frag_h(const char* tile, const LaneOff128& lo, int s) {
+  return *reinterpret_cast<const bf16x8*>(tile + lo.rf[s] + 256 * R0);
+}
+template <int R0>
+__device__ __forceinline__ void tr_frags_h(bf16x8 (&f)[4], const char* tile, const LaneOff128& lo) {
+  const uint32_t base = lds_off(tile) + 256 * R0;
+  uint32_t a[4], b[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) { a[dt] = base + lo.ta[dt]; b[dt] = base + lo.tb[dt]; }
+  tr_read(f, a, b);
+}
+
 // accumulator registers 8*s2 .. 8*s2+7 -> bf16 B-operand fragment of k-step s2
 __device__ __forceinline__ bf16x8 acc_frag(const f32x16& a, int s2) {
   bf16x8 r;
@@ -309,6 +342,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
   for (int s = 0; s < C::NS; ++s) qf[s] = g_frag(qrow, s, lane, qok);
 
+  [[maybe_unused]] LaneOff128 lo;
+  if constexpr (HD == 128) lo.init(lane);
+  auto kfrag = [&](const char* tile, auto R0c, int st) {
+    constexpr int R0 = decltype(R0c)::value;
+    if constexpr (HD == 128) return row_frag_h<R0>(tile, lo, st);
+    else return row_frag<HD>(tile, R0, st, lane);
+  };
   f32x16 o[C::NDT];
 #pragma unroll
   for (int dt = 0; dt < C::NDT; ++dt) o[dt] = zero16();
@@ -362,12 +402,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
       if (act0) {
 #pragma unroll
         for (int st = 0; st < C::NS; ++st)
-          sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ktile, 0, st, lane), qf[st], sA, 0, 0, 0);
+          sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(ktile, std::integral_constant<int, 0>{}, st), qf[st], sA, 0, 0, 0);
       }
       if (act1) {
 #pragma unroll
         for (int st = 0; st < C::NS; ++st)
-          sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(ktile, 32, st, lane), qf[st], sB, 0, 0, 0);
+          sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(ktile, std::integral_constant<int, 32>{}, st), qf[st], sB, 0, 0, 0);
       }
       auto soft_pv = [&](const int sub, f32x16& s) {
         const int kbase = k0 + 32 * sub;
@@ -450,7 +490,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
         for (int s2 = 0; s2 < 2; ++s2) {
           const bf16x8 pf = acc_frag(s, s2);
           bf16x8 vt[C::NDT];
-          tr_frags<HD>(vt, vtile, 32 * sub + 16 * s2, lane);
+          if constexpr (HD == 128) {
+            if (sub == 0) { if (s2 == 0) tr_frags_h<0>(vt, vtile, lo); else tr_frags_h<16>(vt, vtile, lo); }
+            else { if (s2 == 0) tr_frags_h<32>(vt, vtile, lo); else tr_frags_h<48>(vt, vtile, lo); }
+          } else {
+            tr_frags<HD>(vt, vtile, 32 * sub + 16 * s2, lane);
+          }
 #pragma unroll
           for (int dt = 0; dt < C::NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[dt], pf, o[dt], 0, 0, 0);
         }
