@@ -115,6 +115,12 @@ int64_t ur_lora_bits_ld(int32_t W);
 int ur_lora_dropout_bits(uint64_t seed, float p, int32_t M, int32_t W, int32_t nad, uint8_t* bits, int64_t bits_ld,
                          int64_t bits_stride, void* stream);
 int ur_lora_project(const ur_lora_args* a, void* stream);
+/* RMSNorm forward (ur_rmsnorm_fwd: out = w * (x * rstd), Qwen3RMSNorm modeling_qwen3.py:59-64) fused with the down
+   projection of the 2 or 3 adapters that read the normalised activation (q|k|v or gate|up): `a` as for ur_lora_project with
+   shared = 1 and X ignored (the adapters read `out`): P[m, 16a + j] = alpha * sum_c keep_a(m,c) out[m,c] U_a[j,c].  `out` is
+   written once and not re-read.  D == 1024 (the Qwen3-0.6B hidden size). */
+int ur_rmsnorm_lora_fwd(const void* x, const float* w, void* out, float* rstd, int32_t M, int32_t D, float eps,
+                        const ur_lora_args* a, void* stream);
 int64_t ur_lora_reduce_workspace_bytes(const ur_lora_args* a);
 int ur_lora_reduce(const ur_lora_args* a, void* workspace, int64_t workspace_bytes, void* stream);
 /* ur_lora_bgrad: the B side of the backward in ONE pass over dy (shared = 0, no dropout planes): P = tb = alpha * dy_a B_a

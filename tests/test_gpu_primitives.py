@@ -538,3 +538,27 @@ def test_batched_transpose_matches_per_matrix_transposes():
         assert tuple(o.shape) == (s_.shape[1], s_.shape[0]) and torch.equal(o, s_.t().contiguous())
     srcs[3].mul_(2)                      # sources are live views: a second run picks the new values up
     assert torch.equal(bt.run()[3], srcs[3].t().contiguous())
+
+
+@pytest.mark.parametrize("nad,p", [(3, 0.1), (2, 0.1), (3, 0.0), (2, 0.0)])
+@pytest.mark.parametrize("M", [64, 1000, 4133])
+def test_fused_rmsnorm_lora_projection_matches_the_two_kernels(nad, p, M):
+    """ur_rmsnorm_lora_fwd == ur_rmsnorm_fwd followed by ur_lora_project over its output (same masks), ragged M included."""
+    g = torch.Generator().manual_seed(M + nad)
+    D = 1024
+    x = (torch.randn(M, D, generator=g) * 1.5).to(DEV).to(torch.bfloat16)
+    w = (1.0 + 0.1 * torch.randn(D, generator=g)).to(DEV)
+    U = [(torch.randn(16, D, generator=g) * 0.05).to(DEV).to(torch.bfloat16) for _ in range(nad)]
+    bits = hip.lora_dropout_bits(1234, p, M, D, nad, DEV) if p > 0 else None
+    alpha = 2.0 / (1.0 - p)
+    h0, r0 = hip.rmsnorm_fwd(x, w, 1e-6)
+    t0 = hip.lora_project(h0, U, alpha=alpha, bits=bits)
+    h1, r1, t1 = hip.rmsnorm_lora_fwd(x, w, 1e-6, U, alpha=alpha, bits=bits)
+    torch.testing.assert_close(r1, r0, rtol=2e-6, atol=0)
+    # h: identical up to one bf16 ulp where the two reduction orders of the sum of squares round rstd differently
+    dh = (h1.float() - h0.float()).abs()
+    assert float((dh > 0).float().mean()) < 0.02 and float((dh / (h0.float().abs() + 1e-6)).max()) < 1e-2
+    ref = torch.stack([((h1.float() * (hip.lora_bits_to_keep(bits, D)[a].float() if bits is not None else 1.0)) @ U[a].float().t()) * alpha
+                       for a in range(nad)], 1).reshape(M, 16 * nad)
+    assert float((t1.float() - ref).norm() / ref.norm()) < 1e-2
+    assert float((t1.float() - t0.float()).norm() / t0.float().norm()) < 1e-2

@@ -137,6 +137,24 @@ def gemm_step(args):
         print(f"gemm {name:12s} M={M} N={N} K={K}: {t:.3f} ms  {2 * M * N * K / t / 1e9:.1f} TFLOP/s")
 
 
+def rmslora(args):
+    """RMSNorm forward + lora_project as two kernels against the fused ur_rmsnorm_lora_fwd (q|k|v: 3 adapters, gate|up: 2)."""
+    M, D = args.B * args.S, 1024
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(M, D, generator=g).cuda().to(torch.bfloat16)
+    w = torch.ones(D).cuda()
+    for nad in (3, 2):
+        U = [(torch.randn(16, D, generator=g) * 0.05).cuda().to(torch.bfloat16) for _ in range(nad)]
+        bits = hip.lora_dropout_bits(1, 0.1, M, D, nad, "cuda")
+        t_n = timeit(lambda: hip.rmsnorm_fwd(x, w, 1e-6), args.iters)
+        h, _ = hip.rmsnorm_fwd(x, w, 1e-6)
+        t_p = timeit(lambda: hip.lora_project(h, U, alpha=2.2, bits=bits), args.iters)
+        t_f = timeit(lambda: hip.rmsnorm_lora_fwd(x, w, 1e-6, U, alpha=2.2, bits=bits), args.iters)
+        gb = 2.0 * M * D * 2 / 1e9
+        print(f"nad={nad}: rmsnorm {t_n * 1e3:.1f} us + project {t_p * 1e3:.1f} us = {(t_n + t_p) * 1e3:.1f} us | fused {t_f * 1e3:.1f} us "
+              f"({gb / t_f:.2f} TB/s on x + h)")
+
+
 def gemm_lora(args):
     """What the LoRA term costs inside the projection GEMMs: plain / + second K range (forward: t B^T, K2 = 16) /
     + masked rank-16 epilogue (dX under LoRA dropout)."""
@@ -181,10 +199,10 @@ def lora(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn", "gemm_lora", "gemm_merge", "gemm_step"])
+    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn", "gemm_lora", "gemm_merge", "gemm_step", "rmslora"])
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--S", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--lib", action="store_true", help="gemm: also time torch.matmul on the same operands (reference point)")
     a = ap.parse_args()
-    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora, "gemm_merge": gemm_merge, "gemm_step": gemm_step}[a.what](a)
+    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora, "gemm_merge": gemm_merge, "gemm_step": gemm_step, "rmslora": rmslora}[a.what](a)

@@ -19,6 +19,7 @@
 // (c % 8 == 0): bit i (i < 4) = element c+2i dropped, bit 4+i = element c+2i+1 dropped -- the order in which
 // a 16-byte bf16x8 fragment keeps its elements in 32-bit pairs, so a byte expands to four pair masks with
 // one shift/and + one packed arithmetic shift each.
+#include <type_traits>
 #include "common.cuh"
 #include "unirec_hip.h"
 
@@ -192,6 +193,126 @@ __global__ __launch_bounds__(256, 4) void lora_project_kernel(ProjP p) {
         *reinterpret_cast<uint2*>(p.P + (long)m * p.ldp + 16 * (y + a) + 4 * g) =
             make_uint2(pack_bf2(v[0] * p.alpha, v[1] * p.alpha), pack_bf2(v[2] * p.alpha, v[3] * p.alpha));
       }
+    }
+  }
+}
+
+// ---- RMSNorm forward + the adapters' down projection in ONE pass over the residual stream ---------------------------------
+// h = w * (x * rstd) (Qwen3RMSNorm, modeling_qwen3.py:59-64) is written once and never re-read by a projection kernel:
+// t[m, 16a + j] = alpha * sum_c keep_a(m, c) h[m, c] A_a[j, c] for the NAD adapters that consume h (q|k|v: 3, gate|up: 2)
+// comes out of the same registers.  A wave owns 16 tokens x D = 1024 columns: lane (token l15, column group g) holds its 32
+// 16-byte pieces of the row from one burst of loads (32 KiB in flight per wave, no barrier in front of them), the sum of
+// squares closes over the four lane groups with two shuffles, and the normalised pieces are the MFMA column operand
+// directly (the lora_project layout).  A_a chunks of 128 columns go through the same 2-slot LDS ring as lora_project.
+struct RmsLoraP {
+  const bf16_t* X; const float* W; bf16_t* H; float* rstd; int M; float eps;
+  const bf16_t* U[4]; long ldu[4];
+  const uint8_t* bits; long bits_ld, bits_stride;
+  bf16_t* P; long ldp; float alpha;
+};
+template <int NAD, bool MASKED>
+__global__ __launch_bounds__(256, 2) void rms_lora_kernel(RmsLoraP p) {
+  constexpr int D = 1024, KC = 128, NC = D / 32;
+  constexpr int SUB = NAD * 16 * 128;
+  constexpr int STAGE = 2 * SUB;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int tok = blockIdx.x * 64 + wave * 16 + l15;
+  const int m = min(tok, p.M - 1);
+  const bool mok = tok < p.M;
+  const bf16_t* xrow = p.X + (long)m * D + 8 * g;
+  uint4 xf[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) xf[c] = ld_stream(xrow + 32 * c);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const uint32_t wd[4] = {xf[c].x, xf[c].y, xf[c].z, xf[c].w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float lo = bf_lo(wd[e]), hi = bf_hi(wd[e]); q += lo * lo; q += hi * hi; }
+  }
+  // the row stays PACKED between the two passes: without this hipcc keeps all 256 unpacked floats of the sum of squares for
+  // the normalisation below (256 more registers -> 600-900 bytes of scratch per lane)
+#pragma unroll
+  for (int c = 0; c < NC; ++c) asm volatile("" : "+v"(xf[c].x), "+v"(xf[c].y), "+v"(xf[c].z), "+v"(xf[c].w));
+  q += __shfl_xor(q, 16, 64);
+  q += __shfl_xor(q, 32, 64);
+  const float rs = rsqrtf(q / (float)D + p.eps);
+  if (g == 0 && mok) p.rstd[m] = rs;
+  f32x4 acc[NAD];
+#pragma unroll
+  for (int a = 0; a < NAD; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16_t* hrow = p.H + (long)m * D + 8 * g;
+  // per-lane bases with compile-time chunk offsets on top (no lane-indexed access to the argument arrays: that sends the
+  // whole struct to scratch)
+  const bf16_t* ulane[NAD]; const uint8_t* blane[NAD];
+#pragma unroll
+  for (int i = 0; i < NAD; ++i) {
+    ulane[i] = p.U[i] + (long)((tid >> 4) & 15) * p.ldu[i] + (tid & 15) * 8;
+    blane[i] = MASKED ? p.bits + (long)m * p.bits_ld + (long)i * p.bits_stride : nullptr;
+  }
+  // compile-time chunk index: xf[] must stay in registers (hipcc does not unroll a loop with a barrier in it on request)
+  auto chunk = [&](auto C8) {
+    constexpr int c8 = decltype(C8)::value;
+    const int kc = c8 * KC;
+    asm volatile("" ::: "memory");             // the A / weight / bit-plane loads of a chunk stay in their chunk (hoisted to the top they spill)
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 ureg[NAD];
+#pragma unroll
+    for (int i = 0; i < NAD; ++i)      // piece tid + 256 i = row 16 i + (tid >> 4) of the stacked A matrices: adapter i (uniform)
+      ureg[i] = *reinterpret_cast<const uint4*>(ulane[i] + kc);
+    uint4 bw[NAD];
+    if (MASKED) {
+#pragma unroll
+      for (int a = 0; a < NAD; ++a) bw[a] = *reinterpret_cast<const uint4*>(blane[a] + (kc >> 3));
+    }
+    char* st = smem + (c8 & 1) * STAGE;
+#pragma unroll
+    for (int i = 0; i < NAD; ++i) {
+      const int pi = tid + 256 * i, row = pi >> 4, c16 = pi & 15;
+      *reinterpret_cast<uint4*>(st + (c16 >> 3) * SUB + row * 128 + (((c16 & 7) ^ kc_g(row)) << 4)) = ureg[i];
+    }
+    __syncthreads();       // slot c8 & 1 is re-written two chunks later: every wave has passed the next barrier by then
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) {
+      const int c = 4 * c8 + sx;
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // h = w * (x * rstd), rounded to bf16 exactly as ur_rmsnorm_fwd does
+      float wv[8];
+      {
+        const float4 w0 = *reinterpret_cast<const float4*>(p.W + 32 * c + 8 * g), w1 = *reinterpret_cast<const float4*>(p.W + 32 * c + 8 * g + 4);
+        wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w;
+      }
+      const uint32_t wd[4] = {xf[c].x, xf[c].y, xf[c].z, xf[c].w};
+      uint32_t hw[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hw[e] = pack_bf2(wv[2 * e] * (bf_lo(wd[e]) * rs), wv[2 * e + 1] * (bf_hi(wd[e]) * rs));
+      const uint4 hq = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      if (mok) *reinterpret_cast<uint4*>(hrow + 32 * c) = hq;
+#pragma unroll
+      for (int a = 0; a < NAD; ++a) {
+        const int row = a * 16 + l15, ch = 4 * (sx & 1) + g;
+        const bf16x8 uf = *reinterpret_cast<const bf16x8*>(st + (sx >> 1) * SUB + row * 128 + ((ch ^ kc_g(row)) << 4));
+        uint4 x = hq;
+        if (MASKED) {
+          const uint32_t wsel = sx == 0 ? bw[a].x : sx == 1 ? bw[a].y : sx == 2 ? bw[a].z : bw[a].w;
+          x = drop_apply(x, (wsel >> (8 * g)) & 0xffu);
+        }
+        acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf, __builtin_bit_cast(bf16x8, x), acc[a], 0, 0, 0);
+      }
+    }
+  };
+  chunk(std::integral_constant<int, 0>{}); chunk(std::integral_constant<int, 1>{}); chunk(std::integral_constant<int, 2>{});
+  chunk(std::integral_constant<int, 3>{}); chunk(std::integral_constant<int, 4>{}); chunk(std::integral_constant<int, 5>{});
+  chunk(std::integral_constant<int, 6>{}); chunk(std::integral_constant<int, 7>{});
+  // lane holds P[token l15][16 a + 4 g .. + 3]
+  if (mok) {
+#pragma unroll
+    for (int a = 0; a < NAD; ++a) {
+      const f32x4 v = acc[a];
+      *reinterpret_cast<uint2*>(p.P + (long)m * p.ldp + 16 * a + 4 * g) =
+          make_uint2(pack_bf2(v[0] * p.alpha, v[1] * p.alpha), pack_bf2(v[2] * p.alpha, v[3] * p.alpha));
     }
   }
 }
@@ -564,6 +685,36 @@ extern "C" int ur_lora_project(const ur_lora_args* a, void* stream) {
 #undef UR_PROJ
   }
   UR_CHECK_LAUNCH("ur_lora_project");
+  return 0;
+}
+
+extern "C" int ur_rmsnorm_lora_fwd(const void* x, const float* w, void* out, float* rstd, int32_t M, int32_t D, float eps,
+                                   const ur_lora_args* a, void* stream) {
+  UR_REQUIRE(D == 1024, "ur_rmsnorm_lora_fwd: built for the hidden size 1024 (D=%d)", D);
+  UR_REQUIRE(M >= 0 && x && w && out && rstd && UR_ALIGNED16(x) && UR_ALIGNED16(w) && UR_ALIGNED16(out), "ur_rmsnorm_lora_fwd: null / misaligned");
+  UR_REQUIRE(a && a->nad >= 2 && a->nad <= 3 && a->rank == 16 && a->shared == 1, "ur_rmsnorm_lora_fwd: 2 or 3 rank-16 adapters sharing the normalised input");
+  UR_REQUIRE(a->P && (((uintptr_t)a->P) & 7) == 0 && (a->ldp % 4) == 0 && a->ldp >= 16 * a->nad, "ur_rmsnorm_lora_fwd: P must be 8-byte aligned, ldp %% 4 == 0, ldp >= 16 nad");
+  UR_REQUIRE(!a->drop_bits || (UR_ALIGNED16(a->drop_bits) && (a->bits_ld % 16) == 0 && a->bits_ld >= D / 8 && (a->bits_stride % 16) == 0),
+             "ur_rmsnorm_lora_fwd: bad dropout bit planes");
+  for (int e = 0; e < a->nad; ++e)
+    UR_REQUIRE(a->U[e] && UR_ALIGNED16(a->U[e]) && (a->ldu[e] % 8) == 0 && a->ldu[e] >= D, "ur_rmsnorm_lora_fwd: U[%d] must be a 16-byte aligned [16, D] bf16 matrix", e);
+  if (M == 0) return 0;
+  RmsLoraP p;
+  p.X = (const bf16_t*)x; p.W = w; p.H = (bf16_t*)out; p.rstd = rstd; p.M = M; p.eps = eps;
+  for (int e = 0; e < 4; ++e) { p.U[e] = (const bf16_t*)a->U[e < a->nad ? e : 0]; p.ldu[e] = a->ldu[e < a->nad ? e : 0]; }
+  p.bits = (const uint8_t*)a->drop_bits; p.bits_ld = a->bits_ld; p.bits_stride = a->bits_stride;
+  p.P = (bf16_t*)a->P; p.ldp = a->ldp; p.alpha = a->alpha;
+  const dim3 grid((unsigned)ur_cdiv(M, 64));
+  hipStream_t st = (hipStream_t)stream;
+  const bool masked = a->drop_bits != nullptr;
+  if (a->nad == 2) {
+    if (masked) hipLaunchKernelGGL((rms_lora_kernel<2, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((rms_lora_kernel<2, false>), grid, dim3(256), 0, st, p);
+  } else {
+    if (masked) hipLaunchKernelGGL((rms_lora_kernel<3, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((rms_lora_kernel<3, false>), grid, dim3(256), 0, st, p);
+  }
+  UR_CHECK_LAUNCH("ur_rmsnorm_lora_fwd");
   return 0;
 }
 

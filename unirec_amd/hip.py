@@ -183,6 +183,27 @@ def lora_project(X, U, cols=None, alpha=1.0, bits=None, out=None):
     return out
 
 
+def rmsnorm_lora_fwd(x, w, eps, U, alpha=1.0, bits=None):
+    """RMSNorm forward + the down projection of the 2 or 3 adapters that read the normalised activation, one pass over x:
+    -> (h bf16 like x, rstd f32 [M], t bf16 [M, 16 len(U)]).  D must be 1024."""
+    lib = _lib.load()
+    _need(x, BF16, "x")
+    D = x.shape[-1]
+    M = x.numel() // D
+    out = torch.empty_like(x)
+    rstd = torch.empty((M,), dtype=F32, device=x.device)
+    a = _lora_args(out.view(M, D), [(0, D)] * len(U), True, bits, alpha)
+    for e, u in enumerate(U):
+        if u.dtype != BF16 or u.shape[0] != 16 or u.stride(1) != 1 or u.shape[1] != D:
+            raise ValueError("rmsnorm_lora_fwd: U[a] must be bf16 [16, D]")
+        a.U[e], a.ldu[e] = u.data_ptr(), u.stride(0)
+    t = torch.empty((M, 16 * len(U)), dtype=BF16, device=x.device)
+    a.P, a.ldp = t.data_ptr(), t.stride(0)
+    check(lib.ur_rmsnorm_lora_fwd(x.data_ptr(), w.data_ptr(), out.data_ptr(), rstd.data_ptr(), M, D, eps, ctypes.byref(a), _stream()),
+          "ur_rmsnorm_lora_fwd")
+    return out, rstd, t
+
+
 def lora_reduce(X, V, out, cols=None, nad=None, alpha=1.0, bits=None, transposed=False):
     """G_a[j,w] = alpha * sum_m V[m,16a+j] keep_a(m,w) X[m, c0_a+w] into the dense f32 tensor `out`
     ([16 nad, W] for shared columns, or [sum width, 16] with transposed=True for per-adapter column ranges)."""

@@ -104,6 +104,8 @@ _FUSE_SWIGLU_FWD = os.environ.get("UNIREC_SWIGLU_FWD_FUSED", "0") == "1"
 
 # UNIREC_MERGE_PROJ=0 (lab): one projection launch per LoRA adapter instead of the merged q|k|v and gate|up launches
 _MERGE_PROJ = os.environ.get("UNIREC_MERGE_PROJ", "1") != "0"
+# UNIREC_FUSE_NORM_LORA=0 (lab): RMSNorm forward and the q|k|v / gate|up adapters' down projection as two kernels again
+_FUSE_NORM_LORA = os.environ.get("UNIREC_FUSE_NORM_LORA", "1") != "0"
 
 
 def _split_k(red, out_rows, out_cols):
@@ -391,6 +393,14 @@ class Qwen3LoRAModel(nn.Module):
         outs = bt[2].run()
         return dict(zip(bt[1], outs))
 
+    def _norm_lora_down(self, x, w, eps, a_names, pack, sc, seed, p, pre=None):
+        """(h, rstd, t, bits) = RMSNorm forward + _lora_down of the adapters that read h, as one kernel (ur_rmsnorm_lora_fwd)."""
+        bits = pre
+        if bits is None and p > 0.0:
+            bits = hip.lora_dropout_bits(seed, p, x.shape[0], x.shape[1], len(a_names), x.device)
+        h, rstd, t = hip.rmsnorm_lora_fwd(x, w, eps, [pack.w16(n) for n in a_names], alpha=sc / (1.0 - p), bits=bits)
+        return h, rstd, t, bits
+
     def _lora_down(self, xin, a_names, pack, sc, seed, p, pre=None):
         """(t, bits): t[M, nb*r] = s * dropout_j(x) A_j^T for the nb adapters that share the input x (one dropped-flag
         bit plane per adapter, generated once here and kept for the backward)."""
@@ -437,14 +447,20 @@ class Qwen3LoRAModel(nn.Module):
         else:
             pre = None
         bp = (lambda i, g: pre[(i, g)]) if pre is not None else (lambda i, g: None)
+        fuse_norm = _FUSE_NORM_LORA and pack is not None and c.lora_r == 16 and D == 1024
         for i, fl in enumerate(fz["layers"]):
             lp = f"layers.{i}."
             L = {"x": x}
-            h, rstd1 = hip.rmsnorm_fwd(x, fl["ln1"], eps)
             qkv = torch.empty((M, NQ + 2 * NKV), dtype=BF16, device=dev)
+            if fuse_norm:      # RMSNorm + the q|k|v adapters' down projection in one pass over x (h is written once, never re-read by a projection kernel)
+                h, rstd1, t_qkv, L["bits_qkv"] = self._norm_lora_down(x, fl["ln1"], eps, [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"],
+                                                                      pack, sc, self.lora_dropout_seed(step, i, 0), pdrop, bp(i, 0))
+            else:
+                h, rstd1 = hip.rmsnorm_fwd(x, fl["ln1"], eps)
             if pack is not None:
-                t_qkv, L["bits_qkv"] = self._lora_down(h, [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"], pack, sc,
-                                                       self.lora_dropout_seed(step, i, 0), pdrop, bp(i, 0))     # [M,3r] = s * dropout(h) A^T
+                if not fuse_norm:
+                    t_qkv, L["bits_qkv"] = self._lora_down(h, [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"], pack, sc,
+                                                           self.lora_dropout_seed(step, i, 0), pdrop, bp(i, 0))     # [M,3r] = s * dropout(h) A^T
                 if bc_qkv is not None:
                     hip.gemm(h, fl["qkv"], out=qkv, R2=t_qkv, S2=bc_qkv[i])        # one launch, block-diagonal B
                 else:
@@ -466,11 +482,16 @@ class Qwen3LoRAModel(nn.Module):
                 L["t_o"] = t_o
             else:
                 x2 = hip.gemm(att2, fl["o"], residual=x)
-            h2, rstd2 = hip.rmsnorm_fwd(x2, fl["ln2"], eps)
             gu = torch.empty((M, 2 * I), dtype=BF16, device=dev)
+            if fuse_norm:
+                h2, rstd2, t_gu, L["bits_gu"] = self._norm_lora_down(x2, fl["ln2"], eps, [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"],
+                                                                     pack, sc, self.lora_dropout_seed(step, i, 2), pdrop, bp(i, 2))
+            else:
+                h2, rstd2 = hip.rmsnorm_fwd(x2, fl["ln2"], eps)
             if pack is not None:
-                t_gu, L["bits_gu"] = self._lora_down(h2, [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"], pack, sc,
-                                                     self.lora_dropout_seed(step, i, 2), pdrop, bp(i, 2))
+                if not fuse_norm:
+                    t_gu, L["bits_gu"] = self._lora_down(h2, [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"], pack, sc,
+                                                         self.lora_dropout_seed(step, i, 2), pdrop, bp(i, 2))
                 # gate first; the up projection's epilogue then reads the gate tile and writes act = silu(gate) * up beside up
                 fused = _FUSE_SWIGLU_FWD and bc_gu is None
                 act = torch.empty((M, I), dtype=BF16, device=dev) if fused else None
