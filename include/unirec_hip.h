@@ -119,6 +119,10 @@ int ur_lora_project(const ur_lora_args* a, void* stream);
    projection of the 2 or 3 adapters that read the normalised activation (q|k|v or gate|up): `a` as for ur_lora_project with
    shared = 1 and X ignored (the adapters read `out`): P[m, 16a + j] = alpha * sum_c keep_a(m,c) out[m,c] U_a[j,c].  `out` is
    written once and not re-read.  D == 1024 (the Qwen3-0.6B hidden size). */
+/* SwiGLU forward (ur_swiglu_fwd: act = silu(gate) * up over gu = [gate | up], Qwen3MLP modeling_qwen3.py:81-83) fused with
+   the down projection of the down_proj adapter, which reads act: P[m, j] = alpha * sum_c keep(m,c) act[m,c] U[j,c]
+   (`a`: nad = 1, U[0] = A [16, I], optional bit plane, X ignored).  I a multiple of 128. */
+int ur_swiglu_lora_fwd(const void* gu, void* act, int32_t M, int32_t I, const ur_lora_args* a, void* stream);
 int ur_rmsnorm_lora_fwd(const void* x, const float* w, void* out, float* rstd, int32_t M, int32_t D, float eps,
                         const ur_lora_args* a, void* stream);
 int64_t ur_lora_reduce_workspace_bytes(const ur_lora_args* a);

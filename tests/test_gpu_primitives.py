@@ -562,3 +562,22 @@ def test_fused_rmsnorm_lora_projection_matches_the_two_kernels(nad, p, M):
                        for a in range(nad)], 1).reshape(M, 16 * nad)
     assert float((t1.float() - ref).norm() / ref.norm()) < 1e-2
     assert float((t1.float() - t0.float()).norm() / t0.float().norm()) < 1e-2
+
+
+@pytest.mark.parametrize("p", [0.1, 0.0])
+@pytest.mark.parametrize("M,I", [(64, 3072), (1000, 3072), (4133, 512), (37, 128)])
+def test_fused_swiglu_lora_projection_matches_the_two_kernels(p, M, I):
+    """ur_swiglu_lora_fwd == ur_swiglu_fwd followed by ur_lora_project over act (same masks): act bit-identical, t to bf16 rounding."""
+    g = torch.Generator().manual_seed(M + I)
+    gu = (torch.randn(M, 2 * I, generator=g) * 1.5).to(DEV).to(torch.bfloat16)
+    U = (torch.randn(16, I, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    bits = hip.lora_dropout_bits(77, p, M, I, 1, DEV) if p > 0 else None
+    alpha = 2.0 / (1.0 - p)
+    act0 = hip.swiglu_fwd(gu, I)
+    t0 = hip.lora_project(act0, [U], alpha=alpha, bits=bits)
+    act1, t1 = hip.swiglu_lora_fwd(gu, I, U, alpha=alpha, bits=bits)
+    assert torch.equal(act0, act1)
+    keep = hip.lora_bits_to_keep(bits, I)[0].float() if bits is not None else 1.0
+    ref = ((act0.float() * keep) @ U.float().t()) * alpha
+    assert float((t1.float() - ref).norm() / ref.norm()) < 1e-2
+    assert float((t1.float() - t0.float()).norm() / t0.float().norm()) < 1e-2

@@ -155,6 +155,21 @@ def rmslora(args):
               f"({gb / t_f:.2f} TB/s on x + h)")
 
 
+def swilora(args):
+    """SwiGLU forward + the down adapter's lora_project as two kernels against the fused ur_swiglu_lora_fwd."""
+    M, I = args.B * args.S, 3072
+    g = torch.Generator().manual_seed(0)
+    gu = torch.randn(M, 2 * I, generator=g).cuda().to(torch.bfloat16)
+    U = (torch.randn(16, I, generator=g) * 0.05).cuda().to(torch.bfloat16)
+    bits = hip.lora_dropout_bits(1, 0.1, M, I, 1, "cuda")
+    t_s = timeit(lambda: hip.swiglu_fwd(gu, I), args.iters)
+    act = hip.swiglu_fwd(gu, I)
+    t_p = timeit(lambda: hip.lora_project(act, [U], alpha=2.2, bits=bits), args.iters)
+    t_f = timeit(lambda: hip.swiglu_lora_fwd(gu, I, U, alpha=2.2, bits=bits), args.iters)
+    gb = 3.0 * M * I * 2 / 1e9
+    print(f"swiglu {t_s * 1e3:.1f} us + project {t_p * 1e3:.1f} us = {(t_s + t_p) * 1e3:.1f} us | fused {t_f * 1e3:.1f} us ({gb / t_f:.2f} TB/s on gate|up + act)")
+
+
 def gemm_lora(args):
     """What the LoRA term costs inside the projection GEMMs: plain / + second K range (forward: t B^T, K2 = 16) /
     + masked rank-16 epilogue (dX under LoRA dropout)."""
@@ -199,10 +214,10 @@ def lora(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn", "gemm_lora", "gemm_merge", "gemm_step", "rmslora"])
+    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn", "gemm_lora", "gemm_merge", "gemm_step", "rmslora", "swilora"])
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--S", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--lib", action="store_true", help="gemm: also time torch.matmul on the same operands (reference point)")
     a = ap.parse_args()
-    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora, "gemm_merge": gemm_merge, "gemm_step": gemm_step, "rmslora": rmslora}[a.what](a)
+    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora, "gemm_merge": gemm_merge, "gemm_step": gemm_step, "rmslora": rmslora, "swilora": swilora}[a.what](a)

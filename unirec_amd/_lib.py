@@ -74,6 +74,7 @@ SIGNATURES = {
     "ur_lora_bits_ld": (c_i64, [c_int]),
     "ur_lora_dropout_bits": (c_int, [c_u64, c_float, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_void_p]),
     "ur_lora_project": (c_int, [ctypes.POINTER(LoraArgs), c_void_p]),
+    "ur_swiglu_lora_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(LoraArgs), c_void_p]),
     "ur_rmsnorm_lora_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.POINTER(LoraArgs), c_void_p]),
     "ur_lora_reduce_workspace_bytes": (c_i64, [ctypes.POINTER(LoraArgs)]),
     "ur_lora_reduce": (c_int, [ctypes.POINTER(LoraArgs), c_void_p, c_i64, c_void_p]),

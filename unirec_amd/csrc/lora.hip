@@ -317,6 +317,107 @@ __global__ __launch_bounds__(256, 2) void rms_lora_kernel(RmsLoraP p) {
   }
 }
 
+// ---- SwiGLU forward + the down_proj adapter's down projection in ONE pass over gate|up ---------------------------------------
+// act = silu(gate) * up (Qwen3MLP, modeling_qwen3.py:81-83) leaves as before; t[m, j] = alpha * sum_c keep(m, c) act[m, c] A[j, c]
+// is taken from the same registers, so the adapter never re-reads act (805 MB per layer at C4).  lora_project's layout: a
+// wave owns 2 x 16 tokens, lane (token l15, column group g) computes 8 consecutive columns of act per k-step from one
+// 16-byte piece of gate and one of up; A chunks of 128 columns go through the 2-slot LDS ring.
+struct SwiLoraP {
+  const bf16_t* GU; long ldgu; bf16_t* ACT; int M, I;
+  const bf16_t* U; long ldu;
+  const uint8_t* bits; long bits_ld;
+  bf16_t* P; long ldp; float alpha;
+};
+#ifndef UR_SWILORA_DIRECT
+#define UR_SWILORA_DIRECT 1      // 1: A fragments straight from L2 (96 KB, resident), no LDS ring and no block barrier
+#endif
+template <bool MASKED>
+__global__ __launch_bounds__(256, 4) void swiglu_lora_kernel(SwiLoraP p) {
+  constexpr int RB = 2, KC = 128, SUB = 16 * 128, STAGE = 2 * SUB;
+#if !UR_SWILORA_DIRECT
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+#endif
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  const int tok0 = blockIdx.x * (4 * RB * 16) + wave * (RB * 16);
+  f32x4 acc[RB];
+  const bf16_t* grow[RB]; bf16_t* arow[RB]; const uint8_t* brow[RB]; bool ok[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int tk = tok0 + 16 * rb + l15, m = min(tk, p.M - 1);
+    ok[rb] = tk < p.M;
+    grow[rb] = p.GU + (long)m * p.ldgu + 8 * g;
+    arow[rb] = p.ACT + (long)m * p.I + 8 * g;
+    brow[rb] = MASKED ? p.bits + (long)m * p.bits_ld : nullptr;
+    acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#if UR_SWILORA_DIRECT
+  const bf16_t* ulane = p.U + (long)l15 * p.ldu + 8 * g;                     // MFMA row operand: A[l15, kc + 32 sx + 8 g ..]
+#else
+  const bf16_t* ulane = p.U + (long)(tid >> 4) * p.ldu + (tid & 15) * 8;      // piece tid = row tid >> 4 of A, 16-byte chunk tid & 15
+#endif
+  const int nchunks = p.I / KC;
+  for (int c = 0; c < nchunks; ++c) {
+    const int kc = c * KC;
+#if UR_SWILORA_DIRECT
+    bf16x8 afr[4];
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) afr[sx] = *reinterpret_cast<const bf16x8*>(ulane + kc + 32 * sx);
+#else
+    const uint4 ureg = *reinterpret_cast<const uint4*>(ulane + kc);
+#endif
+    uint4 gf[RB][4], uf4[RB][4], bw[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+      for (int sx = 0; sx < 4; ++sx) {
+        gf[rb][sx] = ld_stream(grow[rb] + kc + 32 * sx);
+        uf4[rb][sx] = ld_stream(grow[rb] + p.I + kc + 32 * sx);
+      }
+      if (MASKED) bw[rb] = *reinterpret_cast<const uint4*>(brow[rb] + (kc >> 3));
+    }
+#if !UR_SWILORA_DIRECT
+    char* st = smem + (c & 1) * STAGE;
+    {
+      const int row = tid >> 4, c16 = tid & 15;
+      *reinterpret_cast<uint4*>(st + (c16 >> 3) * SUB + row * 128 + (((c16 & 7) ^ kc_g(row)) << 4)) = ureg;
+    }
+    __syncthreads();       // slot c & 1 is re-written two chunks later: every wave has passed the next barrier by then
+#endif
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) {
+#if UR_SWILORA_DIRECT
+      const bf16x8 af = afr[sx];
+#else
+      const int ch = 4 * (sx & 1) + g;
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(st + (sx >> 1) * SUB + l15 * 128 + ((ch ^ kc_g(l15)) << 4));
+#endif
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const uint32_t gw[4] = {gf[rb][sx].x, gf[rb][sx].y, gf[rb][sx].z, gf[rb][sx].w};
+        const uint32_t uw[4] = {uf4[rb][sx].x, uf4[rb][sx].y, uf4[rb][sx].z, uf4[rb][sx].w};
+        uint32_t aw[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aw[e] = pack_bf2(silu_f(bf_lo(gw[e])) * bf_lo(uw[e]), silu_f(bf_hi(gw[e])) * bf_hi(uw[e]));
+        uint4 x = make_uint4(aw[0], aw[1], aw[2], aw[3]);
+        if (ok[rb]) *reinterpret_cast<uint4*>(arow[rb] + kc + 32 * sx) = x;
+        if (MASKED) {
+          const uint32_t wsel = sx == 0 ? bw[rb].x : sx == 1 ? bw[rb].y : sx == 2 ? bw[rb].z : bw[rb].w;
+          x = drop_apply(x, (wsel >> (8 * g)) & 0xffu);
+        }
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, x), acc[rb], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int m = tok0 + 16 * rb + l15;
+    if (m < p.M) {
+      const f32x4 v = acc[rb];
+      *reinterpret_cast<uint2*>(p.P + (long)m * p.ldp + 4 * g) = make_uint2(pack_bf2(v[0] * p.alpha, v[1] * p.alpha), pack_bf2(v[2] * p.alpha, v[3] * p.alpha));
+    }
+  }
+}
+
 // ---- token-reduction products --------------------------------------------------------------------
 struct RedP {
   const bf16_t* X; long ldx; int M;
@@ -715,6 +816,26 @@ extern "C" int ur_rmsnorm_lora_fwd(const void* x, const float* w, void* out, flo
     else hipLaunchKernelGGL((rms_lora_kernel<3, false>), grid, dim3(256), 0, st, p);
   }
   UR_CHECK_LAUNCH("ur_rmsnorm_lora_fwd");
+  return 0;
+}
+
+extern "C" int ur_swiglu_lora_fwd(const void* gu, void* act, int32_t M, int32_t I, const ur_lora_args* a, void* stream) {
+  UR_REQUIRE(M >= 0 && I > 0 && (I % 128) == 0, "ur_swiglu_lora_fwd: I must be a multiple of 128 (I=%d)", I);
+  UR_REQUIRE(gu && act && UR_ALIGNED16(gu) && UR_ALIGNED16(act), "ur_swiglu_lora_fwd: null / misaligned");
+  UR_REQUIRE(a && a->nad == 1 && a->rank == 16, "ur_swiglu_lora_fwd: one rank-16 adapter (down_proj)");
+  UR_REQUIRE(a->P && (((uintptr_t)a->P) & 7) == 0 && (a->ldp % 4) == 0 && a->ldp >= 16, "ur_swiglu_lora_fwd: P must be 8-byte aligned, ldp %% 4 == 0, ldp >= 16");
+  UR_REQUIRE(a->U[0] && UR_ALIGNED16(a->U[0]) && (a->ldu[0] % 8) == 0 && a->ldu[0] >= I, "ur_swiglu_lora_fwd: U must be a 16-byte aligned [16, I] bf16 matrix");
+  UR_REQUIRE(!a->drop_bits || (UR_ALIGNED16(a->drop_bits) && (a->bits_ld % 16) == 0 && a->bits_ld >= I / 8), "ur_swiglu_lora_fwd: bad dropout bit plane");
+  if (M == 0) return 0;
+  SwiLoraP p;
+  p.GU = (const bf16_t*)gu; p.ldgu = 2L * I; p.ACT = (bf16_t*)act; p.M = M; p.I = I;
+  p.U = (const bf16_t*)a->U[0]; p.ldu = a->ldu[0];
+  p.bits = (const uint8_t*)a->drop_bits; p.bits_ld = a->bits_ld;
+  p.P = (bf16_t*)a->P; p.ldp = a->ldp; p.alpha = a->alpha;
+  const dim3 grid((unsigned)ur_cdiv(M, 128));
+  if (a->drop_bits) hipLaunchKernelGGL((swiglu_lora_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((swiglu_lora_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  UR_CHECK_LAUNCH("ur_swiglu_lora_fwd");
   return 0;
 }
 

@@ -183,6 +183,22 @@ def lora_project(X, U, cols=None, alpha=1.0, bits=None, out=None):
     return out
 
 
+def swiglu_lora_fwd(gu, I, U, alpha=1.0, bits=None):
+    """SwiGLU forward + the down_proj adapter's down projection in one pass over gu [M, 2I]: -> (act bf16 [M, I], t bf16 [M, 16])."""
+    lib = _lib.load()
+    _need(gu, BF16, "gu")
+    M = gu.shape[0]
+    act = torch.empty((M, I), dtype=BF16, device=gu.device)
+    a = _lora_args(act, [(0, I)], True, bits, alpha)
+    if U.dtype != BF16 or U.shape[0] != 16 or U.stride(1) != 1 or U.shape[1] != I:
+        raise ValueError("swiglu_lora_fwd: U must be bf16 [16, I]")
+    a.U[0], a.ldu[0] = U.data_ptr(), U.stride(0)
+    t = torch.empty((M, 16), dtype=BF16, device=gu.device)
+    a.P, a.ldp = t.data_ptr(), t.stride(0)
+    check(lib.ur_swiglu_lora_fwd(gu.data_ptr(), act.data_ptr(), M, I, ctypes.byref(a), _stream()), "ur_swiglu_lora_fwd")
+    return act, t
+
+
 def rmsnorm_lora_fwd(x, w, eps, U, alpha=1.0, bits=None):
     """RMSNorm forward + the down projection of the 2 or 3 adapters that read the normalised activation, one pass over x:
     -> (h bf16 like x, rstd f32 [M], t bf16 [M, 16 len(U)]).  D must be 1024."""

@@ -106,6 +106,8 @@ _FUSE_SWIGLU_FWD = os.environ.get("UNIREC_SWIGLU_FWD_FUSED", "0") == "1"
 _MERGE_PROJ = os.environ.get("UNIREC_MERGE_PROJ", "1") != "0"
 # UNIREC_FUSE_NORM_LORA=0 (lab): RMSNorm forward and the q|k|v / gate|up adapters' down projection as two kernels again
 _FUSE_NORM_LORA = os.environ.get("UNIREC_FUSE_NORM_LORA", "1") != "0"
+# UNIREC_FUSE_SWIGLU_LORA=0 (lab): SwiGLU forward and the down_proj adapter's down projection as two kernels again
+_FUSE_SWIGLU_LORA = os.environ.get("UNIREC_FUSE_SWIGLU_LORA", "1") != "0"
 
 
 def _split_k(red, out_rows, out_cols):
@@ -500,14 +502,22 @@ class Qwen3LoRAModel(nn.Module):
                 for j, p in enumerate(("gate", "up") if bc_gu is None else ()):
                     hip.gemm(h2, fl["gu"][j * I:(j + 1) * I], out=gu[:, j * I:(j + 1) * I], R2=t_gu[:, j * r:(j + 1) * r],
                              S2=pack.w16(lp + f"mlp.{p}_proj.lora_B.weight"), swiglu_fwd=(gu[:, :I], act) if (j == 1 and fused) else None)
-                if not fused:
+                fuse_act = _FUSE_SWIGLU_LORA and not fused and r == 16 and I % 128 == 0
+                if fuse_act:      # act and t_d = s * dropout(act) A_d^T from one pass over gate|up (ur_swiglu_lora_fwd)
+                    bits_d = bp(i, 3)
+                    if bits_d is None and pdrop > 0.0:
+                        bits_d = hip.lora_dropout_bits(self.lora_dropout_seed(step, i, 3), pdrop, M, I, 1, dev)
+                    act, t_d = hip.swiglu_lora_fwd(gu, I, pack.w16(lp + "mlp.down_proj.lora_A.weight"), alpha=sc / (1.0 - pdrop), bits=bits_d)
+                    L["bits_d"] = bits_d
+                elif not fused:
                     act = hip.swiglu_fwd(gu, I)
                 L["t_gu"] = t_gu
             else:
                 hip.gemm(h2, fl["gu"], out=gu)
                 act = hip.swiglu_fwd(gu, I)
             if pack is not None:
-                t_d, L["bits_d"] = self._lora_down(act, [lp + "mlp.down_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 3), pdrop, bp(i, 3))
+                if not fuse_act:
+                    t_d, L["bits_d"] = self._lora_down(act, [lp + "mlp.down_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 3), pdrop, bp(i, 3))
                 x3 = hip.gemm(act, fl["d"], residual=x2, R2=t_d, S2=pack.w16(lp + "mlp.down_proj.lora_B.weight"))
                 L["t_d"] = t_d
             else:
