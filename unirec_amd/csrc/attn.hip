@@ -32,6 +32,9 @@ constexpr float NEG_INF = -__builtin_huge_valf();
 constexpr float F32_MIN = -3.4028234663852886e38f;   // torch.finfo(torch.float32).min
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int KT = 64;                                // keys (or queries, in dK/dV) staged per LDS tile
+#ifndef UR_FWD_ABLATE
+#define UR_FWD_ABLATE 0                               // lab (tools/lab/dkv2_ablate.sh <tag> "<n...>" UR_FWD_ABLATE; results WRONG when != 0): 1 no max/exp2, 2 no LDS fragment reads, 3 no staging of the next tile, 4 no P V MFMAs, 5 = 3 + no barrier
+#endif
 #ifndef UR_ATTN_DEFER_MAX
 #define UR_ATTN_DEFER_MAX 1                           // lab: 0 = rescale O at every 32-key sub-tile
 #endif
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
     const char* ktile = smem + (t & 1) * 2 * C::TILE;
     const char* vtile = ktile + C::TILE;
     char* nk = smem + ((t + 1) & 1) * 2 * C::TILE;
-    if (t + 1 < ntiles) {
+    if (t + 1 < ntiles && UR_FWD_ABLATE != 3 && UR_FWD_ABLATE != 5) {
       ks.issue(nk, kb, p.ldk, k0 + KT, p.Sk, tid);
       vs.issue(nk + C::TILE, vb, p.ldv, k0 + KT, p.Sk, tid);
     }
@@ -402,12 +405,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
       if (act0) {
 #pragma unroll
         for (int st = 0; st < C::NS; ++st)
-          sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(ktile, std::integral_constant<int, 0>{}, st), qf[st], sA, 0, 0, 0);
+          sA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(UR_FWD_ABLATE == 2 ? qf[(st + 1) % C::NS] : kfrag(ktile, std::integral_constant<int, 0>{}, st), qf[st], sA, 0, 0, 0);
       }
       if (act1) {
 #pragma unroll
         for (int st = 0; st < C::NS; ++st)
-          sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(ktile, std::integral_constant<int, 32>{}, st), qf[st], sB, 0, 0, 0);
+          sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(UR_FWD_ABLATE == 2 ? qf[(st + 2) % C::NS] : kfrag(ktile, std::integral_constant<int, 32>{}, st), qf[st], sB, 0, 0, 0);
       }
       auto soft_pv = [&](const int sub, f32x16& s) {
         const int kbase = k0 + 32 * sub;
@@ -425,8 +428,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = ((r & 3) + 8 * (r >> 2) <= dqk) ? s[r] : NEG_INF;
           }
+#if UR_FWD_ABLATE == 1
+          mx = s[0];
+#else
 #pragma unroll
           for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+#endif
           mx *= p.scale;
         } else {
           const uint32_t vh = opaque(v32 >> (4 * h)), ih = opaque(i32 >> (4 * h));
@@ -474,7 +481,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
         float rs = 0.f;
         if (fast) {
 #pragma unroll
+#if UR_FWD_ABLATE == 1
+          for (int r = 0; r < 16; ++r) { rs += s[r]; }
+#else
           for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(fmaf(s[r], c2, -mc)); rs += s[r]; }
+#endif
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
@@ -490,24 +501,33 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
         for (int s2 = 0; s2 < 2; ++s2) {
           const bf16x8 pf = acc_frag(s, s2);
           bf16x8 vt[C::NDT];
-          if constexpr (HD == 128) {
+          if constexpr (UR_FWD_ABLATE == 2) {
+#pragma unroll
+            for (int dt = 0; dt < C::NDT; ++dt) vt[dt] = qf[dt];
+          } else if constexpr (HD == 128) {
             if (sub == 0) { if (s2 == 0) tr_frags_h<0>(vt, vtile, lo); else tr_frags_h<16>(vt, vtile, lo); }
             else { if (s2 == 0) tr_frags_h<32>(vt, vtile, lo); else tr_frags_h<48>(vt, vtile, lo); }
           } else {
             tr_frags<HD>(vt, vtile, 32 * sub + 16 * s2, lane);
           }
 #pragma unroll
+#if UR_FWD_ABLATE == 4
+          for (int dt = 0; dt < C::NDT; ++dt) o[dt][s2] += (float)(vt[dt][0] ^ pf[dt & 7]);
+#else
           for (int dt = 0; dt < C::NDT; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt[dt], pf, o[dt], 0, 0, 0);
+#endif
         }
       };
       if (act0) soft_pv(0, sA);
       if (act1) soft_pv(1, sB);
     }
-    if (t + 1 < ntiles) {
+    if (t + 1 < ntiles && UR_FWD_ABLATE != 3 && UR_FWD_ABLATE != 5) {
       ks.commit(nk, tid);
       vs.commit(nk + C::TILE, tid);
     }
+#if UR_FWD_ABLATE != 5
     __syncthreads();
+#endif
   }
   {
     const float inv = l > 0.f ? 1.0f / l : 0.f;
