@@ -528,6 +528,28 @@ def test_lora_dropout_planes_of_different_sites_are_unrelated():
     assert torch.equal(keep(0, 0, 0, 3), a)               # and a pure function of (seed, step, layer, group)
 
 
+def test_lora_dropout_plane_is_pairwise_independent_inside_a_word():
+    """The 32 decisions of one (row, 32-column group) word come from 16 consecutive states of one small generator: every pair
+    of columns inside the group, neighbouring groups and neighbouring rows must still agree like independent draws."""
+    M, W, p = 4096, 1024, 0.1
+    keep = hip.lora_bits_to_keep(hip.lora_dropout_bits(987654321, p, M, W, 1, DEV), W)[0].float()      # [M, W]
+    assert abs(keep.mean().item() - 0.9) < 2e-3
+    per_col = keep.mean(0)
+    assert float((per_col - 0.9).abs().max()) < 0.025                     # 4096 draws per column: sigma 0.0047
+    k3 = keep.view(M, W // 32, 32)
+    d = (1.0 - k3).reshape(-1, 32)                                         # dropped flags, one row per word
+    n = d.shape[0]
+    co = (d.t() @ d) / n                                                   # P(both dropped) for every column pair
+    off = co - torch.diag(torch.diag(co))
+    # independent: p^2 = 0.01; sigma of the estimate over 131072 words = sqrt(0.01 * 0.99 / n) = 2.7e-4
+    assert float((off + torch.eye(32, device=DEV) * 0.01 - 0.01).abs().max()) < 2e-3
+    ind = 0.82
+    assert abs((k3[:, 1:] == k3[:, :-1]).float().mean().item() - ind) < 5e-3        # same bit of neighbouring groups
+    assert abs((keep[1:] == keep[:-1]).float().mean().item() - ind) < 5e-3          # neighbouring rows
+    runs = (1.0 - keep)[:, 1:] * (1.0 - keep)[:, :-1]                               # adjacent columns both dropped
+    assert abs(runs.mean().item() - 0.01) < 1e-3
+
+
 def test_batched_transpose_matches_per_matrix_transposes():
     g = torch.Generator().manual_seed(3)
     shapes = [(16, 1024), (48, 1024), (2048, 16), (33, 70), (1, 5), (3072, 16), (32, 32)]

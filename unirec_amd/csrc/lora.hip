@@ -63,16 +63,28 @@ __device__ __forceinline__ int f64sw(int r) { return ((r >> 1) & 1) | (((r >> 3)
 __device__ __forceinline__ int sw16(int r) { return (r & 7) ^ ((r & 8) >> 1); }
 
 // ---- dropped-flag bit planes ---------------------------------------------------------------------
-// thread <-> (row m, group q of 32 columns): one 32-bit word per adapter plane.  Every element draws a 15-bit
-// field of a murmur-finalised counter stream; dropped iff field < p * 2^15.
+// thread <-> (row m, group q of 32 columns): one 32-bit word per adapter plane.  Every element draws a 15-bit value u;
+// dropped iff u < thr = p * 2^15.  The (row, group, adapter, seed) counter is murmur-finalised ONCE into the word's key h;
+// UR_BITS_XORSHIFT = 2 (default): the 32 values are BIT-SLICED over up to 15 consecutive states of a xorshift32 started at h
+//   (state k carries bit k of all 32 values, least significant first) and the 32 comparisons are one boolean step per state:
+//   lt_k = t_k ? (~b_k | lt_{k-1}) : (~b_k & lt_{k-1});  bits below thr's lowest set bit cannot decide and are not drawn.
+//   7 vector instructions per state for 32 decisions (the kernel is VALU-bound: profiles/README.md r2_lora_bits.txt).
+// = 1: 16 states, two 15-bit fields of each compared by a packed subtract; = 0: a second finaliser per pair (round 1).
+// Streams of different words start at hashed, unrelated points of the generator's single 2^32 - 1 cycle.
+#ifndef UR_BITS_XORSHIFT
+#define UR_BITS_XORSHIFT 2
+#endif
 __global__ void lora_bits_kernel(uint64_t seed, uint32_t thr15, int M, int W, int nad, long bits_ld, long bits_stride,
                                  uint8_t* __restrict__ bits) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int ng = (int)(bits_ld >> 2);
-  const long m = gid / ng;
-  const int q = (int)(gid - m * ng);
-  if (m >= M) return;
-  const uint32_t thr_pk = thr15 * 0x10001u;
+  // blockIdx.y counts chunks of 2^20 rows so that the (row, group) split is ONE 32-bit division (a 64-bit one costs ~150 vector
+  // instructions per thread, a sixth of the kernel)
+  const uint32_t ng = (uint32_t)(bits_ld >> 2);
+  const uint32_t lid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t ml = lid / ng;
+  const int q = (int)(lid - ml * ng);
+  const long m = ((long)blockIdx.y << 20) + ml;
+  if (ml >= (1u << 20) || m >= M) return;
+  [[maybe_unused]] const uint32_t thr_pk = thr15 * 0x10001u;
   // seed-only key (scalar unit), entered between the two mixing rounds as ur_hash2 does: the streams of two seeds are
   // neither shifted nor XOR-permuted copies of each other even when the seeds differ in a few low bits only
   const uint32_t s_lo = (uint32_t)seed, s_hi = (uint32_t)(seed >> 32);
@@ -80,19 +92,38 @@ __global__ void lora_bits_kernel(uint64_t seed, uint32_t thr15, int M, int W, in
   for (int a = 0; a < nad; ++a) {
     uint32_t out = 0;
     if (q * 32 < W) {
-      const uint64_t ctr = (((uint64_t)m * (uint64_t)ng + (uint64_t)q) << 2) + (uint64_t)a;
+      const uint64_t ctr = (((uint64_t)m * (uint64_t)ng + (uint64_t)(uint32_t)q) << 2) + (uint64_t)a;
       const uint32_t h = fmix32((((uint32_t)ctr ^ s_lo) + fmix32((uint32_t)(ctr >> 32) + s_hi + 0x9E3779B9u)) ^ k2) + k2;
+      uint32_t w = h ? h : 0x9E3779B9u;            // xorshift32 state: never zero
+#if UR_BITS_XORSHIFT == 2
+      if (thr15 != 0) {
+        const int k0 = __builtin_ctz(thr15);       // uniform (kernel argument): a scalar loop of 15 - k0 states
+        uint32_t lt = 0;
+#pragma unroll 1
+        for (uint32_t tb = (thr15 >> k0) | (0x8000u >> k0); tb != 1; tb >>= 1) {     // sentinel above bit 14: the zero bits above thr's top bit count
+          w ^= w << 13; w ^= w >> 17; w ^= w << 5;
+          const uint32_t T = 0u - (tb & 1u);                             // all ones where thr has this bit
+          lt = (~w & lt) | (T & (~w | lt));
+        }
+        out = lt;
+      }
+#else
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         uint32_t v = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const uint32_t w = fmix32(h + (uint32_t)(4 * b + i + 1) * 0x9E3779B9u);
+#if UR_BITS_XORSHIFT == 1
+          w ^= w << 13; w ^= w >> 17; w ^= w << 5;
+#else
+          w = fmix32(h + (uint32_t)(4 * b + i + 1) * 0x9E3779B9u);       // lab: the second finaliser per pair of decisions
+#endif
           const uint32_t d = pk_sub16(w & 0x7fff7fffu, thr_pk);        // sign of each half set iff field < thr
           v |= ((d >> 15) & 0x10001u) << i;
         }
         out |= ((v | (v >> 12)) & 0xffu) << (8 * b);
       }
+#endif
     }
     *reinterpret_cast<uint32_t*>(bits + (long)a * bits_stride + m * bits_ld + 4 * q) = out;
   }
@@ -333,7 +364,8 @@ struct SwiLoraP {
 #endif
 template <bool MASKED>
 __global__ __launch_bounds__(256, 4) void swiglu_lora_kernel(SwiLoraP p) {
-  constexpr int RB = 2, KC = 128, SUB = 16 * 128, STAGE = 2 * SUB;
+  constexpr int RB = 2, KC = 128;
+  [[maybe_unused]] constexpr int SUB = 16 * 128, STAGE = 2 * SUB;
 #if !UR_SWILORA_DIRECT
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
 #endif
@@ -747,8 +779,10 @@ extern "C" int ur_lora_dropout_bits(uint64_t seed, float p, int32_t M, int32_t W
   if (M == 0) return 0;
   double t = (double)p * 32768.0 + 0.5;
   const uint32_t thr15 = t > 32767.0 ? 32767u : (uint32_t)t;
-  const long n = (long)M * (bits_ld / 4);
-  hipLaunchKernelGGL(lora_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed, thr15, (int)M, (int)W,
+  UR_REQUIRE(bits_ld / 4 <= 2048, "ur_lora_dropout_bits: W up to 65536 columns");
+  const long rows_y = 1L << 20;
+  const long n = (long)(M < rows_y ? M : rows_y) * (bits_ld / 4);         // threads per grid.y slice (< 2^31)
+  hipLaunchKernelGGL(lora_bits_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)((M + rows_y - 1) / rows_y)), dim3(256), 0, (hipStream_t)stream, seed, thr15, (int)M, (int)W,
                      (int)nad, (long)bits_ld, (long)bits_stride, bits);
   UR_CHECK_LAUNCH("ur_lora_dropout_bits");
   return 0;
