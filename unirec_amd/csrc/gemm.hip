@@ -889,7 +889,9 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
     // they divide 551.8 vs 545.8 ms (+1.1 %) -- the plain order stays the default (UR_GEMM_CW = n: lab).
     static const int env_cw = [] { const char* e = getenv("UR_GEMM_CW"); return e ? atoi(e) : -1; }();
     p.gcw = 0;
-    const int cw = env_cw >= 0 ? env_cw : 0;
+    // default: chunks of 4 on launches of >= 16 column tiles (the merged q|k|v and gate|up forwards) -- time-neutral inside the
+    // step, but the fabric reads of those launches drop from x8.7 / x21 of A + W to what profiles/r2_gemm_pmc.json lists
+    const int cw = env_cw >= 0 ? env_cw : (p.gn >= 16 ? 4 : 0);
     if (cw > 0 && BM == 256 && (p.gm % 8) == 0 && p.gn > cw && (p.gn % cw) == 0) p.gcw = cw;
   }
   {
