@@ -164,18 +164,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       }
     }
   }
-  float* base = part + (long)(blockIdx.x * ROWS_PER_BLOCK + wave) * 3 * H;
+  // one partial row per BLOCK: the four waves fold their column sums in LDS, in wave order (deterministic), so the grid can be
+  // four times larger at the same number of partial rows (M = 8192 rows used to be 16 dependent rows per wave on half the CUs)
+  __shared__ __attribute__((aligned(16))) float comb[3 * NCH * 512];
+#pragma unroll 1
+  for (int w = 0; w < ROWS_PER_BLOCK; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int i = 0; i < NCH; ++i) {
-    const int e0 = (lane + i * 64) * 8;
-    if (e0 < H) {
+      for (int i = 0; i < NCH; ++i) {
+        const int e0 = (lane + i * 64) * 8;
+        float* c0 = comb + e0; float* c1 = comb + NCH * 512 + e0; float* c2 = comb + 2 * NCH * 512 + e0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        base[e0 + e] = pg[i][e];
-        base[H + e0 + e] = pb[i][e];
-        base[2 * H + e0 + e] = pd[i][e];
+        for (int e = 0; e < 8; ++e) {
+          if (w == 0) { c0[e] = pg[i][e]; c1[e] = pb[i][e]; c2[e] = pd[i][e]; }
+          else { c0[e] += pg[i][e]; c1[e] += pb[i][e]; c2[e] += pd[i][e]; }
+        }
       }
     }
+    __syncthreads();
+  }
+  float* base = part + (long)blockIdx.x * 3 * H;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    base[c] = comb[c];
+    base[H + c] = comb[NCH * 512 + c];
+    base[2 * H + c] = comb[2 * NCH * 512 + c];
   }
 }
 
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(256) void rms_bwd_kernel(const bf16_t* __restrict__
 
 inline int nch_for(int H) { int c = ur_cdiv(H, 512); return c <= 1 ? 1 : (c <= 2 ? 2 : 4); }
 inline int row_grid(int M, int cap) { int g = ur_cdiv(M, ROWS_PER_BLOCK); return g < cap ? (g > 0 ? g : 1) : cap; }
-constexpr int LN_BWD_BLOCKS = 128;
+constexpr int LN_BWD_BLOCKS = 512;   // partial rows of the column sums = blocks (ln_bwd_kernel folds its four waves)
 
 }  // namespace
 
@@ -359,7 +371,7 @@ extern "C" int ur_layernorm_fwd(const void* y, int32_t y_rows, const void* resid
 }
 
 extern "C" int64_t ur_layernorm_bwd_workspace_bytes(int32_t H) {
-  return (int64_t)LN_BWD_BLOCKS * ROWS_PER_BLOCK * 3 * H * (int64_t)sizeof(float);
+  return (int64_t)LN_BWD_BLOCKS * 3 * H * (int64_t)sizeof(float);
 }
 
 extern "C" int ur_layernorm_bwd(const void* dout, const void* z, const float* mean, const float* rstd,
@@ -381,7 +393,7 @@ extern "C" int ur_layernorm_bwd(const void* dout, const void* z, const float* me
   UR_CHECK_LAUNCH("ur_layernorm_bwd");
   const int ncols = 3 * H;
   hipLaunchKernelGGL(colpart_reduce_kernel, dim3(ur_cdiv(ncols, 64)), dim3(1024), 0, st, (const float*)part,
-                     grid * ROWS_PER_BLOCK, ncols, dgamma, dbeta, dbias, H);
+                     grid, ncols, dgamma, dbeta, dbias, H);
   UR_CHECK_LAUNCH("ur_layernorm_bwd(reduce)");
   return 0;
 }

@@ -15,6 +15,7 @@ invert_attention_mask; BertSelfAttention :169-275; BertSelfOutput :285-289; Bert
 :402-484; BertEncoder loop :517-566; BertModel.forward :804-972.
 """
 import math
+import os
 import re
 from types import SimpleNamespace
 
@@ -112,6 +113,7 @@ class _EncoderParams(nn.Module):
         self.layer = nn.ModuleList([_LayerParams(config, i) for i in range(config.num_hidden_layers)])
 
 
+_USE_WT = os.environ.get("UNIREC_QF_WT", "1") != "0"     # lab: 0 = dX products read the [out, in] weights as K-strided operands again
 _DEAD_RE = re.compile(r"(^|\.)layer\.\d+\.(intermediate\.dense|output\.dense|output\.LayerNorm)\.")
 
 
@@ -363,6 +365,32 @@ class BertModel(nn.Module):
             x = x3
         return x.view(B, Qn, H), (S if keep else None)
 
+    def _weight_transposes(self, pack, pre, with_enc):
+        """W^T of every weight a dX product reads (dx = dy W), refreshed by ONE launch per backward: with [in, out] copies the
+        dX launches are K-contiguous on both operands and take the 8-phase loop like the forward (the token-major [out, in]
+        weight as a K-strided operand runs the 2-slot loop: 110 vs 84 us at M 8192, N 3072, K 768).  UNIREC_QF_WT=0: lab."""
+        if not _USE_WT:
+            return None
+        bt = getattr(self, "_wt", None)
+        if bt is None or bt[0] is not pack or bt[1] != (pre, with_enc):
+            keys, srcs = [], []
+            for i, lyr in enumerate(self.encoder.layer):
+                lp = pre + f"encoder.layer.{i}."
+                a = lp + "attention."
+                groups = [((a + "self.query.weight", a + "self.key.weight", a + "self.value.weight"),), ((a + "output.dense.weight",),),
+                          ((lp + "intermediate_query.dense.weight",),), ((lp + "output_query.dense.weight",),)]
+                if lyr.has_cross_attention:
+                    c = lp + "crossattention."
+                    groups += [((c + "self.query.weight",),), ((c + "output.dense.weight",),)]
+                    if with_enc:
+                        groups += [((c + "self.key.weight", c + "self.value.weight"),)]
+                for (names,) in groups:
+                    keys.append(names if len(names) > 1 else names[0])
+                    srcs.append(pack.fused16(list(names)) if len(names) > 1 else pack.w16(names[0]))
+            bt = (pack, (pre, with_enc), keys, hip.BatchedTranspose(srcs))
+            self._wt = bt
+        return dict(zip(bt[2], bt[3].run()))
+
     def _backward_impl(self, S, dout, enc_needs_grad, qe_param_name=None):
         cfg = self.config
         pack = self._ensure_pack(dout.device)
@@ -378,6 +406,14 @@ class BertModel(nn.Module):
             dx = hip.cast_f32_to_bf16(dx)
         d_enc = None
         g = lambda n: pack.g32(pre + n)
+        wt = self._weight_transposes(pack, pre, enc_needs_grad)
+
+        def dX(dy, names, **kw):
+            """dy W for one weight (or several adjacent ones): through the transposed copy when there is one."""
+            key = tuple(names) if len(names) > 1 else names[0]
+            if wt is not None:
+                return hip.gemm(dy, wt[key], **kw)
+            return hip.gemm(dy, pack.fused16(list(names)) if len(names) > 1 else pack.w16(names[0]), s_kcontig=False, **kw)
 
         def dW(dy, xin, names):
             """grad of an [out,in] weight (or several adjacent ones): dY^T X, token reduction split over CUs."""
@@ -394,10 +430,10 @@ class BertModel(nn.Module):
             dz3, dy3 = hip.layernorm_bwd(dx, z3, m3, r3, pack.w32(f2 + "LayerNorm.weight"), pack.g32(f2 + "LayerNorm.weight"),
                                          pack.g32(f2 + "LayerNorm.bias"), dbias=pack.g32(f2 + "dense.bias"), p_pre=p_h, seed_pre=s_h3)
             dW(dy3, hbuf, [f2 + "dense.weight"])
-            du = hip.gemm(dy3, pack.w16(f2 + "dense.weight"), s_kcontig=False, gelu_grad_aux=u)
+            du = dX(dy3, [f2 + "dense.weight"], gelu_grad_aux=u)
             hip.colsum(du, out=pack.g32(f1 + "bias"))
             dW(du, xc, [f1 + "weight"])
-            dx = hip.gemm(du, pack.w16(f1 + "weight"), s_kcontig=False, residual=dz3)
+            dx = dX(du, [f1 + "weight"], residual=dz3)
             # ---- cross attention
             if lyr.has_cross_attention:
                 c = lp + "crossattention."
@@ -406,7 +442,7 @@ class BertModel(nn.Module):
                                              pack.g32(c + "output.LayerNorm.weight"), pack.g32(c + "output.LayerNorm.bias"),
                                              dbias=pack.g32(c + "output.dense.bias"), p_pre=p_h, seed_pre=s_h2)
                 dW(dy2, ctx2.view(M, H), [c + "output.dense.weight"])
-                dctx2 = hip.gemm(dy2, pack.w16(c + "output.dense.weight"), s_kcontig=False)
+                dctx2 = dX(dy2, [c + "output.dense.weight"])
                 dkv = torch.empty_like(kv)
                 dkv5 = dkv.view(B, T, 2, nh, dh)
                 dqc = torch.empty_like(qc)
@@ -416,9 +452,8 @@ class BertModel(nn.Module):
                 dW(dkv, enc16, [c + "self.key.weight", c + "self.value.weight"])
                 hip.colsum(dkv, out=pack.fusedg([c + "self.key.bias", c + "self.value.bias"]))
                 if enc_needs_grad:
-                    Wkv = pack.fused16([c + "self.key.weight", c + "self.value.weight"])
-                    d_enc = hip.gemm(dkv, Wkv, s_kcontig=False, residual=d_enc)
-                dx = hip.gemm(dqc, pack.w16(c + "self.query.weight"), s_kcontig=False, residual=dz2)
+                    d_enc = dX(dkv, [c + "self.key.weight", c + "self.value.weight"], residual=d_enc)
+                dx = dX(dqc, [c + "self.query.weight"], residual=dz2)
             # ---- self attention
             a = lp + "attention."
             x0, qkv, actx, ctx_o, z1, m1, r1, s_h = L["self"]
@@ -426,14 +461,14 @@ class BertModel(nn.Module):
                                          pack.g32(a + "output.LayerNorm.weight"), pack.g32(a + "output.LayerNorm.bias"),
                                          dbias=pack.g32(a + "output.dense.bias"), p_pre=p_h, seed_pre=s_h)
             dW(dy1, ctx_o.view(M, H), [a + "output.dense.weight"])
-            dctx = hip.gemm(dy1, pack.w16(a + "output.dense.weight"), s_kcontig=False)
+            dctx = dX(dy1, [a + "output.dense.weight"])
             dqkv = torch.empty_like(qkv)
             d5 = dqkv.view(B, Qn, 3, nh, dh)
             hip.attn_bwd(actx, dctx.view(B, Qn, nh, dh), dq=d5[:, :, 0], dk=d5[:, :, 1], dv=d5[:, :, 2])
             names = [a + "self.query.weight", a + "self.key.weight", a + "self.value.weight"]
             dW(dqkv, x0, names)
             hip.colsum(dqkv, out=pack.fusedg([a + "self.query.bias", a + "self.key.bias", a + "self.value.bias"]))
-            dx = hip.gemm(dqkv, pack.fused16(names), s_kcontig=False, residual=dz1)
+            dx = dX(dqkv, names, residual=dz1)
             L.clear()
             if self.grad_ready_hook is not None:      # dp.GradBuckets: layer i's gradients are final
                 self.grad_ready_hook(i)
