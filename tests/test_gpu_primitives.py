@@ -603,3 +603,27 @@ def test_fused_swiglu_lora_projection_matches_the_two_kernels(p, M, I):
     ref = ((act0.float() * keep) @ U.float().t()) * alpha
     assert float((t1.float() - ref).norm() / ref.norm()) < 1e-2
     assert float((t1.float() - t0.float()).norm() / t0.float().norm()) < 1e-2
+
+
+@pytest.mark.parametrize("B,Q,F,E", [(5, 32, 14, 256), (300, 32, 14, 1024), (7, 32, 16, 384), (6, 4, 8, 256), (3, 32, 14, 100)])
+def test_field_projection_fwd_bwd_match_torch(B, Q, F, E):
+    """ur_field_projection_fwd/bwd (models/qformer_utils.py:54: Linear(Q -> F) over the query axis) against torch fp32 -- the
+    Q = 32 fast paths (MFMA weight gradient) and the generic kernels (Q = 4; E = 100 is not a multiple of 4)."""
+    g = torch.Generator().manual_seed(B * 1000 + E)
+    rec = (torch.randn(B, Q, E, generator=g) * 0.5).to(DEV).to(torch.bfloat16)
+    W = (torch.randn(F, Q, generator=g) * 0.2).to(DEV)
+    b = (torch.randn(F, generator=g) * 0.1).to(DEV)
+    out = hip.field_projection_fwd(rec, W, b)
+    want = torch.einsum("fq,bqe->bfe", W, rec.float()) + b[None, :, None]
+    torch.testing.assert_close(out, want, rtol=1e-5, atol=1e-5)
+    dout = (torch.randn(B, F, E, generator=g) * 0.3).to(DEV)
+    dW, db = torch.empty(F, Q, device=DEV), torch.empty(F, device=DEV)
+    drec = hip.field_projection_bwd(dout, rec, W, dW, db)
+    want_drec = torch.einsum("fq,bfe->bqe", W, dout)
+    assert float((drec.float() - want_drec).norm() / want_drec.norm()) < 4e-3              # bf16 output
+    want_dW = torch.einsum("bfe,bqe->fq", dout, rec.float())
+    assert float((dW - want_dW).norm() / want_dW.norm()) < 4e-3                              # fast path: dout rounded to bf16
+    torch.testing.assert_close(db, dout.sum((0, 2)), rtol=1e-4, atol=1e-3)
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    drec2 = hip.field_projection_bwd(dout, rec, W, dW2, db2)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2) and torch.equal(drec, drec2)        # bitwise reproducible

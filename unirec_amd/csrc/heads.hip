@@ -69,6 +69,107 @@ __global__ __launch_bounds__(256) void fproj_bwd_kernel(const float* __restrict_
   __syncthreads();
   for (int i = threadIdx.x; i < nacc; i += 256) part[(long)blockIdx.x * nacc + i] = (accw[0][i] + accw[1][i]) + (accw[2][i] + accw[3][i]);
 }
+// ---- fast paths for the reference's shape (Q = 32 query tokens, F <= 16 fields, E a multiple of 256) --------------------
+// The generic kernels above index per-thread arrays with runtime bounds (they live in scratch) and, in the backward, pay
+// F*Q wave reductions per element: 165 / 527 us at B 256, E 1024.  Here everything is compile-time indexed; the weight
+// gradient dWf[f][q] = sum_{b,e} dout[b][f][e] rec[b][q][e] is an MFMA contraction over e (both operands are e-contiguous
+// as they lie: dout rows f -> the row operand, rounded to bf16; rec rows q -> the column operand).
+constexpr int FQ = 32, FPAD = 16;
+__global__ __launch_bounds__(256) void fproj_fwd32_kernel(const bf16_t* __restrict__ rec, const float* __restrict__ Wf,
+                                                          const float* __restrict__ bf, float* __restrict__ out, int B, int F, int E) {
+  __shared__ float w[FPAD * FQ];
+  __shared__ float bb[FPAD];
+  for (int i = threadIdx.x; i < FPAD * FQ; i += 256) w[i] = i < F * FQ ? Wf[i] : 0.f;
+  if (threadIdx.x < FPAD) bb[threadIdx.x] = threadIdx.x < F ? bf[threadIdx.x] : 0.f;
+  __syncthreads();
+  const int e4 = E >> 2;
+  const long total = (long)B * e4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / e4; const int e = (int)(i - b * e4) * 4;
+    float acc[FPAD][4];
+#pragma unroll
+    for (int f = 0; f < FPAD; ++f) { acc[f][0] = acc[f][1] = acc[f][2] = acc[f][3] = bb[f]; }
+#pragma unroll 4
+    for (int q = 0; q < FQ; ++q) {
+      const uint2 rv = *reinterpret_cast<const uint2*>(rec + (b * FQ + q) * E + e);
+      const float r0 = bf_lo(rv.x), r1 = bf_hi(rv.x), r2 = bf_lo(rv.y), r3 = bf_hi(rv.y);
+#pragma unroll
+      for (int f = 0; f < FPAD; ++f) {
+        const float wv = w[f * FQ + q];
+        acc[f][0] = fmaf(wv, r0, acc[f][0]); acc[f][1] = fmaf(wv, r1, acc[f][1]);
+        acc[f][2] = fmaf(wv, r2, acc[f][2]); acc[f][3] = fmaf(wv, r3, acc[f][3]);
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < FPAD; ++f)
+      if (f < F) *reinterpret_cast<float4*>(out + (b * F + f) * E + e) = make_float4(acc[f][0], acc[f][1], acc[f][2], acc[f][3]);
+  }
+}
+
+// one block per batch row at a time; part[block][F*32 + F] holds the block's dWf | dbf partial sums
+__global__ __launch_bounds__(256) void fproj_bwd32_kernel(const float* __restrict__ dout, const bf16_t* __restrict__ rec,
+                                                          const float* __restrict__ Wf, bf16_t* __restrict__ drec,
+                                                          float* __restrict__ part, int B, int F, int E) {
+  __shared__ float w[FPAD * FQ];
+  __shared__ float red[4][FPAD * FQ + FPAD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  for (int i = tid; i < FPAD * FQ; i += 256) w[i] = i < F * FQ ? Wf[i] : 0.f;
+  __syncthreads();
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  const int ew = E >> 2;                                     // e range of one wave
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    // ---- dWf / dbf: D[f][q] += sum_e dout[b][f][e] rec[b][q][e], 32 e per MFMA step
+    const float* drow = dout + ((long)b * F + min(l15, F - 1)) * E + wave * ew + 8 * g;
+    const bf16_t* r0 = rec + ((long)b * FQ + l15) * E + wave * ew + 8 * g;
+    const bf16_t* r1 = r0 + 16L * E;
+    for (int e0 = 0; e0 < ew; e0 += 32) {
+      float4 d0 = *reinterpret_cast<const float4*>(drow + e0), d1 = *reinterpret_cast<const float4*>(drow + e0 + 4);
+      if (l15 >= F) { d0 = make_float4(0.f, 0.f, 0.f, 0.f); d1 = d0; }
+      bsum += ((d0.x + d0.y) + (d0.z + d0.w)) + ((d1.x + d1.y) + (d1.z + d1.w));
+      const uint4 ap = make_uint4(pack_bf2(d0.x, d0.y), pack_bf2(d0.z, d0.w), pack_bf2(d1.x, d1.y), pack_bf2(d1.z, d1.w));
+      const bf16x8 af = __builtin_bit_cast(bf16x8, ap);
+      const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(r0 + e0), b1 = *reinterpret_cast<const bf16x8*>(r1 + e0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b1, acc1, 0, 0, 0);
+    }
+    // ---- drec[b][q][e] = sum_f Wf[f][q] dout[b][f][e]: thread <-> 4 consecutive e
+    for (int e = tid * 4; e < E; e += 1024) {
+      float gv[FPAD][4];
+#pragma unroll
+      for (int f = 0; f < FPAD; ++f) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < F) v = *reinterpret_cast<const float4*>(dout + ((long)b * F + f) * E + e);
+        gv[f][0] = v.x; gv[f][1] = v.y; gv[f][2] = v.z; gv[f][3] = v.w;
+      }
+#pragma unroll 4
+      for (int q = 0; q < FQ; ++q) {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int f = 0; f < FPAD; ++f) {
+          const float wv = w[f * FQ + q];
+          s0 = fmaf(wv, gv[f][0], s0); s1 = fmaf(wv, gv[f][1], s1); s2 = fmaf(wv, gv[f][2], s2); s3 = fmaf(wv, gv[f][3], s3);
+        }
+        *reinterpret_cast<uint2*>(drec + ((long)b * FQ + q) * E + e) = make_uint2(pack_bf2(s0, s1), pack_bf2(s2, s3));
+      }
+    }
+  }
+  // accumulator layout of v_mfma_f32_16x16x32: lane holds D[row = 4 g + i][col = l15], i = 0..3  (row = f, col = q)
+  bsum += __shfl_xor(bsum, 16, 64); bsum += __shfl_xor(bsum, 32, 64);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    red[wave][(4 * g + i) * FQ + l15] = acc0[i];
+    red[wave][(4 * g + i) * FQ + 16 + l15] = acc1[i];
+  }
+  if (g == 0) red[wave][FPAD * FQ + l15] = bsum;
+  __syncthreads();
+  const int nacc = F * FQ + F;
+  for (int i = tid; i < nacc; i += 256) {
+    const int j = i < F * FQ ? i : FPAD * FQ + (i - F * FQ);
+    part[(long)blockIdx.x * nacc + i] = (red[0][j] + red[1][j]) + (red[2][j] + red[3][j]);
+  }
+}
+
 __global__ void part_reduce_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ o0, int n0,
                                    float* __restrict__ o1) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -173,6 +274,12 @@ extern "C" int ur_field_projection_fwd(const void* rec, const float* Wf, const f
                                        int32_t E, void* stream) {
   UR_REQUIRE(rec && Wf && bf && out && B >= 0 && Q > 0 && Q <= MAXQ && F > 0 && F <= MAXF && E > 0, "ur_field_projection_fwd: need Q <= 64, F <= 32");
   if (B == 0) return 0;
+  if (Q == FQ && F <= FPAD && (E % 4) == 0 && UR_ALIGNED16(out) && (((uintptr_t)rec) & 7) == 0) {
+    long g4 = ((long)B * (E / 4) + 255) / 256; if (g4 > 4096) g4 = 4096;
+    hipLaunchKernelGGL(fproj_fwd32_kernel, dim3((int)g4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)rec, Wf, bf, out, B, F, E);
+    UR_CHECK_LAUNCH("ur_field_projection_fwd");
+    return 0;
+  }
   long g = ((long)B * E + 255) / 256; if (g > 2048) g = 2048;
   hipLaunchKernelGGL(fproj_fwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)rec, Wf, bf, out, B, Q, F, E);
   UR_CHECK_LAUNCH("ur_field_projection_fwd");
@@ -185,7 +292,12 @@ extern "C" int ur_field_projection_bwd(const float* dout, const void* rec, const
   UR_REQUIRE(workspace && workspace_bytes >= ur_heads_workspace_bytes(Q, F), "ur_field_projection_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   long g = ((long)B * E + 255) / 256; if (g > NBLK) g = NBLK;
-  hipLaunchKernelGGL(fproj_bwd_kernel, dim3((int)g), dim3(256), 0, st, dout, (const bf16_t*)rec, Wf, (bf16_t*)drec, (float*)workspace, B, Q, F, E);
+  if (Q == FQ && F <= FPAD && (E % 128) == 0 && UR_ALIGNED16(dout) && UR_ALIGNED16(rec) && (((uintptr_t)drec) & 7) == 0) {
+    g = B < NBLK ? B : NBLK;
+    hipLaunchKernelGGL(fproj_bwd32_kernel, dim3((int)g), dim3(256), 0, st, dout, (const bf16_t*)rec, Wf, (bf16_t*)drec, (float*)workspace, B, F, E);
+  } else {
+    hipLaunchKernelGGL(fproj_bwd_kernel, dim3((int)g), dim3(256), 0, st, dout, (const bf16_t*)rec, Wf, (bf16_t*)drec, (float*)workspace, B, Q, F, E);
+  }
   UR_CHECK_LAUNCH("ur_field_projection_bwd");
   const int n = F * Q + F;
   hipLaunchKernelGGL(part_reduce_kernel, dim3(ur_cdiv(n, 256)), dim3(256), 0, st, (const float*)workspace, (int)g, n, dWf, F * Q, dbf);
