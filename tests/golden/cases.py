@@ -194,6 +194,9 @@ MID = {
     "qwen_mid": dict(kind="qwen_mid", seed=51, B=4, S=512, pad_side="left", qwen=_MIDQ),
     # the reference's DEFAULT UserQFormer (L4 Q64 H1024 I4096, 32 predicted tokens) over T=1600 keys (C3's shape), B=2
     "user_mid": dict(kind="user_mid", seed=52, B=2, T=1600, cfg=dict(H=1024, L=4, nh=16, I=4096, Q=64, E=1024, n_pred=32)),
+    # BASELINE configs[1]'s architecture exactly (C2: L12 Q32 H768 nh12 I3072 F14 E1024) at C1's batch: the 12-layer post-LN
+    # chain, head_dim 64 x 12 heads, cross-attention over 14 fields, the Q = 32 field-projection paths
+    "item_mid": dict(kind="item_mid", seed=53, B=16, cfg=dict(H=768, L=12, nh=12, I=3072, Q=32, F=14, E=1024)),
 }
 MID_STRIDE = 16
 
@@ -201,3 +204,11 @@ MID_STRIDE = 16
 def mid_sample(x):
     """Fixture-size rule of the mid-size cases: [B,S,D] activations keep every MID_STRIDE-th position."""
     return np.ascontiguousarray(np.asarray(x)[:, ::MID_STRIDE])
+
+
+def item_mid_sample(res):
+    """Fixture-size rule of item_mid: query_outputs keep every 4th query token, reconstructed_fields every 4th element."""
+    out = dict(res)
+    out["query_outputs"] = np.ascontiguousarray(np.asarray(res["query_outputs"])[:, ::4])
+    out["reconstructed_fields"] = np.ascontiguousarray(np.asarray(res["reconstructed_fields"])[..., ::4])
+    return out

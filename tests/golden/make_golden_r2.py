@@ -5,12 +5,14 @@ make_golden.py, which this script imports):
   qwen_mid.npz        installed transformers Qwen3Model, 4 layers D=1024 hd=128 S=512 B=4, left padding, sdpa:
                       pooled output, strided last_hidden_state and gradient w.r.t. inputs_embeds
   user_mid.npz        the reference's default UserQFormer over T=1600 keys, B=2: prediction, MSE loss, gradients
+  item_mid.npz        the reference's QFormerForItemRepresentation at C2's architecture (L12 Q32 H768 F14 E1024), B=16:
+                      outputs (strided), QFormerLoss, eval metrics, gradients
   use_real.npz        models/user_sequence_encoder.py UserSequenceEncoder._get_item_query_tokens_batch /
                       encode_user_sequence with a real (small) reference item Q-Former behind it
   state_dict_shapes.json   key -> shape of the reference modules' state_dict (item default / Q=8 duplicate / C1 / C2,
                       UserQFormer default): the checkpoint-compatibility contract of SURVEY 8(b)
 
-Usage:  python tests/golden/make_golden_r2.py [qwen_mid user_mid use_real shapes]
+Usage:  python tests/golden/make_golden_r2.py [qwen_mid user_mid item_mid use_real shapes]
 """
 import json
 import os
@@ -52,6 +54,14 @@ def gen_qwen_mid(case):
 
 def gen_user_mid(case):
     return mg.gen_user(case)
+
+
+def gen_item_mid(case):
+    res = mg.gen_item(case)          # the reference's QFormerForItemRepresentation + QFormerLoss + eval metrics
+    full = np.asarray(res["reconstructed_fields"])
+    res = cases.item_mid_sample(res)
+    res["reconstructed_fields_norm"] = np.array(np.linalg.norm(full.astype(np.float64)))
+    return res
 
 
 def gen_use_real():
@@ -103,10 +113,10 @@ def gen_shapes():
 def main():
     only = set(sys.argv[1:])
     want = lambda n: not only or n in only
-    for name in ("qwen_mid", "user_mid"):
+    for name in ("qwen_mid", "user_mid", "item_mid"):
         if want(name):
             case = cases.MID[name]
-            res = {"qwen_mid": gen_qwen_mid, "user_mid": gen_user_mid}[name](case)
+            res = {"qwen_mid": gen_qwen_mid, "user_mid": gen_user_mid, "item_mid": gen_item_mid}[name](case)
             path = os.path.join(HERE, name + ".npz")
             np.savez_compressed(path, **{k: np.asarray(v) for k, v in res.items()})
             print(f"{name}: {len(res)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")

@@ -84,6 +84,36 @@ def test_user_qformer_mid_size_matches_reference():
         assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL, "grad/" + k, floor=1e-6)
 
 
+def test_item_qformer_mid_size_matches_reference():
+    """BASELINE configs[1]'s architecture exactly (C2: L12 Q32 H768 nh12 I3072 F14 E1024) at B = 16, against vectors the reference's
+    own QFormerForItemRepresentation / QFormerLoss produced: outputs, loss, eval metrics (HIP loss kernels) and gradients."""
+    from unirec_amd import hip
+    from unirec_amd.qformer_model import QFormerForItemRepresentation
+    case = cases.MID["item_mid"]
+    c = case["cfg"]
+    g = load_golden("item_mid")
+    cfg = R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 2)
+    m = QFormerForItemRepresentation(hidden_size=c["H"], num_hidden_layers=c["L"], num_attention_heads=c["nh"], intermediate_size=c["I"],
+                                     num_query_tokens=c["Q"], field_embedding_dim=c["E"], num_fields=c["F"], dropout=0.0)
+    m = load_generated(m, R.item_qformer_shapes(cfg, c["F"]), case["seed"]).train()
+    x, mask = cases.item_inputs(case)
+    xt, mt = torch.from_numpy(x).to(DEV), torch.from_numpy(mask).to(DEV)
+    out = m(xt, mt)
+    got = cases.item_mid_sample({k: out[k].detach().float().cpu().numpy() for k in ("query_outputs", "item_representation", "reconstructed_fields")})
+    for k in ("query_outputs", "item_representation", "reconstructed_fields"):
+        assert_close(got[k], g[k], OUT_REL, k)
+    sums = hip.recon_stats(out["reconstructed_fields"].detach(), xt, mt.float()).cpu().numpy()
+    assert_close(sums[0] / sums[1], g["eval_mse"], OUT_REL, "eval_mse")
+    assert_close(sums[2], g["eval_cos_sum"], OUT_REL, "eval_cos_sum")
+    pos, neg = cases.triplet_reps(case)
+    loss, rl, cl = R.qformer_loss({k: v for k, v in out.items()}, xt, mt, torch.from_numpy(pos).to(DEV), torch.from_numpy(neg).to(DEV))
+    assert_close(loss, g["loss"], OUT_REL, "loss")
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k in cases.item_grad_keys(c):
+        assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL, "grad/" + k, floor=1e-6)
+
+
 # ---- the UserSequenceEncoder boundary (models/user_sequence_encoder.py:36-142) ----------------------------------------
 USE_CFG = dict(H=dc.CTX_H, L=2, nh=2, I=256, Q=dc.QI, E=dc.E, seed=61)      # = tests/golden/make_golden_r2.py:USE_CFG
 

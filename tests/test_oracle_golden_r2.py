@@ -52,6 +52,32 @@ def test_user_qformer_mid_size(golden_dir):
     _check_grads(P, g, cases.user_grad_keys(c))
 
 
+def test_item_qformer_mid_size(golden_dir):
+    """BASELINE configs[1]'s architecture exactly (C2: L12 Q32 H768 nh12 I3072 F14 E1024) at B = 16."""
+    case = cases.MID["item_mid"]
+    c = case["cfg"]
+    g = _load(golden_dir, "item_mid")
+    cfg = R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 2)
+    P = _params(R.item_qformer_shapes(cfg, c["F"]), case["seed"])
+    x, mask = cases.item_inputs(case)
+    xt, mt = torch.from_numpy(x), torch.from_numpy(mask)
+    out = R.item_qformer_forward(P, cfg, xt, mt)
+    got = cases.item_mid_sample({k: out[k].detach().numpy() for k in ("query_outputs", "item_representation", "reconstructed_fields")})
+    for k in ("query_outputs", "item_representation", "reconstructed_fields"):
+        _close(got[k], g[k], rtol=1e-3, atol=1e-4, what=k)
+    rn = float(np.linalg.norm(out["reconstructed_fields"].detach().numpy().astype(np.float64)))
+    assert abs(rn - float(g["reconstructed_fields_norm"])) <= 1e-4 * rn
+    mse, cos, nvalid = R.eval_reconstruction(out["reconstructed_fields"].detach(), xt, mt)
+    _close(mse, g["eval_mse"], rtol=1e-3, what="eval_mse")
+    _close(cos, g["eval_cos_sum"], rtol=1e-3, atol=1e-3, what="eval_cos_sum")
+    assert nvalid == int(mask.sum())
+    pos, neg = cases.triplet_reps(case)
+    loss, rl, cl = R.qformer_loss(out, xt, mt, torch.from_numpy(pos), torch.from_numpy(neg))
+    _close(loss.detach(), g["loss"], rtol=1e-3, what="loss")
+    loss.backward()
+    _check_grads(P, g, cases.item_grad_keys(c))
+
+
 def test_user_sequence_encoder_real_path_oracle(golden_dir):
     """models/user_sequence_encoder.py:72-142 with a real item Q-Former behind it: field vectors -> np.any mask -> item
     Q-Former (eval) -> + time/geo context -> flatten -> + sinusoidal PE."""
