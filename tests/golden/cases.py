@@ -197,6 +197,11 @@ MID = {
     # BASELINE configs[1]'s architecture exactly (C2: L12 Q32 H768 nh12 I3072 F14 E1024) at C1's batch: the 12-layer post-LN
     # chain, head_dim 64 x 12 heads, cross-attention over 14 fields, the Q = 32 field-projection paths
     "item_mid": dict(kind="item_mid", seed=53, B=16, cfg=dict(H=768, L=12, nh=12, I=3072, Q=32, F=14, E=1024)),
+    # the joint path at the 0.6B decoder's layer shape: item Q-Former (H = D = 1024, Q 2, F 14) -> injection -> 2 Qwen3 layers
+    # (16 / 8 heads of 128, I 3072), S 512, left padding (the real tokenizer's side), hist 10, 15 negatives
+    "joint_mid": dict(kind="joint_mid", seed=54, B=3, S=512, hist=10, N=15, D=1024, first_special_id=200, pad_side="left",
+                      cfg=dict(H=1024, L=2, nh=16, I=2048, Q=2, F=14, E=1024),
+                      qwen=dict(D=1024, L=2, nq=16, nkv=8, hd=128, I=3072, vocab=220)),
 }
 MID_STRIDE = 16
 

@@ -7,12 +7,14 @@ make_golden.py, which this script imports):
   user_mid.npz        the reference's default UserQFormer over T=1600 keys, B=2: prediction, MSE loss, gradients
   item_mid.npz        the reference's QFormerForItemRepresentation at C2's architecture (L12 Q32 H768 F14 E1024), B=16:
                       outputs (strided), QFormerLoss, eval metrics, gradients
+  joint_mid.npz       the reference's MultiModalQwenEmbedding (item Q-Former H=1024 Q=2 F=14 -> injection -> 2 Qwen3 layers of the
+                      0.6B shape, S=512, left padding, hist=10) + InfoNCELoss + MRR ranks: embeddings, loss, ranks, gradients
   use_real.npz        models/user_sequence_encoder.py UserSequenceEncoder._get_item_query_tokens_batch /
                       encode_user_sequence with a real (small) reference item Q-Former behind it
   state_dict_shapes.json   key -> shape of the reference modules' state_dict (item default / Q=8 duplicate / C1 / C2,
                       UserQFormer default): the checkpoint-compatibility contract of SURVEY 8(b)
 
-Usage:  python tests/golden/make_golden_r2.py [qwen_mid user_mid item_mid use_real shapes]
+Usage:  python tests/golden/make_golden_r2.py [qwen_mid user_mid item_mid joint_mid use_real shapes]
 """
 import json
 import os
@@ -64,6 +66,12 @@ def gen_item_mid(case):
     return res
 
 
+def gen_joint_mid(case):
+    """The reference's MultiModalQwenEmbedding.forward + InfoNCELoss + MRR ranks (train_item_individual_token_joint.py:133-212,
+    326-352, 408-419) over the installed Qwen3Model; the sdpa results only (the product's semantics; fixture size)."""
+    return {k: v for k, v in mg.gen_joint(case).items() if k.startswith("sdpa/")}
+
+
 def gen_use_real():
     import models.user_sequence_encoder as ruse
     from models.mwne import TimestampEncoder as RefTime, GeoCoordinateEncoder as RefGeo
@@ -113,10 +121,10 @@ def gen_shapes():
 def main():
     only = set(sys.argv[1:])
     want = lambda n: not only or n in only
-    for name in ("qwen_mid", "user_mid", "item_mid"):
+    for name in ("qwen_mid", "user_mid", "item_mid", "joint_mid"):
         if want(name):
             case = cases.MID[name]
-            res = {"qwen_mid": gen_qwen_mid, "user_mid": gen_user_mid, "item_mid": gen_item_mid}[name](case)
+            res = {"qwen_mid": gen_qwen_mid, "user_mid": gen_user_mid, "item_mid": gen_item_mid, "joint_mid": gen_joint_mid}[name](case)
             path = os.path.join(HERE, name + ".npz")
             np.savez_compressed(path, **{k: np.asarray(v) for k, v in res.items()})
             print(f"{name}: {len(res)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")

@@ -78,6 +78,30 @@ def test_item_qformer_mid_size(golden_dir):
     _check_grads(P, g, cases.item_grad_keys(c))
 
 
+def test_joint_mid_size(golden_dir):
+    """The reference's joint forward / InfoNCE / MRR at the 0.6B decoder's layer shape (D 1024, 16/8 heads of 128, S 512, left padding)."""
+    case = cases.MID["joint_mid"]
+    c = case["cfg"]
+    g = {k[5:]: v for k, v in _load(golden_dir, "joint_mid").items() if k.startswith("sdpa/")}
+    cfg = R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 2)
+    qc = cases.qwen_cfg(case)
+    PQ = _params(R.item_qformer_shapes(cfg, c["F"]), case["seed"])
+    PW = _params(Q.qwen3_shapes(qc, lora=False), case["seed"] + 1)
+    ids, am, hfe, ham, pos, neg, nmask = cases.joint_inputs(case)
+    B, hist = case["B"], case["hist"]
+    out = R.item_qformer_forward(PQ, cfg, torch.from_numpy(hfe).view(B * hist, c["F"], c["E"]), torch.from_numpy(ham).view(B * hist, c["F"]))
+    toks = out["query_outputs"].view(B, hist, c["Q"], c["H"])
+    user = Q.joint_forward(PW, qc, torch.from_numpy(ids), torch.from_numpy(am), toks, case["first_special_id"], fully_masked="zero")
+    _close(user.detach().numpy(), g["user_embeddings"], rtol=2e-3, atol=1e-4, what="user")
+    loss = Q.infonce_loss(user, torch.from_numpy(pos), torch.from_numpy(neg), torch.from_numpy(nmask))
+    _close(loss.detach(), g["loss"], rtol=1e-3, what="loss")
+    _, rank = Q.mrr_ranks(user.detach(), torch.from_numpy(pos), torch.from_numpy(neg))
+    assert rank.tolist() == g["ranks"].tolist()
+    loss.backward()
+    _check_grads(PQ, g, cases.item_grad_keys(c, heads=False))
+    _check_grads(PW, g, cases.qwen_grad_keys(), prefix="grad/qwen/")
+
+
 def test_user_sequence_encoder_real_path_oracle(golden_dir):
     """models/user_sequence_encoder.py:72-142 with a real item Q-Former behind it: field vectors -> np.any mask -> item
     Q-Former (eval) -> + time/geo context -> flatten -> + sinusoidal PE."""
