@@ -169,12 +169,21 @@ def test_joint_with_lora_dropout_matches_oracle(name):
     exactly those bit planes from the layer's seed and feeds the unpacked masks to the oracle, so the arithmetic -- forward, dA with the masked input,
     dB, and the masked gradient into the adapter input -- is checked element for element; the mask statistics
     are checked separately."""
+    _check_lora_dropout(cases.ALL[name], name, 0.25)
+
+
+def test_joint_with_lora_dropout_mid_size_matches_oracle():
+    """The same check where the step's own kernels run: the 0.6B layer shape (D 1024, 16 / 8 heads of 128, I 3072), M = 32 x 512 =
+    16384 tokens -- the 256x256 projection GEMM with its masked rank-16 epilogue (64 x 4 tiles), the merged q|k|v / gate|up launches,
+    the fused RMSNorm / SwiGLU + adapter passes (D = 1024, r = 16) -- at the reference's lora_dropout = 0.1."""
+    _check_lora_dropout(dict(cases.MID["joint_mid"], B=32), "joint_mid B=32", 0.1)
+
+
+def _check_lora_dropout(case, name, pdrop):
     from unirec_amd import hip
     from unirec_amd.joint import InfoNCELoss
-    case = cases.ALL[name]
     c = case["cfg"]
     qc = cases.qwen_cfg(case)
-    pdrop = 0.25
     m, qf = _build_joint(case, use_lora=True, lora_seed=case["seed"] + 2)
     bm = m.base_model
     bm.config.lora_dropout = pdrop
