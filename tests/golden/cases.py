@@ -194,6 +194,9 @@ MID = {
     "qwen_mid": dict(kind="qwen_mid", seed=51, B=4, S=512, pad_side="left", qwen=_MIDQ),
     # the reference's DEFAULT UserQFormer (L4 Q64 H1024 I4096, 32 predicted tokens) over T=1600 keys (C3's shape), B=2
     "user_mid": dict(kind="user_mid", seed=52, B=2, T=1600, cfg=dict(H=1024, L=4, nh=16, I=4096, Q=64, E=1024, n_pred=32)),
+    # the full depth of Qwen3-Embedding-0.6B (28 layers of D 1024, 16 / 8 heads of 128, I 3072) on a short prompt: what 28 pre-norm
+    # layers of bf16 arithmetic accumulate against the installed fp32 Qwen3Model
+    "qwen_deep": dict(kind="qwen_mid", seed=55, B=2, S=128, pad_side="left", qwen=dict(D=1024, L=28, nq=16, nkv=8, hd=128, I=3072, vocab=64)),
     # BASELINE configs[1]'s architecture exactly (C2: L12 Q32 H768 nh12 I3072 F14 E1024) at C1's batch: the 12-layer post-LN
     # chain, head_dim 64 x 12 heads, cross-attention over 14 fields, the Q = 32 field-projection paths
     "item_mid": dict(kind="item_mid", seed=53, B=16, cfg=dict(H=768, L=12, nh=12, I=3072, Q=32, F=14, E=1024)),

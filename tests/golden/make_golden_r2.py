@@ -4,6 +4,7 @@ make_golden.py, which this script imports):
 
   qwen_mid.npz        installed transformers Qwen3Model, 4 layers D=1024 hd=128 S=512 B=4, left padding, sdpa:
                       pooled output, strided last_hidden_state and gradient w.r.t. inputs_embeds
+  qwen_deep.npz       the same at the full depth of the 0.6B model: 28 layers, S=128, B=2
   user_mid.npz        the reference's default UserQFormer over T=1600 keys, B=2: prediction, MSE loss, gradients
   item_mid.npz        the reference's QFormerForItemRepresentation at C2's architecture (L12 Q32 H768 F14 E1024), B=16:
                       outputs (strided), QFormerLoss, eval metrics, gradients
@@ -14,7 +15,7 @@ make_golden.py, which this script imports):
   state_dict_shapes.json   key -> shape of the reference modules' state_dict (item default / Q=8 duplicate / C1 / C2,
                       UserQFormer default): the checkpoint-compatibility contract of SURVEY 8(b)
 
-Usage:  python tests/golden/make_golden_r2.py [qwen_mid user_mid item_mid joint_mid use_real shapes]
+Usage:  python tests/golden/make_golden_r2.py [qwen_mid qwen_deep user_mid item_mid joint_mid use_real shapes]
 """
 import json
 import os
@@ -121,10 +122,10 @@ def gen_shapes():
 def main():
     only = set(sys.argv[1:])
     want = lambda n: not only or n in only
-    for name in ("qwen_mid", "user_mid", "item_mid", "joint_mid"):
+    for name in ("qwen_mid", "qwen_deep", "user_mid", "item_mid", "joint_mid"):
         if want(name):
             case = cases.MID[name]
-            res = {"qwen_mid": gen_qwen_mid, "user_mid": gen_user_mid, "item_mid": gen_item_mid, "joint_mid": gen_joint_mid}[name](case)
+            res = {"qwen_mid": gen_qwen_mid, "qwen_deep": gen_qwen_mid, "user_mid": gen_user_mid, "item_mid": gen_item_mid, "joint_mid": gen_joint_mid}[name](case)
             path = os.path.join(HERE, name + ".npz")
             np.savez_compressed(path, **{k: np.asarray(v) for k, v in res.items()})
             print(f"{name}: {len(res)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")

@@ -51,10 +51,12 @@ def test_decoder_input_gradient_matches_transformers(name):
     assert_close(tok.grad.float(), g["sdpa/grad_inputs_embeds"], GRAD_REL, "grad_inputs_embeds")
 
 
-def test_qwen3_mid_size_matches_transformers():
-    """4 layers of the 0.6B shape at B*S = 2048 tokens: 256x256 GEMM tiles, 8 causal key tiles per head, GQA 16/8."""
-    case = cases.MID["qwen_mid"]
-    g = load_golden("qwen_mid")
+@pytest.mark.parametrize("name", ["qwen_mid", "qwen_deep"])
+def test_qwen3_mid_size_matches_transformers(name):
+    """qwen_mid: 4 layers of the 0.6B shape at B*S = 2048 tokens: 256x256 GEMM tiles, 8 causal key tiles per head, GQA 16/8.
+    qwen_deep: the model's full depth (28 layers) on 2 x 128 tokens: the accumulated bf16 error of the whole pre-norm stack."""
+    case = cases.MID[name]
+    g = load_golden(name)
     pooled, tok, x = _decoder_with_inputs_as_injected_tokens(case)
     assert_close(pooled, g["sdpa/pooled"], OUT_REL, "pooled")
     pooled.pow(2).sum().backward()

@@ -20,9 +20,10 @@ torch.set_num_threads(min(8, os.cpu_count() or 1))
 USE_CFG = dict(H=dc.CTX_H, L=2, nh=2, I=256, Q=dc.QI, E=dc.E, seed=61)      # = tests/golden/make_golden_r2.py:USE_CFG
 
 
-def test_qwen3_mid_size(golden_dir):
-    case = cases.MID["qwen_mid"]
-    g = _load(golden_dir, "qwen_mid")
+@pytest.mark.parametrize("name", ["qwen_mid", "qwen_deep"])
+def test_qwen3_mid_size(golden_dir, name):
+    case = cases.MID[name]
+    g = _load(golden_dir, name)
     qc = cases.qwen_cfg(case)
     P = _params(Q.qwen3_shapes(qc, lora=False), case["seed"] + 1, requires_grad=False)
     x, am = cases.qwen_inputs(case)
