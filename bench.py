@@ -280,7 +280,7 @@ def run_stage(args):
         (xa, ma), (xp, mp), (xn, mn) = fields(), fields(), fields()
         xpn, mpn = torch.cat([xp, xn]), torch.cat([mp, mn])
         loss_fn = QFormerLoss(data_parallel=True)       # the masked MSE divides by the all-reduced sum of the mask
-        dp.set_rank_seeds(rank, m)
+        dp.set_dp_rank(rank, m)                # dropout masks keyed on the global sample index: same seeds, counters offset by rank * B
         pack = m._ensure_pack(device)
         opt = FusedAdamW([pack], lr=1e-4)
         bk = dp.GradBuckets(pack.grad, [0, pack.numel])
@@ -304,7 +304,7 @@ def run_stage(args):
         mask = (torch.arange(T)[None, :] < lens[:, None]).float().to(device)
         x = x * mask[..., None].to(torch.bfloat16)
         tgt = (torch.randn(B, 32, 1024, generator=g) * 0.8).to(device)
-        dp.set_rank_seeds(rank, m)
+        dp.set_dp_rank(rank, m)                # dropout masks keyed on the global sample index: same seeds, counters offset by rank * B
         pack = m._ensure_pack(device)
         opt = FusedAdamW([pack], lr=1e-4)
         bk = dp.GradBuckets(pack.grad, [0, pack.numel])
@@ -416,7 +416,7 @@ def main():
                        1234 + rank, device, n_user=n_user)
     loss_fn = InfoNCELoss(0.07)
     qw = model.base_model
-    dp.set_rank_seeds(rank, model)                 # per-rank dropout / LoRA-dropout mask streams (rank 0 keeps the base seeds)
+    dp.set_dp_rank(rank, model, qf)                # dropout / LoRA-dropout masks keyed on the global sample index (same seeds on every rank)
     qpack, lpack = qf._ensure_pack(device), qw._ensure_pack(device)
     packs = [qpack, lpack]
     ubk = None

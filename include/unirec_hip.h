@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 3
+#define UR_ABI_VERSION 4
 
 int ur_version(void);
 const char* ur_last_error(void);
@@ -97,7 +97,7 @@ int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, voi
  *       Token reduction split deterministically over blocks; partial slabs live in the caller's workspace.
  *   ur_lora_dropout_bits: dropped flags of nad adapters over an [M, W] input: plane a at bits + a*bits_stride, row m at
  *       + m*bits_ld (bits_ld = ur_lora_bits_ld(W) = 16 * ceil(W/128) bytes); the byte at column c/8 (c % 8 == 0) holds
- *       bit i (i<4) = element c+2i dropped, bit 4+i = element c+2i+1 dropped.  A pure function of (seed, p, m, c, a).
+ *       bit i (i<4) = element c+2i dropped, bit 4+i = element c+2i+1 dropped.  A pure function of (seed, p, row0 + m, c, a).
  * drop_bits == NULL: no dropout.  The 1/(1-p) scale is the caller's (alpha).
  * Constraints: rank == 16; column ranges and ldx multiples of 8; X, U, V, G 16-byte aligned; P 8-byte aligned. */
 typedef struct {
@@ -112,8 +112,9 @@ typedef struct {
   void* G; int32_t g_transposed;          /* reduce: f32, dense */
 } ur_lora_args;
 int64_t ur_lora_bits_ld(int32_t W);
+/* row0: rows that precede row 0 of this call in the GLOBAL minibatch (row m draws the flags of global row row0 + m) */
 int ur_lora_dropout_bits(uint64_t seed, float p, int32_t M, int32_t W, int32_t nad, uint8_t* bits, int64_t bits_ld,
-                         int64_t bits_stride, void* stream);
+                         int64_t bits_stride, int64_t row0, void* stream);
 int ur_lora_project(const ur_lora_args* a, void* stream);
 /* RMSNorm forward (ur_rmsnorm_fwd: out = w * (x * rstd), Qwen3RMSNorm modeling_qwen3.py:59-64) fused with the down
    projection of the 2 or 3 adapters that read the normalised activation (q|k|v or gate|up): `a` as for ur_lora_project with
@@ -140,10 +141,12 @@ int ur_lora_bgrad(const ur_lora_args* a, void* workspace, int64_t workspace_byte
  *   y [M,H] bf16 (row m reads y[(m % y_rows)], so a [Q,H] query table broadcasts over the batch);
  *   residual [M,H] bf16 or NULL; z_save [M,H] bf16 or NULL (kept for backward);
  *   mean, rstd [M] f32.  H % 8 == 0, H <= 8192.  Dropout masks are a pure function of
- *   (seed, element index) and are regenerated by the backward. */
+ *   (seed, element index) and are regenerated by the backward.  drop_row0: index of row 0 of this launch in the GLOBAL
+ *   minibatch (element index = (drop_row0 + row) * H + h): a data-parallel rank passes the rows that precede its shard, so
+ *   the masks -- and the training run -- do not depend on the number of ranks; 0 for a single process. */
 int ur_layernorm_fwd(const void* y, int32_t y_rows, const void* residual, const float* gamma, const float* beta,
                      void* out, void* z_save, float* mean, float* rstd, int32_t M, int32_t H, float eps,
-                     float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, void* stream);
+                     float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, int64_t drop_row0, void* stream);
 /* Backward.  dz [M,H] bf16 = gradient w.r.t. z (the residual branch); dy [M,H] bf16 = dz with the
  * pre-dropout mask applied (may alias dz when p_pre == 0; may be NULL when not needed).
  * dgamma, dbeta [H] f32 are OVERWRITTEN; dbias [H] f32 (column sum of dy, i.e. the gradient of the
@@ -151,7 +154,7 @@ int ur_layernorm_fwd(const void* y, int32_t y_rows, const void* residual, const 
 int64_t ur_layernorm_bwd_workspace_bytes(int32_t H);
 int ur_layernorm_bwd(const void* dout, const void* z, const float* mean, const float* rstd, const float* gamma,
                      void* dz, void* dy, float* dgamma, float* dbeta, float* dbias, int32_t M, int32_t H,
-                     float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
+                     float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, int64_t drop_row0,
                      void* workspace, int64_t workspace_bytes, void* stream);
 
 /* out[r][h] (f32, overwritten) = sum_{b<nb} in[(b*rows + r)][h]   (bf16 in).  Used for the
@@ -189,6 +192,8 @@ typedef struct {
   int32_t causal;
   float scale;
   float dropout_p; uint64_t seed;
+  int64_t drop_batch0;   /* batch rows that precede b = 0 of this call in the GLOBAL minibatch: the dropout counter of an element is
+                            (((drop_batch0 + b) * nq + h) * Sq + q) * Sk + key, so a data-parallel rank draws the masks of ITS samples */
 } ur_attn_args;
 /* Backward: dout [B,Sq,nq,hd] -> dq [B,Sq,nq,hd], dk/dv [B,Sk,nkv,hd] (bf16, strides in elements).
  * delta: caller-provided f32 scratch [2,B,nq,Sq] (row constants of the backward: -rowsum(dO*O) and
@@ -244,7 +249,8 @@ int ur_inject_bwd(const void* dx, const int64_t* input_ids, int64_t first_specia
  * item_tokens [B,L,Qi,H], context [B,L,H] bf16; lengths int32 [B] (events per user);
  * out [B,L*Qi,H] bf16 (zeros past the user's length), mask [B,L*Qi] f32 (1 = real token). */
 int ur_user_sequence_assemble(const void* item_tokens, const void* context, const int32_t* lengths, void* out, float* mask,
-                              int32_t B, int32_t L, int32_t Qi, int32_t H, float dropout_p, uint64_t seed, void* stream);
+                              int32_t B, int32_t L, int32_t Qi, int32_t H, float dropout_p, uint64_t seed, int64_t drop_batch0,
+                              void* stream);      /* drop_batch0: users that precede b = 0 in the global minibatch (dropout counter) */
 
 /* Mean over the middle axis, x [B,S,D] bf16 -> [B,D] (f32 and/or bf16 output) --
  * train_item_individual_token_joint.py:179-181 (mean over ALL S positions, padding included),

@@ -37,7 +37,7 @@ def run(outdir, Bg, dropout):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     m = build(dropout).to(dev).train()
-    dp.set_rank_seeds(rank, m)
+    dp.set_dp_rank(rank, m)          # same seeds on every rank; dropout counters offset by rank * local batch (global sample index)
     (xa, ma), (xp, mp_), (xn, mn) = make_global(Bg, 8, 256)
     lo, hi = dp.shard_range(Bg, rank, world)
     xa, ma, xp, mp_, xn, mn = [t[lo:hi].to(dev) for t in (xa, ma, xp, mp_, xn, mn)]

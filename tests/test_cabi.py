@@ -43,7 +43,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     a.r_kcontig = a.s_kcontig = 1
     rc = lib.ur_gemm(ctypes.byref(a), None, 0, None)
     assert rc < 0 and b"multiples of 8" in lib.ur_last_error()
-    assert lib.ur_layernorm_fwd(None, 1, None, None, None, None, None, None, None, 4, 12, 1e-5, 0.0, 0, 0.0, 0, None) < 0
+    assert lib.ur_layernorm_fwd(None, 1, None, None, None, None, None, None, None, 4, 12, 1e-5, 0.0, 0, 0.0, 0, 0, None) < 0
 
 
 def test_product_path_has_no_oracle_import():

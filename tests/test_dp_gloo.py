@@ -130,6 +130,25 @@ def test_rank_seeds_are_distinct_and_rank0_keeps_the_base():
     assert (a.seed, a.lora_seed) == (0x5EED, 0x5EED) and b.seed != 0x5EED and b.lora_seed != 0x5EED
 
 
+def test_set_dp_rank_reaches_every_dropout_owner():
+    """dp.set_dp_rank: same seeds on every rank, `.dp_rank` on every module (or plain object) that owns dropout counters."""
+    class Leaf(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.dp_rank, self.sample_offset, self.seed = 0, None, 0x5EED
+
+    class Top(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = Leaf(), torch.nn.Sequential(Leaf())
+
+    class Plain:
+        dp_rank = 0
+    t, p = Top(), Plain()
+    dp.set_dp_rank(3, t, p, None)
+    assert t.a.dp_rank == 3 and t.b[0].dp_rank == 3 and p.dp_rank == 3 and t.a.seed == 0x5EED and t.a.sample_offset is None
+
+
 def test_bench_gpus_flag_must_match_the_world(monkeypatch):
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))

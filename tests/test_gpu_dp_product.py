@@ -2,7 +2,7 @@
 over gloo (RCCL needs one device per rank; everything above the backend is the shipped path: HIP kernels, bucket hooks
 fired from the backward, sum all-reduce of the flat gradient pack, all-reduced sum(mask) in the item loss, fused AdamW
 with the folded 1/world).  Asserts (i) both ranks end the step with bit-identical parameters, (ii) the reduced gradient
-equals the single-process gradient over the global batch, (iii) per-rank dropout seeds differ."""
+equals the single-process gradient over the global batch -- also with dropout ON: masks are keyed on the global sample index."""
 import os
 import socket
 import subprocess
@@ -56,7 +56,18 @@ def test_two_ranks_match_each_other_and_the_single_process_step(tmp_path):
     assert float(g1.norm()) > 0
 
 
-def test_per_rank_dropout_seeds_differ_and_ranks_stay_in_sync(tmp_path):
-    r0, r1 = _launch(tmp_path, 2, 16, 0.2)
-    assert r0["seed"] != r1["seed"]
-    assert torch.equal(r0["master"], r1["master"])
+def test_dropout_masks_are_keyed_on_the_global_sample_index(tmp_path):
+    """the result must not depend on the number of ranks.  With dropout ON (hidden 0.2, attention 0.2) the reduced
+    gradient of the 2-rank step equals the single-process gradient over the global batch to the same tolerance as without
+    dropout: every rank keeps the SAME seeds and offsets its dropout counters by rank * local batch, so sample i draws the
+    masks of global sample i wherever it runs.  (With per-rank seeds the two gradients differ by the dropout noise itself.)"""
+    Bg = 16
+    d2 = tmp_path / "w2"; d2.mkdir()
+    r0, r1 = _launch(d2, 2, Bg, 0.2)
+    assert r0["seed"] == r1["seed"]
+    assert torch.equal(r0["master"], r1["master"]) and torch.equal(r0["grad"], r1["grad"])
+    d1 = tmp_path / "w1"; d1.mkdir()
+    (s0,) = _launch(d1, 1, Bg, 0.2)
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - s0["loss"]) <= 2e-3 * abs(s0["loss"])
+    rel = float((r0["grad"] - s0["grad"]).norm() / s0["grad"].norm())
+    assert rel <= 2e-2, rel

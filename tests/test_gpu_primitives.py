@@ -627,3 +627,49 @@ def test_field_projection_fwd_bwd_match_torch(B, Q, F, E):
     dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
     drec2 = hip.field_projection_bwd(dout, rec, W, dW2, db2)
     assert torch.equal(dW, dW2) and torch.equal(db, db2) and torch.equal(drec, drec2)        # bitwise reproducible
+
+
+def test_dropout_counters_follow_the_global_sample_index():
+    """every dropout site keys its mask on (seed, GLOBAL element index).  A shard that starts at global sample b1
+    and passes that offset draws bit for bit the masks (and results) of the same samples inside the whole batch."""
+    g = torch.Generator().manual_seed(9)
+    # LoRA bit planes: rows
+    full = hip.lora_dropout_bits(4242, 0.1, 12, 1024, 3, DEV)
+    part = hip.lora_dropout_bits(4242, 0.1, 8, 1024, 3, DEV, row0=4)
+    assert torch.equal(part, full[:, 4:12]) and not torch.equal(hip.lora_dropout_bits(4242, 0.1, 8, 1024, 3, DEV), full[:, 4:12])
+    # LayerNorm with hidden dropout before and after: rows
+    M, H, r1 = 96, 256, 40
+    y = torch.randn(M, H, generator=g).to(DEV).to(torch.bfloat16)
+    res = torch.randn(M, H, generator=g).to(DEV).to(torch.bfloat16)
+    gam, bet = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
+    o_full, z_full, _, _ = hip.layernorm_fwd(y, gam, bet, 1e-12, residual=res, p_pre=0.2, seed_pre=7, p_post=0.2, seed_post=8)
+    o_part, z_part, mu, rs = hip.layernorm_fwd(y[r1:].contiguous(), gam, bet, 1e-12, residual=res[r1:].contiguous(), p_pre=0.2, seed_pre=7,
+                                              p_post=0.2, seed_post=8, drop_row0=r1)
+    assert torch.equal(o_part, o_full[r1:]) and torch.equal(z_part, z_full[r1:])
+    dout = torch.randn(M, H, generator=g).to(DEV).to(torch.bfloat16)
+    _, zf, muf, rsf = hip.layernorm_fwd(y, gam, bet, 1e-12, residual=res, p_pre=0.2, seed_pre=7, p_post=0.2, seed_post=8)
+    dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    dz_full, dy_full = hip.layernorm_bwd(dout, zf, muf, rsf, gam, dg, db, p_pre=0.2, seed_pre=7, p_post=0.2, seed_post=8)
+    dz_part, dy_part = hip.layernorm_bwd(dout[r1:].contiguous(), z_part, mu, rs, gam, dg, db, p_pre=0.2, seed_pre=7, p_post=0.2, seed_post=8,
+                                         drop_row0=r1)
+    assert torch.equal(dz_part, dz_full[r1:]) and torch.equal(dy_part, dy_full[r1:])
+    # attention-probability dropout (non-causal Q-Former attention): batch rows
+    B, Sq, Sk, nh, hd, b1 = 6, 32, 50, 4, 64, 2
+    q = torch.randn(B, Sq, nh, hd, generator=g).to(DEV).to(torch.bfloat16)
+    k = torch.randn(B, Sk, nh, hd, generator=g).to(DEV).to(torch.bfloat16)
+    v = torch.randn(B, Sk, nh, hd, generator=g).to(DEV).to(torch.bfloat16)
+    of, cf = hip.attn_fwd(q, k, v, causal=False, dropout_p=0.3, seed=99)
+    op, cp = hip.attn_fwd(q[b1:].contiguous(), k[b1:].contiguous(), v[b1:].contiguous(), causal=False, dropout_p=0.3, seed=99, drop_batch0=b1)
+    assert torch.equal(op, of[b1:])
+    do = torch.randn(B, Sq, nh, hd, generator=g).to(DEV).to(torch.bfloat16)
+    dqf, dkf, dvf = hip.attn_bwd(cf, do)
+    dqp, dkp, dvp = hip.attn_bwd(cp, do[b1:].contiguous())
+    assert torch.equal(dqp, dqf[b1:]) and torch.equal(dkp, dkf[b1:]) and torch.equal(dvp, dvf[b1:])
+    # user-sequence assembly (positional-encoding dropout): users
+    Bu, L, Qi, Hh = 5, 6, 2, 128
+    tok = torch.randn(Bu, L, Qi, Hh, generator=g).to(DEV).to(torch.bfloat16)
+    ctx = torch.randn(Bu, L, Hh, generator=g).to(DEV).to(torch.bfloat16)
+    lens = torch.tensor([6, 3, 5, 1, 6], dtype=torch.int32, device=DEV)
+    uf, _ = hip.user_sequence_assemble(tok, ctx, lens, 0.1, 31)
+    up, _ = hip.user_sequence_assemble(tok[2:].contiguous(), ctx[2:].contiguous(), lens[2:].contiguous(), 0.1, 31, drop_batch0=2)
+    assert torch.equal(up, uf[2:])

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UNIREC_HIP_LIB selects another build of the SAME library (kernel A/B experiments); there is still no fallback.
 LIB_PATH = os.environ.get("UNIREC_HIP_LIB") or os.path.join(_HERE, "lib", "libunirec_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_void_p, c_int, c_i64, c_u64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
@@ -53,7 +53,7 @@ class AttnArgs(ctypes.Structure):
                 ("ldq", c_i64), ("ldk", c_i64), ("ldv", c_i64), ("ldo", c_i64),
                 ("key_mask", c_void_p),
                 ("B", c_int), ("Sq", c_int), ("Sk", c_int), ("nq", c_int), ("nkv", c_int), ("head_dim", c_int),
-                ("causal", c_int), ("scale", c_float), ("dropout_p", c_float), ("seed", c_u64)]
+                ("causal", c_int), ("scale", c_float), ("dropout_p", c_float), ("seed", c_u64), ("drop_batch0", c_i64)]
 
 
 class AttnBwdArgs(ctypes.Structure):
@@ -72,7 +72,7 @@ SIGNATURES = {
     "ur_gemm_workspace_bytes": (c_i64, [ctypes.POINTER(GemmArgs)]),
     "ur_gemm": (c_int, [ctypes.POINTER(GemmArgs), c_void_p, c_i64, c_void_p]),
     "ur_lora_bits_ld": (c_i64, [c_int]),
-    "ur_lora_dropout_bits": (c_int, [c_u64, c_float, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_void_p]),
+    "ur_lora_dropout_bits": (c_int, [c_u64, c_float, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_i64, c_void_p]),
     "ur_lora_project": (c_int, [ctypes.POINTER(LoraArgs), c_void_p]),
     "ur_swiglu_lora_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(LoraArgs), c_void_p]),
     "ur_rmsnorm_lora_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.POINTER(LoraArgs), c_void_p]),
@@ -81,10 +81,10 @@ SIGNATURES = {
     "ur_lora_bgrad_workspace_bytes": (c_i64, [ctypes.POINTER(LoraArgs)]),
     "ur_lora_bgrad": (c_int, [ctypes.POINTER(LoraArgs), c_void_p, c_i64, c_void_p]),
     "ur_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_int, c_int, c_float, c_float, c_u64, c_float, c_u64, c_void_p]),
+                                 c_int, c_int, c_float, c_float, c_u64, c_float, c_u64, c_i64, c_void_p]),
     "ur_layernorm_bwd_workspace_bytes": (c_i64, [c_int]),
     "ur_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_int, c_int, c_float, c_u64, c_float, c_u64, c_void_p, c_i64, c_void_p]),
+                                 c_void_p, c_int, c_int, c_float, c_u64, c_float, c_u64, c_i64, c_void_p, c_i64, c_void_p]),
     "ur_batch_reduce": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "ur_batch_reduce_workspace_bytes": (c_i64, [c_int, c_int, c_int]),
     "ur_rmsnorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
@@ -99,7 +99,7 @@ SIGNATURES = {
     "ur_embed_inject_fwd": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ur_inject_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ur_user_sequence_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u64,
-                                          c_void_p]),
+                                          c_i64, c_void_p]),
     "ur_mean_pool_workspace_bytes": (c_i64, [c_int, c_int]),
     "ur_mean_pool_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),
     "ur_mean_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

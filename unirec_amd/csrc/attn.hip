@@ -59,6 +59,7 @@ struct AttnP {
   const uint8_t* kmask;
   int B, Sq, Sk, nq, nkv, rep;
   float scale; uint32_t drop_thr; float drop_inv; uint64_t seed;
+  uint64_t didx0;       // dropout counter of (batch row 0, head 0, query 0, key 0) in the GLOBAL minibatch: drop_batch0 * nq * Sq * Sk
   // backward
   const bf16_t* dout; bf16_t* dq; bf16_t* dk; bf16_t* dv; const float* delta;
   long lddo, lddq, lddk, lddv;
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * HD;
   const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * HD;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
-  const uint64_t drow = ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
+  const uint64_t drow = p.didx0 + ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
   const bool dropping = (!CAUSAL) && p.drop_thr != 0;
 
   unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + 4 * C::TILE);
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
   const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * HD;
   const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * HD;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
-  const uint64_t drow = ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
+  const uint64_t drow = p.didx0 + ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
   const bool dropping = (!CAUSAL) && p.drop_thr != 0;
 
   unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + 4 * C::TILE);
@@ -951,7 +952,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
               const float ps = (sc == NEG_INF || qpos >= p.Sq) ? 0.f : fast_exp2((sc - ma[e]) * LOG2E) * iv[e];
               float g = dp[r], pd = ps;
               if (dropping) {
-                const float dsc = ur_dropout_scale(p.seed, (((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)qpos) * (uint64_t)p.Sk) + (uint64_t)keyo,
+                const float dsc = ur_dropout_scale(p.seed, p.didx0 + (((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)qpos) * (uint64_t)p.Sk) + (uint64_t)keyo,
                                                    p.drop_thr, p.drop_inv);
                 g *= dsc; pd *= dsc;
               }
@@ -1025,7 +1026,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
   const int blk_hi = min(nblk, (chunk + 1) * bpc);
   const float c2 = p.scale * LOG2E;
   const bool dropping = p.drop_thr != 0;
-  const uint64_t drop_row0 = (uint64_t)sbase * (uint64_t)p.Sk;       // dropout counter of (b, hq, query 0, key 0)
+  const uint64_t drop_row0 = p.didx0 + (uint64_t)sbase * (uint64_t)p.Sk;       // dropout counter of (b, hq, query 0, key 0)
   const uint8_t* kmrow = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
   const bf16_t* kbase = p.k + (long)b * p.Sk * p.ldk + (long)hq * HD;
   const bf16_t* vbase = p.v + (long)b * p.Sk * p.ldv + (long)hq * HD;
@@ -1795,7 +1796,7 @@ __device__ __forceinline__ void tiny_probs(const AttnP& p, const TinyPair& t, co
     }
     mrow[qi] = mx; inv[qi] = 1.0f / l;             // l >= 1: the maximum itself contributes exp(0)
     if (p.drop_thr != 0) {
-      const uint64_t idx = (((uint64_t)((long)t.b * p.nq + t.hq) * p.Sq + (uint64_t)qi) * (uint64_t)p.Sk) + (uint64_t)t.sl;
+      const uint64_t idx = p.didx0 + (((uint64_t)((long)t.b * p.nq + t.hq) * p.Sq + (uint64_t)qi) * (uint64_t)p.Sk) + (uint64_t)t.sl;
       const bool kp = ur_dropout_scale(p.seed, idx, p.drop_thr, 1.0f) != 0.f;
       keep[qi] = (uint32_t)(__ballot(kp) >> (16 * t.g)) & 0xffffu;
     }
@@ -1956,6 +1957,7 @@ int fill(AttnP& p, const ur_attn_args* a) {
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.kmask = a->key_mask;
   p.B = a->B; p.Sq = a->Sq; p.Sk = a->Sk; p.nq = a->nq; p.nkv = a->nkv; p.rep = a->nq / a->nkv;
   p.scale = a->scale; p.seed = a->seed;
+  p.didx0 = (uint64_t)a->drop_batch0 * (uint64_t)a->nq * (uint64_t)a->Sq * (uint64_t)a->Sk;
   p.drop_thr = a->dropout_p > 0.f ? ur_drop_threshold(a->dropout_p) : 0u;
   p.drop_inv = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
   return 0;

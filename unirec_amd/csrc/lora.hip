@@ -75,7 +75,7 @@ __device__ __forceinline__ int sw16(int r) { return (r & 7) ^ ((r & 8) >> 1); }
 #define UR_BITS_XORSHIFT 2
 #endif
 __global__ void lora_bits_kernel(uint64_t seed, uint32_t thr15, int M, int W, int nad, long bits_ld, long bits_stride,
-                                 uint8_t* __restrict__ bits) {
+                                 uint8_t* __restrict__ bits, long row0) {
   // blockIdx.y counts chunks of 2^20 rows so that the (row, group) split is ONE 32-bit division (a 64-bit one costs ~150 vector
   // instructions per thread, a sixth of the kernel)
   const uint32_t ng = (uint32_t)(bits_ld >> 2);
@@ -92,7 +92,7 @@ __global__ void lora_bits_kernel(uint64_t seed, uint32_t thr15, int M, int W, in
   for (int a = 0; a < nad; ++a) {
     uint32_t out = 0;
     if (q * 32 < W) {
-      const uint64_t ctr = (((uint64_t)m * (uint64_t)ng + (uint64_t)(uint32_t)q) << 2) + (uint64_t)a;
+      const uint64_t ctr = (((uint64_t)(row0 + m) * (uint64_t)ng + (uint64_t)(uint32_t)q) << 2) + (uint64_t)a;     // row0: rows that precede row 0 in the global minibatch
       const uint32_t h = fmix32((((uint32_t)ctr ^ s_lo) + fmix32((uint32_t)(ctr >> 32) + s_hi + 0x9E3779B9u)) ^ k2) + k2;
       uint32_t w = h ? h : 0x9E3779B9u;            // xorshift32 state: never zero
 #if UR_BITS_XORSHIFT == 2
@@ -772,7 +772,7 @@ int validate_common(const ur_lora_args* a, const char* who) {
 extern "C" int64_t ur_lora_bits_ld(int32_t W) { return ((int64_t)W + 127) / 128 * 16; }
 
 extern "C" int ur_lora_dropout_bits(uint64_t seed, float p, int32_t M, int32_t W, int32_t nad, uint8_t* bits, int64_t bits_ld,
-                                    int64_t bits_stride, void* stream) {
+                                    int64_t bits_stride, int64_t row0, void* stream) {
   UR_REQUIRE(p >= 0.f && p < 1.f && M >= 0 && W > 0 && nad >= 1 && nad <= 4, "ur_lora_dropout_bits: bad argument");
   UR_REQUIRE(bits_ld == ur_lora_bits_ld(W) && bits_stride >= (int64_t)M * bits_ld && (bits_stride % 16) == 0 && (M == 0 || (bits && UR_ALIGNED16(bits))),
              "ur_lora_dropout_bits: bits_ld must be ur_lora_bits_ld(W), planes 16-byte aligned and at least M rows apart");
@@ -783,7 +783,7 @@ extern "C" int ur_lora_dropout_bits(uint64_t seed, float p, int32_t M, int32_t W
   const long rows_y = 1L << 20;
   const long n = (long)(M < rows_y ? M : rows_y) * (bits_ld / 4);         // threads per grid.y slice (< 2^31)
   hipLaunchKernelGGL(lora_bits_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)((M + rows_y - 1) / rows_y)), dim3(256), 0, (hipStream_t)stream, seed, thr15, (int)M, (int)W,
-                     (int)nad, (long)bits_ld, (long)bits_stride, bits);
+                     (int)nad, (long)bits_ld, (long)bits_stride, bits, (long)row0);
   UR_CHECK_LAUNCH("ur_lora_dropout_bits");
   return 0;
 }

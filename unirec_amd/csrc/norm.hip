@@ -9,10 +9,13 @@ constexpr int ROWS_PER_BLOCK = 4;   // 256 threads = 4 waves = 4 rows in flight 
 
 struct Drop {
   uint32_t thr; float inv_keep; uint64_t seed;
+  uint64_t idx0;      // element index of this launch's first row in the GLOBAL batch (drop_row0 * H): a data-parallel rank draws the
+                      // masks its samples would get in a single-process run over the whole minibatch
   __device__ __forceinline__ bool on() const { return thr != 0; }
 };
-static Drop make_drop(float p, uint64_t seed) {
+static Drop make_drop(float p, uint64_t seed, int64_t row0, int H) {
   Drop d; d.thr = (p > 0.f) ? ur_drop_threshold(p) : 0u; d.inv_keep = (p > 0.f) ? 1.0f / (1.0f - p) : 1.0f; d.seed = seed;
+  d.idx0 = (uint64_t)row0 * (uint64_t)H;
   return d;
 }
 
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
         unpack8(*reinterpret_cast<const uint4*>(y + yoff + e0), v[i]);
         if (pre.on()) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[i][e] *= ur_dropout_scale(pre.seed, (uint64_t)(roff + e0 + e), pre.thr, pre.inv_keep);
+          for (int e = 0; e < 8; ++e) v[i][e] *= ur_dropout_scale(pre.seed, pre.idx0 + (uint64_t)(roff + e0 + e), pre.thr, pre.inv_keep);
         }
         if (res) {
           float r[8];
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           o[e] = (v[i][e] - mu) * rs * g[e] + b[e];
-          if (post.on()) o[e] *= ur_dropout_scale(post.seed, (uint64_t)(roff + e0 + e), post.thr, post.inv_keep);
+          if (post.on()) o[e] *= ur_dropout_scale(post.seed, post.idx0 + (uint64_t)(roff + e0 + e), post.thr, post.inv_keep);
         }
         *reinterpret_cast<uint4*>(out + roff + e0) = pack8(o);
       }
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         load8f(gamma + e0, g);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          if (post.on()) go[i][e] *= ur_dropout_scale(post.seed, (uint64_t)(roff + e0 + e), post.thr, post.inv_keep);
+          if (post.on()) go[i][e] *= ur_dropout_scale(post.seed, post.idx0 + (uint64_t)(roff + e0 + e), post.thr, post.inv_keep);
           xh[i][e] = (zz[e] - mu) * rs;
           pg[i][e] += go[i][e] * xh[i][e];
           pb[i][e] += go[i][e];
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         *reinterpret_cast<uint4*>(dz + roff + e0) = pk;
         if (pre.on()) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) dd[e] *= ur_dropout_scale(pre.seed, (uint64_t)(roff + e0 + e), pre.thr, pre.inv_keep);
+          for (int e = 0; e < 8; ++e) dd[e] *= ur_dropout_scale(pre.seed, pre.idx0 + (uint64_t)(roff + e0 + e), pre.thr, pre.inv_keep);
           if (dy) *reinterpret_cast<uint4*>(dy + roff + e0) = pack8(dd);
         } else if (dy && dy != dz) {
           *reinterpret_cast<uint4*>(dy + roff + e0) = pk;
@@ -354,14 +357,14 @@ constexpr int LN_BWD_BLOCKS = 512;   // partial rows of the column sums = blocks
 extern "C" int ur_layernorm_fwd(const void* y, int32_t y_rows, const void* residual, const float* gamma,
                                 const float* beta, void* out, void* z_save, float* mean, float* rstd, int32_t M,
                                 int32_t H, float eps, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
-                                void* stream) {
+                                int64_t drop_row0, void* stream) {
   UR_REQUIRE(M >= 0 && H > 0 && (H % 8) == 0 && H <= 2048, "ur_layernorm_fwd: need H %% 8 == 0 and H <= 2048 (H=%d)", H);
   if (M == 0) return 0;
   UR_REQUIRE(y && gamma && beta && out && mean && rstd && y_rows > 0, "ur_layernorm_fwd: null argument");
   UR_REQUIRE(UR_ALIGNED16(y) && UR_ALIGNED16(out) && UR_ALIGNED16(gamma) && UR_ALIGNED16(beta) &&
              (!residual || UR_ALIGNED16(residual)) && (!z_save || UR_ALIGNED16(z_save)), "ur_layernorm_fwd: 16-byte alignment");
   UR_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "ur_layernorm_fwd: dropout p out of range");
-  const Drop pre = make_drop(p_pre, seed_pre), post = make_drop(p_post, seed_post);
+  const Drop pre = make_drop(p_pre, seed_pre, drop_row0, H), post = make_drop(p_post, seed_post, drop_row0, H);
   const int grid = row_grid(M, 4096);
   UR_NCH_DISPATCH(H, hipLaunchKernelGGL((ln_fwd_kernel<NCH>), dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                         (const bf16_t*)y, y_rows, (const bf16_t*)residual, gamma, beta, (bf16_t*)out,
@@ -377,14 +380,14 @@ extern "C" int64_t ur_layernorm_bwd_workspace_bytes(int32_t H) {
 extern "C" int ur_layernorm_bwd(const void* dout, const void* z, const float* mean, const float* rstd,
                                 const float* gamma, void* dz, void* dy, float* dgamma, float* dbeta, float* dbias,
                                 int32_t M, int32_t H, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
-                                void* workspace, int64_t workspace_bytes, void* stream) {
+                                int64_t drop_row0, void* workspace, int64_t workspace_bytes, void* stream) {
   UR_REQUIRE(M >= 0 && H > 0 && (H % 8) == 0 && H <= 2048, "ur_layernorm_bwd: need H %% 8 == 0 and H <= 2048 (H=%d)", H);
   UR_REQUIRE(dout && z && mean && rstd && gamma && dz && dgamma && dbeta, "ur_layernorm_bwd: null argument");
   UR_REQUIRE(workspace && workspace_bytes >= ur_layernorm_bwd_workspace_bytes(H), "ur_layernorm_bwd: workspace too small");
   UR_REQUIRE(UR_ALIGNED16(dout) && UR_ALIGNED16(z) && UR_ALIGNED16(dz) && UR_ALIGNED16(gamma) && (!dy || UR_ALIGNED16(dy)),
              "ur_layernorm_bwd: 16-byte alignment");
   UR_REQUIRE(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "ur_layernorm_bwd: dropout p out of range");
-  const Drop pre = make_drop(p_pre, seed_pre), post = make_drop(p_post, seed_post);
+  const Drop pre = make_drop(p_pre, seed_pre, drop_row0, H), post = make_drop(p_post, seed_post, drop_row0, H);
   const int grid = row_grid(M, LN_BWD_BLOCKS);
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;

@@ -207,7 +207,7 @@ __global__ void pool_bwd_kernel(const float* __restrict__ d32, const bf16_t* __r
 // module in train mode) is the same counter-based hash as everywhere else.
 __global__ __launch_bounds__(256) void user_seq_kernel(const bf16_t* __restrict__ tok, const bf16_t* __restrict__ ctx,
                                                        const int* __restrict__ lens, bf16_t* __restrict__ out, float* __restrict__ mask,
-                                                       int B, int L, int Qi, int H, uint32_t thr, float inv_keep, uint64_t seed) {
+                                                       int B, int L, int Qi, int H, uint32_t thr, float inv_keep, uint64_t seed, uint64_t idx0) {
   const int H8 = H / 8;
   const long rows = (long)B * L * Qi;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void user_seq_kernel(const bf16_t* __restrict_
         }
         if (thr) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] *= ur_dropout_scale(seed, (uint64_t)(row * H + c * 8 + e), thr, inv_keep);
+          for (int e = 0; e < 8; ++e) o[e] *= ur_dropout_scale(seed, idx0 + (uint64_t)(row * H + c * 8 + e), thr, inv_keep);
         }
       }
       *reinterpret_cast<uint4*>(out + row * H + c * 8) = pk8(o);
@@ -356,7 +356,8 @@ extern "C" int ur_mean_pool_bwd(const float* dout_f32, const void* dout_bf16, vo
 }
 
 extern "C" int ur_user_sequence_assemble(const void* item_tokens, const void* context, const int32_t* lengths, void* out, float* mask,
-                                         int32_t B, int32_t L, int32_t Qi, int32_t H, float dropout_p, uint64_t seed, void* stream) {
+                                         int32_t B, int32_t L, int32_t Qi, int32_t H, float dropout_p, uint64_t seed, int64_t drop_batch0,
+                                         void* stream) {
   UR_REQUIRE(item_tokens && context && lengths && out && mask && B >= 0 && L > 0 && Qi > 0 && H > 0 && (H % 8) == 0,
              "ur_user_sequence_assemble: bad argument");
   UR_REQUIRE(UR_ALIGNED16(item_tokens) && UR_ALIGNED16(context) && UR_ALIGNED16(out), "ur_user_sequence_assemble: alignment");
@@ -365,7 +366,8 @@ extern "C" int ur_user_sequence_assemble(const void* item_tokens, const void* co
   const long rows = (long)B * L * Qi;
   hipLaunchKernelGGL(user_seq_kernel, dim3(grid_cap((rows + 3) / 4, 256 * 16)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)item_tokens,
                      (const bf16_t*)context, (const int*)lengths, (bf16_t*)out, mask, B, L, Qi, H,
-                     dropout_p > 0.f ? ur_drop_threshold(dropout_p) : 0u, dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f, seed);
+                     dropout_p > 0.f ? ur_drop_threshold(dropout_p) : 0u, dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f, seed,
+                     (uint64_t)drop_batch0 * (uint64_t)L * (uint64_t)Qi * (uint64_t)H);
   UR_CHECK_LAUNCH("ur_user_sequence_assemble");
   return 0;
 }

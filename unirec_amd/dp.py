@@ -72,6 +72,20 @@ def set_rank_seeds(rank, *modules):
                 sub.seed = rank_seed(sub.seed, rank)
 
 
+def set_dp_rank(rank, *modules):
+    """Key every dropout mask on the GLOBAL sample index: all ranks keep the SAME seeds, and a module's forward
+    over B local samples offsets its dropout counters by rank * B samples (`.dp_rank`; `.sample_offset` overrides it for unequal
+    shards).  The N-rank step then draws, sample for sample, the masks of a single-process step over the concatenation of the
+    ranks' local batches -- training does not depend on the number of ranks (tests/test_gpu_dp_product.py)."""
+    for m in modules:
+        if m is None:
+            continue
+        subs = list(m.modules()) if hasattr(m, "modules") else [m]
+        for sub in subs:
+            if hasattr(sub, "dp_rank"):
+                sub.dp_rank = int(rank)
+
+
 def world_size():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 

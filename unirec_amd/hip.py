@@ -130,12 +130,13 @@ def lora_bits_ld(W):
     return int(_lib.load().ur_lora_bits_ld(int(W)))
 
 
-def lora_dropout_bits(seed, p, M, W, nad, device, out=None):
-    """Dropped-flag bit planes uint8 [nad, M, ur_lora_bits_ld(W)] of nad adapters that share an [M, W] input."""
+def lora_dropout_bits(seed, p, M, W, nad, device, out=None, row0=0):
+    """Dropped-flag bit planes uint8 [nad, M, ur_lora_bits_ld(W)] of nad adapters that share an [M, W] input.  row0: rows that
+    precede row 0 in the global minibatch (a data-parallel rank draws the flags of ITS rows)."""
     lib = _lib.load()
     ld = int(lib.ur_lora_bits_ld(int(W)))
     bits = torch.empty((nad, M, ld), dtype=torch.uint8, device=device) if out is None else out
-    check(lib.ur_lora_dropout_bits(int(seed), float(p), int(M), int(W), int(nad), bits.data_ptr(), ld, bits.stride(0), _stream()),
+    check(lib.ur_lora_dropout_bits(int(seed), float(p), int(M), int(W), int(nad), bits.data_ptr(), ld, bits.stride(0), int(row0), _stream()),
           "ur_lora_dropout_bits")
     return bits
 
@@ -242,8 +243,9 @@ def lora_reduce(X, V, out, cols=None, nad=None, alpha=1.0, bits=None, transposed
 
 
 def layernorm_fwd(y, gamma, beta, eps, residual=None, save_z=True, p_pre=0.0, seed_pre=0, p_post=0.0, seed_post=0,
-                  M=None):
-    """Returns (out, z, mean, rstd).  y may have fewer rows than M (row m reads y[m % y.shape[0]])."""
+                  M=None, drop_row0=0):
+    """Returns (out, z, mean, rstd).  y may have fewer rows than M (row m reads y[m % y.shape[0]]).  drop_row0: rows that
+    precede this launch's row 0 in the global minibatch (dropout masks keyed on the global element index)."""
     lib = _lib.load()
     _need(y, BF16, "y")
     H = y.shape[-1]
@@ -256,13 +258,13 @@ def layernorm_fwd(y, gamma, beta, eps, residual=None, save_z=True, p_pre=0.0, se
     mean = torch.empty((M,), dtype=F32, device=dev)
     rstd = torch.empty((M,), dtype=F32, device=dev)
     check(lib.ur_layernorm_fwd(y.data_ptr(), y_rows, _p(residual), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), _p(z),
-                               mean.data_ptr(), rstd.data_ptr(), M, H, eps, p_pre, seed_pre, p_post, seed_post, _stream()),
+                               mean.data_ptr(), rstd.data_ptr(), M, H, eps, p_pre, seed_pre, p_post, seed_post, int(drop_row0), _stream()),
           "ur_layernorm_fwd")
     return out, z, mean, rstd
 
 
 def layernorm_bwd(dout, z, mean, rstd, gamma, dgamma, dbeta, dbias=None, p_pre=0.0, seed_pre=0, p_post=0.0, seed_post=0,
-                  need_dy=True):
+                  need_dy=True, drop_row0=0):
     """Returns (dz, dy); dgamma/dbeta/dbias (f32 [H]) are overwritten in place."""
     lib = _lib.load()
     M, H = z.shape
@@ -272,7 +274,7 @@ def layernorm_bwd(dout, z, mean, rstd, gamma, dgamma, dbeta, dbias=None, p_pre=0
     ws = workspace(wsb, z.device, "ln")
     check(lib.ur_layernorm_bwd(dout.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                dz.data_ptr(), dy.data_ptr() if need_dy else 0, dgamma.data_ptr(), dbeta.data_ptr(), _p(dbias),
-                               M, H, p_pre, seed_pre, p_post, seed_post, ws.data_ptr(), wsb, _stream()), "ur_layernorm_bwd")
+                               M, H, p_pre, seed_pre, p_post, seed_post, int(drop_row0), ws.data_ptr(), wsb, _stream()), "ur_layernorm_bwd")
     return dz, dy
 
 
@@ -327,7 +329,7 @@ def _tok_stride(t):
     return t.stride(1)
 
 
-def attn_fwd(q, k, v, *, causal, key_mask=None, scale=None, dropout_p=0.0, seed=0, out=None):
+def attn_fwd(q, k, v, *, causal, key_mask=None, scale=None, dropout_p=0.0, seed=0, out=None, drop_batch0=0):
     """q [B,Sq,nq,hd], k/v [B,Sk,nkv,hd] bf16 (strided views allowed).  key_mask uint8 [B,Sk] or None.
     Returns (o [B,Sq,nq,hd] contiguous, ctx)."""
     lib = _lib.load()
@@ -345,7 +347,7 @@ def attn_fwd(q, k, v, *, causal, key_mask=None, scale=None, dropout_p=0.0, seed=
     a.B, a.Sq, a.Sk, a.nq, a.nkv, a.head_dim = B, Sq, Sk, nq, nkv, hd
     a.causal = int(causal)
     a.scale = float(scale if scale is not None else hd ** -0.5)
-    a.dropout_p, a.seed = float(dropout_p), int(seed)
+    a.dropout_p, a.seed, a.drop_batch0 = float(dropout_p), int(seed), int(drop_batch0)
     check(lib.ur_attn_fwd(ctypes.byref(a), _stream()), "ur_attn_fwd")
     ctx = AttnCtx()
     ctx.args, ctx.keep, ctx.o, ctx.stats = a, (q, k, v, key_mask), out, stats
@@ -760,7 +762,7 @@ def mse_loss(a, b, coef=1.0, need_grad=True):
     return loss, da
 
 
-def user_sequence_assemble(item_tokens, context, lengths, dropout_p=0.0, seed=0):
+def user_sequence_assemble(item_tokens, context, lengths, dropout_p=0.0, seed=0, drop_batch0=0):
     """item_tokens [B,L,Qi,H] bf16, context [B,L,H] bf16, lengths int32 [B] -> (out [B,L*Qi,H] bf16, mask [B,L*Qi] f32)."""
     lib = _lib.load()
     _need(item_tokens, BF16, "item_tokens")
@@ -770,5 +772,5 @@ def user_sequence_assemble(item_tokens, context, lengths, dropout_p=0.0, seed=0)
     out = torch.empty((B, L * Qi, H), dtype=BF16, device=item_tokens.device)
     mask = torch.empty((B, L * Qi), dtype=F32, device=item_tokens.device)
     check(lib.ur_user_sequence_assemble(item_tokens.data_ptr(), context.data_ptr(), lengths.data_ptr(), out.data_ptr(), mask.data_ptr(),
-                                        B, L, Qi, H, dropout_p, seed, _stream()), "ur_user_sequence_assemble")
+                                        B, L, Qi, H, dropout_p, seed, int(drop_batch0), _stream()), "ur_user_sequence_assemble")
     return out, mask

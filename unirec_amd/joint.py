@@ -98,7 +98,8 @@ class MultiModalQwenEmbedding(nn.Module):
         if self.use_lora and self.training and input_ids.is_cuda:
             # this step's LoRA dropout bit planes do not depend on any activation: generate them on a side stream under the
             # Q-Former forward(s) below
-            self.base_model.prefetch_lora_bits(input_ids.shape[0] * input_ids.shape[1], dev)
+            self.base_model.prefetch_lora_bits(input_ids.shape[0] * input_ids.shape[1], dev,
+                                               row0=self.base_model.first_sample(input_ids.shape[0]) * input_ids.shape[1])
         if history_field_embeddings is not None and history_attention_mask is not None:
             hfe = history_field_embeddings.to(dev)
             ham = history_attention_mask.to(dev)

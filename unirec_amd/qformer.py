@@ -188,6 +188,11 @@ class BertModel(nn.Module):
         self._pack_prefix = ""
         self._step = 0
         self.seed = 0x5EED
+        # index of this forward's first sample in the GLOBAL minibatch (unirec_amd.dp.set_sample_offset): every dropout mask is
+        # keyed on (seed, global element index), so a data-parallel rank draws exactly the masks its samples would get in a
+        # single-process run over the whole minibatch -- training does not depend on the number of ranks
+        self.dp_rank = 0               # unirec_amd.dp.set_dp_rank: first sample of a forward over B local samples = dp_rank * B ...
+        self.sample_offset = None      # ... unless given explicitly (unequal shards)
         self.grad_ready_hook = None
 
     # models/qformer.py:664-674
@@ -317,11 +322,13 @@ class BertModel(nn.Module):
         qe16 = hip.cast_f32_to_bf16(query_embeds.detach().contiguous().view(-1, H)) if query_embeds.dtype == F32 \
             else query_embeds.detach().contiguous().view(-1, H)
         enc16 = (hip.cast_f32_to_bf16(enc.detach().contiguous()) if enc.dtype == F32 else enc.detach().contiguous()).view(Me, -1)
+        b0 = int(self.sample_offset) if self.sample_offset is not None else int(self.dp_rank) * B
+        row0 = b0 * Qn                                   # rows of [B*Q, H] activations that precede this shard
         S = {"B": B, "Q": Qn, "T": T, "p_h": p_h, "p_a": p_a, "layers": [], "enc16": enc16, "mask": mask_u8,
-             "qe_rows": qe16.shape[0], "step_seed": self._step}
+             "qe_rows": qe16.shape[0], "step_seed": self._step, "row0": row0}
         w = lambda n: pack.w32(pre + n)
         x, z0, mean0, rstd0 = hip.layernorm_fwd(qe16, w("embeddings.LayerNorm.weight"), w("embeddings.LayerNorm.bias"), eps,
-                                                M=M, p_post=p_h, seed_post=self._seed(1023, 0))
+                                                M=M, p_post=p_h, seed_post=self._seed(1023, 0), drop_row0=row0)
         S["emb"] = (z0, mean0, rstd0, self._seed(1023, 0))
         for i, lyr in enumerate(self.encoder.layer):
             lp = pre + f"encoder.layer.{i}."
@@ -333,11 +340,11 @@ class BertModel(nn.Module):
             qkv = hip.gemm(x, Wqkv, bias=bqkv)
             q5 = qkv.view(B, Qn, 3, nh, dh)
             s_att = self._seed(i, 1)
-            ctx_o, actx = hip.attn_fwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=False, dropout_p=p_a, seed=s_att)
+            ctx_o, actx = hip.attn_fwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=False, dropout_p=p_a, seed=s_att, drop_batch0=b0)
             y = hip.gemm(ctx_o.view(M, H), pack.w16(a + "output.dense.weight"), bias=pack.w32(a + "output.dense.bias"))
             s_h = self._seed(i, 2)
             x1, z1, m1, r1 = hip.layernorm_fwd(y, pack.w32(a + "output.LayerNorm.weight"), pack.w32(a + "output.LayerNorm.bias"),
-                                               eps, residual=x, p_pre=p_h, seed_pre=s_h)
+                                               eps, residual=x, p_pre=p_h, seed_pre=s_h, drop_row0=row0)
             L["self"] = (x, qkv, actx, ctx_o, z1, m1, r1, s_h)
             xc = x1
             # ---- cross attention (models/qformer.py:432-447)
@@ -350,11 +357,11 @@ class BertModel(nn.Module):
                 kv5 = kv.view(B, T, 2, nh, dh)
                 s_att2 = self._seed(i, 3)
                 ctx2, actx2 = hip.attn_fwd(qc.view(B, Qn, nh, dh), kv5[:, :, 0], kv5[:, :, 1], causal=False, key_mask=mask_u8,
-                                           dropout_p=p_a, seed=s_att2)
+                                           dropout_p=p_a, seed=s_att2, drop_batch0=b0)
                 y2 = hip.gemm(ctx2.view(M, H), pack.w16(c + "output.dense.weight"), bias=pack.w32(c + "output.dense.bias"))
                 s_h2 = self._seed(i, 4)
                 x2, z2, m2, r2 = hip.layernorm_fwd(y2, pack.w32(c + "output.LayerNorm.weight"),
-                                                   pack.w32(c + "output.LayerNorm.bias"), eps, residual=x1, p_pre=p_h, seed_pre=s_h2)
+                                                   pack.w32(c + "output.LayerNorm.bias"), eps, residual=x1, p_pre=p_h, seed_pre=s_h2, drop_row0=row0)
                 L["cross"] = (x1, qc, kv, actx2, ctx2, z2, m2, r2, s_h2)
                 xc = x2
             # ---- query FFN (models/qformer.py:449-454, 481-484)
@@ -364,7 +371,7 @@ class BertModel(nn.Module):
             y3 = hip.gemm(hbuf, pack.w16(f2 + "dense.weight"), bias=pack.w32(f2 + "dense.bias"))
             s_h3 = self._seed(i, 5)
             x3, z3, m3, r3 = hip.layernorm_fwd(y3, pack.w32(f2 + "LayerNorm.weight"), pack.w32(f2 + "LayerNorm.bias"), eps,
-                                               residual=xc, p_pre=p_h, seed_pre=s_h3)
+                                               residual=xc, p_pre=p_h, seed_pre=s_h3, drop_row0=row0)
             L["ffn"] = (xc, u, hbuf, z3, m3, r3, s_h3)
             if keep:
                 S["layers"].append(L)
@@ -406,6 +413,7 @@ class BertModel(nn.Module):
         B, Qn, T = S["B"], S["Q"], S["T"]
         M, Me = B * Qn, B * T
         p_h = S["p_h"]
+        row0 = S["row0"]
         enc16 = S["enc16"]
         dx = dout.contiguous().view(M, H)
         if dx.dtype != BF16:
@@ -434,7 +442,7 @@ class BertModel(nn.Module):
             xc, u, hbuf, z3, m3, r3, s_h3 = L["ffn"]
             f1, f2 = lp + "intermediate_query.dense.", lp + "output_query."
             dz3, dy3 = hip.layernorm_bwd(dx, z3, m3, r3, pack.w32(f2 + "LayerNorm.weight"), pack.g32(f2 + "LayerNorm.weight"),
-                                         pack.g32(f2 + "LayerNorm.bias"), dbias=pack.g32(f2 + "dense.bias"), p_pre=p_h, seed_pre=s_h3)
+                                         pack.g32(f2 + "LayerNorm.bias"), dbias=pack.g32(f2 + "dense.bias"), p_pre=p_h, seed_pre=s_h3, drop_row0=row0)
             dW(dy3, hbuf, [f2 + "dense.weight"])
             du = dX(dy3, [f2 + "dense.weight"], gelu_grad_aux=u)
             hip.colsum(du, out=pack.g32(f1 + "bias"))
@@ -446,7 +454,7 @@ class BertModel(nn.Module):
                 x1, qc, kv, actx2, ctx2, z2, m2, r2, s_h2 = L["cross"]
                 dz2, dy2 = hip.layernorm_bwd(dx, z2, m2, r2, pack.w32(c + "output.LayerNorm.weight"),
                                              pack.g32(c + "output.LayerNorm.weight"), pack.g32(c + "output.LayerNorm.bias"),
-                                             dbias=pack.g32(c + "output.dense.bias"), p_pre=p_h, seed_pre=s_h2)
+                                             dbias=pack.g32(c + "output.dense.bias"), p_pre=p_h, seed_pre=s_h2, drop_row0=row0)
                 dW(dy2, ctx2.view(M, H), [c + "output.dense.weight"])
                 dctx2 = dX(dy2, [c + "output.dense.weight"])
                 dkv = torch.empty_like(kv)
@@ -465,7 +473,7 @@ class BertModel(nn.Module):
             x0, qkv, actx, ctx_o, z1, m1, r1, s_h = L["self"]
             dz1, dy1 = hip.layernorm_bwd(dx, z1, m1, r1, pack.w32(a + "output.LayerNorm.weight"),
                                          pack.g32(a + "output.LayerNorm.weight"), pack.g32(a + "output.LayerNorm.bias"),
-                                         dbias=pack.g32(a + "output.dense.bias"), p_pre=p_h, seed_pre=s_h)
+                                         dbias=pack.g32(a + "output.dense.bias"), p_pre=p_h, seed_pre=s_h, drop_row0=row0)
             dW(dy1, ctx_o.view(M, H), [a + "output.dense.weight"])
             dctx = dX(dy1, [a + "output.dense.weight"])
             dqkv = torch.empty_like(qkv)
@@ -482,7 +490,7 @@ class BertModel(nn.Module):
         z0, mean0, rstd0, s0 = S["emb"]
         dz0, _ = hip.layernorm_bwd(dx, z0, mean0, rstd0, pack.w32(pre + "embeddings.LayerNorm.weight"),
                                    g("embeddings.LayerNorm.weight"), g("embeddings.LayerNorm.bias"), p_post=p_h, seed_post=s0,
-                                   need_dy=False)
+                                   need_dy=False, drop_row0=row0)
         rows = S["qe_rows"]
         touched = list(self._live_names())
         if qe_param_name is not None:      # wrapper-owned [1,Q,H] table: gradient goes straight into the pack

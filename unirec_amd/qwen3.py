@@ -144,7 +144,12 @@ class Qwen3LoRAModel(nn.Module):
         self._frozen = None
         self._rope = None
         self.grad_ready_hook = None
-        self.lora_seed = 0x5EED        # base seed of the LoRA dropout masks (set per rank / per run by the trainer)
+        self.lora_seed = 0x5EED        # base seed of the LoRA dropout masks (per run; identical on every data-parallel rank)
+        # index of this forward's first sequence in the GLOBAL minibatch = dp_rank * B (unirec_amd.dp.set_dp_rank) unless
+        # sample_offset is given: masks are keyed on the global token row (first * S + local row), so a data-parallel rank
+        # draws exactly the masks its sequences would get in a single-process run over the whole minibatch
+        self.dp_rank = 0
+        self.sample_offset = None
         self._lora_step = 0            # forward calls with dropout so far: every step draws new masks
         self._bcomb = None             # block-diagonal LoRA B operands of the merged q|k|v and gate|up launches
         self._bits_stream = None       # side stream + planes of prefetch_lora_bits
@@ -321,12 +326,15 @@ class Qwen3LoRAModel(nn.Module):
         z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
         return (z ^ (z >> 31)) & 0x7FFFFFFFFFFFFFFF
 
+    def first_sample(self, B):
+        return int(self.sample_offset) if self.sample_offset is not None else int(self.dp_rank) * int(B)
+
     def _bits_groups(self):
         """(input width, adapters sharing it) of the four adapter groups of a layer: q|k|v, o, gate|up, down."""
         c = self.config
         return ((c.hidden_size, 3), (c.num_attention_heads * c.head_dim, 1), (c.hidden_size, 2), (c.intermediate_size, 1))
 
-    def prefetch_lora_bits(self, M, device):
+    def prefetch_lora_bits(self, M, device, row0=0):
         """Generate the NEXT forward's LoRA dropout bit planes (all layers, all adapter groups) on a side stream.  The planes
         are pure functions of (seed, step, layer, group) -- nothing on the main stream feeds them -- so the caller starts
         this before the item Q-Former's forward, whose small launches leave most of the chip idle, and the 8 ms of mask
@@ -346,9 +354,9 @@ class Qwen3LoRAModel(nn.Module):
         with torch.cuda.stream(side):
             for (i, g), buf in planes.items():
                 W, nad = self._bits_groups()[g]
-                hip.lora_dropout_bits(self.lora_dropout_seed(step, i, g), p, M, W, nad, device, out=buf)
+                hip.lora_dropout_bits(self.lora_dropout_seed(step, i, g), p, M, W, nad, device, out=buf, row0=row0)
             ev = side.record_event()
-        self._bits_pre = {"step": step, "M": M, "planes": planes, "event": ev}
+        self._bits_pre = {"step": step, "M": M, "planes": planes, "event": ev, "row0": int(row0)}
 
     def _lora_bcomb(self, pack, device):
         """Second-K-range operands of the merged projection launches: y[q|k|v] = h W^T + [t_q|t_k|t_v] Bc^T with
@@ -395,15 +403,15 @@ class Qwen3LoRAModel(nn.Module):
         outs = bt[2].run()
         return dict(zip(bt[1], outs))
 
-    def _norm_lora_down(self, x, w, eps, a_names, pack, sc, seed, p, pre=None):
+    def _norm_lora_down(self, x, w, eps, a_names, pack, sc, seed, p, pre=None, row0=0):
         """(h, rstd, t, bits) = RMSNorm forward + _lora_down of the adapters that read h, as one kernel (ur_rmsnorm_lora_fwd)."""
         bits = pre
         if bits is None and p > 0.0:
-            bits = hip.lora_dropout_bits(seed, p, x.shape[0], x.shape[1], len(a_names), x.device)
+            bits = hip.lora_dropout_bits(seed, p, x.shape[0], x.shape[1], len(a_names), x.device, row0=row0)
         h, rstd, t = hip.rmsnorm_lora_fwd(x, w, eps, [pack.w16(n) for n in a_names], alpha=sc / (1.0 - p), bits=bits)
         return h, rstd, t, bits
 
-    def _lora_down(self, xin, a_names, pack, sc, seed, p, pre=None):
+    def _lora_down(self, xin, a_names, pack, sc, seed, p, pre=None, row0=0):
         """(t, bits): t[M, nb*r] = s * dropout_j(x) A_j^T for the nb adapters that share the input x (one dropped-flag
         bit plane per adapter, generated once here and kept for the backward)."""
         if self.config.lora_r != 16:
@@ -413,7 +421,7 @@ class Qwen3LoRAModel(nn.Module):
             return hip.gemm(xin, A, alpha=sc), None
         bits = pre
         if bits is None and p > 0.0:
-            bits = hip.lora_dropout_bits(seed, p, xin.shape[0], xin.shape[1], len(a_names), xin.device)
+            bits = hip.lora_dropout_bits(seed, p, xin.shape[0], xin.shape[1], len(a_names), xin.device, row0=row0)
         t = hip.lora_project(xin, [pack.w16(n) for n in a_names], alpha=sc / (1.0 - p), bits=bits)
         return t, bits
 
@@ -442,8 +450,9 @@ class Qwen3LoRAModel(nn.Module):
             self._lora_step += 1
         saved = {"B": B, "S": S, "T": T, "ids": input_ids, "first": first_special_id, "mask": mask_u8, "layers": [],
                  "pdrop": pdrop, "step": step}
+        row0 = self.first_sample(B) * S                # token rows that precede this shard in the global minibatch
         pre, self._bits_pre = self._bits_pre, None
-        if pre is not None and pdrop > 0.0 and pre["step"] == step and pre["M"] == M and pack is not None:
+        if pre is not None and pdrop > 0.0 and pre["step"] == step and pre["M"] == M and pre["row0"] == row0 and pack is not None:
             torch.cuda.current_stream(dev).wait_event(pre["event"])      # planes prefetched on the side stream
             pre = pre["planes"]
         else:
@@ -456,13 +465,13 @@ class Qwen3LoRAModel(nn.Module):
             qkv = torch.empty((M, NQ + 2 * NKV), dtype=BF16, device=dev)
             if fuse_norm:      # RMSNorm + the q|k|v adapters' down projection in one pass over x (h is written once, never re-read by a projection kernel)
                 h, rstd1, t_qkv, L["bits_qkv"] = self._norm_lora_down(x, fl["ln1"], eps, [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"],
-                                                                      pack, sc, self.lora_dropout_seed(step, i, 0), pdrop, bp(i, 0))
+                                                                      pack, sc, self.lora_dropout_seed(step, i, 0), pdrop, bp(i, 0), row0=row0)
             else:
                 h, rstd1 = hip.rmsnorm_fwd(x, fl["ln1"], eps)
             if pack is not None:
                 if not fuse_norm:
                     t_qkv, L["bits_qkv"] = self._lora_down(h, [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"], pack, sc,
-                                                           self.lora_dropout_seed(step, i, 0), pdrop, bp(i, 0))     # [M,3r] = s * dropout(h) A^T
+                                                           self.lora_dropout_seed(step, i, 0), pdrop, bp(i, 0), row0=row0)     # [M,3r] = s * dropout(h) A^T
                 if bc_qkv is not None:
                     hip.gemm(h, fl["qkv"], out=qkv, R2=t_qkv, S2=bc_qkv[i])        # one launch, block-diagonal B
                 else:
@@ -479,7 +488,7 @@ class Qwen3LoRAModel(nn.Module):
             att, actx = hip.attn_fwd(q_r.view(B, S, nq, hd), k_r.view(B, S, nkv, hd), v4, causal=True, key_mask=mask_u8)
             att2 = att.view(M, NQ)
             if pack is not None:
-                t_o, L["bits_o"] = self._lora_down(att2, [lp + "self_attn.o_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 1), pdrop, bp(i, 1))
+                t_o, L["bits_o"] = self._lora_down(att2, [lp + "self_attn.o_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 1), pdrop, bp(i, 1), row0=row0)
                 x2 = hip.gemm(att2, fl["o"], residual=x, R2=t_o, S2=pack.w16(lp + "self_attn.o_proj.lora_B.weight"))
                 L["t_o"] = t_o
             else:
@@ -487,13 +496,13 @@ class Qwen3LoRAModel(nn.Module):
             gu = torch.empty((M, 2 * I), dtype=BF16, device=dev)
             if fuse_norm:
                 h2, rstd2, t_gu, L["bits_gu"] = self._norm_lora_down(x2, fl["ln2"], eps, [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"],
-                                                                     pack, sc, self.lora_dropout_seed(step, i, 2), pdrop, bp(i, 2))
+                                                                     pack, sc, self.lora_dropout_seed(step, i, 2), pdrop, bp(i, 2), row0=row0)
             else:
                 h2, rstd2 = hip.rmsnorm_fwd(x2, fl["ln2"], eps)
             if pack is not None:
                 if not fuse_norm:
                     t_gu, L["bits_gu"] = self._lora_down(h2, [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"], pack, sc,
-                                                         self.lora_dropout_seed(step, i, 2), pdrop, bp(i, 2))
+                                                         self.lora_dropout_seed(step, i, 2), pdrop, bp(i, 2), row0=row0)
                 # gate first; the up projection's epilogue then reads the gate tile and writes act = silu(gate) * up beside up
                 fused = _FUSE_SWIGLU_FWD and bc_gu is None
                 act = torch.empty((M, I), dtype=BF16, device=dev) if fused else None
@@ -506,7 +515,7 @@ class Qwen3LoRAModel(nn.Module):
                 if fuse_act:      # act and t_d = s * dropout(act) A_d^T from one pass over gate|up (ur_swiglu_lora_fwd)
                     bits_d = bp(i, 3)
                     if bits_d is None and pdrop > 0.0:
-                        bits_d = hip.lora_dropout_bits(self.lora_dropout_seed(step, i, 3), pdrop, M, I, 1, dev)
+                        bits_d = hip.lora_dropout_bits(self.lora_dropout_seed(step, i, 3), pdrop, M, I, 1, dev, row0=row0)
                     act, t_d = hip.swiglu_lora_fwd(gu, I, pack.w16(lp + "mlp.down_proj.lora_A.weight"), alpha=sc / (1.0 - pdrop), bits=bits_d)
                     L["bits_d"] = bits_d
                 elif not fused:
@@ -517,7 +526,7 @@ class Qwen3LoRAModel(nn.Module):
                 act = hip.swiglu_fwd(gu, I)
             if pack is not None:
                 if not fuse_act:
-                    t_d, L["bits_d"] = self._lora_down(act, [lp + "mlp.down_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 3), pdrop, bp(i, 3))
+                    t_d, L["bits_d"] = self._lora_down(act, [lp + "mlp.down_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 3), pdrop, bp(i, 3), row0=row0)
                 x3 = hip.gemm(act, fl["d"], residual=x2, R2=t_d, S2=pack.w16(lp + "mlp.down_proj.lora_B.weight"))
                 L["t_d"] = t_d
             else:

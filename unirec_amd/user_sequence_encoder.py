@@ -40,6 +40,7 @@ class UserSequenceAssembler:
         self.positional_encoder = PositionalEncoding(embedding_dim, dropout)
         self.training = training       # the reference leaves nn.Dropout in train mode (user_sequence_encoder.py:50)
         self._step = 0
+        self.dp_rank, self.sample_offset = 0, None      # dropout counters keyed on the global user index (unirec_amd.dp.set_dp_rank)
 
     def encode_user_sequences(self, item_query_tokens, context_embs, lengths):
         """Batched encode_user_sequence + collate padding.
@@ -51,7 +52,9 @@ class UserSequenceAssembler:
         c = context_embs if context_embs.dtype == torch.bfloat16 else hip.cast_f32_to_bf16(context_embs.contiguous())
         self._step += 1
         p = self.positional_encoder.p if self.training else 0.0
-        return hip.user_sequence_assemble(t.contiguous(), c.contiguous(), lengths.to(torch.int32).contiguous(), p, 0xA55E + self._step)
+        b0 = int(self.sample_offset) if self.sample_offset is not None else int(self.dp_rank) * int(t.shape[0])
+        return hip.user_sequence_assemble(t.contiguous(), c.contiguous(), lengths.to(torch.int32).contiguous(), p, 0xA55E + self._step,
+                                          drop_batch0=b0)
 
 
 # ---- event context encoders + batched sequence encoding from the token cache --------
