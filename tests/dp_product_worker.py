@@ -1,7 +1,7 @@
 """One rank of the 2-rank PRODUCT-path data-parallel test (tests/test_gpu_dp_product.py starts two of these as child
 processes, both on cuda:0, backend gloo -- RCCL needs one device per rank; the code path above the backend is the one
 bench.py runs: HIP forward/backward, bucket hooks, sum all-reduce of the flat gradient pack, fused AdamW with 1/world).
-Usage: python tests/dp_product_worker.py <outdir> <global_batch> [dropout]   (RANK / WORLD_SIZE / MASTER_* from the env)"""
+Usage: python tests/dp_product_worker.py <outdir> <global_batch> [dropout] [joint]   (RANK / WORLD_SIZE / MASTER_* from the env)"""
 import os
 import sys
 
@@ -66,5 +66,45 @@ def run(outdir, Bg, dropout):
         torch.distributed.destroy_process_group()
 
 
+def run_joint(outdir, Bg, dropout):
+    """The JOINT step (item Q-Former -> injection -> Qwen3 + LoRA -> InfoNCE) on this rank's shard of a global batch, with
+    hidden / attention dropout in the Q-Former and LoRA dropout in the decoder: the reduced gradients of both packs."""
+    import numpy as np
+    from tests.golden import cases
+    from tests.test_gpu_joint import _build_joint
+    from unirec_amd import dp
+    from unirec_amd.joint import InfoNCELoss
+    rank, world, _ = dp.init_from_env()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    case = dict(cases.ALL["joint_left"], B=Bg, drop_one_special=False)
+    m, qf = _build_joint(case, use_lora=True, lora_seed=case["seed"] + 2)
+    bm = m.base_model
+    bm.config.lora_dropout = dropout
+    qf.qformer.config.hidden_dropout_prob = dropout
+    qf.qformer.config.attention_probs_dropout_prob = dropout
+    dp.set_dp_rank(rank, m)
+    ids, am, hfe, ham, pos, neg, nmask = cases.joint_inputs(case)
+    lo, hi = dp.shard_range(Bg, rank, world)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a[lo:hi])).to(dev)
+    user = m(t(ids), t(am), t(hfe), t(ham))
+    loss = InfoNCELoss()(user, t(pos), t(neg), t(nmask))
+    loss.backward()
+    grads = {}
+    for name, pack in (("lora", bm._ensure_pack(dev)), ("qformer", qf._ensure_pack(dev))):
+        bk = dp.GradBuckets(pack.grad, [0, pack.numel])
+        bk.ready_all(); bk.wait()
+        torch.cuda.synchronize()
+        grads[name] = (pack.grad / world).cpu()
+    torch.save({"grads": grads, "loss": float(loss), "n": hi - lo, "world": world, "lora_seed": int(bm.lora_seed), "seed": int(qf.qformer.seed)},
+               os.path.join(outdir, f"rank{rank}.pt"))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 if __name__ == "__main__":
-    run(sys.argv[1], int(sys.argv[2]), float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)
+    if len(sys.argv) > 4 and sys.argv[4] == "joint":
+        run_joint(sys.argv[1], int(sys.argv[2]), float(sys.argv[3]))
+    else:
+        run(sys.argv[1], int(sys.argv[2]), float(sys.argv[3]) if len(sys.argv) > 3 else 0.0)

@@ -24,13 +24,13 @@ def _free_port():
     return p
 
 
-def _launch(outdir, world, Bg, dropout):
+def _launch(outdir, world, Bg, dropout, mode=None):
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    UNIREC_DP_BACKEND="gloo", OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, WORKER, str(outdir), str(Bg), str(dropout)], env=env,
+        procs.append(subprocess.Popen([sys.executable, WORKER, str(outdir), str(Bg), str(dropout)] + ([mode] if mode else []), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = [p.communicate(timeout=600)[0] for p in procs]
     for p, o in zip(procs, outs):
@@ -71,3 +71,21 @@ def test_dropout_masks_are_keyed_on_the_global_sample_index(tmp_path):
     assert abs(0.5 * (r0["loss"] + r1["loss"]) - s0["loss"]) <= 2e-3 * abs(s0["loss"])
     rel = float((r0["grad"] - s0["grad"]).norm() / s0["grad"].norm())
     assert rel <= 2e-2, rel
+
+
+def test_joint_step_under_two_ranks_equals_the_single_process_step_with_dropout_on(tmp_path):
+    """The headline path under data parallelism: item Q-Former (hidden + attention dropout 0.1) -> injection -> Qwen3 + LoRA
+    (lora_dropout 0.1) -> InfoNCE.  Two ranks of two sequences each reduce to the gradient of ONE process over the four
+    sequences -- LoRA A / B and every Q-Former tensor -- because all masks are keyed on the global sample index."""
+    d2 = tmp_path / "w2"; d2.mkdir()
+    r0, r1 = _launch(d2, 2, 4, 0.1, "joint")
+    assert r0["world"] == 2 and r0["n"] == 2 and r1["n"] == 2 and r0["lora_seed"] == r1["lora_seed"] and r0["seed"] == r1["seed"]
+    d1 = tmp_path / "w1"; d1.mkdir()
+    (s0,) = _launch(d1, 1, 4, 0.1, "joint")
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - s0["loss"]) <= 5e-3 * abs(s0["loss"])
+    for k in ("lora", "qformer"):
+        assert torch.equal(r0["grads"][k], r1["grads"][k])
+        g2, g1 = r0["grads"][k], s0["grads"][k]
+        rel = float((g2 - g1).norm() / g1.norm())
+        print(k, "2-rank vs 1-rank gradient rel err", rel)
+        assert float(g1.norm()) > 0 and rel <= 3e-2, (k, rel)
