@@ -478,12 +478,14 @@ def main():
         step()
     sync()
     hip.PROFILE = []
+    hip.PROFILE_ATTN = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     sync()
     dt = time.perf_counter() - t0
     prof, hip.PROFILE = hip.PROFILE, None
+    aprof, hip.PROFILE_ATTN = hip.PROFILE_ATTN, None
     if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -528,6 +530,16 @@ def main():
                 # operands sustains 2.05 PFLOP/s at this part's 1400 W cap, and this kernel runs at that cap
                 "sustained_mfma_peak": 2050.0, "frac_of_sustained": round(ach / 2050.0, 4),
                 "sustained_note": "tools/lab/mfma_power_lab.hip, profiles/r2_mfma_power_lab.txt, profiles/r2_power_gemm_step.txt"}
+        # the causal attention family of the decoder (second-largest group of the step), HIP events around every launch; FLOPs are the
+        # ALGORITHMIC dense-causal ones (forward 4 B nq S^2 hd / 2, backward 2.5x): left padding only makes the kernels skip work
+        att = {"fwd": [0.0, 0.0, 0], "bwd": [0.0, 0.0, 0]}
+        for (e0, e1, kind, aB, aSq, aSk, anq, ahd, acausal) in aprof:
+            if acausal and ahd == 128:
+                f = 4.0 * aB * anq * aSq * aSk * ahd / 2 * (1.0 if kind == "fwd" else 2.5)
+                att[kind][0] += e0.elapsed_time(e1); att[kind][1] += f; att[kind][2] += 1
+        attn = {k: {"launches": v[2], "avg_launch_ms": round(v[0] / max(v[2], 1), 4), "ms_per_step": round(v[0] / args.steps, 2),
+                    "tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 1), "frac_of_peak": round(v[1] / max(v[0], 1e-9) / 1e9 / 2500.0, 4)} for k, v in att.items()}
+        attn["kernels"] = "attn_fwd_kernel<128,true,4>; attn_bwd_dq_kernel<128,true,4> + attn_bwd_dkv2_kernel<true> (one ur_attn_bwd call)"
         fl = flops_per_step(args, B, cfg, dims)
         out = {"metric": "user-sequences/sec joint fwd+bwd (Qwen3-0.6B+LoRA, hist=50)", "value": round(world * B * args.steps / dt, 3),
                "unit": "user-sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -540,7 +552,7 @@ def main():
                           "hist": args.hist, "pool": args.pool, "dropout": 0.0 if args.no_dropout else 0.2, "lora_dropout": 0.0 if args.no_dropout else args.lora_dropout,
                           "micro_batches": nmb, "parallelism": f"dp{world}", "random_init": True},
                "step_tflops_per_gpu": round(fl / (dt / args.steps) / 1e12, 1), "loss": round(lossv, 4),
-               "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "comm": _comm_info(world)}
+               "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "attention": attn, "comm": _comm_info(world)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
         print(json.dumps(out), flush=True)

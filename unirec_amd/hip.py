@@ -37,6 +37,7 @@ _ws_cache = {}
 # Optional live kernel timing (bench.py roofline leg): when PROFILE is a list, every ur_gemm launch is
 # bracketed by HIP events recorded on the launching (current) stream and logged with its shape.
 PROFILE = None
+PROFILE_ATTN = None     # bench.py: list of (event0, event1, 'fwd' | 'bwd', B, Sq, Sk, nq, head_dim, causal) around every attention launch
 
 
 def workspace(nbytes, device, tag="default"):
@@ -348,7 +349,14 @@ def attn_fwd(q, k, v, *, causal, key_mask=None, scale=None, dropout_p=0.0, seed=
     a.causal = int(causal)
     a.scale = float(scale if scale is not None else hd ** -0.5)
     a.dropout_p, a.seed, a.drop_batch0 = float(dropout_p), int(seed), int(drop_batch0)
-    check(lib.ur_attn_fwd(ctypes.byref(a), _stream()), "ur_attn_fwd")
+    if PROFILE_ATTN is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ur_attn_fwd(ctypes.byref(a), _stream()), "ur_attn_fwd")
+        e1.record()
+        PROFILE_ATTN.append((e0, e1, "fwd", B, Sq, Sk, nq, hd, int(causal)))
+    else:
+        check(lib.ur_attn_fwd(ctypes.byref(a), _stream()), "ur_attn_fwd")
     ctx = AttnCtx()
     ctx.args, ctx.keep, ctx.o, ctx.stats = a, (q, k, v, key_mask), out, stats
     return out, ctx
@@ -377,7 +385,14 @@ def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None):
         g.rope_cos, g.rope_sin, g.rope_eps = cos.data_ptr(), sin.data_ptr(), float(eps)
         g.rope_dq_raw, g.rope_lddraw = dq_raw.data_ptr(), dq_raw.stride(0)
     g.delta = delta.data_ptr()
-    check(lib.ur_attn_bwd(ctypes.byref(a), ctypes.byref(g), _stream()), "ur_attn_bwd")
+    if PROFILE_ATTN is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ur_attn_bwd(ctypes.byref(a), ctypes.byref(g), _stream()), "ur_attn_bwd")
+        e1.record()
+        PROFILE_ATTN.append((e0, e1, "bwd", a.B, a.Sq, a.Sk, a.nq, a.head_dim, a.causal))
+    else:
+        check(lib.ur_attn_bwd(ctypes.byref(a), ctypes.byref(g), _stream()), "ur_attn_bwd")
     return dq, dk, dv
 
 
