@@ -470,6 +470,9 @@ __device__ __forceinline__ void tr_pair(bf16x8 (&f)[2], uint32_t a0, uint32_t b0
 // grid: x = 64-column block, y = token split, z = entry (separate column ranges, NAD == 1) or 0 (NAD adapters share X).
 // Per 64-token step the block stages X[64 tokens][64 columns] (one masked copy per adapter) and V[64 tokens][16 NAD]
 // row-major in LDS; ds_read_b64_tr_b16 turns both into token-packed MFMA operands.  Wave w owns columns 16w..16w+15.
+#ifndef UR_RED_ABLATE
+#define UR_RED_ABLATE 0     // lab (results WRONG when != 0): 1 = one LDS copy instead of one per adapter, 2 = no transposed reads / MFMAs,
+#endif                      // 3 = no flag-byte loads, 4 = no barriers, 5 = no global loads of X
 template <int NAD, bool MASKED>
 __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
   constexpr int TOK = NAD <= 3 ? 128 : 64;          // tokens per step (two barriers per step)
@@ -504,13 +507,14 @@ __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
   }
 
   uint4 xr[XP], vr[VP];
-  uint32_t br[XP][NAD];
+  uint32_t br[XP][NAD] = {};
   auto gload = [&](int t0) {
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int m = min(t0 + prow[i], p.M - 1);
-      xr[i] = ld_stream(p.X + (long)m * p.ldx + col0 + pcol[i]);
-      if (MASKED) {
+      if (UR_RED_ABLATE != 5) xr[i] = ld_stream(p.X + (long)m * p.ldx + col0 + pcol[i]);
+      else xr[i] = make_uint4(m, i, t0, 1);
+      if (MASKED && UR_RED_ABLATE != 3) {
 #pragma unroll
         for (int a = 0; a < NAD; ++a) br[i][a] = p.bits[(long)a * p.bits_stride + (long)m * p.bits_ld + (pcol[i] >> 3)];
       }
@@ -533,16 +537,16 @@ __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
     for (int i = 0; i < XP; ++i) {
       const int off = prow[i] * 128 + ((((pch[i] >> 1) ^ f64sw(prow[i])) << 5) | ((pch[i] & 1) << 4));
 #pragma unroll
-      for (int a = 0; a < NAD; ++a)
-        *reinterpret_cast<uint4*>(smem + a * XT + off) = MASKED ? drop_apply(xr[i], br[i][a]) : xr[i];
+      for (int a = 0; a < (UR_RED_ABLATE == 1 ? 1 : NAD); ++a)
+        *reinterpret_cast<uint4*>(smem + a * XT + off) = (MASKED && UR_RED_ABLATE != 3) ? drop_apply(xr[i], br[i][a]) : xr[i];
     }
 #pragma unroll
     for (int i = 0; i < VP; ++i)
       if (vthr[i]) *reinterpret_cast<uint4*>(vt + vrow[i] * VROW + vpart[i] * 16) = vr[i];
-    __syncthreads();
+    if (UR_RED_ABLATE != 4) __syncthreads();
     if (t0 + TOK < tend) gload(t0 + TOK);
 #pragma unroll
-    for (int ks = 0; ks < TOK / 32; ++ks) {
+    for (int ks = 0; ks < (UR_RED_ABLATE == 2 ? 0 : TOK / 32); ++ks) {
       const int ka = 32 * ks + 8 * g + q;
       const uint32_t xo = lds_off(smem) + ka * 128 + ((wave ^ f64sw(ka)) << 5) + pp * 8;
       const uint32_t vo = lds_off(vt) + ka * VROW + pp * 8;
@@ -555,7 +559,7 @@ __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
         acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[a], 0, 0, 0);
       }
     }
-    __syncthreads();
+    if (UR_RED_ABLATE != 4) __syncthreads();
   }
   // partial (or final) result of this token range, dense layout: entry e at goff[e], [16][W] or [W][16]
   long total = 0;
