@@ -340,3 +340,46 @@ def test_c5_shaped_step_properties():
     idx, val = hip.topk(scores, 10)
     order = torch.sort(scores, dim=1, descending=True, stable=True)
     assert torch.equal(idx.long(), order.indices[:, :10]) and torch.equal(val, order.values[:, :10])
+
+
+# ---- empty and degenerate inputs at the class boundary -------------------------------------------------------------------
+def test_empty_and_single_sample_batches():
+    """B = 0 goes through every stage without a launch fault and returns correctly shaped empty tensors (the reference's modules do
+    the same on empty tensors); B = 1 with a fully masked item / a length-1 user history matches the oracle."""
+    from unirec_amd.qformer_model import QFormerForItemRepresentation
+    from unirec_amd.user_qformer import UserQFormer
+    c = cases.ALL["item_c1"]["cfg"]
+    cfg = R.QFormerCfg(c["H"], c["L"], c["nh"], c["I"], c["Q"], c["E"], 2)
+    m = QFormerForItemRepresentation(hidden_size=c["H"], num_hidden_layers=c["L"], num_attention_heads=c["nh"], intermediate_size=c["I"],
+                                     num_query_tokens=c["Q"], field_embedding_dim=c["E"], num_fields=c["F"], dropout=0.0)
+    m = load_generated(m, R.item_qformer_shapes(cfg, c["F"]), 11).eval()
+    with torch.no_grad():
+        out = m(torch.zeros(0, c["F"], c["E"], device=DEV), torch.zeros(0, c["F"], dtype=torch.long, device=DEV))
+    assert out["query_outputs"].shape == (0, c["Q"], c["H"]) and out["item_representation"].shape == (0, c["E"])
+    assert out["reconstructed_fields"].shape == (0, c["F"], c["E"])
+    # one item whose fields are ALL masked (uniform attention over the masked keys, SURVEY I3) against the oracle
+    g = torch.Generator().manual_seed(3)
+    x1 = torch.randn(1, c["F"], c["E"], generator=g)
+    mk = torch.zeros(1, c["F"], dtype=torch.long)
+    with torch.no_grad():
+        got = m(x1.to(DEV), mk.to(DEV))["query_outputs"]
+    P = {k: torch.from_numpy(v) for k, v in W.fill_state_dict(R.item_qformer_shapes(cfg, c["F"]), 11).items()}
+    want = R.item_qformer_forward(P, cfg, x1, mk)["query_outputs"]
+    assert_close(got, want.numpy(), OUT_REL, "fully masked single item")
+    # user Q-Former: empty batch, and one user with a single valid key
+    uc = cases.ALL["user_t8"]["cfg"]
+    ucfg = R.QFormerCfg(uc["H"], uc["L"], uc["nh"], uc["I"], uc["Q"], uc["E"], 1)
+    u = UserQFormer(hidden_size=uc["H"], num_hidden_layers=uc["L"], num_attention_heads=uc["nh"], intermediate_size=uc["I"],
+                    num_query_tokens=uc["Q"], input_embedding_dim=uc["E"], num_item_tokens_to_predict=uc["n_pred"], dropout=0.0)
+    u = load_generated(u, R.user_qformer_shapes(ucfg, uc["n_pred"]), 22).eval()
+    with torch.no_grad():
+        e = u(torch.zeros(0, 8, uc["E"], device=DEV), torch.zeros(0, 8, device=DEV))
+    assert e.shape == (0, uc["n_pred"], uc["E"])
+    xs = torch.randn(1, 8, uc["E"], generator=g) * 0.8
+    ms = torch.zeros(1, 8); ms[0, 0] = 1.0
+    xs = xs * ms[..., None]
+    with torch.no_grad():
+        got = u(xs.to(DEV), ms.to(DEV))
+    PU = {k: torch.from_numpy(v) for k, v in W.fill_state_dict(R.user_qformer_shapes(ucfg, uc["n_pred"]), 22).items()}
+    want, _ = R.user_qformer_forward(PU, ucfg, xs, ms, uc["n_pred"])
+    assert_close(got, want.numpy(), OUT_REL, "single user, one valid key")

@@ -283,6 +283,8 @@ class BertModel(nn.Module):
             if tuple(encoder_attention_mask.shape) != (B, enc.shape[1]):
                 raise ValueError("Wrong shape for encoder_attention_mask")
             mask_u8 = (encoder_attention_mask != 0).to(torch.uint8).contiguous()
+        if B == 0:          # an empty batch is an empty result (as the reference's modules return on empty tensors); nothing to launch
+            return torch.empty((0, Q, H), dtype=BF16, device=query_embeds.device)
         # the reference expands one [1,Q,H] parameter over the batch (models/qformer_utils.py:39):
         # keep it un-expanded so the LayerNorm kernel broadcasts it and the gradient reduces over B.
         qe = query_embeds

@@ -111,5 +111,10 @@ class QFormerForItemRepresentation(nn.Module):
 
     def forward(self, field_embeddings: torch.Tensor, attention_mask: torch.Tensor = None):
         h16 = self.encode_bf16(field_embeddings, attention_mask)
+        if h16.shape[0] == 0:
+            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=h16.device)
+            E = self.qformer.config.encoder_width
+            return {"query_outputs": z(0, h16.shape[1], h16.shape[2]), "item_representation": z(0, E),
+                    "reconstructed_fields": z(0, self.field_projection.out_features, E)}
         item, rec = _ItemHeadsFn.apply(self, h16)
         return {"query_outputs": _CastFn.apply(h16), "item_representation": item, "reconstructed_fields": rec}

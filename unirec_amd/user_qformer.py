@@ -101,5 +101,7 @@ class UserQFormer(nn.Module):
     def forward(self, user_sequence_tokens: torch.Tensor, attention_mask: torch.Tensor):
         batch_size = user_sequence_tokens.shape[0]
         h16 = self.encode_bf16(user_sequence_tokens, attention_mask)
+        if batch_size == 0:
+            return torch.zeros((0, self.num_item_tokens_to_predict, self.input_embedding_dim), dtype=torch.float32, device=h16.device)
         flat = _UserHeadFn.apply(self, h16)
         return flat.view(batch_size, self.num_item_tokens_to_predict, self.input_embedding_dim)
