@@ -427,7 +427,7 @@ def main():
     opt = FusedAdamW(packs, lr=1e-4, weight_decay=0.01)
 
     # ---- gradient buckets in backward-completion order (LoRA 27..0, Q-Former 11..0, query table) ----
-    lgrp, qgrp = 7, 3
+    lgrp, qgrp = 7, 1          # LoRA: 4 buckets of 7 layers (10 MB each); Q-Former: one bucket per layer (60 MB f32): the exposed tail is the last layer's all-reduce
     lb = dp.layer_boundaries(lpack, [f"layers.{i}." for i in range(cfg.num_hidden_layers)], lgrp)
     qb = dp.layer_boundaries(qpack, [f"qformer.encoder.layer.{i}." for i in range(12)], qgrp)
     lbk, qbk = dp.GradBuckets(lpack.grad, lb), dp.GradBuckets(qpack.grad, qb)
