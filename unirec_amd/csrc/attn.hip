@@ -32,6 +32,11 @@ constexpr float NEG_INF = -__builtin_huge_valf();
 constexpr float F32_MIN = -3.4028234663852886e38f;   // torch.finfo(torch.float32).min
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr int KT = 64;                                // keys (or queries, in dK/dV) staged per LDS tile
+#ifndef UR_FWD_PRIO
+#define UR_FWD_PRIO 1                                 // s_setprio(1) around the forward kernel's MFMA bursts (S chains, P V), 0 around the softmax: of the two waves of a
+                                                      // SIMD the one in its matrix segment issues first (1801 -> 1764 us dense causal B 64 S 2048; the same hint in
+                                                      // the dQ kernel is 1.5 % slower and is not applied there)
+#endif
 #ifndef UR_FWD_ABLATE
 #define UR_FWD_ABLATE 0                               // lab (tools/lab/dkv2_ablate.sh <tag> "<n...>" UR_FWD_ABLATE; results WRONG when != 0): 1 no max/exp2, 2 no LDS fragment reads, 3 no staging of the next tile, 4 no P V MFMAs, 5 = 3 + no barrier
 #endif
@@ -409,6 +414,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
       const bool act0 = k0 < kend && !(CAUSAL && (k0 > qblk + 31 || (uint32_t)kbits.valid == 0u));
       const bool act1 = (k0 + 32) < kend && !(CAUSAL && (k0 + 32 > qblk + 31 || (uint32_t)(kbits.valid >> 32) == 0u));
       f32x16 sA = zero16(), sB = zero16();
+#if UR_FWD_PRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
       if (act0) {
 #pragma unroll
         for (int st = 0; st < C::NS; ++st)
@@ -419,6 +427,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
         for (int st = 0; st < C::NS; ++st)
           sB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(UR_FWD_ABLATE == 2 ? qf[(st + 2) % C::NS] : kfrag(ktile, std::integral_constant<int, 32>{}, st), qf[st], sB, 0, 0, 0);
       }
+#if UR_FWD_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       auto soft_pv = [&](const int sub, f32x16& s) {
         const int kbase = k0 + 32 * sub;
         const uint32_t v32 = (uint32_t)(kbits.valid >> (32 * sub)), i32 = (uint32_t)(kbits.inr >> (32 * sub));
@@ -504,6 +515,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
         }
         rs += __shfl_xor(rs, 32, 64);
         l += rs;
+#if UR_FWD_PRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const bf16x8 pf = acc_frag(s, s2);
@@ -526,7 +540,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
         }
       };
       if (act0) soft_pv(0, sA);
+#if UR_FWD_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if (act1) soft_pv(1, sB);
+#if UR_FWD_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     if (t + 1 < ntiles && UR_FWD_ABLATE != 3 && UR_FWD_ABLATE != 5) {
       ks.commit(nk, tid);
