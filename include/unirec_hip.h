@@ -83,6 +83,13 @@ typedef struct {
 } ur_gemm_args;
 int64_t ur_gemm_workspace_bytes(const ur_gemm_args* a);
 int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, void* stream);
+/* Launches with K-contiguous operands, bf16 output, M, N multiples of 256, K a multiple of 64 (>= 256), >= 512 output tiles and
+ * a plain / bias / residual / masked-LoRA / SwiGLU-backward epilogue run on the persistent kernel (csrc/gemm_pers.hip: one
+ * workgroup per CU walks its tiles, the LDS-DMA ring never drains, epilogue from registers) -- bit-identical to the generic
+ * kernel.  ur_gemm_persistent_mode(0) keeps every launch on the generic kernel, (1) enables the persistent one, (-1) returns
+ * to the default (environment UR_GEMM_PERSISTENT, default 1); returns the previous setting.  Process-wide; for A/B timing
+ * and the bit-identity tests. */
+int ur_gemm_persistent_mode(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * LoRA adapter products, rank 16 (peft LoraLayer; call site training/train_item_individual_token_joint.py:121-131,

@@ -1,0 +1,135 @@
+"""GPU: the persistent 256x256 projection GEMM (csrc/gemm_pers.hip) against the generic kernel (bit for bit: same
+accumulation order, same roundings) and against exact integer references.  Replaces nn.Linear at
+/root/reference/models/qformer.py:126-130 and installed modeling_qwen3.py:81-83,227-238 on the decoder's big launches."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from unirec_amd import hip  # noqa: E402
+
+DEV = "cuda"
+
+
+def _ints(shape, lo=-2, hi=3, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randint(lo, hi, shape, generator=g).to(torch.float32)
+
+
+def _randn(shape, seed=0, std=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * std).to(DEV).to(torch.bfloat16).contiguous()
+
+
+def _bf(x):
+    return x.to(DEV).to(torch.bfloat16).contiguous()
+
+
+def _both(fn):
+    """fn() once on the generic kernel, once with the persistent kernel enabled."""
+    prev = hip.gemm_persistent_mode(0)
+    try:
+        ref = fn()
+        torch.cuda.synchronize()
+        hip.gemm_persistent_mode(1)
+        got = fn()
+        torch.cuda.synchronize()
+    finally:
+        hip.gemm_persistent_mode(prev)
+    return ref, got
+
+
+# 512 tiles is the smallest eligible launch; 33 x 16 = 528 tiles leaves workgroups with 2 and 3 tiles (and no column chunks);
+# K = 256 is the shortest K stream (4 K tiles), 320 an odd number of K tiles (the ring slot parity flips from tile to tile)
+@pytest.mark.parametrize("M,N,K", [(8192, 4096, 256), (8448, 4096, 320), (8192, 4096, 1024), (4096, 8192, 576), (16384, 2048, 2048)])
+def test_persistent_plain_is_exact_and_identical(M, N, K):
+    Rm, Sm = _ints((M, K), seed=31), _ints((N, K), seed=32)
+    R, S = _bf(Rm), _bf(Sm)
+    ref = ((Rm.to(DEV).double() @ Sm.to(DEV).double().t()) / 8).to(torch.bfloat16)
+    a, b = _both(lambda: hip.gemm(R, S, alpha=0.125))
+    assert torch.equal(a, ref)
+    assert torch.equal(b, ref), f"{(b.float() - ref.float()).abs().max().item()}"
+
+
+@pytest.mark.parametrize("K2", [16, 32, 48, 64])
+def test_persistent_second_k_range(K2):
+    """The LoRA term t B^T as one more K tile of the stream; k chunks beyond K2 come from the zero word, so the row
+    strides of t / B stay K2 (no padded copies)."""
+    M, N, K = 8192, 4096, 512
+    Rm, Sm = _ints((M, K), seed=41), _ints((N, K), seed=42)
+    R2m, S2m = _ints((M, K2), lo=-1, hi=2, seed=43), _ints((N, K2), lo=-1, hi=2, seed=44)
+    R, S, R2, S2 = _bf(Rm), _bf(Sm), _bf(R2m), _bf(S2m)
+    ref = ((Rm.to(DEV).double() @ Sm.to(DEV).double().t() + R2m.to(DEV).double() @ S2m.to(DEV).double().t()) / 16).to(torch.bfloat16)
+    a, b = _both(lambda: hip.gemm(R, S, R2=R2, S2=S2, alpha=1.0 / 16))
+    assert torch.equal(a, ref)
+    assert torch.equal(b, ref)
+    # views with a wider row stride (the merged q|k|v launch reads t [M, 48] and a block-diagonal B [N, 48])
+    R2w, S2w = _randn((M, 80), 45), _randn((N, 80), 46, 0.1)
+    Rr, Sr = _randn((M, K), 47), _randn((N, K), 48, 0.05)
+    a, b = _both(lambda: hip.gemm(Rr, Sr, R2=R2w[:, 8:8 + K2], S2=S2w[:, 16:16 + K2]))
+    assert torch.equal(a, b)
+
+
+def test_persistent_bias_and_residual_identical():
+    M, N, K = 8192, 4096, 384
+    R, S = _randn((M, K), 51), _randn((N, K), 52, 0.05)
+    res = _randn((M, N), 53)
+    bias = torch.randn(N, device=DEV)
+    t, Bm = _randn((M, 16), 54), _randn((N, 16), 55, 0.1)
+    for kw in (dict(residual=res), dict(bias=bias), dict(bias=bias, residual=res, alpha=0.5), dict(residual=res, R2=t, S2=Bm)):
+        a, b = _both(lambda: hip.gemm(R, S, **kw))
+        assert torch.equal(a, b), str(list(kw))
+    ref = (R.float() @ S.float().t() + res.float())
+    a, b = _both(lambda: hip.gemm(R, S, residual=res))
+    assert (b.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("nad", [1, 2, 3])
+def test_persistent_masked_lora_epilogue_identical(nad):
+    """dX under LoRA dropout: dy W + sum_a keep_a / (1 - p) * (tb_a A_a)."""
+    M, N, K, r, p = 8192, 4096, 512, 16, 0.1
+    dy, Wt = _randn((M, K), 61), _randn((N, K), 62, 0.05)
+    tb, At = _randn((M, nad * r), 63), _randn((N, nad * r), 64, 0.1)
+    bits = hip.lora_dropout_bits(7, p, M, N, nad, DEV)
+    a, b = _both(lambda: hip.gemm(dy, Wt, R2=tb, S2=At, drop=(bits, p, r)))
+    assert torch.equal(a, b)
+    plain = hip.gemm(dy, Wt)
+    assert not torch.equal(a, plain)
+
+
+@pytest.mark.parametrize("drop", [False, True])
+def test_persistent_swiglu_backward_epilogue_identical(drop):
+    M, I, K, r, p = 8192, 4096, 256, 16, 0.1
+    dy, Wt = _randn((M, K), 71), _randn((I, K), 72, 0.05)
+    gu = _randn((M, 2 * I), 73)
+    tb, At = _randn((M, r), 74), _randn((I, r), 75, 0.1)
+    bits = hip.lora_dropout_bits(9, p, M, I, 1, DEV) if drop else None
+
+    def run():
+        dgu = torch.empty_like(gu)
+        hip.gemm(dy, Wt, R2=tb, S2=At, drop=(bits, p, r) if drop else None, swiglu_bwd=(gu, dgu))
+        return dgu
+    a, b = _both(run)
+    assert torch.equal(a, b)
+
+
+def test_persistent_stream_stress_exact():
+    """The K stream crosses output tiles under counted vmcnt waits with epilogue stores in the queue: exact integer
+    results, repeated under memory load from a second stream (a scheduling bug shows up as rare wrong tiles)."""
+    M, N, K = 16384, 8192, 1024
+    Rm, Sm = _ints((M, K), seed=81), _ints((N, K), seed=82)
+    R, S = _bf(Rm), _bf(Sm)
+    ref = ((Rm.to(DEV).double() @ Sm.to(DEV).double().t()) / 32).to(torch.bfloat16)
+    big = torch.randn(64 * 1024 * 1024, device=DEV)
+    s2 = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    prev = hip.gemm_persistent_mode(1)
+    try:
+        for it in range(6):
+            with torch.cuda.stream(s2):
+                big.mul_(1.0001)
+            out = hip.gemm(R, S, alpha=1.0 / 32)
+            assert torch.equal(out, ref), f"iteration {it}: {(out.float() - ref.float()).abs().max().item()}"
+        torch.cuda.synchronize()
+    finally:
+        hip.gemm_persistent_mode(prev)

@@ -71,6 +71,7 @@ SIGNATURES = {
     "ur_last_error": (ctypes.c_char_p, []),
     "ur_gemm_workspace_bytes": (c_i64, [ctypes.POINTER(GemmArgs)]),
     "ur_gemm": (c_int, [ctypes.POINTER(GemmArgs), c_void_p, c_i64, c_void_p]),
+    "ur_gemm_persistent_mode": (c_int, [c_int]),
     "ur_lora_bits_ld": (c_i64, [c_int]),
     "ur_lora_dropout_bits": (c_int, [c_u64, c_float, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_i64, c_void_p]),
     "ur_lora_project": (c_int, [ctypes.POINTER(LoraArgs), c_void_p]),

@@ -24,6 +24,10 @@
 #include <type_traits>
 #include "common.cuh"
 #include "unirec_hip.h"
+#include "gemm_common.cuh"
+
+using urgemm::GemmP;
+using urgemm::uniform_ptr;
 
 namespace {
 
@@ -59,30 +63,6 @@ template <int T> struct Tile {
   static constexpr int KS_ROWB = T * 2;
   static constexpr int KS_BYTES = BK * KS_ROWB;
 };
-struct GemmP {
-  const bf16_t* R; const bf16_t* S; long ldr, lds; int K;
-  const bf16_t* R2; const bf16_t* S2; long ldr2, lds2; int K2;
-  void* C; long ldc; int M, N; float alpha;
-  const float* bias; const bf16_t* res; long ldres;
-  bf16_t* gelu_out; long ldg; const bf16_t* aux; long ldaux;
-  int ksplit_len; long slab_stride;
-  int gm, gn;
-  int gcw;    // column-chunk width (tiles) of the per-XCD tile order; 0 = plain row-major runs
-  int stagger;   // cycles between the start groups of the launch's first wave of workgroups (0 = all start together)
-  // LoRA dropout (ur_gemm_args.drop_*): masked rank-r LoRA epilogue driven by the adapters' dropped-flag bit planes
-  const uint8_t* drop_bits; long drop_bits_ld, drop_bits_stride; int drop_rank; float drop_inv_keep;
-  // SwiGLU backward epilogue (ur_gemm_args.swiglu_*): the result is d(act); dgate / dup leave instead of C
-  // (forward epilogue, sw_mode 2: sw_gu = gate, sw_dgu = act)
-  const bf16_t* sw_gu; long sw_ldgu; bf16_t* sw_dgu; long sw_lddgu; int sw_I; int sw_mode;
-};
-
-__device__ __forceinline__ const char* uniform_ptr(const char* p) {
-  const uint64_t v = reinterpret_cast<uint64_t>(p);
-  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  asm volatile("" : "+s"(lo), "+s"(hi));     // opaque SGPR pair: keeps loop strength reduction from turning
-                                             // (uniform base + lane offset) into per-lane 64-bit pointers
-  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
-}
 __device__ __forceinline__ int ks_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 __device__ __forceinline__ int kc_g(int r) { return (r >> 1) & 7; }
 
@@ -910,6 +890,7 @@ template <bool RK, bool SK, bool OUTF32>
 int launch(const GemmP& p, int splits, hipStream_t st) {
   const long big_wgs = (long)ur_cdiv(p.M, 256) * ur_cdiv(p.N, 256) * splits;
   if constexpr (RK && SK && !OUTF32) {
+    if (urgemm::gemm_pers_eligible(p, splits, RK, SK, OUTF32)) return urgemm::gemm_pers_launch(p, st);    // gemm_pers.hip
     if (p.sw_gu && p.sw_mode == 1) {       // SwiGLU backward epilogue: K-contiguous bf16 launches only (ur_gemm checks)
       if (p.M >= 256 && p.N >= 256 && big_wgs >= 256) return launch_cfg<true, true, false, 256, 256, 2, 4, 1>(p, splits, st);
       return launch_cfg<true, true, false, 128, 128, 2, 2, 1>(p, splits, st);

@@ -1,0 +1,484 @@
+// Persistent 256x256 bf16 projection GEMM for gfx950: the K-contiguous forward / frozen-weight dX launches of the Qwen3 decoder
+// (C = R S^T: R = activations [M,K], S = nn.Linear weight [N,K]; replaces nn.Linear at modeling_qwen3.py:81-83,227-238).
+//
+// Why a second kernel: gemm.hip's 256x256 kernel pays a fixed ~11.6 us per output tile (first-DMA latency, LDS-staged epilogue,
+// the gap between a workgroup's exit and its successor's entry on the CU) -- a third of a tile's life at K = 1024.  Here ONE
+// workgroup per CU walks its output tiles and the LDS-DMA ring never drains:
+//   * the K tiles of ALL of a workgroup's output tiles form one stream; K tile q+2 (which may belong to the NEXT output tile)
+//     is issued while K tile q is consumed, exactly as inside a tile, so a new tile starts with its first two K tiles landed;
+//   * the epilogue runs from the accumulator registers with no LDS staging and no barrier: v_permlane16_swap turns the MFMA
+//     layout (4 consecutive columns per lane) into 8 consecutive columns per lane = one 16-byte store per lane and 16x16
+//     sub-tile pair, 16 rows x 64 contiguous bytes per store instruction; stores stay in flight under the next tile's K loop;
+//   * the first K tile of a tile multiplies into a zero C operand (no accumulator clearing);
+//   * the LoRA second K range (t B^T, K2 <= 64) is one more K tile of the stream: lanes whose k chunk lies beyond K2 fetch
+//     from a 16-byte zero word, so no padded copies of t / B are needed.
+// The steady state is gemm.hip's 8-phase ping-pong (two wave groups one barrier interval apart, half tiles refilled one phase
+// after their last read, counted vmcnt), see the comments there; the hazards below refer to it.
+// Scope: M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 256, bf16 output, epilogues: plain, bias, residual, masked LoRA
+// (dropout), SwiGLU backward.  Everything else stays on gemm.hip.
+#include <atomic>
+#include <cstdlib>
+#include <type_traits>
+#include "gemm_common.cuh"
+#include "unirec_hip.h"
+
+namespace {
+using urgemm::GemmP;
+using urgemm::uniform_ptr;
+
+constexpr int BK = 64, BM = 256, BN = 256;
+constexpr int S_BYTES = BN * 128, R_BYTES = BM * 128, STAGE = S_BYTES + R_BYTES;      // one ring slot = 64 KiB
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4];                         // zero-initialised: source of k chunks beyond K2
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ char* uniform_wptr(char* p) { return const_cast<char*>(uniform_ptr(p)); }
+
+// XCD-aware tile order of gemm.hip, as a function of the (virtual) block id: ids equal mod 8 share an XCD
+// n / d for n * d < 2^32 by one scalar multiply-high: magic = ceil(2^32 / d) (host, TileOrder)
+struct TileOrder { int nwg, gn, gcw, rows_x, per; uint32_t m_gn, m_per, m_gcw; };
+__device__ __forceinline__ int fdiv(int n, uint32_t magic) { return (int)__umulhi((uint32_t)n, magic); }
+__device__ __forceinline__ void tile_coords(const TileOrder& o, int vid, int& bm, int& bn) {
+  const int q = o.nwg >> 3, r = o.nwg & 7, x = vid & 7;
+  const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (vid >> 3);
+  if (o.gcw > 0) {
+    const int j = id - x * q;                        // gm % 8 == 0: every XCD owns rows_x whole tile rows (r == 0)
+    const int ch = fdiv(j, o.m_per), rem = j - ch * o.per;
+    const int rr = fdiv(rem, o.m_gcw);
+    bm = x * o.rows_x + rr;
+    bn = ch * o.gcw + (rem - rr * o.gcw);
+  } else {
+    bm = fdiv(id, o.m_gn); bn = id - bm * o.gn;
+  }
+}
+
+// two lanes 16 apart exchange halves: afterwards (a, b) of a lane in 16-lane row rho hold 2 x 4 CONSECUTIVE columns
+//   a' = [a.row0, b.row0, a.row2, b.row2], b' = [a.row1, b.row1, a.row3, b.row3]
+__device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
+  const u32x2_t r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+  a = r[0]; b = r[1];
+}
+__device__ __forceinline__ void swap16f(float& a, float& b) {
+  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+  swap16(ua, ub);
+  a = __uint_as_float(ua); b = __uint_as_float(ub);
+}
+
+// EPI: 0 = plain (alpha only), 2 = bias / residual, 1 = SwiGLU backward (result is d(act); dgate | dup leave instead of C).
+// MODE: 0 = no second K range, 1 = the LoRA second K range rides in the K stream (one zero-padded K tile per output tile),
+//       2 = masked rank-16 LoRA epilogue (dX under LoRA dropout; the second operand pair is read by the epilogue only).
+template <int EPI, int MODE>
+__global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder ord, int ntiles) {
+  constexpr bool DROP = MODE == 2, K2S = MODE == 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = uwave >> 2, wc = uwave & 3;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  // fragment reads: lane holds [row = 16 i + l15][k = 32 h + 8 g4 .. + 7], 16-byte chunk c of row r stored at chunk c ^ ((r >> 1) & 7)
+  const uint32_t lo0 = l15 * 128 + (((g4) ^ ((l15 >> 1) & 7)) << 4), lo1 = l15 * 128 + (((4 + g4) ^ ((l15 >> 1) & 7)) << 4);
+  // LDS-DMA: wave instruction `inst` = li * 8 + wave moves rows inst * 8 .. + 7 of an operand tile (128 B each); this lane
+  // fetches row (lane >> 3) of them, k chunk kch (the swizzle lives on the source address)
+  const int kch = (lane & 7) ^ (((lane >> 4) + 4 * (uwave & 1)) & 7);
+  const uint32_t vo_s = (uint32_t)((lane >> 3) * p.lds * 2 + kch * 16), vo_r = (uint32_t)((lane >> 3) * p.ldr * 2 + kch * 16);
+  const int nk1 = p.K / BK;                                // >= 4 (host)
+  const int nkt = nk1 + (K2S ? 1 : 0);
+  const int gstride = gridDim.x;
+
+  // ---- producer: where the K tile that is fetched next comes from (scalars + one lane offset per operand) ----
+  int vid = blockIdx.x, m0, n0;                            // current output tile
+  { int bm, bn; tile_coords(ord, vid, bm, bn); m0 = bm * BM; n0 = bn * BN; }
+  int tiles_left = (ntiles - (int)blockIdx.x + gstride - 1) / gstride;      // >= 1: the grid never exceeds ntiles
+  auto s_base = [&](int n) { return reinterpret_cast<const char*>(p.S + (long)(n + uwave * 8) * p.lds); };
+  auto r_base = [&](int m) { return reinterpret_cast<const char*>(p.R + (long)(m + uwave * 8) * p.ldr); };
+  const char* ubs = uniform_ptr(s_base(n0));               // K tile being fetched: uniform bases of this wave's first piece
+  const char* ubr = uniform_ptr(r_base(m0));
+  const long sp_main = 64 * p.lds * 2, rp_main = 64 * p.ldr * 2;            // bytes between the wave's pieces (64 rows)
+  // the two LDS-DMA pieces of this wave for half `hf` (rows 128 hf ..) of the S or R tile at (ubs, ubr)
+  auto dma_half = [&](char* slot, auto is_s, int hf, auto zc) {
+    constexpr bool IS_S = decltype(is_s)::value, Z = decltype(zc)::value;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int li = 2 * hf + d;
+      char* dst = slot + (IS_S ? 0 : S_BYTES) + (li * 8 + uwave) * 1024;
+      if constexpr (!Z) {
+        const char* src = (IS_S ? ubs + li * sp_main : ubr + li * rp_main) + (IS_S ? vo_s : vo_r);
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+      } else {
+        // the K2 tile: rows of lds2 / ldr2 elements, k chunks at or beyond K2 come from the zero word
+        const long ld2 = IS_S ? p.lds2 : p.ldr2;
+        const char* src = (IS_S ? ubs : ubr) + (long)(li * 64) * ld2 * 2 + (uint32_t)((lane >> 3) * ld2 * 2 + kch * 16);
+        src = (kch * 8 < p.K2) ? src : reinterpret_cast<const char*>(g_zero16);
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- consumer ----
+  f32x4 acc[4][8];                       // [2 sh + ii][4 rh + jj]: columns sh*128 + wc*32 + ii*16 .., rows rh*128 + wr*64 + jj*16 ..
+  bf16x8 R0[4][2], R1[4][2], S0[2][2], S1[2][2];
+  auto rdR = [&](bf16x8 (&F)[4][2], const char* slot, int rh) {
+    const char* b = slot + S_BYTES + (rh * 128 + wr * 64) * 128;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      F[jj][0] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + lo0);
+      F[jj][1] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + lo1);
+    }
+  };
+  auto rdS = [&](bf16x8 (&F)[2][2], const char* slot, int sh) {
+    const char* b = slot + (sh * 128 + wc * 32) * 128;
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      F[ii][0] = *reinterpret_cast<const bf16x8*>(b + ii * 2048 + lo0);
+      F[ii][1] = *reinterpret_cast<const bf16x8*>(b + ii * 2048 + lo1);
+    }
+  };
+  auto quad = [&](const bf16x8 (&S)[2][2], const bf16x8 (&R)[4][2], auto shc, auto rhc, auto firstc) {
+    constexpr int sh = decltype(shc)::value, rh = decltype(rhc)::value;
+    constexpr bool FIRST = decltype(firstc)::value;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          f32x4& a = acc[2 * sh + ii][4 * rh + jj];
+          if (FIRST && h == 0) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S[ii][h], R[jj][h], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          else a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(S[ii][h], R[jj][h], a, 0, 0, 0);
+        }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto mat_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const std::integral_constant<int, 0> c0;
+  const std::integral_constant<int, 1> c1;
+  // One K tile = 4 phases (gemm.hip).  VM = the counted wait of a load segment: 12 = the two pieces of each of the six phases
+  // issued after the half tile that the NEXT phase reads; in the first K tile after an epilogue the epilogue's >= 16 stores
+  // (issued after the pieces of the previous K tile, before this one's) sit in the queue as well: 28.
+  auto ktile = [&](char* slot, const char* nslot, auto firstc, auto vmc, auto zc) {
+    constexpr int VM = decltype(vmc)::value;
+    auto seg_end = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VM) : "memory");
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // phase 1
+    rdS(S0, slot, 0);
+    dma_half(slot, std::false_type{}, 0, zc);
+    seg_end();
+    quad(S0, R0, c0, c0, firstc);
+    mat_end();
+    // phase 2
+    rdS(S1, slot, 1);
+    dma_half(slot, std::true_type{}, 0, zc);
+    seg_end();
+    quad(S1, R0, c1, c0, firstc);
+    mat_end();
+    // phase 3
+    rdR(R1, slot, 1);
+    dma_half(slot, std::true_type{}, 1, zc);
+    seg_end();
+    quad(S1, R1, c1, c1, firstc);
+    mat_end();
+    // phase 4
+    rdR(R0, nslot, 0);
+    dma_half(slot, std::false_type{}, 1, zc);
+    seg_end();
+    quad(S0, R1, c0, c1, firstc);
+    mat_end();
+  };
+
+  // prologue: the first two K tiles in consumption order R0 S0 S1 R1 (the loop's issue order shifted back 8 phases)
+#pragma unroll 1
+  for (int tt = 0; tt < 2; ++tt) {
+    char* slot = smem + tt * STAGE;
+    dma_half(slot, std::false_type{}, 0, std::false_type{}); __builtin_amdgcn_sched_barrier(0);
+    dma_half(slot, std::true_type{}, 0, std::false_type{});  __builtin_amdgcn_sched_barrier(0);
+    dma_half(slot, std::true_type{}, 1, std::false_type{});  __builtin_amdgcn_sched_barrier(0);
+    dma_half(slot, std::false_type{}, 1, std::false_type{}); __builtin_amdgcn_sched_barrier(0);
+    ubs = uniform_ptr(ubs + BK * 2); ubr = uniform_ptr(ubr + BK * 2);
+  }
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");       // R half 0 and S half 0 of K tile 0 have landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  rdR(R0, smem, 0);
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();               // stagger: this group now runs one barrier interval behind
+  __builtin_amdgcn_sched_barrier(0);
+
+  int q = 0;                                               // K tiles consumed so far: K tile q lives in ring slot q & 1
+  bool first_tile = true;
+  // consumer K tile kt fetches K tile kt + 2 of the stream: the main K tiles of this output tile up to kt = nk1 - 3, then
+  // (MODE 1) its K2 tile, then K tiles 0 and 1 of the NEXT output tile (past the last one: of this one again, never consumed)
+  const int sw = nkt - 2;
+#pragma unroll 1
+  for (;;) {
+    int nm0 = m0, nn0 = n0;
+    if (tiles_left > 1) {
+      vid += gstride;
+      int bm, bn; tile_coords(ord, vid, bm, bn); nm0 = bm * BM; nn0 = bn * BN;
+    }
+    {
+      char* slot = smem + (q & 1) * STAGE;
+      const char* nslot = smem + ((q + 1) & 1) * STAGE;
+      if (first_tile) ktile(slot, nslot, std::true_type{}, std::integral_constant<int, 12>{}, std::false_type{});
+      else ktile(slot, nslot, std::true_type{}, std::integral_constant<int, 28>{}, std::false_type{});
+      ++q;
+      first_tile = false;
+    }
+    if constexpr (!K2S) {
+#pragma unroll 1
+      for (int kt = 1; kt < nkt; ++kt, ++q) {
+        char* slot = smem + (q & 1) * STAGE;
+        const char* nslot = smem + ((q + 1) & 1) * STAGE;
+        if (kt == sw) { ubs = uniform_ptr(s_base(nn0)); ubr = uniform_ptr(r_base(nm0)); }
+        else { ubs = uniform_ptr(ubs + BK * 2); ubr = uniform_ptr(ubr + BK * 2); }
+        ktile(slot, nslot, std::false_type{}, std::integral_constant<int, 12>{}, std::false_type{});
+      }
+    } else {
+      // (two different K tile bodies inside ONE loop make hipcc spill hundreds of registers: straight-line sequence instead)
+#pragma unroll 1
+      for (int kt = 1; kt < nk1 - 2; ++kt, ++q) {
+        char* slot = smem + (q & 1) * STAGE;
+        const char* nslot = smem + ((q + 1) & 1) * STAGE;
+        ubs = uniform_ptr(ubs + BK * 2); ubr = uniform_ptr(ubr + BK * 2);
+        ktile(slot, nslot, std::false_type{}, std::integral_constant<int, 12>{}, std::false_type{});
+      }
+      {
+        char* slot = smem + (q & 1) * STAGE;
+        const char* nslot = smem + ((q + 1) & 1) * STAGE;
+        ubs = uniform_ptr(reinterpret_cast<const char*>(p.S2 + (long)(n0 + uwave * 8) * p.lds2));
+        ubr = uniform_ptr(reinterpret_cast<const char*>(p.R2 + (long)(m0 + uwave * 8) * p.ldr2));
+        ktile(slot, nslot, std::false_type{}, std::integral_constant<int, 12>{}, std::true_type{});
+        ++q;
+      }
+      ubs = uniform_ptr(s_base(nn0)); ubr = uniform_ptr(r_base(nm0));
+#pragma unroll 1
+      for (int kt = 0; kt < 2; ++kt, ++q) {
+        char* slot = smem + (q & 1) * STAGE;
+        const char* nslot = smem + ((q + 1) & 1) * STAGE;
+        ktile(slot, nslot, std::false_type{}, std::integral_constant<int, 12>{}, std::false_type{});
+        ubs = uniform_ptr(ubs + BK * 2); ubr = uniform_ptr(ubr + BK * 2);
+      }
+    }
+    // the next tile's first K tile fetches ITS K tile 2
+    ubs = uniform_ptr(s_base(nn0) + 2 * BK * 2); ubr = uniform_ptr(r_base(nm0) + 2 * BK * 2);
+    // ================= epilogue, from the accumulators (no LDS, no barrier) =================
+    // lane: rows m0 + rh*128 + wr*64 + jj*16 + l15; MFMA layout columns n0 + sh*128 + wc*32 + ii*16 + g4*4 + 0..3
+    if constexpr (DROP) {
+      // C(m,n) += sum_a keep_a(m,n)/(1-p) * tb_a(m,:) . A_a(:,n): one rank-r MFMA per adapter and 16x16 sub-tile into a scratch
+      // accumulator; keep flags from the adapters' dropped-flag bit planes (lora.hip: pair-interleaved byte order)
+      // (rank 16 exactly: v_mfma_f32_16x16x16_bf16, lane holds k = 4 g4 .. + 3 of its row -- half the fragment registers of the
+      // zero-padded 16x16x32 form, which matters here: R0 of the next tile stays live across the epilogue)
+      const int nad = p.K2 >> 4, kq = 4 * g4;
+      // every address = uniform base (scalar registers) + ONE 32-bit lane offset per tensor
+      const uint32_t lo_s2 = (uint32_t)((l15 * p.lds2 + kq) * 2), lo_r2 = (uint32_t)((l15 * p.ldr2 + kq) * 2), lo_fl = (uint32_t)(l15 * p.drop_bits_ld);
+      for (int a = 0; a < nad; ++a) {
+        bf16x4 s2[4], r2[8];
+        uint2 fl[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const char* ub = uniform_ptr(reinterpret_cast<const char*>(p.S2 + (long)(n0 + (i >> 1) * 128 + wc * 32 + (i & 1) * 16) * p.lds2 + a * 16));
+          s2[i] = *reinterpret_cast<const bf16x4*>(ub + lo_s2);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const long mb = m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16;
+          const char* ub = uniform_ptr(reinterpret_cast<const char*>(p.R2 + mb * p.ldr2 + a * 16));
+          r2[j] = *reinterpret_cast<const bf16x4*>(ub + lo_r2);
+          const char* fb = uniform_ptr(reinterpret_cast<const char*>(p.drop_bits + (long)a * p.drop_bits_stride + mb * p.drop_bits_ld + ((n0 + wc * 32) >> 3)));
+          fl[j] = make_uint2(*reinterpret_cast<const uint32_t*>(fb + lo_fl), *reinterpret_cast<const uint32_t*>(fb + lo_fl + 16));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s2[i], r2[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const uint32_t wsel = (i >= 2) ? fl[j].y : fl[j].x;
+            const uint32_t f = (wsel >> (16 * (i & 1) + 8 * (g4 >> 1) + 2 * (g4 & 1))) & 0x33u;
+            f32x4& c = acc[i][j];
+            if (!(f & 0x01u)) c[0] += d[0] * p.drop_inv_keep;
+            if (!(f & 0x10u)) c[1] += d[1] * p.drop_inv_keep;
+            if (!(f & 0x02u)) c[2] += d[2] * p.drop_inv_keep;
+            if (!(f & 0x20u)) c[3] += d[3] * p.drop_inv_keep;
+          }
+      }
+    }
+    {
+      // after the 16-lane swap a lane holds 8 consecutive columns of row m: cs = (g4 & 1) * 16 + (g4 >> 1) * 8 within the wave's 32
+      const int cs = (g4 & 1) * 16 + (g4 >> 1) * 8;
+      const float alpha = p.alpha;
+      if constexpr (EPI == 0) {
+        const uint32_t loff = (uint32_t)((l15 * p.ldc + cs) * 2);
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
+            uint32_t a0 = pack_bf2(a[0] * alpha, a[1] * alpha), a1 = pack_bf2(a[2] * alpha, a[3] * alpha);
+            uint32_t b0 = pack_bf2(b[0] * alpha, b[1] * alpha), b1 = pack_bf2(b[2] * alpha, b[3] * alpha);
+            swap16(a0, b0); swap16(a1, b1);
+            char* base = uniform_wptr(reinterpret_cast<char*>(p.C) +
+                                      ((long)(m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16) * p.ldc + n0 + sh * 128 + wc * 32) * 2);
+            const u32x4_t v = {a0, a1, b0, b1};
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(base + loff));
+          }
+      } else {
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+          const int ncol = n0 + sh * 128 + wc * 32 + cs;
+          float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (p.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ncol), b1 = *reinterpret_cast<const float4*>(p.bias + ncol + 4);
+            bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
+          }
+#pragma unroll
+          for (int rh = 0; rh < 2; ++rh) {
+            // four rows' worth of residual / gate / up pieces go out together (one wait instead of one per row)
+            uint4 rw[4], gw[4], uw[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const long m = m0 + rh * 128 + wr * 64 + jj * 16 + l15;
+              if (EPI == 2 && p.res) rw[jj] = *reinterpret_cast<const uint4*>(p.res + m * p.ldres + ncol);
+              if (EPI == 1) {
+                gw[jj] = *reinterpret_cast<const uint4*>(p.sw_gu + m * p.sw_ldgu + ncol);
+                uw[jj] = *reinterpret_cast<const uint4*>(p.sw_gu + m * p.sw_ldgu + p.sw_I + ncol);
+              }
+            }
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const long m = m0 + rh * 128 + wr * 64 + jj * 16 + l15;
+              f32x4 a = acc[2 * sh][4 * rh + jj], b = acc[2 * sh + 1][4 * rh + jj];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { float x = a[e], y = b[e]; swap16f(x, y); a[e] = x; b[e] = y; }
+              float v[8] = {a[0] * alpha + bs[0], a[1] * alpha + bs[1], a[2] * alpha + bs[2], a[3] * alpha + bs[3],
+                            b[0] * alpha + bs[4], b[1] * alpha + bs[5], b[2] * alpha + bs[6], b[3] * alpha + bs[7]};
+              if (EPI == 2) {
+                if (p.res) {
+                  const uint32_t w[4] = {rw[jj].x, rw[jj].y, rw[jj].z, rw[jj].w};
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
+                }
+                const u32x4_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + ncol) = o;
+              } else {
+                // d(act) = v (f32, unrounded): dgate = v u silu'(g), dup = v silu(g)   (elementwise.hip: swiglu_bwd_kernel)
+                const uint32_t gq[4] = {gw[jj].x, gw[jj].y, gw[jj].z, gw[jj].w}, uq[4] = {uw[jj].x, uw[jj].y, uw[jj].z, uw[jj].w};
+                uint32_t og[4], ou[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float dgv[2], duv[2];
+#pragma unroll
+                  for (int hh = 0; hh < 2; ++hh) {
+                    const float gg = hh ? bf_hi(gq[e]) : bf_lo(gq[e]), uu = hh ? bf_hi(uq[e]) : bf_lo(uq[e]);
+                    const float d = v[2 * e + hh];
+                    const float sg = 1.0f / (1.0f + __expf(-gg));
+                    duv[hh] = d * (gg * sg);
+                    dgv[hh] = d * uu * (sg * (1.0f + gg * (1.0f - sg)));
+                  }
+                  og[e] = pack_bf2(dgv[0], dgv[1]); ou[e] = pack_bf2(duv[0], duv[1]);
+                }
+                const u32x4_t vg = {og[0], og[1], og[2], og[3]}, vu = {ou[0], ou[1], ou[2], ou[3]};
+                *reinterpret_cast<u32x4_t*>(p.sw_dgu + m * p.sw_lddgu + ncol) = vg;
+                *reinterpret_cast<u32x4_t*>(p.sw_dgu + m * p.sw_lddgu + p.sw_I + ncol) = vu;
+              }
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tiles_left -= 1;
+    if (tiles_left == 0) break;
+    m0 = nm0; n0 = nn0;
+  }
+  // drain: re-join the wave groups, let the never-consumed tail of the stream land before the workgroup's LDS is released
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int EPI, int MODE>
+int launch_pers(const GemmP& p, hipStream_t st) {
+  static std::atomic<bool> attr_set{false};
+  constexpr int SMEM = 2 * STAGE;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<EPI, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) UR_FAIL((int)e, "ur_gemm(persistent): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  static const int ncu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; }
+    n -= n % 8;                    // ids equal mod 8 share an XCD: the stride of the tile walk must keep that
+    return n > 0 ? n : 8;
+  }();
+  const int ntiles = p.gm * p.gn;
+  const int grid = ntiles < ncu ? ntiles : ncu;
+  auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
+  TileOrder o;
+  o.nwg = ntiles; o.gn = p.gn; o.gcw = p.gcw;
+  o.rows_x = (ntiles >> 3) / p.gn; o.per = o.rows_x * (p.gcw > 0 ? p.gcw : 1);
+  o.m_gn = magic(p.gn); o.m_per = magic(o.per > 0 ? o.per : 1); o.m_gcw = magic(p.gcw > 0 ? p.gcw : 1);
+  hipLaunchKernelGGL((gemm_pers_kernel<EPI, MODE>), dim3(grid), dim3(512), SMEM, st, p, o, ntiles);
+  UR_CHECK_LAUNCH("ur_gemm(persistent)");
+  return 0;
+}
+
+}  // namespace
+
+namespace urgemm {
+
+static std::atomic<int> g_pers_mode{-1};     // -1 = not set: UR_GEMM_PERSISTENT (default 1); 0 = generic kernel only (A/B runs, bit-identity tests)
+
+bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf32) {
+  static const int env_mode = [] { const char* e = getenv("UR_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
+  const int set = g_pers_mode.load(std::memory_order_relaxed);
+  const int mode = set >= 0 ? set : env_mode;
+  if (!mode || !rk || !sk || outf32 || splits > 1) return false;
+  if ((p.M % BM) || (p.N % BN) || (p.K % BK) || p.K < 4 * BK) return false;
+  if ((long)(p.M / BM) * (p.N / BN) < 512) return false;                       // at least two tiles per CU
+  if ((long)(p.M / BM) * (p.N / BN) >= (1L << 20) || p.N / BN >= (1 << 12) || p.M / BM >= (1 << 15)) return false;      // fdiv: n * d < 2^32
+  if (p.gelu_out || p.aux || p.sw_mode == 2) return false;
+  if (p.K2 > 0 && !p.drop_bits && p.K2 > BK) return false;
+  if (p.sw_mode == 1 && (p.bias || p.res)) return false;
+  // 16-byte pieces everywhere
+  if ((p.ldc & 7) || (reinterpret_cast<uintptr_t>(p.C) & 15)) return false;
+  if (p.res && ((p.ldres & 7) || (reinterpret_cast<uintptr_t>(p.res) & 15))) return false;
+  if (p.sw_mode == 1 && ((p.sw_ldgu & 7) || (p.sw_lddgu & 7) || (p.sw_I & 7) || (reinterpret_cast<uintptr_t>(p.sw_gu) & 15) ||
+                         (reinterpret_cast<uintptr_t>(p.sw_dgu) & 15))) return false;
+  // 32-bit lane offsets
+  if (p.lds * 16 >= (1L << 31) || p.ldr * 16 >= (1L << 31) || p.ldc * 32 >= (1L << 31)) return false;
+  return true;
+}
+
+int gemm_pers_launch(GemmP p, hipStream_t st) {
+  p.gm = p.M / BM; p.gn = p.N / BN;
+  p.gcw = 0;
+  if (p.gn >= 16 && (p.gm % 8) == 0 && p.gn > 4 && (p.gn % 4) == 0) p.gcw = 4;     // column chunks on wide launches (gemm.hip)
+  const bool drop = p.drop_bits != nullptr && p.K2 > 0;
+  const int mode = drop ? 2 : (p.K2 > 0 ? 1 : 0);
+  const int epi = p.sw_mode == 1 ? 1 : ((p.res || p.bias) ? 2 : 0);
+#define UR_PERS_CASE(E, MD) if (epi == E && mode == MD) return launch_pers<E, MD>(p, st)
+  UR_PERS_CASE(0, 0); UR_PERS_CASE(0, 1); UR_PERS_CASE(0, 2);
+  UR_PERS_CASE(1, 0); UR_PERS_CASE(1, 1); UR_PERS_CASE(1, 2);
+  UR_PERS_CASE(2, 0); UR_PERS_CASE(2, 1); UR_PERS_CASE(2, 2);
+#undef UR_PERS_CASE
+  UR_FAIL(-1, "ur_gemm(persistent): no kernel for epilogue %d, mode %d", epi, mode);
+}
+
+}  // namespace urgemm
+
+extern "C" int ur_gemm_persistent_mode(int mode) {
+  const int prev = urgemm::g_pers_mode.exchange(mode < 0 ? -1 : (mode ? 1 : 0));
+  return prev;
+}

@@ -126,6 +126,12 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
     return out
 
 
+def gemm_persistent_mode(mode):
+    """0 = generic GEMM kernel only, 1 = persistent kernel where eligible, -1 = default; returns the previous setting
+    (ur_gemm_persistent_mode, include/unirec_hip.h)."""
+    return int(_lib.load().ur_gemm_persistent_mode(int(mode)))
+
+
 # ---- LoRA adapter products (rank 16): include/unirec_hip.h, csrc/lora.hip ---------------------------
 def lora_bits_ld(W):
     return int(_lib.load().ur_lora_bits_ld(int(W)))
