@@ -26,6 +26,21 @@ namespace {
 using urgemm::GemmP;
 using urgemm::uniform_ptr;
 
+#ifndef UR_PERS_ABLATE
+#define UR_PERS_ABLATE 0          // lab builds only (WRONG results): 1 = epilogue without its stores, 2 = no epilogue, 3 = vmcnt(12) in every K tile, 4 = plain (not non-temporal) stores
+#endif
+#ifndef UR_PERS_JOIN
+#define UR_PERS_JOIN 0            // lab: 1 = the two wave groups re-join for EVERY epilogue (measured neutral for the plain one: the CU's store rate under load, ~17 B/clk, is the limit either way)
+#endif
+#ifndef UR_PERS_STAMPS
+#define UR_PERS_STAMPS 0          // lab builds only: n > 0 = waves 0 and 4 of every workgroup log s_memtime around their n-th output tile (ur_lab_pers_stamps)
+#endif
+#if UR_PERS_STAMPS
+__device__ long long g_pers_stamps[256 * 2 * 8];
+#define UR_PSTAMP(k) do { if (tile_ord == UR_PERS_STAMPS && lane == 0 && (uwave & 3) == 0 && blockIdx.x < 256) g_pers_stamps[(blockIdx.x * 2 + (uwave >> 2)) * 8 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define UR_PSTAMP(k) do { } while (0)
+#endif
 constexpr int BK = 64, BM = 256, BN = 256;
 constexpr int S_BYTES = BN * 128, R_BYTES = BM * 128, STAGE = S_BYTES + R_BYTES;      // one ring slot = 64 KiB
 __device__ __attribute__((aligned(16))) uint32_t g_zero16[4];                         // zero-initialised: source of k chunks beyond K2
@@ -88,6 +103,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
   const int nkt = nk1 + (K2S ? 1 : 0);
   const int gstride = gridDim.x;
 
+  // De-phase the CUs.  Every output tile takes the same time, so without this all 256 workgroups reach their epilogues together:
+  // 32 MiB of C arrive at the L2s at once (4 MiB per XCD = the whole L2), the stores drain at the HBM write rate and, vmcnt
+  // being an in-order counter, every wave's next LDS-DMA waits behind them (measured: 5 us per output tile at K = 1024, ALL of
+  // the kernel's fixed cost per tile; 0.1 us with the stores removed).  Workgroup w starts (w / 8) % 16 steps late, so the
+  // epilogues of an XCD's CUs spread over the tile period and C leaves at the launch's average rate instead.
+  if (p.stagger > 0) {
+    const long long until = (long long)__builtin_readcyclecounter() + (long long)((blockIdx.x >> 3) & 15) * p.stagger;
+    while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(8);
+  }
   // ---- producer: where the K tile that is fetched next comes from (scalars + one lane offset per operand) ----
   int vid = blockIdx.x, m0, n0;                            // current output tile
   { int bm, bn; tile_coords(ord, vid, bm, bn); m0 = bm * BM; n0 = bn * BN; }
@@ -218,11 +242,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
 
   int q = 0;                                               // K tiles consumed so far: K tile q lives in ring slot q & 1
   bool first_tile = true;
+#if UR_PERS_STAMPS
+  int tile_ord = 0;
+#endif
   // consumer K tile kt fetches K tile kt + 2 of the stream: the main K tiles of this output tile up to kt = nk1 - 3, then
   // (MODE 1) its K2 tile, then K tiles 0 and 1 of the NEXT output tile (past the last one: of this one again, never consumed)
   const int sw = nkt - 2;
 #pragma unroll 1
   for (;;) {
+#if UR_PERS_STAMPS
+    ++tile_ord;
+#endif
+    UR_PSTAMP(0);
     int nm0 = m0, nn0 = n0;
     if (tiles_left > 1) {
       vid += gstride;
@@ -232,10 +263,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
       char* slot = smem + (q & 1) * STAGE;
       const char* nslot = smem + ((q + 1) & 1) * STAGE;
       if (first_tile) ktile(slot, nslot, std::true_type{}, std::integral_constant<int, 12>{}, std::false_type{});
-      else ktile(slot, nslot, std::true_type{}, std::integral_constant<int, 28>{}, std::false_type{});
+      else ktile(slot, nslot, std::true_type{}, std::integral_constant<int, (UR_PERS_ABLATE == 3 || UR_PERS_ABLATE == 1 || UR_PERS_ABLATE == 2) ? 12 : 28>{}, std::false_type{});
       ++q;
       first_tile = false;
     }
+    UR_PSTAMP(1);
     if constexpr (!K2S) {
 #pragma unroll 1
       for (int kt = 1; kt < nkt; ++kt, ++q) {
@@ -244,6 +276,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
         if (kt == sw) { ubs = uniform_ptr(s_base(nn0)); ubr = uniform_ptr(r_base(nm0)); }
         else { ubs = uniform_ptr(ubs + BK * 2); ubr = uniform_ptr(ubr + BK * 2); }
         ktile(slot, nslot, std::false_type{}, std::integral_constant<int, 12>{}, std::false_type{});
+#if UR_PERS_STAMPS
+        if (kt <= 4) UR_PSTAMP(1 + kt);
+#endif
       }
     } else {
       // (two different K tile bodies inside ONE loop make hipcc spill hundreds of registers: straight-line sequence instead)
@@ -273,16 +308,33 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
     }
     // the next tile's first K tile fetches ITS K tile 2
     ubs = uniform_ptr(s_base(nn0) + 2 * BK * 2); ubr = uniform_ptr(r_base(nm0) + 2 * BK * 2);
+#if UR_PERS_ABLATE == 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" :: "v"(acc[i][j]));
+    if (true) { tiles_left -= 1; if (tiles_left == 0) break; m0 = nm0; n0 = nn0; continue; }
+#endif
+    // The masked LoRA epilogue is a chain of load -> wait -> MFMA -> add: one barrier interval apart the two groups would run
+    // it one after the other (each waiting at the other's barrier); re-joined they run it together.
+    constexpr bool JOIN = UR_PERS_JOIN || DROP;
+    if (JOIN && wr == 0) __builtin_amdgcn_s_barrier();
+    UR_PSTAMP(6);
     // ================= epilogue, from the accumulators (no LDS, no barrier) =================
-    // lane: rows m0 + rh*128 + wr*64 + jj*16 + l15; MFMA layout columns n0 + sh*128 + wc*32 + ii*16 + g4*4 + 0..3
+    // Lane constants of the epilogue are derived from an opaque copy of the lane id EVERY tile: hoisted out of the tile loop they
+    // would stay live across the 256-register K loop (hipcc then spills inside it, and a scratch reload's vmcnt(0) drains the DMA ring)
+    int elane = lane;
+    asm volatile("" : "+v"(elane));
+    const int el15 = elane & 15, eg4 = elane >> 4;
+    // lane: rows m0 + rh*128 + wr*64 + jj*16 + el15; MFMA layout columns n0 + sh*128 + wc*32 + ii*16 + eg4*4 + 0..3
     if constexpr (DROP) {
       // C(m,n) += sum_a keep_a(m,n)/(1-p) * tb_a(m,:) . A_a(:,n): one rank-r MFMA per adapter and 16x16 sub-tile into a scratch
       // accumulator; keep flags from the adapters' dropped-flag bit planes (lora.hip: pair-interleaved byte order)
-      // (rank 16 exactly: v_mfma_f32_16x16x16_bf16, lane holds k = 4 g4 .. + 3 of its row -- half the fragment registers of the
+      // (rank 16 exactly: v_mfma_f32_16x16x16_bf16, lane holds k = 4 eg4 .. + 3 of its row -- half the fragment registers of the
       // zero-padded 16x16x32 form, which matters here: R0 of the next tile stays live across the epilogue)
-      const int nad = p.K2 >> 4, kq = 4 * g4;
+      const int nad = p.K2 >> 4, kq = 4 * eg4;
       // every address = uniform base (scalar registers) + ONE 32-bit lane offset per tensor
-      const uint32_t lo_s2 = (uint32_t)((l15 * p.lds2 + kq) * 2), lo_r2 = (uint32_t)((l15 * p.ldr2 + kq) * 2), lo_fl = (uint32_t)(l15 * p.drop_bits_ld);
+      const uint32_t lo_s2 = (uint32_t)((el15 * p.lds2 + kq) * 2), lo_r2 = (uint32_t)((el15 * p.ldr2 + kq) * 2), lo_fl = (uint32_t)(el15 * p.drop_bits_ld);
       for (int a = 0; a < nad; ++a) {
         bf16x4 s2[4], r2[8];
         uint2 fl[8];
@@ -305,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
           for (int j = 0; j < 8; ++j) {
             const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s2[i], r2[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             const uint32_t wsel = (i >= 2) ? fl[j].y : fl[j].x;
-            const uint32_t f = (wsel >> (16 * (i & 1) + 8 * (g4 >> 1) + 2 * (g4 & 1))) & 0x33u;
+            const uint32_t f = (wsel >> (16 * (i & 1) + 8 * (eg4 >> 1) + 2 * (eg4 & 1))) & 0x33u;
             f32x4& c = acc[i][j];
             if (!(f & 0x01u)) c[0] += d[0] * p.drop_inv_keep;
             if (!(f & 0x10u)) c[1] += d[1] * p.drop_inv_keep;
@@ -315,11 +367,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
       }
     }
     {
-      // after the 16-lane swap a lane holds 8 consecutive columns of row m: cs = (g4 & 1) * 16 + (g4 >> 1) * 8 within the wave's 32
-      const int cs = (g4 & 1) * 16 + (g4 >> 1) * 8;
+      // after the 16-lane swap a lane holds 8 consecutive columns of row m: cs = (eg4 & 1) * 16 + (eg4 >> 1) * 8 within the wave's 32
+      const int cs = (eg4 & 1) * 16 + (eg4 >> 1) * 8;
       const float alpha = p.alpha;
       if constexpr (EPI == 0) {
-        const uint32_t loff = (uint32_t)((l15 * p.ldc + cs) * 2);
+        const uint32_t loff = (uint32_t)((el15 * p.ldc + cs) * 2);
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
@@ -331,7 +383,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             char* base = uniform_wptr(reinterpret_cast<char*>(p.C) +
                                       ((long)(m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16) * p.ldc + n0 + sh * 128 + wc * 32) * 2);
             const u32x4_t v = {a0, a1, b0, b1};
+#if UR_PERS_ABLATE == 1
+            asm volatile("" :: "v"(v), "v"(base + loff));
+#elif UR_PERS_ABLATE == 4
+            *reinterpret_cast<u32x4_t*>(base + loff) = v;
+#else
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(base + loff));
+#endif
           }
       } else {
 #pragma unroll
@@ -348,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             uint4 rw[4], gw[4], uw[4];
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-              const long m = m0 + rh * 128 + wr * 64 + jj * 16 + l15;
+              const long m = m0 + rh * 128 + wr * 64 + jj * 16 + el15;
               if (EPI == 2 && p.res) rw[jj] = *reinterpret_cast<const uint4*>(p.res + m * p.ldres + ncol);
               if (EPI == 1) {
                 gw[jj] = *reinterpret_cast<const uint4*>(p.sw_gu + m * p.sw_ldgu + ncol);
@@ -357,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-              const long m = m0 + rh * 128 + wr * 64 + jj * 16 + l15;
+              const long m = m0 + rh * 128 + wr * 64 + jj * 16 + el15;
               f32x4 a = acc[2 * sh][4 * rh + jj], b = acc[2 * sh + 1][4 * rh + jj];
 #pragma unroll
               for (int e = 0; e < 4; ++e) { float x = a[e], y = b[e]; swap16f(x, y); a[e] = x; b[e] = y; }
@@ -398,12 +456,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    UR_PSTAMP(7);
+    if (JOIN && wr == 1 && tiles_left > 1) __builtin_amdgcn_s_barrier();
     tiles_left -= 1;
     if (tiles_left == 0) break;
     m0 = nm0; n0 = nn0;
   }
   // drain: re-join the wave groups, let the never-consumed tail of the stream land before the workgroup's LDS is released
-  if (wr == 0) __builtin_amdgcn_s_barrier();
+  if (!(UR_PERS_JOIN || DROP) && wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
@@ -423,7 +483,9 @@ int launch_pers(const GemmP& p, hipStream_t st) {
     return n > 0 ? n : 8;
   }();
   const int ntiles = p.gm * p.gn;
-  const int grid = ntiles < ncu ? ntiles : ncu;
+  static const int env_grid = [] { const char* e = getenv("UR_PERS_GRID"); return e ? atoi(e) : 0; }();      // lab: fewer workgroups (a multiple of 8)
+  const int cap = (env_grid >= 8 && env_grid < ncu) ? env_grid - env_grid % 8 : ncu;
+  const int grid = ntiles < cap ? ntiles : cap;
   auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
   TileOrder o;
   o.nwg = ntiles; o.gn = p.gn; o.gcw = p.gcw;
@@ -450,6 +512,13 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
   if ((long)(p.M / BM) * (p.N / BN) >= (1L << 20) || p.N / BN >= (1 << 12) || p.M / BM >= (1 << 15)) return false;      // fdiv: n * d < 2^32
   if (p.gelu_out || p.aux || p.sw_mode == 2) return false;
   if (p.K2 > 0 && !p.drop_bits && p.K2 > BK) return false;
+  if (p.drop_bits && p.K2 > 0) {
+    if (p.drop_rank != 16 || (p.K2 & 15)) return false;                        // the masked epilogue here is rank 16 only
+    // measured (tools/lab/gemm_pers_ab.py, C4 shapes): with the masked LoRA epilogue the persistent kernel wins at K = 1024
+    // (+4 %, +12..18 % with the SwiGLU backward epilogue) and loses 1..7 % at K >= 4096 (few, long tiles: nothing to hide)
+    static const int kmax = [] { const char* e = getenv("UR_PERS_DROP_KMAX"); return e ? atoi(e) : 2048; }();
+    if (p.K > kmax) return false;
+  }
   if (p.sw_mode == 1 && (p.bias || p.res)) return false;
   // 16-byte pieces everywhere
   if ((p.ldc & 7) || (reinterpret_cast<uintptr_t>(p.C) & 15)) return false;
@@ -466,6 +535,12 @@ int gemm_pers_launch(GemmP p, hipStream_t st) {
   p.gcw = 0;
   if (p.gn >= 16 && (p.gm % 8) == 0 && p.gn > 4 && (p.gn % 4) == 0) p.gcw = 4;     // column chunks on wide launches (gemm.hip)
   const bool drop = p.drop_bits != nullptr && p.K2 > 0;
+  {
+    // stagger step in shader cycles: the tile period (~2900 cycles per K tile at the clock the chip holds) spread over 16 groups
+    static const int env_st = [] { const char* e = getenv("UR_PERS_STAGGER"); return e ? atoi(e) : -1; }();      // lab: cycles per step; 0 = off
+    const int nkt = p.K / BK + ((!drop && p.K2 > 0) ? 1 : 0);
+    p.stagger = env_st >= 0 ? env_st : (nkt * 2900) / 16;
+  }
   const int mode = drop ? 2 : (p.K2 > 0 ? 1 : 0);
   const int epi = p.sw_mode == 1 ? 1 : ((p.res || p.bias) ? 2 : 0);
 #define UR_PERS_CASE(E, MD) if (epi == E && mode == MD) return launch_pers<E, MD>(p, st)
@@ -477,6 +552,12 @@ int gemm_pers_launch(GemmP p, hipStream_t st) {
 }
 
 }  // namespace urgemm
+
+#if UR_PERS_STAMPS
+extern "C" int ur_lab_pers_stamps(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pers_stamps), sizeof(long long) * n);
+}
+#endif
 
 extern "C" int ur_gemm_persistent_mode(int mode) {
   const int prev = urgemm::g_pers_mode.exchange(mode < 0 ? -1 : (mode ? 1 : 0));
