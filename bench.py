@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--micro-batches", type=int, default=1,
                     help="split the per-GPU batch into this many micro-batches inside one optimizer step (gradient accumulation; "
                          "C5: --batch 64 --micro-batches 2 keeps S=4096 within 288 GB)")
+    ap.add_argument("--no-stages", dest="stages", action="store_false",
+                    help="joint workload: skip the item (C2) / user (C3) stage measurements that follow the headline in the same process")
+    ap.add_argument("--stage-steps", type=int, default=10)
+    ap.add_argument("--stage-cpu-budget", type=float, default=25.0, help="seconds of oracle work per stage cpu_baseline leg")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--lora-dropout", type=float, default=0.1, help="LoRA adapter dropout (reference lora_dropout=0.1)")
     return ap.parse_args()
@@ -257,13 +261,24 @@ def cpu_baseline_subprocess(args):
 # ---- per-stage workloads (BASELINE configs[1], configs[2]); reported with their own metric names ----
 def run_stage(args):
     from unirec_amd import dp
-    from unirec_amd.losses import QFormerLoss, mse_loss
-    from unirec_amd.optim import FusedAdamW
-    from unirec_amd import hip
     rank, world, local = dp.init_from_env()
     _check_world(args, world)
     device = torch.device("cuda", local % max(1, torch.cuda.device_count()))      # (modulo: gloo rehearsal of N ranks on one GPU)
     torch.cuda.set_device(device)
+    out = measure_stage(args, rank, world, device)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def measure_stage(args, rank, world, device):
+    """One stage workload (args.workload = item | user) on an initialised device / process group -> the stage's JSON object
+    (rank 0; None elsewhere).  Also called by the joint bench for the `stages` entry of its line."""
+    from unirec_amd import dp
+    from unirec_amd.losses import QFormerLoss, mse_loss
+    from unirec_amd.optim import FusedAdamW
+    from unirec_amd import hip
     torch.manual_seed(1234)
     g = torch.Generator().manual_seed(1234 + rank)
     p = 0.0 if args.no_dropout else None
@@ -288,7 +303,9 @@ def run_stage(args):
             opt.zero_grad()
             out = m(xa, ma)
             with torch.no_grad():         # samples are independent: positives and negatives share ONE no-grad forward of 2B items
+                dp.set_sample_offset(rank * 2 * B, m)      # its own counters: rank r's 2B rows of the ranks' concatenated pos|neg forwards
                 rep = m(xpn, mpn)["item_representation"]; pr, nr = rep[:B], rep[B:]
+                dp.set_sample_offset(None, m)
             loss, _, _ = loss_fn(out, {"field_embeddings": xa}, pr, nr, ma)
             loss.backward(); bk.ready_all(); bk.wait(); opt.step(grad_scale=1.0 / world)
             return loss
@@ -362,9 +379,10 @@ def run_stage(args):
                "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "comm": _comm_info(world)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
-        print(json.dumps(out), flush=True)
-    if dist_on:
-        torch.distributed.destroy_process_group()
+        else:
+            out["cpu_baseline_note"] = "the CPU oracle leg runs on rank 0 of the N=1 line only"
+        return out
+    return None
 
 
 def _check_world(args, world):
@@ -450,6 +468,8 @@ def main():
             for bk in (lbk, qbk, ubk):
                 if bk is not None:
                     bk.begin_micro_batch(last)
+            if nmb > 1:         # dropout counters follow the GLOBAL sample index: rank r's micro-batch k starts at r * B + k * mb
+                dp.set_sample_offset(rank * B + k * mb, model, qf, model.user_qformer)
             ut, um = batch["user_sequence_tokens"], batch["user_attention_mask"]
             user = model(batch["input_ids"][sl], batch["attention_mask"][sl], batch["history_field_embeddings"][sl],
                          batch["history_attention_mask"][sl], None if ut is None else ut[sl], None if um is None else um[sl])
@@ -493,6 +513,9 @@ def main():
     lossv = float(loss.item())
     if not math.isfinite(lossv):
         raise SystemExit("non-finite loss")
+    # what the timed steps left in the trainable parameters (f64 sums of the flat fp32 masters): equal runs give equal digits,
+    # and under data parallelism every rank must print the same ones (tests/test_gpu_dp_rccl.py)
+    checksum = {"lora": float(lpack.master.double().abs().sum().item()), "qformer": float(qpack.master.double().abs().sum().item())}
 
     if rank == 0:
         # ---- roofline of the dominant kernel: forward projection GEMM gemm_kernel<RK=1,SK=1,bf16> -----
@@ -521,7 +544,8 @@ def main():
         except Exception:
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-                "traffic": traffic, "kernel": "gemm_kernel<true,true,false,256,256,2,4> (K-contiguous projection GEMM: forward + frozen-weight dX)",
+                "traffic": traffic, "kernel": "gemm_pers_kernel<EPI 0|2, MODE> + gemm_kernel<true,true,false,256,256,2,4,0> (K-contiguous 256x256 projection GEMM: forward + "
+                          "frozen-weight dX; the persistent kernel takes the launches csrc/gemm_pers.hip:gemm_pers_eligible accepts)",
                 "traffic_note": tnote,
                 "launches": n, "avg_launch_ms": round(tot_ms / max(n, 1), 4),
                 "all_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,
@@ -541,7 +565,7 @@ def main():
                     "tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 1), "frac_of_peak": round(v[1] / max(v[0], 1e-9) / 1e9 / 2500.0, 4)} for k, v in att.items()}
         attn["kernels"] = "attn_fwd_kernel<128,true,4>; attn_bwd_dq_kernel<128,true,4> + attn_bwd_dkv2_kernel<true> (one ur_attn_bwd call)"
         fl = flops_per_step(args, B, cfg, dims)
-        out = {"metric": "user-sequences/sec joint fwd+bwd (Qwen3-0.6B+LoRA, hist=50)", "value": round(world * B * args.steps / dt, 3),
+        out = {"metric": f"user-sequences/sec joint fwd+bwd (Qwen3-0.6B+LoRA, hist={args.hist})", "value": round(world * B * args.steps / dt, 3),
                "unit": "user-sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "bf16", "data": "synthetic",
@@ -552,9 +576,31 @@ def main():
                           "hist": args.hist, "pool": args.pool, "dropout": 0.0 if args.no_dropout else 0.2, "lora_dropout": 0.0 if args.no_dropout else args.lora_dropout,
                           "micro_batches": nmb, "parallelism": f"dp{world}", "random_init": True},
                "step_tflops_per_gpu": round(fl / (dt / args.steps) / 1e12, 1), "loss": round(lossv, 4),
-               "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "attention": attn, "comm": _comm_info(world)}
+               "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "attention": attn, "comm": _comm_info(world), "param_checksum": checksum}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
+        elif world > 1:
+            out["cpu_baseline_note"] = "the CPU oracle leg runs on rank 0 of the N=1 line only"
+    # ---- per-stage lines (items/s of the item Q-Former step C2, sequences/s of the user Q-Former step C3), measured in
+    # this same process after the headline; every rank takes part (the stages all-reduce their gradient packs like the joint step)
+    stages = {}
+    if args.stages and args.batch == 64 and args.hist == 50 and not args.user_tokens:
+        del model, qf, batch, opt, lbk, qbk, loss_fn, qpack, lpack, packs, step
+        qw.grad_ready_hook = None
+        del qw
+        import gc
+        gc.collect(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+        for wl, key in (("item", "item_c2"), ("user", "user_c3")):
+            sa = argparse.Namespace(**{**vars(args), "workload": wl, "steps": args.stage_steps, "warmup": 3, "cpu_budget": args.stage_cpu_budget})
+            so = measure_stage(sa, rank, world, device)
+            if rank == 0:
+                stages[key] = {k: so[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "step_tflops_per_gpu", "max_mem_gb", "config", "roofline") if k in so}
+                if "cpu_baseline" in so:
+                    stages[key]["cpu_baseline"] = so["cpu_baseline"]
+            gc.collect(); torch.cuda.empty_cache()
+    if rank == 0:
+        if stages:
+            out["stages"] = stages
         print(json.dumps(out), flush=True)
     if dist_on:
         torch.distributed.destroy_process_group()

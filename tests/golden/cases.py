@@ -209,6 +209,25 @@ MID = {
 MID_STRIDE = 16
 
 
+# LoRA pinned through the INSTALLED transformers Qwen3Model with MERGED weights W' = W + (alpha / r) B A (peft's
+# merge_and_unload identity; peft itself is not installed -- call site train_item_individual_token_joint.py:121-131):
+# 2 layers of the 0.6B shape, B 2 x S 256, left padding.  lora_B ~ N(0, 0.05) so the adapter term is ~40 % of |W|.
+LORA = dict(kind="qwen_lora", seed=57, B=2, S=256, pad_side="left", lora_r=16, lora_alpha=32.0, lora_b_std=0.05,
+            qwen=dict(D=1024, L=2, nq=16, nkv=8, hd=128, I=3072, vocab=64))
+LORA_PROJ = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
+# adapter gradients stored in full (the others by their norms): one of every projection kind, both layers touched
+LORA_FULL = ("layers.0.self_attn.q_proj", "layers.0.self_attn.v_proj", "layers.1.self_attn.o_proj", "layers.1.mlp.gate_proj", "layers.0.mlp.down_proj")
+
+
+def lora_weight_rules(case):
+    """oracle.weights rule: lora_B with the case's std (the default 0.02 makes the adapter term a few % of the base)."""
+    def rule(k, shp):
+        if k.endswith("lora_B.weight"):
+            return W.normal(k, shp, case["seed"] + 1, std=case["lora_b_std"])
+        return None
+    return rule
+
+
 def mid_sample(x):
     """Fixture-size rule of the mid-size cases: [B,S,D] activations keep every MID_STRIDE-th position."""
     return np.ascontiguousarray(np.asarray(x)[:, ::MID_STRIDE])

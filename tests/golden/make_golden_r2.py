@@ -12,10 +12,14 @@ make_golden.py, which this script imports):
                       0.6B shape, S=512, left padding, hist=10) + InfoNCELoss + MRR ranks: embeddings, loss, ranks, gradients
   use_real.npz        models/user_sequence_encoder.py UserSequenceEncoder._get_item_query_tokens_batch /
                       encode_user_sequence with a real (small) reference item Q-Former behind it
+  qwen_lora.npz       LoRA (J4) pinned through the installed Qwen3Model with MERGED weights W + (alpha/r) B A: 2 layers of the
+                      0.6B shape, B 2 x S 256: pooled output, gradient w.r.t. inputs_embeds, and dA / dB of every adapter
+                      derived from the merged weights' gradients dW' (peft is not installed; its call site is
+                      training/train_item_individual_token_joint.py:121-131)
   state_dict_shapes.json   key -> shape of the reference modules' state_dict (item default / Q=8 duplicate / C1 / C2,
                       UserQFormer default): the checkpoint-compatibility contract of SURVEY 8(b)
 
-Usage:  python tests/golden/make_golden_r2.py [qwen_mid qwen_deep user_mid item_mid joint_mid use_real shapes]
+Usage:  python tests/golden/make_golden_r2.py [qwen_mid qwen_deep user_mid item_mid joint_mid qwen_lora use_real shapes]
 """
 import json
 import os
@@ -53,6 +57,49 @@ def gen_qwen_mid(case):
     return {"sdpa/pooled": pooled.detach().numpy(), "sdpa/last_hidden_state_s": cases.mid_sample(last.detach().numpy()),
             "sdpa/grad_inputs_embeds_s": cases.mid_sample(g),
             "sdpa/grad_inputs_embeds_norm": np.array(np.linalg.norm(g.astype(np.float64)))}
+
+
+def gen_qwen_lora(case):
+    """LoRA pinned to a reference-held implementation: the installed Qwen3Model runs with every projection weight set to
+    W + (alpha / r) B A (what peft's LoraLayer computes with dropout off, merged); forward, input gradient and the gradient
+    dW' of every merged weight come from transformers + torch autograd, and the adapters' gradients follow from dW' by the
+    chain rule of the merge alone: dA = (alpha / r) B^T dW', dB = (alpha / r) dW' A^T."""
+    qc = cases.qwen_cfg(case)
+    sc = case["lora_alpha"] / case["lora_r"]
+    x, am = cases.qwen_inputs(case)
+    from oracle.qwen3_ref import qwen3_shapes
+    gen = W.fill_state_dict(qwen3_shapes(qc, lora=True), case["seed"] + 1, rules=cases.lora_weight_rules(case))
+    base = mg.build_hf_qwen3(qc, case["seed"] + 1, "sdpa")
+    sd = base.state_dict()
+    for i in range(qc.num_hidden_layers):
+        for pj in cases.LORA_PROJ:
+            n = f"layers.{i}.{pj}"
+            a, b = gen[n + ".lora_A.weight"].astype(np.float64), gen[n + ".lora_B.weight"].astype(np.float64)
+            assert np.array_equal(sd[n + ".weight"].numpy(), gen[n + ".weight"])
+            sd[n + ".weight"] = torch.from_numpy((gen[n + ".weight"].astype(np.float64) + sc * (b @ a)).astype(np.float32))
+    base.load_state_dict(sd)
+    for p_ in base.parameters():
+        p_.requires_grad_(True)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    h = base(inputs_embeds=xt, attention_mask=torch.from_numpy(am), output_hidden_states=True)
+    pooled = h.hidden_states[-1].mean(dim=1)
+    pooled.pow(2).sum().backward()
+    g = xt.grad.numpy()
+    res = {"pooled": pooled.detach().numpy(), "grad_inputs_embeds_s": cases.mid_sample(g),
+           "grad_inputs_embeds_norm": np.array(np.linalg.norm(g.astype(np.float64)))}
+    named = dict(base.named_parameters())
+    for i in range(qc.num_hidden_layers):
+        for pj in cases.LORA_PROJ:
+            n = f"layers.{i}.{pj}"
+            dW = named[n + ".weight"].grad.numpy().astype(np.float64)
+            a, b = gen[n + ".lora_A.weight"].astype(np.float64), gen[n + ".lora_B.weight"].astype(np.float64)
+            dA, dB = sc * (b.T @ dW), sc * (dW @ a.T)
+            res["gnorm/" + n + ".lora_A.weight"] = np.array(np.linalg.norm(dA))
+            res["gnorm/" + n + ".lora_B.weight"] = np.array(np.linalg.norm(dB))
+            if n in cases.LORA_FULL:
+                res["grad/" + n + ".lora_A.weight"] = dA.astype(np.float32)
+                res["grad/" + n + ".lora_B.weight"] = dB.astype(np.float32)
+    return res
 
 
 def gen_user_mid(case):
@@ -129,6 +176,11 @@ def main():
             path = os.path.join(HERE, name + ".npz")
             np.savez_compressed(path, **{k: np.asarray(v) for k, v in res.items()})
             print(f"{name}: {len(res)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+    if want("qwen_lora"):
+        res = gen_qwen_lora(cases.LORA)
+        path = os.path.join(HERE, "qwen_lora.npz")
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in res.items()})
+        print(f"qwen_lora: {len(res)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
     if want("use_real"):
         res = gen_use_real()
         path = os.path.join(HERE, "use_real.npz")

@@ -116,18 +116,25 @@ def test_shard_range_keeps_the_remainder():
     assert got == [(0, 3), (3, 6), (6, 8), (8, 10)]
 
 
-def test_rank_seeds_are_distinct_and_rank0_keeps_the_base():
-    seeds = [dp.rank_seed(0x5EED, r) for r in range(8)]
-    assert seeds[0] == 0x5EED and len(set(seeds)) == 8 and all(0 <= s < 2 ** 46 for s in seeds)
-
-    class M(torch.nn.Module):
+def test_set_sample_offset_overrides_the_rank_rule_and_resets():
+    """dp.set_sample_offset: micro-batch k of mb samples on rank r (B samples per rank) starts at r * B + k * mb; None returns
+    to dp_rank * B.  Every rank keeps the SAME seeds (there is no per-rank seed any more)."""
+    class Leaf(torch.nn.Module):
         def __init__(self):
             super().__init__()
-            self.seed, self.lora_seed = 0x5EED, 0x5EED
-    a, b = M(), M()
-    dp.set_rank_seeds(0, a)
-    dp.set_rank_seeds(3, b)
-    assert (a.seed, a.lora_seed) == (0x5EED, 0x5EED) and b.seed != 0x5EED and b.lora_seed != 0x5EED
+            self.dp_rank, self.sample_offset, self.seed = 0, None, 0x5EED
+
+    class Top(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = Leaf(), Leaf()
+    t, plain = Top(), Leaf()
+    dp.set_dp_rank(3, t, plain)
+    dp.set_sample_offset(3 * 64 + 1 * 32, t, plain, None)
+    assert [m.sample_offset for m in (t.a, t.b, plain)] == [224, 224, 224] and t.a.seed == 0x5EED and t.a.dp_rank == 3
+    dp.set_sample_offset(None, t, plain)
+    assert [m.sample_offset for m in (t.a, t.b, plain)] == [None, None, None]
+    assert not hasattr(dp, "set_rank_seeds") and not hasattr(dp, "rank_seed")
 
 
 def test_set_dp_rank_reaches_every_dropout_owner():

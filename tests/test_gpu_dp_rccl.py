@@ -1,0 +1,98 @@
+"""GPU: the RCCL launch path and the micro-batched step on the PRODUCT path.
+
+* `UNIREC_DP_FORCE=1 python bench.py ...` initialises the `nccl` (= RCCL) process group with ONE rank and runs every bucket's
+  async all-reduce on RCCL's stream with its event fences -- the only way to execute that path on a one-GPU box; the step
+  must equal the step without a process group, digit for digit.
+* with >= 2 GPUs visible, `bench.py --gpus 2 --micro-batches 2` runs two real ranks over RCCL (skipped otherwise).
+* two micro-batches of B/2 (GradBuckets.begin_micro_batch) give the gradients of one batch of B on the joint step.
+The reference has no distributed code; contract = SURVEY 8(e)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--layers", "2", "--batch", "8", "--seq", "512", "--hist", "10", "--pool", "50", "--steps", "2", "--warmup", "1",
+         "--no-cpu-baseline", "--no-stages"]
+
+
+def _bench(extra_args=(), env=None, timeout=600):
+    e = dict(os.environ, OMP_NUM_THREADS="2")
+    e.pop("UNIREC_DP_FORCE", None)
+    e.pop("UNIREC_DP_BACKEND", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + list(extra_args), env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_one_rank_rccl_step_equals_the_step_without_a_process_group():
+    plain = _bench()
+    forced = _bench(env={"UNIREC_DP_FORCE": "1", "MASTER_PORT": "29517"})
+    assert plain["comm"] == {"backend": None, "ranks": 1}
+    assert forced["comm"] == {"backend": "rccl (torch.distributed nccl)", "ranks": 1}
+    for d in (plain, forced):
+        assert d["loss"] == d["loss"] and abs(d["loss"]) < 1e4 and d["value"] > 0
+    assert forced["loss"] == plain["loss"]
+    assert forced["param_checksum"] == plain["param_checksum"]        # all-reduce over one rank is the identity: same digits
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's 8-GPU node); one-GPU boxes run the 1-rank RCCL test above")
+def test_two_ranks_over_rccl_with_micro_batches():
+    d = _bench(["--gpus", "2", "--micro-batches", "2"], timeout=900)
+    assert d["comm"] == {"backend": "rccl (torch.distributed nccl)", "ranks": 2} and d["n_gpus"] == 2
+    assert d["loss"] == d["loss"] and abs(d["loss"]) < 1e4 and d["value"] > 0
+    assert d["config"]["global_batch"] == 16 and d["config"]["micro_batches"] == 2
+
+
+def _joint_grads(nmb, B=4, S=256, hist=6, pool=20, layers=2, repeat=1):
+    """LoRA and Q-Former gradients of ONE joint step over B sequences, as nmb micro-batches (bench.py's step, dropout off)."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    from unirec_amd import dp
+    from unirec_amd.joint import InfoNCELoss
+    args = argparse.Namespace(layers=layers, no_dropout=True, lora_dropout=0.0, hist=hist, user_tokens=False)
+    dev = torch.device("cuda", 0)          # with its index: ParamPack compares devices exactly
+    model, qf, cfg, (Qi, F, E, D) = bench.build(args, dev)
+    batch = bench.make_batch(B, hist, S, pool, F, E, D, Qi, model.first_special_id, model.first_special_id, 99, dev)
+    qw = model.base_model
+    qpack, lpack = qf._ensure_pack(dev), qw._ensure_pack(dev)
+    lb = dp.layer_boundaries(lpack, [f"layers.{i}." for i in range(layers)], 1)
+    qb = dp.layer_boundaries(qpack, [f"qformer.encoder.layer.{i}." for i in range(12)], 1)
+    lbk, qbk = dp.GradBuckets(lpack.grad, lb), dp.GradBuckets(qpack.grad, qb)
+    qw.grad_ready_hook = lambda i: lbk.ready(i)
+    qf.qformer.grad_ready_hook = lambda i: qbk.ready(0) if i == -1 else qbk.ready(1 + i)
+    loss_fn = InfoNCELoss(0.07)
+    outs = []
+    for _ in range(repeat):
+        lpack.clear_grads(); qpack.clear_grads()
+        mb = B // nmb
+        for k in range(nmb):
+            sl = slice(k * mb, (k + 1) * mb)
+            for bk in (lbk, qbk):
+                bk.begin_micro_batch(k == nmb - 1)
+            user = model(batch["input_ids"][sl], batch["attention_mask"][sl], batch["history_field_embeddings"][sl], batch["history_attention_mask"][sl])
+            loss = loss_fn(user, batch["positive_item_embeddings"][sl], batch["negative_item_embeddings"][sl], None) / nmb
+            loss.backward()
+        lbk.wait(); qbk.wait()
+        torch.cuda.synchronize()
+        # the tensors this step's backward wrote (the flat buffers' padding and untouched heads are never initialised)
+        outs.append(tuple(torch.cat([pk.g32(n).reshape(-1) for n in pk.names if n in pk.live]).clone() for pk in (lpack, qpack)))
+    return outs
+
+
+def test_two_micro_batches_give_the_gradients_of_one_batch():
+    """Product path, joint step: every backward OVERWRITES the flat gradient buffers, non-final micro-batches stash their
+    buckets as the backward completes them and the final one folds the stash in right before each bucket would leave."""
+    (l1, q1), = _joint_grads(1)
+    (l2, q2), (l2b, q2b) = _joint_grads(2, repeat=2)
+    assert torch.equal(l2, l2b) and torch.equal(q2, q2b), "the micro-batched step must be bit-reproducible"
+    for name, a, b in (("lora", l2, l1), ("qformer", q2, q1)):
+        rel = float((a - b).norm() / b.norm())
+        print(f"  {name}: ||g(2 x B/2) - g(B)|| / ||g(B)|| = {rel:.3e}")
+        assert float(b.norm()) > 0 and rel <= 2e-2, (name, rel)

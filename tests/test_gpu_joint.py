@@ -10,7 +10,7 @@ from oracle import qformer_ref as R  # noqa: E402
 from oracle import qwen3_ref as Q  # noqa: E402
 from oracle import weights as W  # noqa: E402
 from tests.golden import cases  # noqa: E402
-from tests.parity_utils import GRAD_REL, OUT_REL, assert_close, load_generated, load_golden  # noqa: E402
+from tests.parity_utils import GRAD_REL, OUT_REL, assert_close, grad_scale, load_generated, load_golden  # noqa: E402
 
 DEV = "cuda"
 JOINT = [n for n, c in cases.ALL.items() if c["kind"] == "joint"]
@@ -96,9 +96,10 @@ def test_joint_matches_reference(name):
     # for this fixture's seed).  Their error is held against 5 % of the query-table gradient's norm instead of their own.
     ill = 0.05 * float(np.linalg.norm(g["grad/query_embeddings"]))
     ILL_KEYS = ("qformer.encoder.layer.0.attention.self.query.weight", "qformer.encoder.layer.0.attention.self.key.bias")
+    gs = grad_scale(g, cases.item_grad_keys(c, heads=False))
     for k in cases.item_grad_keys(c, heads=False):
         assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL * 1.5, "grad/" + k, floor=1e-6,
-                     abs_scale=ill if k in ILL_KEYS else 0.0)
+                     abs_scale=ill if k in ILL_KEYS else 0.0, ref_scale=gs)
     assert named["item_representation_head.weight"].grad is None      # unused heads stay untouched (as in the reference)
 
 

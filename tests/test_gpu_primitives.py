@@ -550,6 +550,37 @@ def test_lora_dropout_plane_is_pairwise_independent_inside_a_word():
     assert abs(runs.mean().item() - 0.01) < 1e-3
 
 
+@pytest.mark.parametrize("p", [0.1, 0.25])
+def test_lora_dropout_word_popcounts_and_triples_follow_the_binomial(p):
+    """The 32 decisions of a word are bit-sliced over consecutive states of one small generator (csrc/lora.hip): beyond
+    pairs, the NUMBER of dropped columns per word must follow Binomial(32, p) and column triples / quadruples inside a word
+    must be dropped together with probability p^3 / p^4 (peft's nn.Dropout draws are fully independent)."""
+    M, W = 16384, 1024
+    keep = hip.lora_bits_to_keep(hip.lora_dropout_bits(24681357, p, M, W, 1, DEV), W)[0]
+    d = (1 - keep.view(-1, 32).to(torch.float64))                           # dropped flags, one row per word
+    n = d.shape[0]
+    cnt = d.sum(1)
+    # popcount histogram against the binomial pmf: every bin with >= 200 expected words within 6 sigma
+    hist = torch.bincount(cnt.long(), minlength=33).double().cpu()
+    for k in range(33):
+        pm = math.comb(32, k) * p ** k * (1 - p) ** (32 - k)
+        if n * pm >= 200:
+            assert abs(hist[k].item() - n * pm) <= 6 * math.sqrt(n * pm * (1 - pm)), (k, hist[k].item(), n * pm)
+    assert abs(cnt.mean().item() - 32 * p) < 0.02 and abs(cnt.var().item() - 32 * p * (1 - p)) < 0.05 * 32 * p * (1 - p)
+    # triples and quadruples of columns inside a word (neighbours, strided, scattered)
+    g = torch.Generator().manual_seed(5)
+    sets = [(0, 1, 2), (3, 4, 5), (0, 8, 16), (1, 9, 17), (5, 13, 30), (29, 30, 31), (0, 15, 31), (2, 11, 23)]
+    sets += [tuple(sorted(torch.randperm(32, generator=g)[:3].tolist())) for _ in range(24)]
+    for cs in sets:
+        pr = p ** len(cs)
+        obs = d[:, list(cs)].prod(1).sum().item()
+        assert abs(obs - n * pr) <= 6 * math.sqrt(n * pr) + 1, (cs, obs, n * pr)
+    for cs in [(0, 1, 2, 3), (4, 12, 20, 28), (7, 8, 9, 31), (1, 6, 18, 27)]:
+        pr = p ** 4
+        obs = d[:, list(cs)].prod(1).sum().item()
+        assert abs(obs - n * pr) <= 6 * math.sqrt(n * pr) + 3, (cs, obs, n * pr)
+
+
 def test_batched_transpose_matches_per_matrix_transposes():
     g = torch.Generator().manual_seed(3)
     shapes = [(16, 1024), (48, 1024), (2048, 16), (33, 70), (1, 5), (3072, 16), (32, 32)]

@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import qformer_ref as R  # noqa: E402
 from tests.golden import cases  # noqa: E402
-from tests.parity_utils import GRAD_REL, OUT_REL, assert_close, load_generated, load_golden  # noqa: E402
+from tests.parity_utils import GRAD_REL, OUT_REL, assert_close, grad_scale, load_generated, load_golden  # noqa: E402
 
 DEV = "cuda"
 ITEM = [n for n, c in cases.ALL.items() if c["kind"] == "item"]
@@ -46,10 +46,11 @@ def test_item_qformer_matches_reference(name):
     assert_close(loss, g["loss"], OUT_REL, "loss")
     loss.backward()
     named = dict(m.named_parameters())
+    gs = grad_scale(g, cases.item_grad_keys(c))
     for k in cases.item_grad_keys(c):
         want = g["grad/" + k]
         got = cases.trim_like(_grad_np(named[k]))
-        assert_close(got, want, GRAD_REL, "grad/" + k, floor=1e-6)
+        assert_close(got, want, GRAD_REL, "grad/" + k, floor=1e-6, ref_scale=gs)
     # dead reference tensors never receive gradients
     assert named["qformer.embeddings.word_embeddings.weight"].grad is None
     assert named["qformer.encoder.layer.0.intermediate.dense.weight"].grad is None
@@ -94,8 +95,9 @@ def test_user_qformer_matches_reference(name):
     assert_close(loss, g["loss"], OUT_REL, "loss")
     loss.backward()
     named = dict(m.named_parameters())
+    gs = grad_scale(g, cases.user_grad_keys(c))
     for k in cases.user_grad_keys(c):
-        assert_close(cases.trim_like(_grad_np(named[k])), g["grad/" + k], GRAD_REL, "grad/" + k, floor=1e-6)
+        assert_close(cases.trim_like(_grad_np(named[k])), g["grad/" + k], GRAD_REL, "grad/" + k, floor=1e-6, ref_scale=gs)
 
 
 def test_fully_masked_item_is_finite_and_uniform():

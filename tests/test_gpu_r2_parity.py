@@ -17,7 +17,7 @@ from oracle import qwen3_ref as Q  # noqa: E402
 from oracle import weights as W  # noqa: E402
 from tests.golden import cases  # noqa: E402
 from tests.golden import data_cases as dc  # noqa: E402
-from tests.parity_utils import GRAD_REL, OUT_REL, assert_close, load_generated, load_golden  # noqa: E402
+from tests.parity_utils import GRAD_REL, OUT_REL, assert_close, grad_scale, load_generated, load_golden  # noqa: E402
 from tests.test_gpu_joint import _qwen_cfg  # noqa: E402
 
 DEV = "cuda"
@@ -66,6 +66,48 @@ def test_qwen3_mid_size_matches_transformers(name):
     assert abs(gn - float(g["sdpa/grad_inputs_embeds_norm"])) <= GRAD_REL * gn
 
 
+def test_lora_matches_merged_transformers():
+    """J4 pinned to a reference-held implementation: the HIP LoRA path (fused RMSNorm / SwiGLU + adapter passes, the second
+    K range of the merged q|k|v and gate|up launches, lora_bgrad / lora_reduce; dropout off) against the installed
+    transformers Qwen3Model run with MERGED weights W + (alpha / r) B A (tests/golden/qwen_lora.npz): pooled output,
+    gradient w.r.t. the input embeddings, and dA = (alpha / r) B^T dW', dB = (alpha / r) dW' A^T of every adapter
+    (peft call site training/train_item_individual_token_joint.py:121-131)."""
+    from unirec_amd.qwen3 import Qwen3LoRAModel
+    case = cases.LORA
+    g = load_golden("qwen_lora")
+    qc = cases.qwen_cfg(case)
+    qc.lora_r, qc.lora_alpha = case["lora_r"], case["lora_alpha"]
+    m = Qwen3LoRAModel(_qwen_cfg(qc, True), use_lora=True)
+    gen = W.fill_state_dict(Q.qwen3_shapes(qc, lora=True), case["seed"] + 1, rules=cases.lora_weight_rules(case))
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in gen.items()}, strict=False)
+    assert not unexpected and not [k for k in missing if "embed_tokens" not in k], (missing, unexpected)
+    x, am = cases.qwen_inputs(case)
+    B, S, _ = x.shape
+    m.resize_token_embeddings(qc.vocab_size + S)
+    m = m.to(DEV).train()
+    assert m._drop_p() == 0.0
+    ids = (qc.vocab_size + torch.arange(S, device=DEV)).expand(B, S).contiguous()
+    tok = torch.from_numpy(x).to(DEV).to(torch.bfloat16).requires_grad_(True)
+    pooled = m.forward_pooled(ids, torch.from_numpy(am).to(DEV), tok, qc.vocab_size)
+    assert_close(pooled, g["pooled"], OUT_REL, "pooled")
+    pooled.pow(2).sum().backward()
+    got = tok.grad.float().cpu().numpy()
+    assert_close(cases.mid_sample(got), g["grad_inputs_embeds_s"], GRAD_REL, "grad_inputs_embeds (every 16th position)")
+    gn = float(np.linalg.norm(got.astype(np.float64)))
+    assert abs(gn - float(g["grad_inputs_embeds_norm"])) <= GRAD_REL * gn
+    named = dict(m.named_parameters())
+    for i in range(qc.num_hidden_layers):
+        for pj in cases.LORA_PROJ:
+            for ab in ("lora_A", "lora_B"):
+                k = f"layers.{i}.{pj}.{ab}.weight"
+                gk = named[k].grad.float().cpu().numpy().astype(np.float64)
+                ref = float(g["gnorm/" + k])
+                assert abs(float(np.linalg.norm(gk)) - ref) <= GRAD_REL * ref, (k, float(np.linalg.norm(gk)), ref)
+                if "grad/" + k in g:
+                    assert_close(gk, g["grad/" + k], GRAD_REL, "grad/" + k)
+    assert named["layers.0.self_attn.q_proj.weight"].grad is None      # base weights stay frozen
+
+
 def test_user_qformer_mid_size_matches_reference():
     """The reference's default UserQFormer (L4 Q64 H1024 I4096) over T = 1600 keys: C3's shapes at B = 2."""
     from unirec_amd.user_qformer import UserQFormer
@@ -82,8 +124,9 @@ def test_user_qformer_mid_size_matches_reference():
     assert_close(loss, g["loss"], OUT_REL, "loss")
     loss.backward()
     named = dict(m.named_parameters())
+    gs = grad_scale(g, cases.user_grad_keys(c))
     for k in cases.user_grad_keys(c):
-        assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL, "grad/" + k, floor=1e-6)
+        assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL, "grad/" + k, floor=1e-6, ref_scale=gs)
 
 
 def test_item_qformer_mid_size_matches_reference():
@@ -112,8 +155,9 @@ def test_item_qformer_mid_size_matches_reference():
     assert_close(loss, g["loss"], OUT_REL, "loss")
     loss.backward()
     named = dict(m.named_parameters())
+    gs = grad_scale(g, cases.item_grad_keys(c))
     for k in cases.item_grad_keys(c):
-        assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL, "grad/" + k, floor=1e-6)
+        assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL, "grad/" + k, floor=1e-6, ref_scale=gs)
 
 
 def test_joint_mid_size_matches_reference():
@@ -138,9 +182,10 @@ def test_joint_mid_size_matches_reference():
     named = dict(qf.named_parameters())
     ill = 0.05 * float(np.linalg.norm(g["grad/query_embeddings"]))
     ILL_KEYS = ("qformer.encoder.layer.0.attention.self.query.weight", "qformer.encoder.layer.0.attention.self.key.bias")       # see test_gpu_joint.py
+    gs = grad_scale(g, cases.item_grad_keys(c, heads=False))
     for k in cases.item_grad_keys(c, heads=False):
         assert_close(cases.trim_like(named[k].grad.float().cpu().numpy()), g["grad/" + k], GRAD_REL * 1.5, "grad/" + k, floor=1e-6,
-                     abs_scale=ill if k in ILL_KEYS else 0.0)
+                     abs_scale=ill if k in ILL_KEYS else 0.0, ref_scale=gs)
 
 
 # ---- the UserSequenceEncoder boundary (models/user_sequence_encoder.py:36-142) ----------------------------------------

@@ -38,6 +38,42 @@ def test_qwen3_mid_size(golden_dir, name):
     assert abs(gn - float(g["sdpa/grad_inputs_embeds_norm"])) <= 1e-3 * gn
 
 
+def test_lora_unmerged_matches_merged_transformers(golden_dir):
+    """J4 pin: the oracle's UNMERGED LoRA (y = W x + (alpha / r) B A x, oracle/qwen3_ref.py:lora_linear) against the installed
+    Qwen3Model run with merged weights W + (alpha / r) B A (tests/golden/make_golden_r2.py:gen_qwen_lora): pooled output,
+    input gradient, and dA / dB of every adapter (full tensors for cases.LORA_FULL, norms for all 14 x 2)."""
+    case = cases.LORA
+    g = _load(golden_dir, "qwen_lora")
+    qc = cases.qwen_cfg(case)
+    qc.lora_r, qc.lora_alpha, qc.lora_dropout = case["lora_r"], case["lora_alpha"], 0.0
+    sd = W.fill_state_dict(Q.qwen3_shapes(qc, lora=True), case["seed"] + 1, rules=cases.lora_weight_rules(case))
+    P = {k: torch.from_numpy(v).requires_grad_(".lora_" in k) for k, v in sd.items()}
+    x, am = cases.qwen_inputs(case)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    h = Q.qwen3_forward(P, qc, xt, torch.from_numpy(am), fully_masked="zero")
+    pooled = h.mean(dim=1)
+    pooled.pow(2).sum().backward()
+    _close(pooled.detach().numpy(), g["pooled"], rtol=1e-3, atol=1e-4, what="pooled")
+    # merged and unmerged weights round differently in fp32: the gradient is compared in the Frobenius norm
+    gs, ws = cases.mid_sample(xt.grad.numpy()).astype(np.float64), g["grad_inputs_embeds_s"].astype(np.float64)
+    assert np.linalg.norm(gs - ws) <= 1e-3 * np.linalg.norm(ws), np.linalg.norm(gs - ws) / np.linalg.norm(ws)
+    gn = float(np.linalg.norm(xt.grad.numpy().astype(np.float64)))
+    assert abs(gn - float(g["grad_inputs_embeds_norm"])) <= 1e-3 * gn
+    n_checked = 0
+    for i in range(qc.num_hidden_layers):
+        for pj in cases.LORA_PROJ:
+            for ab in ("lora_A", "lora_B"):
+                k = f"layers.{i}.{pj}.{ab}.weight"
+                got = P[k].grad.numpy().astype(np.float64)
+                ref = float(g["gnorm/" + k])
+                assert abs(float(np.linalg.norm(got)) - ref) <= 2e-3 * ref, (k, float(np.linalg.norm(got)), ref)
+                if "grad/" + k in g:
+                    want = g["grad/" + k].astype(np.float64)
+                    assert np.linalg.norm(got - want) <= 2e-3 * np.linalg.norm(want), k
+                    n_checked += 1
+    assert n_checked == 2 * len(cases.LORA_FULL)
+
+
 def test_user_qformer_mid_size(golden_dir):
     case = cases.MID["user_mid"]
     c = case["cfg"]

@@ -65,7 +65,7 @@ __device__ __forceinline__ int sw16(int r) { return (r & 7) ^ ((r & 8) >> 1); }
 // ---- dropped-flag bit planes ---------------------------------------------------------------------
 // thread <-> (row m, group q of 32 columns): one 32-bit word per adapter plane.  Every element draws a 15-bit value u;
 // dropped iff u < thr = p * 2^15.  The (row, group, adapter, seed) counter is murmur-finalised ONCE into the word's key h;
-// UR_BITS_XORSHIFT = 2 (default): the 32 values are BIT-SLICED over up to 15 consecutive states of a xorshift32 started at h
+// UR_BITS_XORSHIFT = 2 (default): the 32 values are BIT-SLICED over up to 15 consecutive states of a multiply-xorshift chain started at h
 //   (state k carries bit k of all 32 values, least significant first) and the 32 comparisons are one boolean step per state:
 //   lt_k = t_k ? (~b_k | lt_{k-1}) : (~b_k & lt_{k-1});  bits below thr's lowest set bit cannot decide and are not drawn.
 //   7 vector instructions per state for 32 decisions (the kernel is VALU-bound: profiles/README.md r2_lora_bits.txt).
@@ -101,7 +101,12 @@ __global__ void lora_bits_kernel(uint64_t seed, uint32_t thr15, int M, int W, in
         uint32_t lt = 0;
 #pragma unroll 1
         for (uint32_t tb = (thr15 >> k0) | (0x8000u >> k0); tb != 1; tb >>= 1) {     // sentinel above bit 14: the zero bits above thr's top bit count
-          w ^= w << 13; w ^= w >> 17; w ^= w << 5;
+          // one multiply-xorshift round per state (half of the lowbias32 finaliser; a bijection whose only fixed point is 0).
+          // Round 2 used xorshift32 here: GF(2)-linear, so the 15 x 32 value bits of a word were linear functions of its
+          // 32-bit key -- pairs of columns were independent, but the number of dropped columns per word was not binomial
+          // (P(no column dropped) 6.5 % low at p = 0.1: tests/test_gpu_primitives.py popcount test).  The multiply's carries
+          // break the linearity for one quarter-rate instruction per state.
+          w ^= w >> 16; w *= 0x7FEB352Du; w ^= w >> 15;
           const uint32_t T = 0u - (tb & 1u);                             // all ones where thr has this bit
           lt = (~w & lt) | (T & (~w | lt));
         }

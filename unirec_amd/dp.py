@@ -48,34 +48,10 @@ def shard_range(n_global, rank, world):
     return lo, lo + per + (1 if rank < rem else 0)
 
 
-def rank_seed(base, rank):
-    """Dropout base seed of one rank: splitmix64 of (base, rank), so the ranks' mask streams are unrelated (rank 0 keeps
-    `base`: a 1-rank run is bit-identical to a run without data parallelism)."""
-    if rank == 0:
-        return int(base)
-    z = (int(base) + (int(rank) * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
-    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
-    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
-    return (z ^ (z >> 31)) & 0x3FFFFFFFFFFF          # 46 bits: the per-site arithmetic on top stays below 2^63
-
-
-def set_rank_seeds(rank, *modules):
-    """Give every dropout site of the models a per-rank seed (the masks of a sample must not repeat on another rank).
-    Touches the attributes the modules read their seeds from: `.seed` (Q-Former backbones), `.lora_seed` (Qwen3 LoRA)."""
-    for m in modules:
-        if m is None:
-            continue
-        for sub in m.modules():
-            if hasattr(sub, "lora_seed"):
-                sub.lora_seed = rank_seed(sub.lora_seed, rank)
-            if hasattr(sub, "seed") and isinstance(getattr(sub, "seed"), int):
-                sub.seed = rank_seed(sub.seed, rank)
-
-
 def set_dp_rank(rank, *modules):
     """Key every dropout mask on the GLOBAL sample index: all ranks keep the SAME seeds, and a module's forward
-    over B local samples offsets its dropout counters by rank * B samples (`.dp_rank`; `.sample_offset` overrides it for unequal
-    shards).  The N-rank step then draws, sample for sample, the masks of a single-process step over the concatenation of the
+    over B local samples offsets its dropout counters by rank * B samples (`.dp_rank`; `set_sample_offset` overrides it for
+    micro-batches, extra forwards and unequal shards).  The N-rank step then draws, sample for sample, the masks of a single-process step over the concatenation of the
     ranks' local batches -- training does not depend on the number of ranks (tests/test_gpu_dp_product.py)."""
     for m in modules:
         if m is None:
@@ -84,6 +60,19 @@ def set_dp_rank(rank, *modules):
         for sub in subs:
             if hasattr(sub, "dp_rank"):
                 sub.dp_rank = int(rank)
+
+
+def set_sample_offset(offset, *modules):
+    """Explicit index of a forward's first sample in the GLOBAL minibatch (overrides `dp_rank * B`): needed whenever a rank
+    runs more than one forward per step or shards are unequal -- micro-batch k of `mb` samples on rank r of a step over
+    B samples per rank starts at r * B + k * mb.  None returns to the `dp_rank * B` rule."""
+    for m in modules:
+        if m is None:
+            continue
+        subs = list(m.modules()) if hasattr(m, "modules") else [m]
+        for sub in subs:
+            if hasattr(sub, "sample_offset"):
+                sub.sample_offset = None if offset is None else int(offset)
 
 
 def world_size():
@@ -101,19 +90,15 @@ def launch_ranks(n, script, argv, extra_env=None):
     """Start `n` ranks of `script` on this node as CHILD processes (python -m torch.distributed.run, rendezvous on
     127.0.0.1) and return the launcher's exit code.  Must be called before the calling process touches the GPU: the
     parent only waits and relays, it never re-execs itself."""
-    import socket
     import subprocess
     import sys
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     env.update(extra_env or {})
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), script] + list(argv)
+    # the c10d rendezvous on port 0 lets torchrun pick a free port itself (no bind / close / reuse race on a busy host)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", "--local-addr", "127.0.0.1", script] + list(argv)
     return subprocess.run(cmd, env=env).returncode
 
 

@@ -31,6 +31,11 @@ class FusedAdamW:
     def step(self, grad_scale=1.0):
         self.step_count += 1
         for pack, (m, v), steps in zip(self.packs, self.state, self.steps):
+            # torch.optim.AdamW's rule whoever reset the gradients: a tensor whose .grad is None now (model.zero_grad(),
+            # HF Trainer, a torch optimizer's zero_grad -- none of which clears pack.live) is not stepped
+            stale = [n for n in pack.live if pack.params[n].grad is None]
+            for n in stale:
+                pack.live.discard(n)
             if not pack.live:
                 continue
             for n in pack.live:

@@ -18,6 +18,15 @@ from . import hip
 ALIGN = 8   # elements: keeps every bf16 view 16-byte aligned
 
 
+def norm_device(device):
+    """torch.device with an explicit index ("cuda" -> the current device): packs compare devices exactly, and a forward sees
+    its inputs' indexed device, so an index-less handle must not look like another device (it would rebuild the pack)."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
 class ParamPack:
     def __init__(self, named_params, device):
         """named_params: ordered list of (name, nn.Parameter).  Adjacent entries are adjacent in memory
@@ -31,7 +40,7 @@ class ParamPack:
             self.shapes[n] = tuple(p.shape)
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
-        self.device = torch.device(device)
+        self.device = norm_device(device)
         self.master = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
         self.grad = torch.zeros(off, dtype=torch.float32, device=self.device)

@@ -23,7 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .packing import ParamPack
+from .packing import ParamPack, norm_device
 
 try:  # the reference re-exports transformers' BertConfig (models/qformer.py:46); checkpoints pickle it
     from transformers.models.bert.configuration_bert import BertConfig
@@ -230,7 +230,7 @@ class BertModel(nn.Module):
     def _ensure_pack(self, device, prefix=""):
         if self._pack_owner is not None:
             return self._pack_owner._ensure_pack(device)
-        if self._pack is None or not self._pack.is_current() or self._pack.device != torch.device(device):
+        if self._pack is None or not self._pack.is_current() or self._pack.device != norm_device(device):
             for p in self.dead_parameters():
                 p.requires_grad_(False)
             self._pack = ParamPack(self.live_named_parameters(), device)

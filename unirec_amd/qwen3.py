@@ -25,7 +25,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .packing import ParamPack
+from .packing import ParamPack, norm_device
 
 BF16, F32 = torch.bfloat16, torch.float32
 LORA_TARGETS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
@@ -239,7 +239,7 @@ class Qwen3LoRAModel(nn.Module):
     def _ensure_pack(self, device):
         if not self.use_lora:
             return None
-        if self._pack is None or not self._pack.is_current() or self._pack.device != torch.device(device):
+        if self._pack is None or not self._pack.is_current() or self._pack.device != norm_device(device):
             self._pack = ParamPack(self.lora_named_parameters(), device)
         return self._pack
 

@@ -8,7 +8,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .packing import ParamPack
+from .packing import ParamPack, norm_device
 from .qformer import BertConfig, BertModel, _split_k_for
 
 BF16, F32 = torch.bfloat16, torch.float32
@@ -82,7 +82,7 @@ class UserQFormer(nn.Module):
                 + [(n, named[n]) for n in head])
 
     def _ensure_pack(self, device):
-        if self._pack is None or not self._pack.is_current() or self._pack.device != torch.device(device):
+        if self._pack is None or not self._pack.is_current() or self._pack.device != norm_device(device):
             for p in self.qformer.dead_parameters():
                 p.requires_grad_(False)
             self._pack = ParamPack(self.live_named_parameters(), device)
