@@ -12,7 +12,7 @@ def per_dispatch(d, counter):
     rows = []
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and "gemm_kernel" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and ("gemm_kernel" in r["Kernel_Name"] or "gemm_pers_kernel" in r["Kernel_Name"]):
                 rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     rows.sort()
     return [v for _, v in rows]

@@ -103,11 +103,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
   const int nkt = nk1 + (K2S ? 1 : 0);
   const int gstride = gridDim.x;
 
-  // De-phase the CUs.  Every output tile takes the same time, so without this all 256 workgroups reach their epilogues together:
-  // 32 MiB of C arrive at the L2s at once (4 MiB per XCD = the whole L2), the stores drain at the HBM write rate and, vmcnt
-  // being an in-order counter, every wave's next LDS-DMA waits behind them (measured: 5 us per output tile at K = 1024, ALL of
-  // the kernel's fixed cost per tile; 0.1 us with the stores removed).  Workgroup w starts (w / 8) % 16 steps late, so the
-  // epilogues of an XCD's CUs spread over the tile period and C leaves at the launch's average rate instead.
+  // Lab switch (UR_PERS_STAGGER = cycles per step, default 0 = off): workgroup w starts (w / 8) % 16 steps late.  Built to test
+  // whether the store bursts of the epilogues (all CUs reach them together) are what makes them slow: they are not -- de-phased
+  // epilogues take as long (in-kernel stamps: 3.85 k cycles per wave group either way), and the de-phasing costs the operand
+  // panels their L2 sharing: CUs that read the same A / W panel a few K tiles apart no longer hit the lines their neighbours
+  // fetched (rocprofv3 FETCH_SIZE of the N = 1024 launches x1.5 of A + W in lockstep, x2.9-4.3 staggered).  See DESIGN.md 11.
   if (p.stagger > 0) {
     const long long until = (long long)__builtin_readcyclecounter() + (long long)((blockIdx.x >> 3) & 15) * p.stagger;
     while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(8);
@@ -536,10 +536,8 @@ int gemm_pers_launch(GemmP p, hipStream_t st) {
   if (p.gn >= 16 && (p.gm % 8) == 0 && p.gn > 4 && (p.gn % 4) == 0) p.gcw = 4;     // column chunks on wide launches (gemm.hip)
   const bool drop = p.drop_bits != nullptr && p.K2 > 0;
   {
-    // stagger step in shader cycles: the tile period (~2900 cycles per K tile at the clock the chip holds) spread over 16 groups
-    static const int env_st = [] { const char* e = getenv("UR_PERS_STAGGER"); return e ? atoi(e) : -1; }();      // lab: cycles per step; 0 = off
-    const int nkt = p.K / BK + ((!drop && p.K2 > 0) ? 1 : 0);
-    p.stagger = env_st >= 0 ? env_st : (nkt * 2900) / 16;
+    static const int env_st = [] { const char* e = getenv("UR_PERS_STAGGER"); return e ? atoi(e) : 0; }();      // lab: cycles per start step; 0 = off (default)
+    p.stagger = env_st > 0 ? env_st : 0;
   }
   const int mode = drop ? 2 : (p.K2 > 0 ? 1 : 0);
   const int epi = p.sw_mode == 1 ? 1 : ((p.res || p.bias) ? 2 : 0);
