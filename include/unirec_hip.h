@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 4
+#define UR_ABI_VERSION 5
 
 int ur_version(void);
 const char* ur_last_error(void);
@@ -80,7 +80,27 @@ typedef struct {
    * ROUNDED C, the value the backward reads).  bf16 output, no split_k, no residual / gelu modes. */
   const void* swiglu_gate; int64_t swiglu_ldgate;
   void* swiglu_act; int64_t swiglu_ldact;
+  /* q/k-norm + RoPE as the epilogue of the merged q|k|v projection (Qwen3Attention: q_norm / k_norm over each head, then
+   * apply_rotary_pos_emb -- transformers modeling_qwen3.py:59-64,107-137,227-245).  qkr_q != NULL: the N output columns are
+   * qkr_nq_cols of q heads, then qkr_nk_cols of k heads, then the v columns (head_dim 128).  The ROWS of S (and S2) of every
+   * q / k head must be stored in the paired order ur_qkrope_perm (tile column c of a head holds feature
+   * ((c >> 4) & 1) * 64 + (c >> 5) * 16 + (c & 15): a lane of the MFMA tile then owns the rotate-half partners d, d + 64).
+   * C is not written.  qkr_q [M, qkr_nq_cols] and qkr_k [M, qkr_nk_cols] receive RoPE(RMSNorm(x) * weight) of the f32
+   * accumulators in the STANDARD feature order, qkr_v [M, N - nq_cols - nk_cols] the plain projection, qkr_rstd
+   * [M, (nq_cols + nk_cols) / 128] f32 the 1 / rms of every (token, head) -- what ur_qknorm_rope_bwd_roped needs instead of
+   * the raw q, k, which are never stored.  Position of row m = m % qkr_S; cos / sin tables [S, 64] f32 (ur_rope_table).
+   * Runs on the persistent kernel only (M, N multiples of 256, K of 64, >= 512 tiles, S >= 256, nq / nk columns multiples
+   * of 256, no other epilogue): ur_gemm_qkrope_supported tells; ur_gemm fails loudly otherwise. */
+  void* qkr_q; int64_t qkr_ldq; void* qkr_k; int64_t qkr_ldk; void* qkr_v; int64_t qkr_ldv;
+  float* qkr_rstd;
+  const float* qkr_qw; const float* qkr_kw; const float* qkr_cos; const float* qkr_sin;
+  int32_t qkr_S, qkr_nq_cols, qkr_nk_cols; float qkr_eps;
 } ur_gemm_args;
+/* 1 when ur_gemm would run the q/k-norm + RoPE epilogue for these arguments, 0 when the caller must use the separate
+ * ur_qknorm_rope_fwd pass. */
+int ur_gemm_qkrope_supported(const ur_gemm_args* a);
+/* feature index stored at tile column c (0..127) of a head under the paired order */
+int ur_qkrope_perm(int c);
 int64_t ur_gemm_workspace_bytes(const ur_gemm_args* a);
 int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, void* stream);
 /* Launches with K-contiguous operands, bf16 output, M, N multiples of 256, K a multiple of 64 (>= 256), >= 512 output tiles and
@@ -237,6 +257,12 @@ int ur_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const void* qkv_r
                        const float* q_norm_w, const float* k_norm_w, const float* cos_tab, const float* sin_tab,
                        void* dqkv_raw, int64_t lddraw, int64_t M, int32_t S, int32_t nq, int32_t nkv,
                        int32_t head_dim, float eps, void* stream);
+/* The same backward when the forward ran as the q|k|v GEMM's epilogue (ur_gemm_args.qkr_*) and the raw projections were never
+ * stored: q_roped [M, >= nq*hd] / k_roped [M, >= nkv*hd] are the forward's outputs, rstd [M, nq + nkv] its row constants; the
+ * normalised rows are recovered by rotating back (x^ = R^T(o) / weight: the norm weights must be non-zero).  head_dim 128. */
+int ur_qknorm_rope_bwd_roped(const void* dq_out, const void* dk_out, const void* q_roped, int64_t ldq, const void* k_roped, int64_t ldk,
+                             const float* rstd, const float* q_norm_w, const float* k_norm_w, const float* cos_tab, const float* sin_tab,
+                             void* dqkv_raw, int64_t lddraw, int64_t M, int32_t S, int32_t nq, int32_t nkv, int32_t head_dim, void* stream);
 
 /* Embedding gather fused with Q-Former token injection --
  * training/train_item_individual_token_joint.py:143 (embed) and :160-171 (triple python loop with a

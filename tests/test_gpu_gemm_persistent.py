@@ -133,3 +133,44 @@ def test_persistent_stream_stress_exact():
         torch.cuda.synchronize()
     finally:
         hip.gemm_persistent_mode(prev)
+
+
+def _paired_rows(W, nqk_heads):
+    perm = hip.qkrope_perm(128)
+    rows = torch.cat([(torch.arange(nqk_heads)[:, None] * 128 + perm[None, :]).reshape(-1), torch.arange(nqk_heads * 128, W.shape[0])])
+    return W[rows.to(W.device)].contiguous()
+
+
+@pytest.mark.parametrize("lora", [False, True])
+def test_qkv_projection_with_qknorm_rope_epilogue(lora):
+    """q/k-norm + RoPE as the epilogue of the merged q|k|v launch (ur_gemm_args.qkr_*; Qwen3Attention, modeling_qwen3.py:227-245)
+    against the projection followed by ur_qknorm_rope_fwd: v bit for bit, q_r / k_r to bf16 rounding (the epilogue normalises
+    the f32 accumulators, the separate pass the bf16-rounded projection), and its backward from the roped outputs."""
+    B, S, D, nq, nkv, hd = 4, 2048, 1024, 16, 8, 128
+    M, NQ, NKV = B * S, nq * hd, nkv * hd
+    x, W = _randn((M, D), 91), _randn((NQ + 2 * NKV, D), 92, 0.05)
+    qw = (1.0 + 0.1 * torch.randn(hd, generator=torch.Generator().manual_seed(93))).to(DEV)
+    kw = (1.0 + 0.1 * torch.randn(hd, generator=torch.Generator().manual_seed(94))).to(DEV)
+    cos, sin = hip.rope_table(S, hd, 1e6, DEV)
+    t, Bm = (_randn((M, 48), 95), _randn((NQ + 2 * NKV, 48), 96, 0.1)) if lora else (None, None)
+    assert hip.gemm_qkrope_supported(M, NQ + 2 * NKV, D, 48 if lora else 0, S, NQ, NKV, DEV)
+    assert not hip.gemm_qkrope_supported(2048, NQ + 2 * NKV, D, 0, S, NQ, NKV, DEV)          # too few tiles: the separate pass
+    raw = hip.gemm(x, W, R2=t, S2=Bm)
+    q0, k0 = hip.qknorm_rope_fwd(raw, qw, kw, cos, sin, S, nq, nkv, hd, 1e-6)
+    q1, k1, v1, rstd = hip.gemm_qkv_rope(x, _paired_rows(W, nq + nkv), qw, kw, cos, sin, S, NQ, NKV, 1e-6, R2=t,
+                                         S2=None if Bm is None else _paired_rows(Bm, nq + nkv))
+    torch.cuda.synchronize()
+    assert torch.equal(v1, raw[:, NQ + NKV:])
+    for a, b, n in ((q1, q0, "q_r"), (k1, k0, "k_r")):
+        rel = float((a.float() - b.float()).norm() / b.float().norm())
+        assert rel <= 6e-3, (n, rel)
+    ref_rs = torch.rsqrt(raw[:, :NQ + NKV].float().view(M, nq + nkv, hd).pow(2).mean(-1) + 1e-6)
+    assert float((rstd - ref_rs).abs().max() / ref_rs.abs().max()) <= 1e-2
+    # backward: gradients of the raw q, k from the roped outputs + rstd against the kernel that reads the raw projection
+    dq, dk = _randn((M, NQ), 97), _randn((M, NKV), 98)
+    d0 = torch.zeros((M, NQ + 2 * NKV), dtype=torch.bfloat16, device=DEV)
+    d1 = torch.zeros_like(d0)
+    hip.qknorm_rope_bwd(dq, dk, raw, qw, kw, cos, sin, d0, S, nq, nkv, hd, 1e-6)
+    hip.qknorm_rope_bwd_roped(dq, dk, q1, k1, rstd, qw, kw, cos, sin, d1, S, nq, nkv, hd)
+    rel = float((d1.float() - d0.float()).norm() / d0.float().norm())
+    assert rel <= 1e-2, rel

@@ -108,6 +108,54 @@ def test_lora_matches_merged_transformers():
     assert named["layers.0.self_attn.q_proj.weight"].grad is None      # base weights stay frozen
 
 
+def test_fused_qknorm_rope_epilogue_matches_the_separate_pass(monkeypatch):
+    """Decoder level: with >= 8192 tokens the q|k|v launch carries q/k-norm + RoPE in its epilogue (csrc/gemm_pers.hip, the raw
+    q, k are never stored; the backward recovers the rows from the roped outputs).  Same weights, inputs and LoRA dropout
+    masks: pooled output, input gradient and every LoRA gradient against the path with the separate ur_qknorm_rope pass."""
+    import unirec_amd.qwen3 as qmod
+    from unirec_amd.qwen3 import Qwen3Config, Qwen3LoRAModel
+    B, S, L = 4, 2048, 2
+    cfg = Qwen3Config(vocab_size=512, num_hidden_layers=L, lora_dropout=0.1)
+    torch.manual_seed(7)
+    m = Qwen3LoRAModel(cfg, use_lora=True)
+    m.reset_parameters(lora_b_std=0.02)
+    with torch.no_grad():
+        for lyr in m.layers:
+            lyr.self_attn.q_norm.weight.copy_(1.0 + 0.1 * torch.randn(128))
+            lyr.self_attn.k_norm.weight.copy_(1.0 + 0.1 * torch.randn(128))
+    m = m.to(DEV).train()
+    g = torch.Generator().manual_seed(3)
+    ids = torch.randint(0, 512, (B, S), generator=g).to(DEV)
+    am = torch.ones(B, S, dtype=torch.long)
+    am[1, :300] = 0
+    am[3, :77] = 0
+    am = am.to(DEV)
+    calls = []
+    real = qmod.hip.gemm_qkv_rope
+    monkeypatch.setattr(qmod.hip, "gemm_qkv_rope", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+
+    def run(fused):
+        monkeypatch.setattr(qmod, "_FUSE_QK_ROPE", fused)
+        m._lora_step, m._bcomb = 11, None
+        for p_ in m.parameters():
+            p_.grad = None
+        if m.pack is not None:
+            m.pack.clear_grads()
+        pooled = m.forward_pooled(ids, am)
+        pooled.pow(2).sum().backward()
+        torch.cuda.synchronize()
+        return pooled.detach().clone(), {n: p_.grad.detach().clone() for n, p_ in m.named_parameters() if p_.grad is not None}
+    p0, g0 = run(False)
+    assert not calls
+    p1, g1 = run(True)
+    assert len(calls) == L, "the fused epilogue did not run"
+    assert float((p1 - p0).norm() / p0.norm()) <= 5e-3
+    assert set(g0) == set(g1) and len(g0) == 14 * L
+    for n in g0:
+        rel = float((g1[n] - g0[n]).norm() / g0[n].norm())
+        assert rel <= 2e-2, (n, rel)
+
+
 def test_user_qformer_mid_size_matches_reference():
     """The reference's default UserQFormer (L4 Q64 H1024 I4096) over T = 1600 keys: C3's shapes at B = 2."""
     from unirec_amd.user_qformer import UserQFormer

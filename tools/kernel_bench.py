@@ -189,6 +189,22 @@ def gemm_lora(args):
         print(f"gemm {name:12s} N={N} K={K}: plain {t0:.3f} ms | + K2={nad * r} range {t1:.3f} ms | + masked epilogue ({nad} adapters) {t2:.3f} ms")
 
 
+def rope(args):
+    """q/k-norm + RoPE forward / backward over the raw q|k|v projection (16 q + 8 kv heads of 128): TB/s of raw q|k in + q_r|k_r out."""
+    M, S, nq, nkv, hd = args.B * args.S, args.S, 16, 8, 128
+    g = torch.Generator().manual_seed(0)
+    qkv = torch.randn(M, (nq + 2 * nkv) * hd, generator=g).cuda().to(torch.bfloat16)
+    qn, kn = torch.ones(hd).cuda(), torch.ones(hd).cuda()
+    cos, sin = hip.rope_table(S, hd, 1e6, "cuda")
+    t = timeit(lambda: hip.qknorm_rope_fwd(qkv, qn, kn, cos, sin, S, nq, nkv, hd, 1e-6), args.iters)
+    nb = 2.0 * M * (nq + nkv) * hd * 2
+    print(f"qknorm_rope fwd: {t * 1e3:.1f} us  {nb / t / 1e9:.2f} TB/s (raw q|k read + q_r|k_r written)")
+    q_r, k_r = hip.qknorm_rope_fwd(qkv, qn, kn, cos, sin, S, nq, nkv, hd, 1e-6)
+    dqkv = torch.empty_like(qkv)
+    t = timeit(lambda: hip.qknorm_rope_bwd(q_r, k_r, qkv, qn, kn, cos, sin, dqkv, S, nq, nkv, hd, 1e-6), args.iters)
+    print(f"qknorm_rope bwd: {t * 1e3:.1f} us  {1.5 * nb / t / 1e9:.2f} TB/s (dq_r|dk_r + raw q|k read, dq|dk raw written)")
+
+
 def lora(args):
     """The rank-16 LoRA side kernels at the C4 shapes (M = B*S tokens): GB/s of the activation they stream."""
     M, r = args.B * args.S, 16
@@ -214,10 +230,10 @@ def lora(args):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["attn", "gemm", "lora", "dw", "xattn", "gemm_lora", "gemm_merge", "gemm_step", "rmslora", "swilora"])
+    ap.add_argument("what", choices=["attn", "gemm", "lora", "rope", "dw", "xattn", "gemm_lora", "gemm_merge", "gemm_step", "rmslora", "swilora"])
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--S", type=int, default=2048)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--lib", action="store_true", help="gemm: also time torch.matmul on the same operands (reference point)")
     a = ap.parse_args()
-    {"attn": attn, "gemm": gemm, "lora": lora, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora, "gemm_merge": gemm_merge, "gemm_step": gemm_step, "rmslora": rmslora, "swilora": swilora}[a.what](a)
+    {"attn": attn, "gemm": gemm, "lora": lora, "rope": rope, "dw": dw, "xattn": xattn, "gemm_lora": gemm_lora, "gemm_merge": gemm_merge, "gemm_step": gemm_step, "rmslora": rmslora, "swilora": swilora}[a.what](a)

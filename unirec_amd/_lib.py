@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UNIREC_HIP_LIB selects another build of the SAME library (kernel A/B experiments); there is still no fallback.
 LIB_PATH = os.environ.get("UNIREC_HIP_LIB") or os.path.join(_HERE, "lib", "libunirec_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_void_p, c_int, c_i64, c_u64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
@@ -31,7 +31,11 @@ class GemmArgs(ctypes.Structure):
                 ("drop_rank", c_int), ("drop_p", c_float),
                 ("swiglu_gu", c_void_p), ("swiglu_ldgu", c_i64), ("swiglu_dgu", c_void_p), ("swiglu_lddgu", c_i64),
                 ("swiglu_I", c_int),
-                ("swiglu_gate", c_void_p), ("swiglu_ldgate", c_i64), ("swiglu_act", c_void_p), ("swiglu_ldact", c_i64)]
+                ("swiglu_gate", c_void_p), ("swiglu_ldgate", c_i64), ("swiglu_act", c_void_p), ("swiglu_ldact", c_i64),
+                ("qkr_q", c_void_p), ("qkr_ldq", c_i64), ("qkr_k", c_void_p), ("qkr_ldk", c_i64), ("qkr_v", c_void_p), ("qkr_ldv", c_i64),
+                ("qkr_rstd", c_void_p),
+                ("qkr_qw", c_void_p), ("qkr_kw", c_void_p), ("qkr_cos", c_void_p), ("qkr_sin", c_void_p),
+                ("qkr_S", c_int), ("qkr_nq_cols", c_int), ("qkr_nk_cols", c_int), ("qkr_eps", c_float)]
 
 
 class LoraArgs(ctypes.Structure):
@@ -72,6 +76,8 @@ SIGNATURES = {
     "ur_gemm_workspace_bytes": (c_i64, [ctypes.POINTER(GemmArgs)]),
     "ur_gemm": (c_int, [ctypes.POINTER(GemmArgs), c_void_p, c_i64, c_void_p]),
     "ur_gemm_persistent_mode": (c_int, [c_int]),
+    "ur_gemm_qkrope_supported": (c_int, [ctypes.POINTER(GemmArgs)]),
+    "ur_qkrope_perm": (c_int, [c_int]),
     "ur_lora_bits_ld": (c_i64, [c_int]),
     "ur_lora_dropout_bits": (c_int, [c_u64, c_float, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_i64, c_void_p]),
     "ur_lora_project": (c_int, [ctypes.POINTER(LoraArgs), c_void_p]),
@@ -97,6 +103,8 @@ SIGNATURES = {
                                    c_int, c_int, c_int, c_float, c_void_p]),
     "ur_qknorm_rope_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
                                    c_i64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ur_qknorm_rope_bwd_roped": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
     "ur_embed_inject_fwd": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ur_inject_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ur_user_sequence_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u64,

@@ -915,6 +915,50 @@ extern "C" int ur_lab_gemm_stamps(long long* host, int n) {
 }
 #endif
 
+static void fill_params(const ur_gemm_args* a, GemmP& p) {
+  p.R = (const bf16_t*)a->R; p.S = (const bf16_t*)a->S; p.ldr = a->ldr; p.lds = a->lds; p.K = a->K;
+  p.R2 = (const bf16_t*)a->R2; p.S2 = (const bf16_t*)a->S2; p.ldr2 = a->ldr2; p.lds2 = a->lds2; p.K2 = a->K2;
+  p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.alpha = a->alpha;
+  p.bias = a->bias; p.res = (const bf16_t*)a->residual; p.ldres = a->ldres;
+  p.gelu_out = (bf16_t*)a->gelu_out; p.ldg = a->ldg; p.aux = (const bf16_t*)a->gelu_grad_aux; p.ldaux = a->ldaux;
+  p.gm = 0; p.gn = 0;   // set by launch_cfg for the chosen tile
+  p.drop_bits = (const uint8_t*)a->drop_bits; p.drop_bits_ld = a->drop_bits_ld; p.drop_bits_stride = a->drop_bits_stride;
+  p.drop_rank = a->drop_rank;
+  p.drop_inv_keep = a->drop_bits ? 1.0f / (1.0f - a->drop_p) : 1.0f;
+  p.sw_gu = (const bf16_t*)a->swiglu_gu; p.sw_ldgu = a->swiglu_ldgu; p.sw_dgu = (bf16_t*)a->swiglu_dgu; p.sw_lddgu = a->swiglu_lddgu;
+  p.sw_I = a->swiglu_I; p.sw_mode = a->swiglu_gu ? 1 : 0;
+  if (a->swiglu_gate) {
+    p.sw_gu = (const bf16_t*)a->swiglu_gate; p.sw_ldgu = a->swiglu_ldgate; p.sw_dgu = (bf16_t*)a->swiglu_act; p.sw_lddgu = a->swiglu_ldact;
+    p.sw_I = 0; p.sw_mode = 2;
+  }
+  p.qk_q = (bf16_t*)a->qkr_q; p.qk_ldq = a->qkr_ldq; p.qk_k = (bf16_t*)a->qkr_k; p.qk_ldk = a->qkr_ldk; p.qk_v = (bf16_t*)a->qkr_v; p.qk_ldv = a->qkr_ldv;
+  p.qk_rstd = a->qkr_rstd; p.qk_qw = a->qkr_qw; p.qk_kw = a->qkr_kw; p.qk_cos = a->qkr_cos; p.qk_sin = a->qkr_sin;
+  p.qk_S = a->qkr_S; p.qk_nq = a->qkr_nq_cols; p.qk_nk = a->qkr_nk_cols; p.qk_eps = a->qkr_eps;
+  p.ksplit_len = 0; p.slab_stride = 0; p.gcw = 0; p.stagger = 0;
+}
+
+// the q/k-norm + RoPE epilogue exists on the persistent kernel only: everything ur_gemm_args.qkr_* promises, checked once
+static bool qkrope_ok(const ur_gemm_args* a, const GemmP& p) {
+  if (!a->qkr_q || !a->qkr_k || !a->qkr_v || !a->qkr_rstd || !a->qkr_qw || !a->qkr_kw || !a->qkr_cos || !a->qkr_sin) return false;
+  if (!a->r_kcontig || !a->s_kcontig || a->c_f32 || a->split_k > 1) return false;
+  if (a->bias || a->residual || a->gelu_out || a->gelu_grad_aux || a->drop_bits || a->swiglu_gu || a->swiglu_gate || a->alpha != 1.0f) return false;
+  if (a->qkr_S < 256 || (a->qkr_nq_cols % 256) || (a->qkr_nk_cols % 256) || a->qkr_nq_cols < 0 || a->qkr_nk_cols < 0 ||
+      a->qkr_nq_cols + a->qkr_nk_cols > a->N || ((a->N - a->qkr_nq_cols - a->qkr_nk_cols) % 256)) return false;
+  if ((a->qkr_ldq & 7) || (a->qkr_ldk & 7) || (a->qkr_ldv & 7) || !UR_ALIGNED16(a->qkr_q) || !UR_ALIGNED16(a->qkr_k) || !UR_ALIGNED16(a->qkr_v) ||
+      !UR_ALIGNED16(a->qkr_qw) || !UR_ALIGNED16(a->qkr_kw) || !UR_ALIGNED16(a->qkr_cos) || !UR_ALIGNED16(a->qkr_sin)) return false;
+  if (a->qkr_ldq < a->qkr_nq_cols || a->qkr_ldk < a->qkr_nk_cols || a->qkr_ldv < a->N - a->qkr_nq_cols - a->qkr_nk_cols) return false;
+  return urgemm::gemm_pers_eligible(p, 1, true, true, false);
+}
+
+extern "C" int ur_qkrope_perm(int c) { return ((c >> 4) & 1) * 64 + ((c >> 5) & 3) * 16 + (c & 15); }
+
+extern "C" int ur_gemm_qkrope_supported(const ur_gemm_args* a) {
+  if (!a || a->M <= 0 || a->N <= 0 || !a->R || !a->S) return 0;
+  GemmP p;
+  fill_params(a, p);
+  return qkrope_ok(a, p) ? 1 : 0;
+}
+
 extern "C" int64_t ur_gemm_workspace_bytes(const ur_gemm_args* a) {
   if (!a || a->split_k <= 1) return 0;
   return (int64_t)a->split_k * a->M * a->ldc * (int64_t)sizeof(float);
@@ -933,7 +977,7 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
   UR_REQUIRE(a->r_kcontig || (a->M % 8) == 0, "ur_gemm: K-strided R needs M %% 8 == 0 (M=%d)", a->M);
   UR_REQUIRE(a->s_kcontig || (a->N % 8) == 0, "ur_gemm: K-strided S needs N %% 8 == 0 (N=%d)", a->N);
   UR_REQUIRE(UR_ALIGNED16(a->R) && UR_ALIGNED16(a->S) && UR_ALIGNED16(a->C), "ur_gemm: operands must be 16-byte aligned");
-  UR_REQUIRE(a->ldr >= (a->r_kcontig ? a->K : a->M) && a->lds >= (a->s_kcontig ? a->K : a->N) && a->ldc >= a->N,
+  UR_REQUIRE(a->ldr >= (a->r_kcontig ? a->K : a->M) && a->lds >= (a->s_kcontig ? a->K : a->N) && (a->ldc >= a->N || a->qkr_q),
              "ur_gemm: leading dimension smaller than row length");
   if (a->K2 > 0) {
     UR_REQUIRE(a->R2 && a->S2 && UR_ALIGNED16(a->R2) && UR_ALIGNED16(a->S2), "ur_gemm: bad second operand pair");
@@ -980,21 +1024,7 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
                ((uintptr_t)a->drop_bits & 15) == 0, "ur_gemm: bad LoRA dropout bit planes (rows of ur_lora_bits_ld(N) bytes, 16-byte aligned)");
   }
   GemmP p;
-  p.R = (const bf16_t*)a->R; p.S = (const bf16_t*)a->S; p.ldr = a->ldr; p.lds = a->lds; p.K = a->K;
-  p.R2 = (const bf16_t*)a->R2; p.S2 = (const bf16_t*)a->S2; p.ldr2 = a->ldr2; p.lds2 = a->lds2; p.K2 = a->K2;
-  p.C = a->C; p.ldc = a->ldc; p.M = a->M; p.N = a->N; p.alpha = a->alpha;
-  p.bias = a->bias; p.res = (const bf16_t*)a->residual; p.ldres = a->ldres;
-  p.gelu_out = (bf16_t*)a->gelu_out; p.ldg = a->ldg; p.aux = (const bf16_t*)a->gelu_grad_aux; p.ldaux = a->ldaux;
-  p.gm = 0; p.gn = 0;   // set by launch_cfg for the chosen tile
-  p.drop_bits = (const uint8_t*)a->drop_bits; p.drop_bits_ld = a->drop_bits_ld; p.drop_bits_stride = a->drop_bits_stride;
-  p.drop_rank = a->drop_rank;
-  p.drop_inv_keep = a->drop_bits ? 1.0f / (1.0f - a->drop_p) : 1.0f;
-  p.sw_gu = (const bf16_t*)a->swiglu_gu; p.sw_ldgu = a->swiglu_ldgu; p.sw_dgu = (bf16_t*)a->swiglu_dgu; p.sw_lddgu = a->swiglu_lddgu;
-  p.sw_I = a->swiglu_I; p.sw_mode = a->swiglu_gu ? 1 : 0;
-  if (a->swiglu_gate) {
-    p.sw_gu = (const bf16_t*)a->swiglu_gate; p.sw_ldgu = a->swiglu_ldgate; p.sw_dgu = (bf16_t*)a->swiglu_act; p.sw_lddgu = a->swiglu_ldact;
-    p.sw_I = 0; p.sw_mode = 2;
-  }
+  fill_params(a, p);
   p.slab_stride = 0;
   if (splits > 1) {
     int tiles = ur_cdiv(a->K, BK);
@@ -1005,6 +1035,10 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
     p.ksplit_len = a->K > 0 ? ur_cdiv(a->K, BK) * BK : BK;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (a->qkr_q) {
+    UR_REQUIRE(qkrope_ok(a, p), "ur_gemm: the q/k-norm + RoPE epilogue is not available for these arguments (ur_gemm_qkrope_supported)");
+    return urgemm::gemm_pers_launch(p, st);
+  }
   int rc;
   const bool rk = a->r_kcontig != 0, sk = a->s_kcontig != 0, f32 = a->c_f32 != 0;
   if (rk && sk) rc = f32 ? launch<true, true, true>(p, splits, st) : launch<true, true, false>(p, splits, st);

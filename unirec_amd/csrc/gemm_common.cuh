@@ -19,6 +19,9 @@ struct GemmP {
   // SwiGLU backward epilogue (ur_gemm_args.swiglu_*): the result is d(act); dgate / dup leave instead of C
   // (forward epilogue, sw_mode 2: sw_gu = gate, sw_dgu = act)
   const bf16_t* sw_gu; long sw_ldgu; bf16_t* sw_dgu; long sw_lddgu; int sw_I; int sw_mode;
+  // q/k-norm + RoPE epilogue of the q|k|v projection (ur_gemm_args.qkr_*; persistent kernel only)
+  bf16_t* qk_q; long qk_ldq; bf16_t* qk_k; long qk_ldk; bf16_t* qk_v; long qk_ldv; float* qk_rstd;
+  const float* qk_qw; const float* qk_kw; const float* qk_cos; const float* qk_sin; int qk_S, qk_nq, qk_nk; float qk_eps;
 };
 
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {

@@ -82,7 +82,8 @@ __device__ __forceinline__ void swap16f(float& a, float& b) {
   a = __uint_as_float(ua); b = __uint_as_float(ub);
 }
 
-// EPI: 0 = plain (alpha only), 2 = bias / residual, 1 = SwiGLU backward (result is d(act); dgate | dup leave instead of C).
+// EPI: 0 = plain (alpha only), 2 = bias / residual, 1 = SwiGLU backward (result is d(act); dgate | dup leave instead of C),
+//      3 = q/k-norm + RoPE of the q|k|v projection (ur_gemm_args.qkr_*; q_r, k_r, v and the row constants leave instead of C).
 // MODE: 0 = no second K range, 1 = the LoRA second K range rides in the K stream (one zero-padded K tile per output tile),
 //       2 = masked rank-16 LoRA epilogue (dX under LoRA dropout; the second operand pair is read by the epilogue only).
 template <int EPI, int MODE>
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
 #endif
     // The masked LoRA epilogue is a chain of load -> wait -> MFMA -> add: one barrier interval apart the two groups would run
     // it one after the other (each waiting at the other's barrier); re-joined they run it together.
-    constexpr bool JOIN = UR_PERS_JOIN || DROP;
+    constexpr bool JOIN = UR_PERS_JOIN || DROP || EPI == 3;      // (EPI 3: its row sums cross the waves through LDS behind a workgroup barrier)
     if (JOIN && wr == 0) __builtin_amdgcn_s_barrier();
     UR_PSTAMP(6);
     // ================= epilogue, from the accumulators (no LDS, no barrier) =================
@@ -366,6 +367,83 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
           }
       }
     }
+    if constexpr (EPI == 3) {
+      // ---- q/k-norm + RoPE (modeling_qwen3.py:59-64,107-137,227-245) from the accumulators.  The tile is two whole heads (its two
+      // 128-column halves sh); the head's rows of W were stored in the paired order, so acc[2 sh][j][e] is feature
+      // d = wc*16 + 4*g4 + e and acc[2 sh + 1][j][e] its rotate-half partner d + 64: RoPE is register-local.  Only the row sums
+      // of squares cross lanes (the 4 g4 lanes of a row: two shuffles) and waves (the 4 wc waves of a head: 8 KiB of LDS behind
+      // one workgroup barrier; both wave groups are joined here).
+      const int qkc = p.qk_nq + p.qk_nk;
+      if (n0 < qkc) {           // uniform: a q / k tile
+        float* part = reinterpret_cast<float*>(smem + 2 * STAGE);          // [2 sh][256 rows][4 wc]
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
+            float ss = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const int row = (j >> 2) * 128 + wr * 64 + (j & 3) * 16 + el15;
+            if (eg4 == 0) part[(sh * 256 + row) * 4 + wc] = ss;
+          }
+        __syncthreads();
+        const bool isq = n0 < p.qk_nq;
+        const float* wgt = isq ? p.qk_qw : p.qk_kw;
+        const int dq0 = wc * 16 + 4 * eg4;                                  // this lane's features dq0 .. + 3 (and + 64)
+        const float4 w0 = *reinterpret_cast<const float4*>(wgt + dq0), w1 = *reinterpret_cast<const float4*>(wgt + 64 + dq0);
+        bf16_t* outb = isq ? p.qk_q : p.qk_k;
+        const long ldo = isq ? p.qk_ldq : p.qk_ldk;
+        const int c0 = isq ? n0 : n0 - p.qk_nq;                             // first column of the tile inside q_out / k_out
+        const int nheads = qkc >> 7, head0 = n0 >> 7;
+        const int pos0 = m0 % p.qk_S;                                       // (scalar) positions of the tile's rows: pos0 + row, wrapping at S >= 256
+        // after the 16-lane swap: 16-lane row rho even -> the 8 features (rho >> 1) * 8 .. of block d, odd -> of block d + 64
+        const int ocol = (eg4 & 1) * 64 + wc * 16 + (eg4 >> 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int row = (j >> 2) * 128 + wr * 64 + (j & 3) * 16 + el15;
+          int pos = pos0 + row;
+          pos = pos >= p.qk_S ? pos - p.qk_S : pos;
+          const float4 cc = *reinterpret_cast<const float4*>(p.qk_cos + (long)pos * 64 + dq0), sn = *reinterpret_cast<const float4*>(p.qk_sin + (long)pos * 64 + dq0);
+          const float cv[4] = {cc.x, cc.y, cc.z, cc.w}, sv[4] = {sn.x, sn.y, sn.z, sn.w};
+          const float wa[4] = {w0.x, w0.y, w0.z, w0.w}, wb[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+          for (int sh = 0; sh < 2; ++sh) {
+            const float4 pr = *reinterpret_cast<const float4*>(part + (sh * 256 + row) * 4);
+            const float rs = rsqrtf((pr.x + pr.y + pr.z + pr.w) * (1.0f / 128.0f) + p.qk_eps);
+            const f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
+            float o0[4], o1[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float xa = a[e] * rs * wa[e], xb = b[e] * rs * wb[e];
+              o0[e] = xa * cv[e] - xb * sv[e];
+              o1[e] = xb * cv[e] + xa * sv[e];
+            }
+            uint32_t a0 = pack_bf2(o0[0], o0[1]), a1 = pack_bf2(o0[2], o0[3]), b0 = pack_bf2(o1[0], o1[1]), b1 = pack_bf2(o1[2], o1[3]);
+            swap16(a0, b0); swap16(a1, b1);
+            const long m = m0 + row;
+            const u32x4_t v = {a0, a1, b0, b1};
+            *reinterpret_cast<u32x4_t*>(outb + m * ldo + c0 + sh * 128 + ocol) = v;
+            if (wc == 0 && eg4 == 0) p.qk_rstd[m * nheads + head0 + sh] = rs;
+          }
+        }
+      } else {                  // a v tile: the plain projection into v_out
+        const int cs = (eg4 & 1) * 16 + (eg4 >> 1) * 8;
+        const uint32_t loff = (uint32_t)((el15 * p.qk_ldv + cs) * 2);
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
+            uint32_t a0 = pack_bf2(a[0], a[1]), a1 = pack_bf2(a[2], a[3]), b0 = pack_bf2(b[0], b[1]), b1 = pack_bf2(b[2], b[3]);
+            swap16(a0, b0); swap16(a1, b1);
+            char* base = uniform_wptr(reinterpret_cast<char*>(p.qk_v) +
+                                      ((long)(m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16) * p.qk_ldv + (n0 - qkc) + sh * 128 + wc * 32) * 2);
+            const u32x4_t v = {a0, a1, b0, b1};
+            *reinterpret_cast<u32x4_t*>(base + loff) = v;
+          }
+      }
+    } else
     {
       // after the 16-lane swap a lane holds 8 consecutive columns of row m: cs = (eg4 & 1) * 16 + (eg4 >> 1) * 8 within the wave's 32
       const int cs = (eg4 & 1) * 16 + (eg4 >> 1) * 8;
@@ -463,14 +541,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
     m0 = nm0; n0 = nn0;
   }
   // drain: re-join the wave groups, let the never-consumed tail of the stream land before the workgroup's LDS is released
-  if (!(UR_PERS_JOIN || DROP) && wr == 0) __builtin_amdgcn_s_barrier();
+  if (!(UR_PERS_JOIN || DROP || EPI == 3) && wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 template <int EPI, int MODE>
 int launch_pers(const GemmP& p, hipStream_t st) {
   static std::atomic<bool> attr_set{false};
-  constexpr int SMEM = 2 * STAGE;
+  constexpr int SMEM = 2 * STAGE + (EPI == 3 ? 2 * 256 * 4 * (int)sizeof(float) : 0);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<EPI, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) UR_FAIL((int)e, "ur_gemm(persistent): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -540,11 +618,12 @@ int gemm_pers_launch(GemmP p, hipStream_t st) {
     p.stagger = env_st > 0 ? env_st : 0;
   }
   const int mode = drop ? 2 : (p.K2 > 0 ? 1 : 0);
-  const int epi = p.sw_mode == 1 ? 1 : ((p.res || p.bias) ? 2 : 0);
+  const int epi = p.qk_q ? 3 : (p.sw_mode == 1 ? 1 : ((p.res || p.bias) ? 2 : 0));
 #define UR_PERS_CASE(E, MD) if (epi == E && mode == MD) return launch_pers<E, MD>(p, st)
   UR_PERS_CASE(0, 0); UR_PERS_CASE(0, 1); UR_PERS_CASE(0, 2);
   UR_PERS_CASE(1, 0); UR_PERS_CASE(1, 1); UR_PERS_CASE(1, 2);
   UR_PERS_CASE(2, 0); UR_PERS_CASE(2, 1); UR_PERS_CASE(2, 2);
+  UR_PERS_CASE(3, 0); UR_PERS_CASE(3, 1);
 #undef UR_PERS_CASE
   UR_FAIL(-1, "ur_gemm(persistent): no kernel for epilogue %d, mode %d", epi, mode);
 }

@@ -52,45 +52,135 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const bf16_t* __restri
     float c[8], s[8];
     ld8f(cs + (long)pos * HALF + (li % (LPH / 2)) * 8, c);
     ld8f(sn + (long)pos * HALF + (li % (LPH / 2)) * 8, s);
-    for (int hh = 0; hh < nq + nkv; ++hh) {
-      const bool isq = hh < nq;
-      float x[8], ww[8];
-      un8(*reinterpret_cast<const uint4*>(raw + m * ldraw + (long)hh * HD + li * 8), x);
+    // heads in batches of UH: the batch's loads are issued together (one 16-byte load per lane and head in flight was the
+    // kernel's whole memory-level parallelism: 3.3 TB/s on q|k raw + outputs; the reductions below are a dependent chain per head)
+#ifndef UR_ROPE_UH
+#define UR_ROPE_UH 4            // lab: heads per load batch of the forward (1 = the round-2 kernel)
+#endif
+    constexpr int UH = BWD ? (UR_ROPE_UH > 1 ? 2 : 1) : UR_ROPE_UH;        // (backward: two loads per head, its operands mostly come from L2 -- and 4 would cost a wave per SIMD)
+    const int nh = nq + nkv;
+    for (int h0 = 0; h0 < nh; h0 += UH) {
+      uint4 xr[UH], dyr[UH];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ww[e] = isq ? wq[e] : wk[e];
-      float ss = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-      ss = group_sum<LPH>(ss);
-      const float rs = rsqrtf(ss / (float)HD + eps);
-      bf16_t* op = isq ? (qo + m * (long)nq * HD + (long)hh * HD) : (ko + m * (long)nkv * HD + (long)(hh - nq) * HD);
-      if (!BWD) {
-        float xn[8], o[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) xn[e] = x[e] * rs * ww[e];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float partner = __shfl_xor(xn[e], LPH / 2, 64);
-          o[e] = xn[e] * c[e] + sign * partner * s[e];
+      for (int u = 0; u < UH; ++u) {
+        const int hh = min(h0 + u, nh - 1);
+        xr[u] = *reinterpret_cast<const uint4*>(raw + m * ldraw + (long)hh * HD + li * 8);
+        if (BWD) {
+          const bool isq = hh < nq;
+          const bf16_t* op = isq ? (qo + m * (long)nq * HD + (long)hh * HD) : (ko + m * (long)nkv * HD + (long)(hh - nq) * HD);
+          dyr[u] = *reinterpret_cast<const uint4*>(op + li * 8);
         }
-        *reinterpret_cast<uint4*>(op + li * 8) = pk8(o);
-      } else {
-        float dy[8], g[8], xh[8];
-        un8(*reinterpret_cast<const uint4*>(op + li * 8), dy);
+      }
+#pragma unroll
+      for (int u = 0; u < UH; ++u) {
+        const int hh = h0 + u;
+        if (hh >= nh) break;
+        const bool isq = hh < nq;
+        float x[8], ww[8];
+        un8(xr[u], x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ww[e] = isq ? wq[e] : wk[e];
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
+        ss = group_sum<LPH>(ss);
+        const float rs = rsqrtf(ss / (float)HD + eps);
+        bf16_t* op = isq ? (qo + m * (long)nq * HD + (long)hh * HD) : (ko + m * (long)nkv * HD + (long)(hh - nq) * HD);
+        if (!BWD) {
+          float xn[8], o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) xn[e] = x[e] * rs * ww[e];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float partner = __shfl_xor(xn[e], LPH / 2, 64);
+            o[e] = xn[e] * c[e] + sign * partner * s[e];
+          }
+          *reinterpret_cast<uint4*>(op + li * 8) = pk8(o);
+        } else {
+          float dy[8], g[8], xh[8];
+          un8(dyr[u], dy);
+          float t = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float partner = __shfl_xor(dy[e] * s[e], LPH / 2, 64);   // (dout*sin) of the paired element
+            const float dxn = dy[e] * c[e] - sign * partner;               // d<half: +partner, d>=half: -partner
+            g[e] = dxn * ww[e];
+            xh[e] = x[e] * rs;
+            t += g[e] * xh[e];
+          }
+          t = group_sum<LPH>(t) / (float)HD;
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = rs * (g[e] - xh[e] * t);
+          *reinterpret_cast<uint4*>(draw + m * lddraw + (long)hh * HD + li * 8) = pk8(o);
+        }
+      }
+    }
+  }
+}
+
+// Backward of q/k-norm + RoPE when the forward ran as the q|k|v GEMM's epilogue (ur_gemm_args.qkr_*): the raw projections were
+// never stored.  The normalised row is recovered from the ROPED output (the rotation is orthogonal): xn = R^T o, x^ = xn / w,
+// and 1 / rms comes from the forward (rstd [M, nq + nkv]).  Same lane layout as qknorm_rope_kernel (LPH lanes per token, 8
+// consecutive features each; the rotate-half partner sits LPH / 2 lanes away).  Needs non-zero norm weights (host check).
+template <int HD>
+__global__ __launch_bounds__(256) void qknorm_rope_bwd_roped_kernel(const bf16_t* __restrict__ dqo, const bf16_t* __restrict__ dko,
+                                                                    const bf16_t* __restrict__ qr, long ldqr, const bf16_t* __restrict__ kr, long ldkr,
+                                                                    const float* __restrict__ rstd, const float* __restrict__ qw, const float* __restrict__ kw,
+                                                                    const float* __restrict__ cs, const float* __restrict__ sn,
+                                                                    bf16_t* __restrict__ draw, long lddraw, long M, int S, int nq, int nkv) {
+  constexpr int LPH = HD / 8, HALF = HD / 2;
+  const int lane = threadIdx.x & 63;
+  const int li = lane % LPH;
+  const long toks_per_block = 256 / LPH;
+  float wq[8], wk[8], iwq[8], iwk[8];
+  ld8f(qw + li * 8, wq);
+  ld8f(kw + li * 8, wk);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { iwq[e] = 1.0f / wq[e]; iwk[e] = 1.0f / wk[e]; }
+  const float sign = (li < LPH / 2) ? -1.f : 1.f;
+  const int nh = nq + nkv;
+  for (long m = (long)blockIdx.x * toks_per_block + threadIdx.x / LPH; m < M; m += (long)gridDim.x * toks_per_block) {
+    const int pos = (int)(m % S);
+    float c[8], s[8];
+    ld8f(cs + (long)pos * HALF + (li % (LPH / 2)) * 8, c);
+    ld8f(sn + (long)pos * HALF + (li % (LPH / 2)) * 8, s);
+    constexpr int UH = 2;
+    for (int h0 = 0; h0 < nh; h0 += UH) {
+      uint4 orr[UH], dyr[UH];
+      float rsv[UH];
+#pragma unroll
+      for (int u = 0; u < UH; ++u) {
+        const int hh = min(h0 + u, nh - 1);
+        const bool isq = hh < nq;
+        orr[u] = *reinterpret_cast<const uint4*>((isq ? qr + m * ldqr + (long)hh * HD : kr + m * ldkr + (long)(hh - nq) * HD) + li * 8);
+        dyr[u] = *reinterpret_cast<const uint4*>((isq ? dqo + m * (long)nq * HD + (long)hh * HD : dko + m * (long)nkv * HD + (long)(hh - nq) * HD) + li * 8);
+        rsv[u] = rstd[m * nh + hh];
+      }
+#pragma unroll
+      for (int u = 0; u < UH; ++u) {
+        const int hh = h0 + u;
+        if (hh >= nh) break;
+        const bool isq = hh < nq;
+        float o[8], dy[8], g[8], xh[8];
+        un8(orr[u], o);
+        un8(dyr[u], dy);
+        const float rs = rsv[u];
         float t = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float partner = __shfl_xor(dy[e] * s[e], LPH / 2, 64);   // (dout*sin) of the paired element
-          const float dxn = dy[e] * c[e] - sign * partner;               // d<half: +partner, d>=half: -partner
-          g[e] = dxn * ww[e];
-          xh[e] = x[e] * rs;
+          const float ww = isq ? wq[e] : wk[e], iw = isq ? iwq[e] : iwk[e];
+          const float po = __shfl_xor(o[e] * s[e], LPH / 2, 64);            // forward: o = xn c + sign * partner(xn) s  =>  xn = o c - sign * partner(o s)
+          xh[e] = (o[e] * c[e] - sign * po) * iw;                           // x^ = x * rstd
+          const float pd = __shfl_xor(dy[e] * s[e], LPH / 2, 64);
+          g[e] = (dy[e] * c[e] - sign * pd) * ww;
           t += g[e] * xh[e];
         }
         t = group_sum<LPH>(t) / (float)HD;
-        float o[8];
+        float dx[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = rs * (g[e] - xh[e] * t);
-        *reinterpret_cast<uint4*>(draw + m * lddraw + (long)hh * HD + li * 8) = pk8(o);
+        for (int e = 0; e < 8; ++e) dx[e] = rs * (g[e] - xh[e] * t);
+        *reinterpret_cast<uint4*>(draw + m * lddraw + (long)hh * HD + li * 8) = pk8(dx);
       }
     }
   }
@@ -299,6 +389,26 @@ extern "C" int ur_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const 
     hipLaunchKernelGGL((qknorm_rope_kernel<64, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)qkv_raw, (long)ldraw,
                        q_norm_w, k_norm_w, cos_tab, sin_tab, (bf16_t*)dq_out, (bf16_t*)dk_out, (bf16_t*)dqkv_raw, (long)lddraw, (long)M, S, nq, nkv, eps);
   UR_CHECK_LAUNCH("ur_qknorm_rope_bwd");
+  return 0;
+}
+
+extern "C" int ur_qknorm_rope_bwd_roped(const void* dq_out, const void* dk_out, const void* q_roped, int64_t ldq, const void* k_roped, int64_t ldk,
+                                        const float* rstd, const float* q_norm_w, const float* k_norm_w, const float* cos_tab, const float* sin_tab,
+                                        void* dqkv_raw, int64_t lddraw, int64_t M, int32_t S, int32_t nq, int32_t nkv, int32_t head_dim, void* stream) {
+  UR_REQUIRE(head_dim == 128, "ur_qknorm_rope_bwd_roped: head_dim must be 128 (the q|k|v epilogue it pairs with)");
+  UR_REQUIRE(dq_out && dk_out && q_roped && k_roped && rstd && q_norm_w && k_norm_w && cos_tab && sin_tab && dqkv_raw && M >= 0 && S > 0 && nq > 0 && nkv > 0,
+             "ur_qknorm_rope_bwd_roped: null / bad argument");
+  UR_REQUIRE((ldq % 8) == 0 && (ldk % 8) == 0 && (lddraw % 8) == 0 && ldq >= (int64_t)nq * head_dim && ldk >= (int64_t)nkv * head_dim &&
+             lddraw >= (int64_t)(nq + nkv) * head_dim && UR_ALIGNED16(dq_out) && UR_ALIGNED16(dk_out) && UR_ALIGNED16(q_roped) && UR_ALIGNED16(k_roped) &&
+             UR_ALIGNED16(q_norm_w) && UR_ALIGNED16(k_norm_w) && UR_ALIGNED16(cos_tab) && UR_ALIGNED16(sin_tab) && UR_ALIGNED16(dqkv_raw),
+             "ur_qknorm_rope_bwd_roped: alignment / stride");
+  if (M == 0) return 0;
+  const int tpb = 256 / (head_dim / 8);
+  const int grid = grid_cap(((long)M + tpb - 1) / tpb, 256 * 16);
+  hipLaunchKernelGGL((qknorm_rope_bwd_roped_kernel<128>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dq_out, (const bf16_t*)dk_out,
+                     (const bf16_t*)q_roped, (long)ldq, (const bf16_t*)k_roped, (long)ldk, rstd, q_norm_w, k_norm_w, cos_tab, sin_tab,
+                     (bf16_t*)dqkv_raw, (long)lddraw, (long)M, S, nq, nkv);
+  UR_CHECK_LAUNCH("ur_qknorm_rope_bwd_roped");
   return 0;
 }
 

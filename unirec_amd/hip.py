@@ -126,6 +126,81 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
     return out
 
 
+def qkrope_perm(head_dim=128):
+    """Feature stored at tile column c of a head under the paired row order of the fused q|k|v + q/k-norm + RoPE launch
+    (ur_qkrope_perm, include/unirec_hip.h): index tensor `perm` with W_paired[h * 128 + c] = W[h * 128 + perm[c]]."""
+    if head_dim != 128:
+        raise ValueError("the fused q/k-norm + RoPE epilogue is built for head_dim 128")
+    lib = _lib.load()
+    return torch.tensor([lib.ur_qkrope_perm(c) for c in range(128)], dtype=torch.long)
+
+
+def _qkrope_args(R, S, R2, S2, qw, kw, cos, sin, Sseq, nq_cols, nk_cols, eps, outs):
+    M, N, K = R.shape[0], S.shape[0], R.shape[1]
+    a = GemmArgs()
+    a.R, a.ldr, a.r_kcontig = R.data_ptr(), R.stride(0), 1
+    a.S, a.lds, a.s_kcontig = S.data_ptr(), S.stride(0), 1
+    a.K, a.M, a.N, a.alpha, a.split_k = K, M, N, 1.0, 1
+    if R2 is not None:
+        a.R2, a.ldr2, a.S2, a.lds2, a.K2 = R2.data_ptr(), R2.stride(0), S2.data_ptr(), S2.stride(0), R2.shape[1]
+    q, k, v, rstd = outs
+    a.C, a.ldc, a.c_f32 = q.data_ptr(), q.stride(0), 0                # not written in this mode: any valid pointer
+    a.qkr_q, a.qkr_ldq, a.qkr_k, a.qkr_ldk, a.qkr_v, a.qkr_ldv = q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0)
+    a.qkr_rstd = rstd.data_ptr()
+    a.qkr_qw, a.qkr_kw, a.qkr_cos, a.qkr_sin = qw.data_ptr(), kw.data_ptr(), cos.data_ptr(), sin.data_ptr()
+    a.qkr_S, a.qkr_nq_cols, a.qkr_nk_cols, a.qkr_eps = int(Sseq), int(nq_cols), int(nk_cols), float(eps)
+    return a
+
+
+def gemm_qkrope_supported(M, N, K, K2, Sseq, nq_cols, nk_cols, device):
+    """True when the q|k|v projection of these sizes can carry q/k-norm + RoPE in its epilogue (ur_gemm_qkrope_supported)."""
+    lib = _lib.load()
+    d = torch.empty(16, dtype=BF16, device=device)          # any valid 16-byte aligned pointer: only sizes / flags are inspected
+    f = torch.empty(4, dtype=F32, device=device)
+    a = GemmArgs()
+    a.R = a.S = a.C = a.qkr_q = a.qkr_k = a.qkr_v = d.data_ptr()
+    a.qkr_rstd = a.qkr_qw = a.qkr_kw = a.qkr_cos = a.qkr_sin = f.data_ptr()
+    a.ldr = a.lds = K
+    a.r_kcontig = a.s_kcontig = 1
+    a.K, a.M, a.N, a.alpha, a.split_k, a.ldc = K, M, N, 1.0, 1, N
+    if K2:
+        a.R2 = a.S2 = d.data_ptr(); a.ldr2 = a.lds2 = K2; a.K2 = K2
+    a.qkr_ldq, a.qkr_ldk, a.qkr_ldv = nq_cols, nk_cols, N - nq_cols - nk_cols
+    a.qkr_S, a.qkr_nq_cols, a.qkr_nk_cols, a.qkr_eps = int(Sseq), int(nq_cols), int(nk_cols), 1e-6
+    return bool(lib.ur_gemm_qkrope_supported(ctypes.byref(a)))
+
+
+def gemm_qkv_rope(R, S, qw, kw, cos, sin, Sseq, nq_cols, nk_cols, eps, R2=None, S2=None):
+    """The merged q|k|v projection with q/k-norm + RoPE in its epilogue (ur_gemm_args.qkr_*): R [M,K] activations, S [N,K]
+    weights whose q / k head rows are in the paired order (qkrope_perm), optional LoRA pair (S2 rows paired likewise).
+    Returns (q_r [M,nq_cols], k_r [M,nk_cols], v [M,N-nq-nk], rstd [M,(nq+nk)/128]); the raw q, k are never stored."""
+    lib = _lib.load()
+    M, N = R.shape[0], S.shape[0]
+    dev = R.device
+    outs = (torch.empty((M, nq_cols), dtype=BF16, device=dev), torch.empty((M, nk_cols), dtype=BF16, device=dev),
+            torch.empty((M, N - nq_cols - nk_cols), dtype=BF16, device=dev), torch.empty((M, (nq_cols + nk_cols) // 128), dtype=F32, device=dev))
+    a = _qkrope_args(R, S, R2, S2, qw, kw, cos, sin, Sseq, nq_cols, nk_cols, eps, outs)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ur_gemm(ctypes.byref(a), 0, 0, _stream()), "ur_gemm(qkrope)")
+        e1.record()
+        PROFILE.append((e0, e1, 1, 1, 0, M, N, R.shape[1] + int(a.K2), 1, 3))
+        return outs
+    check(lib.ur_gemm(ctypes.byref(a), 0, 0, _stream()), "ur_gemm(qkrope)")
+    return outs
+
+
+def qknorm_rope_bwd_roped(dq_out, dk_out, q_r, k_r, rstd, qw, kw, cos, sin, dqkv_raw, S, nq, nkv, hd):
+    """Backward of the fused q|k|v epilogue: dq|dk raw into dqkv_raw[:, :(nq+nkv)*hd] from the ROPED forward outputs + rstd."""
+    lib = _lib.load()
+    M = q_r.shape[0]
+    check(lib.ur_qknorm_rope_bwd_roped(dq_out.data_ptr(), dk_out.data_ptr(), q_r.data_ptr(), q_r.stride(0), k_r.data_ptr(), k_r.stride(0),
+                                       rstd.data_ptr(), qw.data_ptr(), kw.data_ptr(), cos.data_ptr(), sin.data_ptr(), dqkv_raw.data_ptr(),
+                                       dqkv_raw.stride(0), M, S, nq, nkv, hd, _stream()), "ur_qknorm_rope_bwd_roped")
+    return dqkv_raw
+
+
 def gemm_persistent_mode(mode):
     """0 = generic GEMM kernel only, 1 = persistent kernel where eligible, -1 = default; returns the previous setting
     (ur_gemm_persistent_mode, include/unirec_hip.h)."""

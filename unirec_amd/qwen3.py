@@ -106,6 +106,9 @@ _FUSE_SWIGLU_FWD = os.environ.get("UNIREC_SWIGLU_FWD_FUSED", "0") == "1"
 _MERGE_PROJ = os.environ.get("UNIREC_MERGE_PROJ", "1") != "0"
 # UNIREC_FUSE_NORM_LORA=0 (lab): RMSNorm forward and the q|k|v / gate|up adapters' down projection as two kernels again
 _FUSE_NORM_LORA = os.environ.get("UNIREC_FUSE_NORM_LORA", "1") != "0"
+# UNIREC_FUSE_QK_ROPE=0 (lab): q/k-norm + RoPE as their own pass over the raw q|k|v again (the fused form needs the persistent GEMM:
+# >= 512 output tiles, S >= 256, head_dim 128; smaller launches take the separate pass anyway)
+_FUSE_QK_ROPE = os.environ.get("UNIREC_FUSE_QK_ROPE", "1") != "0"
 # UNIREC_FUSE_SWIGLU_LORA=0 (lab): SwiGLU forward and the down_proj adapter's down projection as two kernels again
 _FUSE_SWIGLU_LORA = os.environ.get("UNIREC_FUSE_SWIGLU_LORA", "1") != "0"
 
@@ -265,15 +268,34 @@ class Qwen3LoRAModel(nn.Module):
             a, m = lyr.self_attn, lyr.mlp
             wqkv = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0)
             wgu = torch.cat([m.gate_proj.weight, m.up_proj.weight], 0)
+            rp = self._qk_row_perm(dev)
             fz["layers"].append({
-                "qkv": c16(wqkv), "o": c16(a.o_proj.weight), "gu": c16(wgu), "d": c16(m.down_proj.weight),
+                "qkv": c16(wqkv),
+                # q|k|v with the rows of every q / k head in the paired order of the fused q/k-norm + RoPE epilogue (hip.qkrope_perm)
+                "qkvP": c16(wqkv.to(dev)[rp]) if rp is not None else None, "o": c16(a.o_proj.weight), "gu": c16(wgu), "d": c16(m.down_proj.weight),
                 # frozen => one-time transposed copies, so every dX GEMM is K-contiguous on both operands
                 "qkvT": c16(wqkv.t()), "oT": c16(a.o_proj.weight.t()), "guT": c16(wgu.t()), "dT": c16(m.down_proj.weight.t()),
                 "qn": a.q_norm.weight.detach().to(dev, F32).contiguous(), "kn": a.k_norm.weight.detach().to(dev, F32).contiguous(),
                 "ln1": lyr.input_layernorm.weight.detach().to(dev, F32).contiguous(),
                 "ln2": lyr.post_attention_layernorm.weight.detach().to(dev, F32).contiguous()})
+        # the fused epilogue's backward divides by the norm weights (x^ = R^T(o) / w)
+        fz["qk_norm_nonzero"] = all(bool((l["qn"] != 0).all()) and bool((l["kn"] != 0).all()) for l in fz["layers"])
         self._frozen = fz
         return fz
+
+    def _qk_row_perm(self, device):
+        """Row order of the paired q|k|v operand: inside every q / k head tile column c holds feature qkrope_perm[c]; v rows stay."""
+        c = self.config
+        if c.head_dim != 128:
+            return None
+        key = (str(device), c.num_attention_heads, c.num_key_value_heads)
+        if getattr(self, "_rp", None) is None or self._rp[0] != key:
+            perm = hip.qkrope_perm(128)
+            nqk = c.num_attention_heads + c.num_key_value_heads
+            rows = torch.cat([(torch.arange(nqk)[:, None] * 128 + perm[None, :]).reshape(-1),
+                              torch.arange(nqk * 128, (nqk + c.num_key_value_heads) * 128)])
+            self._rp = (key, rows.to(device))
+        return self._rp[1]
 
     def _rope_tables(self, S, device):
         if self._rope is None or self._rope[0] != (S, str(device)):
@@ -379,6 +401,8 @@ class Qwen3LoRAModel(nn.Module):
                     dst.append(gu[i, j * I:(j + 1) * I, j * r:(j + 1) * r]); src.append(pack.w16(lp + f"mlp.{pn}_proj.lora_B.weight"))
             self._bcomb = {"dev": torch.device(device), "pack": pack, "qkv": qkv, "gu": gu, "dst": dst, "src": src}
         torch._foreach_copy_(self._bcomb["dst"], self._bcomb["src"])
+        rp = self._qk_row_perm(device) if _FUSE_QK_ROPE else None
+        self._bcomb["qkvP"] = self._bcomb["qkv"].index_select(1, rp) if rp is not None else None      # rows paired like fz["qkvP"]
         return self._bcomb["qkv"], self._bcomb["gu"]
 
     def _lora_transposes(self, pack):
@@ -462,7 +486,10 @@ class Qwen3LoRAModel(nn.Module):
         for i, fl in enumerate(fz["layers"]):
             lp = f"layers.{i}."
             L = {"x": x}
-            qkv = torch.empty((M, NQ + 2 * NKV), dtype=BF16, device=dev)
+            # q/k-norm + RoPE inside the q|k|v launch (the raw q, k are never written or re-read) when the persistent GEMM takes it
+            fuse_rope = (_FUSE_QK_ROPE and hd == 128 and fl["qkvP"] is not None and fz["qk_norm_nonzero"] and (pack is None or bc_qkv is not None) and
+                         hip.gemm_qkrope_supported(M, NQ + 2 * NKV, D, 3 * r if pack is not None else 0, S, NQ, NKV, dev))
+            qkv = None if fuse_rope else torch.empty((M, NQ + 2 * NKV), dtype=BF16, device=dev)
             if fuse_norm:      # RMSNorm + the q|k|v adapters' down projection in one pass over x (h is written once, never re-read by a projection kernel)
                 h, rstd1, t_qkv, L["bits_qkv"] = self._norm_lora_down(x, fl["ln1"], eps, [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"],
                                                                       pack, sc, self.lora_dropout_seed(step, i, 0), pdrop, bp(i, 0), row0=row0)
@@ -472,7 +499,9 @@ class Qwen3LoRAModel(nn.Module):
                 if not fuse_norm:
                     t_qkv, L["bits_qkv"] = self._lora_down(h, [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"], pack, sc,
                                                            self.lora_dropout_seed(step, i, 0), pdrop, bp(i, 0), row0=row0)     # [M,3r] = s * dropout(h) A^T
-                if bc_qkv is not None:
+                if fuse_rope:
+                    q_r, k_r, v2, rstd_qk = hip.gemm_qkv_rope(h, fl["qkvP"], fl["qn"], fl["kn"], cos, sin, S, NQ, NKV, eps, R2=t_qkv, S2=self._bcomb["qkvP"][i])
+                elif bc_qkv is not None:
                     hip.gemm(h, fl["qkv"], out=qkv, R2=t_qkv, S2=bc_qkv[i])        # one launch, block-diagonal B
                 else:
                     col = 0
@@ -481,10 +510,16 @@ class Qwen3LoRAModel(nn.Module):
                                  S2=pack.w16(lp + f"self_attn.{p}_proj.lora_B.weight"))
                         col += n
                 L["t_qkv"] = t_qkv
+            elif fuse_rope:
+                q_r, k_r, v2, rstd_qk = hip.gemm_qkv_rope(h, fl["qkvP"], fl["qn"], fl["kn"], cos, sin, S, NQ, NKV, eps)
             else:
                 hip.gemm(h, fl["qkv"], out=qkv)
-            q_r, k_r = hip.qknorm_rope_fwd(qkv, fl["qn"], fl["kn"], cos, sin, S, nq, nkv, hd, eps)
-            v4 = qkv[:, NQ + NKV:].view(B, S, nkv, hd)
+            if fuse_rope:
+                v4 = v2.view(B, S, nkv, hd)
+                L.update(q_r=q_r, k_r=k_r, rstd_qk=rstd_qk)
+            else:
+                q_r, k_r = hip.qknorm_rope_fwd(qkv, fl["qn"], fl["kn"], cos, sin, S, nq, nkv, hd, eps)
+                v4 = qkv[:, NQ + NKV:].view(B, S, nkv, hd)
             att, actx = hip.attn_fwd(q_r.view(B, S, nq, hd), k_r.view(B, S, nkv, hd), v4, causal=True, key_mask=mask_u8)
             att2 = att.view(M, NQ)
             if pack is not None:
@@ -531,7 +566,7 @@ class Qwen3LoRAModel(nn.Module):
                 L["t_d"] = t_d
             else:
                 x3 = hip.gemm(act, fl["d"], residual=x2)
-            L.update(rstd1=rstd1, qkv=qkv, actx=actx, att=att2, x2=x2, rstd2=rstd2, gu=gu, act=act)
+            L.update(rstd1=rstd1, qkv=qkv, actx=actx, att=att2, x2=x2, rstd2=rstd2, gu=gu, act=act)      # (qkv is None under the fused q/k-norm + RoPE epilogue)
             if self.keep_norm_outputs:       # 2 x [M,D] bf16 per layer (15 GB at C4) instead of two RMSNorm recomputes
                 L.update(h=h, h2=h2)
             if keep:
@@ -621,9 +656,15 @@ class Qwen3LoRAModel(nn.Module):
                 datt = dx_gemm(dx2, fl["oT"], tb, [lp + "self_attn.o_proj.lora_A.weight"], L["bits_o"])
             else:
                 datt = hip.gemm(dx2, fl["oT"])
-            dqkv = torch.empty_like(qkv)
+            dqkv = torch.empty((M, NQ + 2 * NKV), dtype=BF16, device=dev)
             dk_r = torch.empty((M, NKV), dtype=BF16, device=dev)
-            if hd == 128 and os.environ.get("UNIREC_ROPE_BWD_FUSED", "0") == "1":
+            if "rstd_qk" in L:
+                # the forward ran q/k-norm + RoPE in the q|k|v launch: no raw q, k exist; the rows are recovered from the roped outputs
+                dq_r = torch.empty((M, NQ), dtype=BF16, device=dev)
+                hip.attn_bwd(L["actx"], datt.view(B, S, nq, hd), dq=dq_r.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd),
+                             dv=dqkv[:, NQ + NKV:].view(B, S, nkv, hd))
+                hip.qknorm_rope_bwd_roped(dq_r, dk_r, L["q_r"], L["k_r"], L["rstd_qk"], fl["qn"], fl["kn"], cos, sin, dqkv, S, nq, nkv, hd)
+            elif hd == 128 and os.environ.get("UNIREC_ROPE_BWD_FUSED", "0") == "1":
                 # UNIREC_ROPE_BWD_FUSED=1: the dQ kernel carries the q-norm + RoPE backward of the q heads (its lanes own whole
                 # rows) and writes straight into dqkv; the stand-alone kernel is left with the k heads (nq = 0, operands offset
                 # to the k columns).  Parity-tested; measured neutral on the joint step (115.7 vs 115.9 seq/s, alternating
