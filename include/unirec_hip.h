@@ -95,7 +95,15 @@ typedef struct {
   float* qkr_rstd;
   const float* qkr_qw; const float* qkr_kw; const float* qkr_cos; const float* qkr_sin;
   int32_t qkr_S, qkr_nq_cols, qkr_nk_cols; float qkr_eps;
+  /* SwiGLU forward as the epilogue of the MERGED gate|up projection (Qwen3MLP: act_fn(gate_proj(x)) * up_proj(x), transformers
+   * modeling_qwen3.py:81-91).  swp_act != NULL: N == 2 * swp_I, and the ROWS of S (and S2) are interleaved in blocks of 128:
+   * tile column block t holds [gate rows 128 t .. 128 t + 127 | up rows 128 t .. 128 t + 127], so one lane of the 256-column
+   * tile owns gate and up of the same feature.  C [M, 2 I] receives gate | up in the STANDARD order (what the backward reads)
+   * and swp_act [M, swp_I] = silu(gate) * up computed from the bf16-rounded C values (bit-identical to ur_swiglu_fwd).
+   * Persistent kernel only: ur_gemm_swiglu_paired_supported tells; ur_gemm fails loudly otherwise. */
+  void* swp_act; int64_t swp_ldact; int32_t swp_I;
 } ur_gemm_args;
+int ur_gemm_swiglu_paired_supported(const ur_gemm_args* a);
 /* 1 when ur_gemm would run the q/k-norm + RoPE epilogue for these arguments, 0 when the caller must use the separate
  * ur_qknorm_rope_fwd pass. */
 int ur_gemm_qkrope_supported(const ur_gemm_args* a);

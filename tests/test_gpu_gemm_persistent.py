@@ -174,3 +174,23 @@ def test_qkv_projection_with_qknorm_rope_epilogue(lora):
     hip.qknorm_rope_bwd_roped(dq, dk, q1, k1, rstd, qw, kw, cos, sin, d1, S, nq, nkv, hd)
     rel = float((d1.float() - d0.float()).norm() / d0.float().norm())
     assert rel <= 1e-2, rel
+
+
+@pytest.mark.parametrize("lora", [False, True])
+def test_gate_up_projection_with_paired_swiglu_epilogue(lora):
+    """SwiGLU forward as the epilogue of the merged gate|up launch (ur_gemm_args.swp_*; Qwen3MLP, modeling_qwen3.py:81-91):
+    gate | up in the standard order and act = silu(gate) * up, bit for bit what the projection + ur_swiglu_fwd give."""
+    M, D, I = 8192, 1024, 3072
+    x, W = _randn((M, D), 101), _randn((2 * I, D), 102, 0.05)
+    t, Bm = (_randn((M, 32), 103), _randn((2 * I, 32), 104, 0.1)) if lora else (None, None)
+    assert hip.gemm_swiglu_paired_supported(M, I, D, 32 if lora else 0, DEV)
+    assert not hip.gemm_swiglu_paired_supported(1024, I, D, 0, DEV)
+    rows = hip.swiglu_pair_rows(I).to(DEV)
+    gu0 = hip.gemm(x, W, R2=t, S2=Bm)
+    act0 = hip.swiglu_fwd(gu0, I)
+    gu1 = torch.empty_like(gu0)
+    act1 = torch.empty((M, I), dtype=torch.bfloat16, device=DEV)
+    hip.gemm(x, W[rows].contiguous(), out=gu1, R2=t, S2=None if Bm is None else Bm[rows].contiguous(), swiglu_paired=act1)
+    torch.cuda.synchronize()
+    assert torch.equal(gu1, gu0)
+    assert torch.equal(act1, act0)

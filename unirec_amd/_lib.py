@@ -35,7 +35,8 @@ class GemmArgs(ctypes.Structure):
                 ("qkr_q", c_void_p), ("qkr_ldq", c_i64), ("qkr_k", c_void_p), ("qkr_ldk", c_i64), ("qkr_v", c_void_p), ("qkr_ldv", c_i64),
                 ("qkr_rstd", c_void_p),
                 ("qkr_qw", c_void_p), ("qkr_kw", c_void_p), ("qkr_cos", c_void_p), ("qkr_sin", c_void_p),
-                ("qkr_S", c_int), ("qkr_nq_cols", c_int), ("qkr_nk_cols", c_int), ("qkr_eps", c_float)]
+                ("qkr_S", c_int), ("qkr_nq_cols", c_int), ("qkr_nk_cols", c_int), ("qkr_eps", c_float),
+                ("swp_act", c_void_p), ("swp_ldact", c_i64), ("swp_I", c_int)]
 
 
 class LoraArgs(ctypes.Structure):
@@ -77,6 +78,7 @@ SIGNATURES = {
     "ur_gemm": (c_int, [ctypes.POINTER(GemmArgs), c_void_p, c_i64, c_void_p]),
     "ur_gemm_persistent_mode": (c_int, [c_int]),
     "ur_gemm_qkrope_supported": (c_int, [ctypes.POINTER(GemmArgs)]),
+    "ur_gemm_swiglu_paired_supported": (c_int, [ctypes.POINTER(GemmArgs)]),
     "ur_qkrope_perm": (c_int, [c_int]),
     "ur_lora_bits_ld": (c_i64, [c_int]),
     "ur_lora_dropout_bits": (c_int, [c_u64, c_float, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_i64, c_void_p]),

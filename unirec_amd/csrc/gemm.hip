@@ -934,7 +934,23 @@ static void fill_params(const ur_gemm_args* a, GemmP& p) {
   p.qk_q = (bf16_t*)a->qkr_q; p.qk_ldq = a->qkr_ldq; p.qk_k = (bf16_t*)a->qkr_k; p.qk_ldk = a->qkr_ldk; p.qk_v = (bf16_t*)a->qkr_v; p.qk_ldv = a->qkr_ldv;
   p.qk_rstd = a->qkr_rstd; p.qk_qw = a->qkr_qw; p.qk_kw = a->qkr_kw; p.qk_cos = a->qkr_cos; p.qk_sin = a->qkr_sin;
   p.qk_S = a->qkr_S; p.qk_nq = a->qkr_nq_cols; p.qk_nk = a->qkr_nk_cols; p.qk_eps = a->qkr_eps;
+  p.sp_act = (bf16_t*)a->swp_act; p.sp_ldact = a->swp_ldact; p.sp_I = a->swp_I;
   p.ksplit_len = 0; p.slab_stride = 0; p.gcw = 0; p.stagger = 0;
+}
+
+static bool swiglu_paired_ok(const ur_gemm_args* a, const GemmP& p) {
+  if (!a->swp_act || a->swp_I <= 0 || a->N != 2 * a->swp_I || (a->swp_I % 128)) return false;
+  if (!a->r_kcontig || !a->s_kcontig || a->c_f32 || a->split_k > 1) return false;
+  if (a->bias || a->residual || a->gelu_out || a->gelu_grad_aux || a->drop_bits || a->swiglu_gu || a->swiglu_gate || a->qkr_q || a->alpha != 1.0f) return false;
+  if ((a->swp_ldact & 7) || a->swp_ldact < a->swp_I || !UR_ALIGNED16(a->swp_act) || a->ldc < a->N) return false;
+  return urgemm::gemm_pers_eligible(p, 1, true, true, false);
+}
+
+extern "C" int ur_gemm_swiglu_paired_supported(const ur_gemm_args* a) {
+  if (!a || a->M <= 0 || a->N <= 0 || !a->R || !a->S) return 0;
+  GemmP p;
+  fill_params(a, p);
+  return swiglu_paired_ok(a, p) ? 1 : 0;
 }
 
 // the q/k-norm + RoPE epilogue exists on the persistent kernel only: everything ur_gemm_args.qkr_* promises, checked once
@@ -1035,6 +1051,10 @@ extern "C" int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace
     p.ksplit_len = a->K > 0 ? ur_cdiv(a->K, BK) * BK : BK;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (a->swp_act) {
+    UR_REQUIRE(swiglu_paired_ok(a, p), "ur_gemm: the paired SwiGLU forward epilogue is not available for these arguments (ur_gemm_swiglu_paired_supported)");
+    return urgemm::gemm_pers_launch(p, st);
+  }
   if (a->qkr_q) {
     UR_REQUIRE(qkrope_ok(a, p), "ur_gemm: the q/k-norm + RoPE epilogue is not available for these arguments (ur_gemm_qkrope_supported)");
     return urgemm::gemm_pers_launch(p, st);

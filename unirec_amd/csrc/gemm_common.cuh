@@ -22,6 +22,8 @@ struct GemmP {
   // q/k-norm + RoPE epilogue of the q|k|v projection (ur_gemm_args.qkr_*; persistent kernel only)
   bf16_t* qk_q; long qk_ldq; bf16_t* qk_k; long qk_ldk; bf16_t* qk_v; long qk_ldv; float* qk_rstd;
   const float* qk_qw; const float* qk_kw; const float* qk_cos; const float* qk_sin; int qk_S, qk_nq, qk_nk; float qk_eps;
+  // SwiGLU forward epilogue of the merged gate|up projection with 128-row interleaved weights (ur_gemm_args.swp_*; persistent kernel only)
+  bf16_t* sp_act; long sp_ldact; int sp_I;
 };
 
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {

@@ -83,7 +83,8 @@ __device__ __forceinline__ void swap16f(float& a, float& b) {
 }
 
 // EPI: 0 = plain (alpha only), 2 = bias / residual, 1 = SwiGLU backward (result is d(act); dgate | dup leave instead of C),
-//      3 = q/k-norm + RoPE of the q|k|v projection (ur_gemm_args.qkr_*; q_r, k_r, v and the row constants leave instead of C).
+//      3 = q/k-norm + RoPE of the q|k|v projection (ur_gemm_args.qkr_*; q_r, k_r, v and the row constants leave instead of C),
+//      4 = SwiGLU forward of the merged gate|up projection with 128-row interleaved weights (ur_gemm_args.swp_*).
 // MODE: 0 = no second K range, 1 = the LoRA second K range rides in the K stream (one zero-padded K tile per output tile),
 //       2 = masked rank-16 LoRA epilogue (dX under LoRA dropout; the second operand pair is read by the epilogue only).
 template <int EPI, int MODE>
@@ -367,6 +368,38 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
           }
       }
     }
+    if constexpr (EPI == 4) {
+      // ---- SwiGLU forward (modeling_qwen3.py:81-91): the tile's first 128 columns are gate features 128 bn .., the second 128 the
+      // up projections of the SAME features (interleaved weight rows), so after the usual pack + 16-lane swap a lane holds gate
+      // and up of the same 8 features: act = silu(gate) * up from the bf16-rounded values (bit-identical to swiglu_fwd_kernel);
+      // gate | up leave in the standard [M, 2 I] order for the backward.
+      const int cs = (eg4 & 1) * 16 + (eg4 >> 1) * 8;
+      const int f0 = (n0 >> 1) + wc * 32 + cs;                               // first of this lane's 8 features
+      bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const long m = m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16 + el15;
+        uint32_t gq[4], uq[4];
+        {
+          const f32x4 a = acc[0][j], b = acc[1][j];
+          gq[0] = pack_bf2(a[0], a[1]); gq[1] = pack_bf2(a[2], a[3]); gq[2] = pack_bf2(b[0], b[1]); gq[3] = pack_bf2(b[2], b[3]);
+          swap16(gq[0], gq[2]); swap16(gq[1], gq[3]);
+        }
+        {
+          const f32x4 a = acc[2][j], b = acc[3][j];
+          uq[0] = pack_bf2(a[0], a[1]); uq[1] = pack_bf2(a[2], a[3]); uq[2] = pack_bf2(b[0], b[1]); uq[3] = pack_bf2(b[2], b[3]);
+          swap16(uq[0], uq[2]); swap16(uq[1], uq[3]);
+        }
+        // (swap16 pairs (x, y): afterwards the lane's 8 consecutive columns are {x regs, y regs} = words 0, 1, 2, 3 in order)
+        uint32_t aq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aq[e] = pack_bf2(silu_f(bf_lo(gq[e])) * bf_lo(uq[e]), silu_f(bf_hi(gq[e])) * bf_hi(uq[e]));
+        const u32x4_t vg = {gq[0], gq[1], gq[2], gq[3]}, vu = {uq[0], uq[1], uq[2], uq[3]}, va = {aq[0], aq[1], aq[2], aq[3]};
+        *reinterpret_cast<u32x4_t*>(Cb + m * p.ldc + f0) = vg;
+        *reinterpret_cast<u32x4_t*>(Cb + m * p.ldc + p.sp_I + f0) = vu;
+        *reinterpret_cast<u32x4_t*>(p.sp_act + m * p.sp_ldact + f0) = va;
+      }
+    } else
     if constexpr (EPI == 3) {
       // ---- q/k-norm + RoPE (modeling_qwen3.py:59-64,107-137,227-245) from the accumulators.  The tile is two whole heads (its two
       // 128-column halves sh); the head's rows of W were stored in the paired order, so acc[2 sh][j][e] is feature
@@ -618,12 +651,13 @@ int gemm_pers_launch(GemmP p, hipStream_t st) {
     p.stagger = env_st > 0 ? env_st : 0;
   }
   const int mode = drop ? 2 : (p.K2 > 0 ? 1 : 0);
-  const int epi = p.qk_q ? 3 : (p.sw_mode == 1 ? 1 : ((p.res || p.bias) ? 2 : 0));
+  const int epi = p.sp_act ? 4 : (p.qk_q ? 3 : (p.sw_mode == 1 ? 1 : ((p.res || p.bias) ? 2 : 0)));
 #define UR_PERS_CASE(E, MD) if (epi == E && mode == MD) return launch_pers<E, MD>(p, st)
   UR_PERS_CASE(0, 0); UR_PERS_CASE(0, 1); UR_PERS_CASE(0, 2);
   UR_PERS_CASE(1, 0); UR_PERS_CASE(1, 1); UR_PERS_CASE(1, 2);
   UR_PERS_CASE(2, 0); UR_PERS_CASE(2, 1); UR_PERS_CASE(2, 2);
   UR_PERS_CASE(3, 0); UR_PERS_CASE(3, 1);
+  UR_PERS_CASE(4, 0); UR_PERS_CASE(4, 1);
 #undef UR_PERS_CASE
   UR_FAIL(-1, "ur_gemm(persistent): no kernel for epilogue %d, mode %d", epi, mode);
 }

@@ -53,11 +53,13 @@ def workspace(nbytes, device, tag="default"):
 # ------------------------------------------------------------------------------------------------
 def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=None, out_f32=False, alpha=1.0,
          bias=None, residual=None, gelu_out=None, gelu_grad_aux=None, R2=None, S2=None, split_k=1, drop=None,
-         swiglu_bwd=None, swiglu_fwd=None):
+         swiglu_bwd=None, swiglu_fwd=None, swiglu_paired=None):
     """C[M,N] = alpha*(R(m,k) S(n,k) + R2 S2) + epilogue.  R/S are 2-D bf16 (row stride = stride(0)).
     drop = (bits, p, rank): masked LoRA epilogue (bits = hip.lora_dropout_bits planes of the adapters' shared input),
     swiglu_bwd = (gu, dgu): the result is d(act) of SwiGLU; dgate | dup are written to dgu [M, 2N] and no C is produced
     (returns dgu).  swiglu_fwd = (gate, act): C is up(x) as usual and act[M, N] = silu(gate) * C is written beside it.
+    swiglu_paired = act [M, N/2]: the merged gate|up projection with 128-row interleaved weight rows (swiglu_pair_rows); C is
+    gate | up in the standard order and act = silu(gate) * up leaves beside it (persistent kernel only: gemm_swiglu_paired_supported).
     See ur_gemm_args in include/unirec_hip.h."""
     lib = _lib.load()
     for t, n in ((R, "R"), (S, "S")):
@@ -106,6 +108,11 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
             if t.dtype != BF16 or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1 or t.shape[0] != M or t.shape[1] != N:
                 raise ValueError(f"gemm: swiglu_fwd {n} must be a bf16 [M, N] device tensor with unit inner stride")
         a.swiglu_gate, a.swiglu_ldgate, a.swiglu_act, a.swiglu_ldact = gate_.data_ptr(), gate_.stride(0), act_.data_ptr(), act_.stride(0)
+    if swiglu_paired is not None:
+        act_ = swiglu_paired
+        if act_.dtype != BF16 or not act_.is_cuda or act_.dim() != 2 or act_.stride(1) != 1 or act_.shape[0] != M or act_.shape[1] * 2 != N:
+            raise ValueError("gemm: swiglu_paired act must be a bf16 [M, N/2] device tensor with unit inner stride")
+        a.swp_act, a.swp_ldact, a.swp_I = act_.data_ptr(), act_.stride(0), N // 2
     if drop is not None:
         bits, pdrop, rank = drop
         a.drop_bits, a.drop_bits_ld, a.drop_bits_stride = bits.data_ptr(), bits.stride(1), bits.stride(0)
@@ -120,7 +127,7 @@ def gemm(R, S, *, r_kcontig=True, s_kcontig=True, M=None, N=None, K=None, out=No
         check(lib.ur_gemm(ctypes.byref(a), ws, wsb, _stream()), "ur_gemm")
         e1.record()
         PROFILE.append((e0, e1, int(r_kcontig), int(s_kcontig), int(out.dtype == F32), M, N, K + int(a.K2), int(split_k),
-                        1 if swiglu_bwd is not None else (2 if swiglu_fwd is not None else 0)))
+                        1 if swiglu_bwd is not None else (2 if swiglu_fwd is not None else (4 if swiglu_paired is not None else 0))))
         return out
     check(lib.ur_gemm(ctypes.byref(a), ws, wsb, _stream()), "ur_gemm")
     return out
@@ -150,6 +157,28 @@ def _qkrope_args(R, S, R2, S2, qw, kw, cos, sin, Sseq, nq_cols, nk_cols, eps, ou
     a.qkr_qw, a.qkr_kw, a.qkr_cos, a.qkr_sin = qw.data_ptr(), kw.data_ptr(), cos.data_ptr(), sin.data_ptr()
     a.qkr_S, a.qkr_nq_cols, a.qkr_nk_cols, a.qkr_eps = int(Sseq), int(nq_cols), int(nk_cols), float(eps)
     return a
+
+
+def swiglu_pair_rows(I):
+    """Row order of the merged gate|up weight (and of its LoRA B operand) for the paired SwiGLU epilogue: blocks of 128 gate rows
+    alternate with the 128 up rows of the same features -- index tensor `rows` with W_paired = W[rows], W = [gate; up] [2 I, K]."""
+    t = torch.arange(I // 128)[:, None, None] * 128 + torch.arange(128)[None, None, :]          # [I/128, 1, 128]
+    return torch.cat([t, t + I], dim=1).reshape(-1)
+
+
+def gemm_swiglu_paired_supported(M, I, K, K2, device):
+    """True when the merged gate|up projection of these sizes can carry the SwiGLU forward in its epilogue."""
+    lib = _lib.load()
+    d = torch.empty(16, dtype=BF16, device=device)
+    a = GemmArgs()
+    a.R = a.S = a.C = a.swp_act = d.data_ptr()
+    a.ldr = a.lds = K
+    a.r_kcontig = a.s_kcontig = 1
+    a.K, a.M, a.N, a.alpha, a.split_k, a.ldc = K, M, 2 * I, 1.0, 1, 2 * I
+    if K2:
+        a.R2 = a.S2 = d.data_ptr(); a.ldr2 = a.lds2 = K2; a.K2 = K2
+    a.swp_ldact, a.swp_I = I, I
+    return bool(lib.ur_gemm_swiglu_paired_supported(ctypes.byref(a)))
 
 
 def gemm_qkrope_supported(M, N, K, K2, Sseq, nq_cols, nk_cols, device):

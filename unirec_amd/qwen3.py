@@ -109,6 +109,10 @@ _FUSE_NORM_LORA = os.environ.get("UNIREC_FUSE_NORM_LORA", "1") != "0"
 # UNIREC_FUSE_QK_ROPE=0 (lab): q/k-norm + RoPE as their own pass over the raw q|k|v again (the fused form needs the persistent GEMM:
 # >= 512 output tiles, S >= 256, head_dim 128; smaller launches take the separate pass anyway)
 _FUSE_QK_ROPE = os.environ.get("UNIREC_FUSE_QK_ROPE", "1") != "0"
+# UNIREC_FUSE_SWIGLU_GEMM=0 (lab): SwiGLU forward as its own pass over gate|up again (the fused form rides in the merged gate|up launch on
+# the persistent GEMM: interleaved weight rows put gate and up of a feature into one lane; the down adapter's t = dropout(act) A^T is
+# then a lora_project pass over act)
+_FUSE_SWIGLU_GEMM = os.environ.get("UNIREC_FUSE_SWIGLU_GEMM", "1") != "0"
 # UNIREC_FUSE_SWIGLU_LORA=0 (lab): SwiGLU forward and the down_proj adapter's down projection as two kernels again
 _FUSE_SWIGLU_LORA = os.environ.get("UNIREC_FUSE_SWIGLU_LORA", "1") != "0"
 
@@ -272,7 +276,9 @@ class Qwen3LoRAModel(nn.Module):
             fz["layers"].append({
                 "qkv": c16(wqkv),
                 # q|k|v with the rows of every q / k head in the paired order of the fused q/k-norm + RoPE epilogue (hip.qkrope_perm)
-                "qkvP": c16(wqkv.to(dev)[rp]) if rp is not None else None, "o": c16(a.o_proj.weight), "gu": c16(wgu), "d": c16(m.down_proj.weight),
+                "qkvP": c16(wqkv.to(dev)[rp]) if rp is not None else None,
+                # gate|up with 128-row blocks of gate and up interleaved (hip.swiglu_pair_rows): the paired SwiGLU forward epilogue
+                "guP": c16(wgu.to(dev)[hip.swiglu_pair_rows(m.gate_proj.weight.shape[0]).to(dev)]) if m.gate_proj.weight.shape[0] % 128 == 0 else None, "o": c16(a.o_proj.weight), "gu": c16(wgu), "d": c16(m.down_proj.weight),
                 # frozen => one-time transposed copies, so every dX GEMM is K-contiguous on both operands
                 "qkvT": c16(wqkv.t()), "oT": c16(a.o_proj.weight.t()), "guT": c16(wgu.t()), "dT": c16(m.down_proj.weight.t()),
                 "qn": a.q_norm.weight.detach().to(dev, F32).contiguous(), "kn": a.k_norm.weight.detach().to(dev, F32).contiguous(),
@@ -403,6 +409,7 @@ class Qwen3LoRAModel(nn.Module):
         torch._foreach_copy_(self._bcomb["dst"], self._bcomb["src"])
         rp = self._qk_row_perm(device) if _FUSE_QK_ROPE else None
         self._bcomb["qkvP"] = self._bcomb["qkv"].index_select(1, rp) if rp is not None else None      # rows paired like fz["qkvP"]
+        self._bcomb["guP"] = (self._bcomb["gu"].index_select(1, hip.swiglu_pair_rows(I).to(device)) if (_FUSE_SWIGLU_GEMM and I % 128 == 0) else None)
         return self._bcomb["qkv"], self._bcomb["gu"]
 
     def _lora_transposes(self, pack):
@@ -541,19 +548,24 @@ class Qwen3LoRAModel(nn.Module):
                 # gate first; the up projection's epilogue then reads the gate tile and writes act = silu(gate) * up beside up
                 fused = _FUSE_SWIGLU_FWD and bc_gu is None
                 act = torch.empty((M, I), dtype=BF16, device=dev) if fused else None
-                if bc_gu is not None:
+                pair = (_FUSE_SWIGLU_GEMM and bc_gu is not None and fl["guP"] is not None and self._bcomb.get("guP") is not None and
+                        hip.gemm_swiglu_paired_supported(M, I, D, 2 * r, dev))
+                if pair:            # ONE launch: gate|up (standard order, for the backward) and act = silu(gate) * up from its registers
+                    act = torch.empty((M, I), dtype=BF16, device=dev)
+                    hip.gemm(h2, fl["guP"], out=gu, R2=t_gu, S2=self._bcomb["guP"][i], swiglu_paired=act)
+                elif bc_gu is not None:
                     hip.gemm(h2, fl["gu"], out=gu, R2=t_gu, S2=bc_gu[i])            # one launch, block-diagonal B
                 for j, p in enumerate(("gate", "up") if bc_gu is None else ()):
                     hip.gemm(h2, fl["gu"][j * I:(j + 1) * I], out=gu[:, j * I:(j + 1) * I], R2=t_gu[:, j * r:(j + 1) * r],
                              S2=pack.w16(lp + f"mlp.{p}_proj.lora_B.weight"), swiglu_fwd=(gu[:, :I], act) if (j == 1 and fused) else None)
-                fuse_act = _FUSE_SWIGLU_LORA and not fused and r == 16 and I % 128 == 0
+                fuse_act = _FUSE_SWIGLU_LORA and not fused and not pair and r == 16 and I % 128 == 0
                 if fuse_act:      # act and t_d = s * dropout(act) A_d^T from one pass over gate|up (ur_swiglu_lora_fwd)
                     bits_d = bp(i, 3)
                     if bits_d is None and pdrop > 0.0:
                         bits_d = hip.lora_dropout_bits(self.lora_dropout_seed(step, i, 3), pdrop, M, I, 1, dev, row0=row0)
                     act, t_d = hip.swiglu_lora_fwd(gu, I, pack.w16(lp + "mlp.down_proj.lora_A.weight"), alpha=sc / (1.0 - pdrop), bits=bits_d)
                     L["bits_d"] = bits_d
-                elif not fused:
+                elif not fused and not pair:
                     act = hip.swiglu_fwd(gu, I)
                 L["t_gu"] = t_gu
             else:
