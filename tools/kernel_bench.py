@@ -203,6 +203,9 @@ def rope(args):
     dqkv = torch.empty_like(qkv)
     t = timeit(lambda: hip.qknorm_rope_bwd(q_r, k_r, qkv, qn, kn, cos, sin, dqkv, S, nq, nkv, hd, 1e-6), args.iters)
     print(f"qknorm_rope bwd: {t * 1e3:.1f} us  {1.5 * nb / t / 1e9:.2f} TB/s (dq_r|dk_r + raw q|k read, dq|dk raw written)")
+    rstd = torch.rsqrt(qkv[:, :(nq + nkv) * hd].float().view(M, nq + nkv, hd).pow(2).mean(-1) + 1e-6)
+    t = timeit(lambda: hip.qknorm_rope_bwd_roped(q_r, k_r, q_r, k_r, rstd, qn, kn, cos, sin, dqkv, S, nq, nkv, hd), args.iters)
+    print(f"qknorm_rope bwd from the roped outputs: {t * 1e3:.1f} us  {1.5 * nb / t / 1e9:.2f} TB/s")
 
 
 def lora(args):

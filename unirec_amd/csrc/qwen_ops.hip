@@ -17,6 +17,29 @@ __device__ __forceinline__ void ld8f(const float* p, float (&f)[8]) {
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
+// Lane exchanges inside the 16-lane group that owns a token row of head_dim 128 as DPP modifiers (no LDS crossbar: __shfl_xor
+// compiles to ds_bpermute_b32, eight of them per lane and head were a third of the roped backward's time)
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+// the rotate-half partner: LPH / 2 lanes away inside the group
+template <int LPH> __device__ __forceinline__ float partner_of(float x) {
+  if constexpr (LPH == 16) return dpp_f<0x128>(x);                    // row_ror:8 == lane ^ 8 inside a 16-lane row
+  else return __shfl_xor(x, LPH / 2, 64);
+}
+// sum over the group's lanes, result in every lane
+template <int LPH> __device__ __forceinline__ float group_sum_dpp(float x) {
+  if constexpr (LPH == 16) {
+    x += dpp_f<0xB1>(x);        // quad_perm [1,0,3,2]
+    x += dpp_f<0x4E>(x);        // quad_perm [2,3,0,1]
+    x += dpp_f<0x141>(x);       // row_half_mirror
+    x += dpp_f<0x140>(x);       // row_mirror
+    return x;
+  } else {
+    return group_sum<LPH>(x);
+  }
+}
+
 // cos/sin [S][hd/2] f32 : inv_freq_i = theta^(-2i/hd), angle = pos * inv_freq_i  (modeling_qwen3.py:107-137)
 __global__ void rope_table_kernel(float* __restrict__ cs, float* __restrict__ sn, int S, int half, float theta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,7 +106,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const bf16_t* __restri
         float ss = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) ss += x[e] * x[e];
-        ss = group_sum<LPH>(ss);
+        ss = group_sum_dpp<LPH>(ss);
         const float rs = rsqrtf(ss / (float)HD + eps);
         bf16_t* op = isq ? (qo + m * (long)nq * HD + (long)hh * HD) : (ko + m * (long)nkv * HD + (long)(hh - nq) * HD);
         if (!BWD) {
@@ -92,7 +115,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const bf16_t* __restri
           for (int e = 0; e < 8; ++e) xn[e] = x[e] * rs * ww[e];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float partner = __shfl_xor(xn[e], LPH / 2, 64);
+            const float partner = partner_of<LPH>(xn[e]);
             o[e] = xn[e] * c[e] + sign * partner * s[e];
           }
           *reinterpret_cast<uint4*>(op + li * 8) = pk8(o);
@@ -102,13 +125,13 @@ __global__ __launch_bounds__(256) void qknorm_rope_kernel(const bf16_t* __restri
           float t = 0.f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float partner = __shfl_xor(dy[e] * s[e], LPH / 2, 64);   // (dout*sin) of the paired element
+            const float partner = partner_of<LPH>(dy[e] * s[e]);   // (dout*sin) of the paired element
             const float dxn = dy[e] * c[e] - sign * partner;               // d<half: +partner, d>=half: -partner
             g[e] = dxn * ww[e];
             xh[e] = x[e] * rs;
             t += g[e] * xh[e];
           }
-          t = group_sum<LPH>(t) / (float)HD;
+          t = group_sum_dpp<LPH>(t) / (float)HD;
           float o[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = rs * (g[e] - xh[e] * t);
@@ -170,13 +193,13 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_roped_kernel(const bf16_t
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float ww = isq ? wq[e] : wk[e], iw = isq ? iwq[e] : iwk[e];
-          const float po = __shfl_xor(o[e] * s[e], LPH / 2, 64);            // forward: o = xn c + sign * partner(xn) s  =>  xn = o c - sign * partner(o s)
+          const float po = partner_of<LPH>(o[e] * s[e]);            // forward: o = xn c + sign * partner(xn) s  =>  xn = o c - sign * partner(o s)
           xh[e] = (o[e] * c[e] - sign * po) * iw;                           // x^ = x * rstd
-          const float pd = __shfl_xor(dy[e] * s[e], LPH / 2, 64);
+          const float pd = partner_of<LPH>(dy[e] * s[e]);
           g[e] = (dy[e] * c[e] - sign * pd) * ww;
           t += g[e] * xh[e];
         }
-        t = group_sum<LPH>(t) / (float)HD;
+        t = group_sum_dpp<LPH>(t) / (float)HD;
         float dx[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) dx[e] = rs * (g[e] - xh[e] * t);
