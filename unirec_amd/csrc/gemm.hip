@@ -958,7 +958,7 @@ static bool qkrope_ok(const ur_gemm_args* a, const GemmP& p) {
   if (!a->qkr_q || !a->qkr_k || !a->qkr_v || !a->qkr_rstd || !a->qkr_qw || !a->qkr_kw || !a->qkr_cos || !a->qkr_sin) return false;
   if (!a->r_kcontig || !a->s_kcontig || a->c_f32 || a->split_k > 1) return false;
   if (a->bias || a->residual || a->gelu_out || a->gelu_grad_aux || a->drop_bits || a->swiglu_gu || a->swiglu_gate || a->alpha != 1.0f) return false;
-  if (a->qkr_S < 256 || (a->qkr_nq_cols % 256) || (a->qkr_nk_cols % 256) || a->qkr_nq_cols < 0 || a->qkr_nk_cols < 0 ||
+  if (a->qkr_S < 256 || (a->qkr_S % 256) || (a->qkr_nq_cols % 256) || (a->qkr_nk_cols % 256) || a->qkr_nq_cols < 0 || a->qkr_nk_cols < 0 ||
       a->qkr_nq_cols + a->qkr_nk_cols > a->N || ((a->N - a->qkr_nq_cols - a->qkr_nk_cols) % 256)) return false;
   if ((a->qkr_ldq & 7) || (a->qkr_ldk & 7) || (a->qkr_ldv & 7) || !UR_ALIGNED16(a->qkr_q) || !UR_ALIGNED16(a->qkr_k) || !UR_ALIGNED16(a->qkr_v) ||
       !UR_ALIGNED16(a->qkr_qw) || !UR_ALIGNED16(a->qkr_kw) || !UR_ALIGNED16(a->qkr_cos) || !UR_ALIGNED16(a->qkr_sin)) return false;

@@ -43,7 +43,6 @@ __device__ long long g_pers_stamps[256 * 2 * 8];
 #endif
 constexpr int BK = 64, BM = 256, BN = 256;
 constexpr int S_BYTES = BN * 128, R_BYTES = BM * 128, STAGE = S_BYTES + R_BYTES;      // one ring slot = 64 KiB
-__device__ __attribute__((aligned(16))) uint32_t g_zero16[4];                         // zero-initialised: source of k chunks beyond K2
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
@@ -134,11 +133,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
         const char* src = (IS_S ? ubs + li * sp_main : ubr + li * rp_main) + (IS_S ? vo_s : vo_r);
         __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
       } else {
-        // the K2 tile: rows of lds2 / ldr2 elements, k chunks at or beyond K2 come from the zero word
+        // the K2 tile: rows of lds2 / ldr2 elements; k chunks at or beyond K2 must read as zero.  A raw buffer descriptor over the
+        // wave's 256-row window does that in hardware: such lanes get an offset past num_records and an out-of-range buffer
+        // load returns 0 -- one v_cndmask per piece and 32-bit offsets (per-lane 64-bit pointers with a select against a zero
+        // word cost this K tile body ~30 more registers, and hipcc spilled inside it)
         const long ld2 = IS_S ? p.lds2 : p.ldr2;
-        const char* src = (IS_S ? ubs : ubr) + (long)(li * 64) * ld2 * 2 + (uint32_t)((lane >> 3) * ld2 * 2 + kch * 16);
-        src = (kch * 8 < p.K2) ? src : reinterpret_cast<const char*>(g_zero16);
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(IS_S ? ubs : ubr), 0, (int)(256 * ld2 * 2), 0x00020000);
+        // ONE lane offset per operand (the piece's 64-row step rides in the scalar offset): eight precomputed per-piece offsets
+        // did not fit beside the loop's registers -- hipcc spilled five and reloaded each behind an s_waitcnt vmcnt(0)
+        const uint32_t vo = (kch * 8 < p.K2) ? (uint32_t)((lane >> 3) * ld2 * 2 + kch * 16) : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, vo, (int)(li * 64 * ld2 * 2), 0, 0);
       }
     }
   };
@@ -409,6 +413,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
       const int qkc = p.qk_nq + p.qk_nk;
       if (n0 < qkc) {           // uniform: a q / k tile
         float* part = reinterpret_cast<float*>(smem + 2 * STAGE);          // [2 sh][256 rows][4 wc]
+        const bool isq = n0 < p.qk_nq;
+        const float* wgt = isq ? p.qk_qw : p.qk_kw;
+        const int dq0 = wc * 16 + 4 * eg4;                                  // this lane's features dq0 .. + 3 (and + 64)
+        const int pos0 = m0 % p.qk_S;                                       // (scalar) S % 256 == 0: the tile's 256 rows are positions pos0 .. pos0 + 255
+        // Every global load of the epilogue is issued HERE, ahead of the row-sum barrier that hides its latency: a load between
+        // the stores below would make hipcc wait vmcnt(0) -- i.e. for the previous rows' stores as well -- once per row block
+        // (measured: ~6 us per tile).  cos / sin of the lane's 8 rows come from ONE table row (the first: position
+        // pos0 + wr*64 + l15) advanced by the angle-addition theorem: + 16 positions per row block, + 80 across the two row halves
+        // (table rows 16 and 80 are cos / sin of exactly those steps).
+        const int prow0 = pos0 + wr * 64 + el15;
+        const float4 w0 = *reinterpret_cast<const float4*>(wgt + dq0), w1 = *reinterpret_cast<const float4*>(wgt + 64 + dq0);
+        const float4 c_0 = *reinterpret_cast<const float4*>(p.qk_cos + (long)prow0 * 64 + dq0), s_0 = *reinterpret_cast<const float4*>(p.qk_sin + (long)prow0 * 64 + dq0);
+        const float4 c16 = *reinterpret_cast<const float4*>(p.qk_cos + 16 * 64 + dq0), s16 = *reinterpret_cast<const float4*>(p.qk_sin + 16 * 64 + dq0);
+        const float4 c80 = *reinterpret_cast<const float4*>(p.qk_cos + 80 * 64 + dq0), s80 = *reinterpret_cast<const float4*>(p.qk_sin + 80 * 64 + dq0);
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
@@ -421,25 +439,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             if (eg4 == 0) part[(sh * 256 + row) * 4 + wc] = ss;
           }
         __syncthreads();
-        const bool isq = n0 < p.qk_nq;
-        const float* wgt = isq ? p.qk_qw : p.qk_kw;
-        const int dq0 = wc * 16 + 4 * eg4;                                  // this lane's features dq0 .. + 3 (and + 64)
-        const float4 w0 = *reinterpret_cast<const float4*>(wgt + dq0), w1 = *reinterpret_cast<const float4*>(wgt + 64 + dq0);
         bf16_t* outb = isq ? p.qk_q : p.qk_k;
         const long ldo = isq ? p.qk_ldq : p.qk_ldk;
         const int c0 = isq ? n0 : n0 - p.qk_nq;                             // first column of the tile inside q_out / k_out
         const int nheads = qkc >> 7, head0 = n0 >> 7;
-        const int pos0 = m0 % p.qk_S;                                       // (scalar) positions of the tile's rows: pos0 + row, wrapping at S >= 256
         // after the 16-lane swap: 16-lane row rho even -> the 8 features (rho >> 1) * 8 .. of block d, odd -> of block d + 64
         const int ocol = (eg4 & 1) * 64 + wc * 16 + (eg4 >> 1) * 8;
+        float cv[4] = {c_0.x, c_0.y, c_0.z, c_0.w}, sv[4] = {s_0.x, s_0.y, s_0.z, s_0.w};
+        const float wa[4] = {w0.x, w0.y, w0.z, w0.w}, wb[4] = {w1.x, w1.y, w1.z, w1.w};
+        const float dc16[4] = {c16.x, c16.y, c16.z, c16.w}, ds16[4] = {s16.x, s16.y, s16.z, s16.w};
+        const float dc80[4] = {c80.x, c80.y, c80.z, c80.w}, ds80[4] = {s80.x, s80.y, s80.z, s80.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const int row = (j >> 2) * 128 + wr * 64 + (j & 3) * 16 + el15;
-          int pos = pos0 + row;
-          pos = pos >= p.qk_S ? pos - p.qk_S : pos;
-          const float4 cc = *reinterpret_cast<const float4*>(p.qk_cos + (long)pos * 64 + dq0), sn = *reinterpret_cast<const float4*>(p.qk_sin + (long)pos * 64 + dq0);
-          const float cv[4] = {cc.x, cc.y, cc.z, cc.w}, sv[4] = {sn.x, sn.y, sn.z, sn.w};
-          const float wa[4] = {w0.x, w0.y, w0.z, w0.w}, wb[4] = {w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
           for (int sh = 0; sh < 2; ++sh) {
             const float4 pr = *reinterpret_cast<const float4*>(part + (sh * 256 + row) * 4);
@@ -458,6 +470,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             const u32x4_t v = {a0, a1, b0, b1};
             *reinterpret_cast<u32x4_t*>(outb + m * ldo + c0 + sh * 128 + ocol) = v;
             if (wc == 0 && eg4 == 0) p.qk_rstd[m * nheads + head0 + sh] = rs;
+          }
+          // the next row block's angles: + 16 positions, or + 80 from the last block of the first row half to the first of the second
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dc = (j == 3) ? dc80[e] : dc16[e], dsn = (j == 3) ? ds80[e] : ds16[e];
+            const float cn = cv[e] * dc - sv[e] * dsn, sn2 = sv[e] * dc + cv[e] * dsn;
+            cv[e] = cn; sv[e] = sn2;
           }
         }
       } else {                  // a v tile: the plain projection into v_out
@@ -502,7 +521,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(base + loff));
 #endif
           }
-      } else {
+      } else if constexpr (EPI == 2) {
+        // (bias / residual: the round-3 first form -- a quarter tile of residual pieces per batch; the restructured form below
+        // costs this variant 30+ spilled registers)
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh) {
           const int ncol = n0 + sh * 128 + wc * 32 + cs;
@@ -543,6 +564,78 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
               } else {
                 // d(act) = v (f32, unrounded): dgate = v u silu'(g), dup = v silu(g)   (elementwise.hip: swiglu_bwd_kernel)
                 const uint32_t gq[4] = {gw[jj].x, gw[jj].y, gw[jj].z, gw[jj].w}, uq[4] = {uw[jj].x, uw[jj].y, uw[jj].z, uw[jj].w};
+                uint32_t og[4], ou[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float dgv[2], duv[2];
+#pragma unroll
+                  for (int hh = 0; hh < 2; ++hh) {
+                    const float gg = hh ? bf_hi(gq[e]) : bf_lo(gq[e]), uu = hh ? bf_hi(uq[e]) : bf_lo(uq[e]);
+                    const float d = v[2 * e + hh];
+                    const float sg = 1.0f / (1.0f + __expf(-gg));
+                    duv[hh] = d * (gg * sg);
+                    dgv[hh] = d * uu * (sg * (1.0f + gg * (1.0f - sg)));
+                  }
+                  og[e] = pack_bf2(dgv[0], dgv[1]); ou[e] = pack_bf2(duv[0], duv[1]);
+                }
+                const u32x4_t vg = {og[0], og[1], og[2], og[3]}, vu = {ou[0], ou[1], ou[2], ou[3]};
+                *reinterpret_cast<u32x4_t*>(p.sw_dgu + m * p.sw_lddgu + ncol) = vg;
+                *reinterpret_cast<u32x4_t*>(p.sw_dgu + m * p.sw_lddgu + p.sw_I + ncol) = vu;
+              }
+            }
+          }
+        }
+      } else {
+        // Every load of a batch is issued BEFORE the batch's first store: hipcc waits vmcnt(0) for a load that follows stores
+        // (the LDS-DMA stream is in flight), i.e. for those stores' acknowledgements too -- one ~1 us round trip per batch.
+        // A quarter tile per batch (residual: 4 pieces = 16 registers, SwiGLU backward gate + up: 8 pieces = 32; bigger batches
+        // spill 30-120 registers beside the accumulators and the next tile's R fragments).
+        const uint32_t loff_c = (uint32_t)((el15 * p.ldc + cs) * 2), loff_res = (uint32_t)((el15 * p.ldres + cs) * 2);
+#pragma unroll
+        for (int sh = 0; sh < 2; ++sh) {
+          const int ncol = n0 + sh * 128 + wc * 32 + cs;
+          float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (p.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ncol), b1 = *reinterpret_cast<const float4*>(p.bias + ncol + 4);
+            bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
+          }
+          uint4 rwa[8], gwa[8], uwa[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (EPI == 2 && p.res && (j & 3) == 0) {
+#pragma unroll
+              for (int jj = j; jj < j + 4; ++jj) {      // uniform base (scalar registers) + ONE 32-bit lane offset per tensor
+                const char* rb = uniform_ptr(reinterpret_cast<const char*>(p.res + (long)(m0 + (jj >> 2) * 128 + wr * 64 + (jj & 3) * 16) * p.ldres + n0 + sh * 128 + wc * 32));
+                rwa[jj] = *reinterpret_cast<const uint4*>(rb + loff_res);
+              }
+            }
+            if (EPI == 1 && (j & 3) == 0) {
+#pragma unroll
+              for (int jj = j; jj < j + 4; ++jj) {
+                const long m = m0 + (jj >> 2) * 128 + wr * 64 + (jj & 3) * 16 + el15;
+                gwa[jj] = *reinterpret_cast<const uint4*>(p.sw_gu + m * p.sw_ldgu + ncol);
+                uwa[jj] = *reinterpret_cast<const uint4*>(p.sw_gu + m * p.sw_ldgu + p.sw_I + ncol);
+              }
+            }
+            {
+              const long m = m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16 + el15;
+              f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { float x = a[e], y = b[e]; swap16f(x, y); a[e] = x; b[e] = y; }
+              float v[8] = {a[0] * alpha + bs[0], a[1] * alpha + bs[1], a[2] * alpha + bs[2], a[3] * alpha + bs[3],
+                            b[0] * alpha + bs[4], b[1] * alpha + bs[5], b[2] * alpha + bs[6], b[3] * alpha + bs[7]};
+              if (EPI == 2) {
+                if (p.res) {
+                  const uint32_t w[4] = {rwa[j].x, rwa[j].y, rwa[j].z, rwa[j].w};
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
+                }
+                const u32x4_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                char* cb = uniform_wptr(reinterpret_cast<char*>(p.C) + ((long)(m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16) * p.ldc + n0 + sh * 128 + wc * 32) * 2);
+                *reinterpret_cast<u32x4_t*>(cb + loff_c) = o;
+              } else {
+                // d(act) = v (f32, unrounded): dgate = v u silu'(g), dup = v silu(g)   (elementwise.hip: swiglu_bwd_kernel)
+                const uint32_t gq[4] = {gwa[j].x, gwa[j].y, gwa[j].z, gwa[j].w}, uq[4] = {uwa[j].x, uwa[j].y, uwa[j].z, uwa[j].w};
                 uint32_t og[4], ou[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -625,9 +718,10 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
   if (p.K2 > 0 && !p.drop_bits && p.K2 > BK) return false;
   if (p.drop_bits && p.K2 > 0) {
     if (p.drop_rank != 16 || (p.K2 & 15)) return false;                        // the masked epilogue here is rank 16 only
-    // measured (tools/lab/gemm_pers_ab.py, C4 shapes): with the masked LoRA epilogue the persistent kernel wins at K = 1024
-    // (+4 %, +12..18 % with the SwiGLU backward epilogue) and loses 1..7 % at K >= 4096 (few, long tiles: nothing to hide)
-    static const int kmax = [] { const char* e = getenv("UR_PERS_DROP_KMAX"); return e ? atoi(e) : 2048; }();
+    // measured (tools/lab/gemm_pers_ab.py, C4 shapes; profiles/r3_gemm_pers_ab.txt): with the masked LoRA epilogue the persistent
+    // kernel wins at K = 1024 (+5 %, +17 % with the SwiGLU backward epilogue), is even at K = 4096 (+1 %) and loses 1.5 % at
+    // K = 6144 (8 long tiles per CU: nothing to hide, and the joined epilogue costs two barrier intervals)
+    static const int kmax = [] { const char* e = getenv("UR_PERS_DROP_KMAX"); return e ? atoi(e) : 4096; }();
     if (p.K > kmax) return false;
   }
   if (p.sw_mode == 1 && (p.bias || p.res)) return false;
