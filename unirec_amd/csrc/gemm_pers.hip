@@ -141,7 +141,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(IS_S ? ubs : ubr), 0, (int)(256 * ld2 * 2), 0x00020000);
         // ONE lane offset per operand (the piece's 64-row step rides in the scalar offset): eight precomputed per-piece offsets
         // did not fit beside the loop's registers -- hipcc spilled five and reloaded each behind an s_waitcnt vmcnt(0)
-        const uint32_t vo = (kch * 8 < p.K2) ? (uint32_t)((lane >> 3) * ld2 * 2 + kch * 16) : 0x80000000u;
+        // (derived from an opaque copy of the lane id at every use: as a loop invariant hipcc keeps it across the K loop, spills it,
+        // and waits vmcnt(0) on the scratch reload in front of the DMA)
+        int zl = lane;
+        asm volatile("" : "+v"(zl));
+        const int zk = (zl & 7) ^ (((zl >> 4) + 4 * (uwave & 1)) & 7);
+        const uint32_t vo = (zk * 8 < p.K2) ? (uint32_t)((zl >> 3) * ld2 * 2 + zk * 16) : 0x80000000u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, vo, (int)(li * 64 * ld2 * 2), 0, 0);
       }
     }
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
     if (JOIN && wr == 0) __builtin_amdgcn_s_barrier();
     UR_PSTAMP(6);
     // ================= epilogue, from the accumulators (no LDS, no barrier) =================
+    __builtin_amdgcn_sched_barrier(0);      // nothing of the epilogue (its loads!) is scheduled up into the last K tile's phases
     // Lane constants of the epilogue are derived from an opaque copy of the lane id EVERY tile: hoisted out of the tile loop they
     // would stay live across the 256-register K loop (hipcc then spills inside it, and a scratch reload's vmcnt(0) drains the DMA ring)
     int elane = lane;
@@ -522,66 +528,41 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
 #endif
           }
       } else if constexpr (EPI == 2) {
-        // (bias / residual: the round-3 first form -- a quarter tile of residual pieces per batch; the restructured form below
-        // costs this variant 30+ spilled registers)
+        // bias / residual in the MFMA layout (lane: row m, 4 consecutive columns of each 16x16 sub-tile: 8-byte residual pieces),
+        // then the plain path's pack + 16-lane swap + 16-byte store.  (Adding after an f32 swap -- 16-byte residual pieces --
+        // costs 8 more live registers per row block; hipcc spilled 16-25 registers around it, some inside the K tiles.)
+        const int nq4 = eg4 * 4;
+        const uint32_t loff_c = (uint32_t)((el15 * p.ldc + cs) * 2), loff_r = (uint32_t)((el15 * p.ldres + nq4) * 2);
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh) {
-          const int ncol = n0 + sh * 128 + wc * 32 + cs;
-          float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          float bsa[4] = {0.f, 0.f, 0.f, 0.f}, bsb[4] = {0.f, 0.f, 0.f, 0.f};
           if (p.bias) {
-            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ncol), b1 = *reinterpret_cast<const float4*>(p.bias + ncol + 4);
-            bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0 + sh * 128 + wc * 32 + nq4), b1 = *reinterpret_cast<const float4*>(p.bias + n0 + sh * 128 + wc * 32 + 16 + nq4);
+            bsa[0] = b0.x; bsa[1] = b0.y; bsa[2] = b0.z; bsa[3] = b0.w; bsb[0] = b1.x; bsb[1] = b1.y; bsb[2] = b1.z; bsb[3] = b1.w;
           }
 #pragma unroll
           for (int rh = 0; rh < 2; ++rh) {
-            // four rows' worth of residual / gate / up pieces go out together (one wait instead of one per row)
-            uint4 rw[4], gw[4], uw[4];
+            uint2 ra[4], rb[4];         // (EPI 2 always carries a residual: a bias alone stays on the generic kernel)
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-              const long m = m0 + rh * 128 + wr * 64 + jj * 16 + el15;
-              if (EPI == 2 && p.res) rw[jj] = *reinterpret_cast<const uint4*>(p.res + m * p.ldres + ncol);
-              if (EPI == 1) {
-                gw[jj] = *reinterpret_cast<const uint4*>(p.sw_gu + m * p.sw_ldgu + ncol);
-                uw[jj] = *reinterpret_cast<const uint4*>(p.sw_gu + m * p.sw_ldgu + p.sw_I + ncol);
-              }
+              const char* rbase = uniform_ptr(reinterpret_cast<const char*>(p.res + (long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldres + n0 + sh * 128 + wc * 32));
+              ra[jj] = *reinterpret_cast<const uint2*>(rbase + loff_r);
+              rb[jj] = *reinterpret_cast<const uint2*>(rbase + loff_r + 32);
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-              const long m = m0 + rh * 128 + wr * 64 + jj * 16 + el15;
-              f32x4 a = acc[2 * sh][4 * rh + jj], b = acc[2 * sh + 1][4 * rh + jj];
+              const int j = 4 * rh + jj;
+              const f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
+              float va[4], vb[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) { float x = a[e], y = b[e]; swap16f(x, y); a[e] = x; b[e] = y; }
-              float v[8] = {a[0] * alpha + bs[0], a[1] * alpha + bs[1], a[2] * alpha + bs[2], a[3] * alpha + bs[3],
-                            b[0] * alpha + bs[4], b[1] * alpha + bs[5], b[2] * alpha + bs[6], b[3] * alpha + bs[7]};
-              if (EPI == 2) {
-                if (p.res) {
-                  const uint32_t w[4] = {rw[jj].x, rw[jj].y, rw[jj].z, rw[jj].w};
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
-                }
-                const u32x4_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-                *reinterpret_cast<u32x4_t*>(reinterpret_cast<bf16_t*>(p.C) + m * p.ldc + ncol) = o;
-              } else {
-                // d(act) = v (f32, unrounded): dgate = v u silu'(g), dup = v silu(g)   (elementwise.hip: swiglu_bwd_kernel)
-                const uint32_t gq[4] = {gw[jj].x, gw[jj].y, gw[jj].z, gw[jj].w}, uq[4] = {uw[jj].x, uw[jj].y, uw[jj].z, uw[jj].w};
-                uint32_t og[4], ou[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  float dgv[2], duv[2];
-#pragma unroll
-                  for (int hh = 0; hh < 2; ++hh) {
-                    const float gg = hh ? bf_hi(gq[e]) : bf_lo(gq[e]), uu = hh ? bf_hi(uq[e]) : bf_lo(uq[e]);
-                    const float d = v[2 * e + hh];
-                    const float sg = 1.0f / (1.0f + __expf(-gg));
-                    duv[hh] = d * (gg * sg);
-                    dgv[hh] = d * uu * (sg * (1.0f + gg * (1.0f - sg)));
-                  }
-                  og[e] = pack_bf2(dgv[0], dgv[1]); ou[e] = pack_bf2(duv[0], duv[1]);
-                }
-                const u32x4_t vg = {og[0], og[1], og[2], og[3]}, vu = {ou[0], ou[1], ou[2], ou[3]};
-                *reinterpret_cast<u32x4_t*>(p.sw_dgu + m * p.sw_lddgu + ncol) = vg;
-                *reinterpret_cast<u32x4_t*>(p.sw_dgu + m * p.sw_lddgu + p.sw_I + ncol) = vu;
-              }
+              for (int e = 0; e < 4; ++e) { va[e] = a[e] * alpha + bsa[e]; vb[e] = b[e] * alpha + bsb[e]; }
+              va[0] += bf_lo(ra[jj].x); va[1] += bf_hi(ra[jj].x); va[2] += bf_lo(ra[jj].y); va[3] += bf_hi(ra[jj].y);
+              vb[0] += bf_lo(rb[jj].x); vb[1] += bf_hi(rb[jj].x); vb[2] += bf_lo(rb[jj].y); vb[3] += bf_hi(rb[jj].y);
+              uint32_t a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]), b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
+              swap16(a0, b0); swap16(a1, b1);
+              char* cb = uniform_wptr(reinterpret_cast<char*>(p.C) + ((long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldc + n0 + sh * 128 + wc * 32) * 2);
+              const u32x4_t o = {a0, a1, b0, b1};
+              *reinterpret_cast<u32x4_t*>(cb + loff_c) = o;
             }
           }
         }
@@ -715,6 +696,7 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
   if ((long)(p.M / BM) * (p.N / BN) < 512) return false;                       // at least two tiles per CU
   if ((long)(p.M / BM) * (p.N / BN) >= (1L << 20) || p.N / BN >= (1 << 12) || p.M / BM >= (1 << 15)) return false;      // fdiv: n * d < 2^32
   if (p.gelu_out || p.aux || p.sw_mode == 2) return false;
+  if (p.bias && !p.res) return false;                        // (the bias epilogue here rides on the residual variant)
   if (p.K2 > 0 && !p.drop_bits && p.K2 > BK) return false;
   if (p.drop_bits && p.K2 > 0) {
     if (p.drop_rank != 16 || (p.K2 & 15)) return false;                        // the masked epilogue here is rank 16 only
@@ -745,7 +727,7 @@ int gemm_pers_launch(GemmP p, hipStream_t st) {
     p.stagger = env_st > 0 ? env_st : 0;
   }
   const int mode = drop ? 2 : (p.K2 > 0 ? 1 : 0);
-  const int epi = p.sp_act ? 4 : (p.qk_q ? 3 : (p.sw_mode == 1 ? 1 : ((p.res || p.bias) ? 2 : 0)));
+  const int epi = p.sp_act ? 4 : (p.qk_q ? 3 : (p.sw_mode == 1 ? 1 : (p.res ? 2 : 0)));
 #define UR_PERS_CASE(E, MD) if (epi == E && mode == MD) return launch_pers<E, MD>(p, st)
   UR_PERS_CASE(0, 0); UR_PERS_CASE(0, 1); UR_PERS_CASE(0, 2);
   UR_PERS_CASE(1, 0); UR_PERS_CASE(1, 1); UR_PERS_CASE(1, 2);
