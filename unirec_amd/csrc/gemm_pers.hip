@@ -81,7 +81,7 @@ __device__ __forceinline__ void swap16f(float& a, float& b) {
   a = __uint_as_float(ua); b = __uint_as_float(ub);
 }
 
-// EPI: 0 = plain (alpha only), 2 = bias / residual, 1 = SwiGLU backward (result is d(act); dgate | dup leave instead of C),
+// EPI: 0 = plain (alpha only), 2 = residual (+ bias), 5 = bias only, 1 = SwiGLU backward (result is d(act); dgate | dup leave instead of C),
 //      3 = q/k-norm + RoPE of the q|k|v projection (ur_gemm_args.qkr_*; q_r, k_r, v and the row constants leave instead of C),
 //      4 = SwiGLU forward of the merged gate|up projection with 128-row interleaved weights (ur_gemm_args.swp_*).
 // MODE: 0 = no second K range, 1 = the LoRA second K range rides in the K stream (one zero-padded K tile per output tile),
@@ -527,7 +527,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(base + loff));
 #endif
           }
-      } else if constexpr (EPI == 2) {
+      } else if constexpr (EPI == 2 || EPI == 5) {
+        constexpr bool RES = EPI == 2;                  // EPI 5: bias only (a RUNTIME residual switch made hipcc spill 16-25 registers)
         // bias / residual in the MFMA layout (lane: row m, 4 consecutive columns of each 16x16 sub-tile: 8-byte residual pieces),
         // then the plain path's pack + 16-lane swap + 16-byte store.  (Adding after an f32 swap -- 16-byte residual pieces --
         // costs 8 more live registers per row block; hipcc spilled 16-25 registers around it, some inside the K tiles.)
@@ -542,12 +543,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
           }
 #pragma unroll
           for (int rh = 0; rh < 2; ++rh) {
-            uint2 ra[4], rb[4];         // (EPI 2 always carries a residual: a bias alone stays on the generic kernel)
+            uint2 ra[4], rb[4];
+            if constexpr (RES) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-              const char* rbase = uniform_ptr(reinterpret_cast<const char*>(p.res + (long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldres + n0 + sh * 128 + wc * 32));
-              ra[jj] = *reinterpret_cast<const uint2*>(rbase + loff_r);
-              rb[jj] = *reinterpret_cast<const uint2*>(rbase + loff_r + 32);
+              for (int jj = 0; jj < 4; ++jj) {
+                const char* rbase = uniform_ptr(reinterpret_cast<const char*>(p.res + (long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldres + n0 + sh * 128 + wc * 32));
+                ra[jj] = *reinterpret_cast<const uint2*>(rbase + loff_r);
+                rb[jj] = *reinterpret_cast<const uint2*>(rbase + loff_r + 32);
+              }
             }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
@@ -556,8 +559,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
               float va[4], vb[4];
 #pragma unroll
               for (int e = 0; e < 4; ++e) { va[e] = a[e] * alpha + bsa[e]; vb[e] = b[e] * alpha + bsb[e]; }
-              va[0] += bf_lo(ra[jj].x); va[1] += bf_hi(ra[jj].x); va[2] += bf_lo(ra[jj].y); va[3] += bf_hi(ra[jj].y);
-              vb[0] += bf_lo(rb[jj].x); vb[1] += bf_hi(rb[jj].x); vb[2] += bf_lo(rb[jj].y); vb[3] += bf_hi(rb[jj].y);
+              if constexpr (RES) {
+                va[0] += bf_lo(ra[jj].x); va[1] += bf_hi(ra[jj].x); va[2] += bf_lo(ra[jj].y); va[3] += bf_hi(ra[jj].y);
+                vb[0] += bf_lo(rb[jj].x); vb[1] += bf_hi(rb[jj].x); vb[2] += bf_lo(rb[jj].y); vb[3] += bf_hi(rb[jj].y);
+              }
               uint32_t a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]), b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
               swap16(a0, b0); swap16(a1, b1);
               char* cb = uniform_wptr(reinterpret_cast<char*>(p.C) + ((long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldc + n0 + sh * 128 + wc * 32) * 2);
@@ -693,10 +698,10 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
   const int mode = set >= 0 ? set : env_mode;
   if (!mode || !rk || !sk || outf32 || splits > 1) return false;
   if ((p.M % BM) || (p.N % BN) || (p.K % BK) || p.K < 4 * BK) return false;
-  if ((long)(p.M / BM) * (p.N / BN) < 512) return false;                       // at least two tiles per CU
+  static const int min_tiles = [] { const char* e = getenv("UR_PERS_MIN_TILES"); return e ? atoi(e) : 512; }();      // lab; default: at least two tiles per CU
+  if ((long)(p.M / BM) * (p.N / BN) < min_tiles) return false;
   if ((long)(p.M / BM) * (p.N / BN) >= (1L << 20) || p.N / BN >= (1 << 12) || p.M / BM >= (1 << 15)) return false;      // fdiv: n * d < 2^32
   if (p.gelu_out || p.aux || p.sw_mode == 2) return false;
-  if (p.bias && !p.res) return false;                        // (the bias epilogue here rides on the residual variant)
   if (p.K2 > 0 && !p.drop_bits && p.K2 > BK) return false;
   if (p.drop_bits && p.K2 > 0) {
     if (p.drop_rank != 16 || (p.K2 & 15)) return false;                        // the masked epilogue here is rank 16 only
@@ -727,13 +732,14 @@ int gemm_pers_launch(GemmP p, hipStream_t st) {
     p.stagger = env_st > 0 ? env_st : 0;
   }
   const int mode = drop ? 2 : (p.K2 > 0 ? 1 : 0);
-  const int epi = p.sp_act ? 4 : (p.qk_q ? 3 : (p.sw_mode == 1 ? 1 : (p.res ? 2 : 0)));
+  const int epi = p.sp_act ? 4 : (p.qk_q ? 3 : (p.sw_mode == 1 ? 1 : (p.res ? 2 : (p.bias ? 5 : 0))));
 #define UR_PERS_CASE(E, MD) if (epi == E && mode == MD) return launch_pers<E, MD>(p, st)
   UR_PERS_CASE(0, 0); UR_PERS_CASE(0, 1); UR_PERS_CASE(0, 2);
   UR_PERS_CASE(1, 0); UR_PERS_CASE(1, 1); UR_PERS_CASE(1, 2);
   UR_PERS_CASE(2, 0); UR_PERS_CASE(2, 1); UR_PERS_CASE(2, 2);
   UR_PERS_CASE(3, 0); UR_PERS_CASE(3, 1);
   UR_PERS_CASE(4, 0); UR_PERS_CASE(4, 1);
+  UR_PERS_CASE(5, 0); UR_PERS_CASE(5, 1); UR_PERS_CASE(5, 2);
 #undef UR_PERS_CASE
   UR_FAIL(-1, "ur_gemm(persistent): no kernel for epilogue %d, mode %d", epi, mode);
 }
