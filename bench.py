@@ -55,6 +55,9 @@ def parse():
                     help="joint workload: skip the item (C2) / user (C3) stage measurements that follow the headline in the same process")
     ap.add_argument("--stage-steps", type=int, default=10)
     ap.add_argument("--stage-cpu-budget", type=float, default=25.0, help="seconds of oracle work per stage cpu_baseline leg")
+    ap.add_argument("--recompute-mlp", action="store_true",
+                    help="drop gate|up and act after each layer's forward and rebuild them in the backward (memory for time: "
+                         "the C5 shape --user-tokens --hist 100 --seq 4096 --batch 64 then runs as ONE launch)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--lora-dropout", type=float, default=0.1, help="LoRA adapter dropout (reference lora_dropout=0.1)")
     return ap.parse_args()
@@ -434,6 +437,7 @@ def main():
                        1234 + rank, device, n_user=n_user)
     loss_fn = InfoNCELoss(0.07)
     qw = model.base_model
+    qw.recompute_mlp = bool(args.recompute_mlp) or qw.recompute_mlp
     dp.set_dp_rank(rank, model, qf)                # dropout / LoRA-dropout masks keyed on the global sample index (same seeds on every rank)
     qpack, lpack = qf._ensure_pack(device), qw._ensure_pack(device)
     packs = [qpack, lpack]
@@ -574,7 +578,7 @@ def main():
                                       f"Qwen3-0.6B-shaped({cfg.num_hidden_layers}L)+LoRA r16 -> mean-pool -> InfoNCE pool {args.pool}; "
                                       f"fwd+bwd+allreduce+AdamW", "per_gpu_batch": B, "global_batch": B * world, "seq_len": args.seq,
                           "hist": args.hist, "pool": args.pool, "dropout": 0.0 if args.no_dropout else 0.2, "lora_dropout": 0.0 if args.no_dropout else args.lora_dropout,
-                          "micro_batches": nmb, "parallelism": f"dp{world}", "random_init": True},
+                          "micro_batches": nmb, "recompute_mlp": bool(qw.recompute_mlp), "parallelism": f"dp{world}", "random_init": True},
                "step_tflops_per_gpu": round(fl / (dt / args.steps) / 1e12, 1), "loss": round(lossv, 4),
                "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "attention": attn, "comm": _comm_info(world), "param_checksum": checksum}
         if world == 1 and not args.no_cpu_baseline:

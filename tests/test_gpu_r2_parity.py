@@ -156,6 +156,61 @@ def test_fused_qknorm_rope_epilogue_matches_the_separate_pass(monkeypatch):
         assert rel <= 2e-2, (n, rel)
 
 
+@pytest.mark.parametrize("tokens", [(4, 2048), (2, 256)])
+def test_recompute_mlp_switch_is_bit_identical_and_frees_the_mlp_activations(tokens):
+    """recompute_mlp drops gate|up and act after the forward and rebuilds them in the backward with the launch that made them:
+    pooled output and every gradient are bit-identical, the saved state holds no [M, 2I] / [M, I] tensor, and the peak memory
+    of forward + backward falls.  (4, 2048) takes the paired SwiGLU epilogue of the persistent GEMM, (2, 256) the merged
+    gate|up launch + stand-alone SwiGLU pass."""
+    from unirec_amd.qwen3 import Qwen3Config, Qwen3LoRAModel
+    B, S = tokens
+    L = 3
+    cfg = Qwen3Config(vocab_size=512, num_hidden_layers=L, lora_dropout=0.1)
+    torch.manual_seed(5)
+    m = Qwen3LoRAModel(cfg, use_lora=True)
+    m.reset_parameters(lora_b_std=0.02)
+    m = m.to(DEV).train()
+    g = torch.Generator().manual_seed(9)
+    ids = torch.randint(0, 512, (B, S), generator=g).to(DEV)
+    am = torch.ones(B, S, dtype=torch.long)
+    am[1, :100] = 0
+    am = am.to(DEV)
+    seen = {}
+    real_bwd = m._backward_impl
+
+    def spy(saved, d_pooled):
+        seen["kinds"] = [lyr.get("mlp_recompute") for lyr in saved["layers"]]
+        seen["big"] = sum(1 for lyr in saved["layers"] for k in ("gu", "act") if lyr.get(k) is not None)
+        return real_bwd(saved, d_pooled)
+    m._backward_impl = spy
+
+    def run(recompute):
+        m.recompute_mlp = recompute
+        m._lora_step = 4
+        for p_ in m.parameters():
+            p_.grad = None
+        if m.pack is not None:
+            m.pack.clear_grads()
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        pooled = m.forward_pooled(ids, am)
+        pooled.pow(2).sum().backward()
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated()
+        return pooled.detach().clone(), {n: p_.grad.detach().clone() for n, p_ in m.named_parameters() if p_.grad is not None}, peak
+    p0, g0, peak0 = run(False)
+    assert seen["big"] == 2 * L and not any(seen["kinds"])
+    p1, g1, peak1 = run(True)
+    assert seen["big"] == 0 and all(seen["kinds"]), seen
+    assert seen["kinds"][0] == ("pair" if B * S >= 8192 else "merged"), seen
+    assert torch.equal(p0, p1)
+    assert set(g0) == set(g1) and len(g0) == 14 * L
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+    M, I = B * S, cfg.intermediate_size
+    assert peak0 - peak1 >= (L - 2) * M * 3 * I * 2, (peak0, peak1)          # L - 1 layers' worth less, give or take where the peak falls
+
+
 def test_user_qformer_mid_size_matches_reference():
     """The reference's default UserQFormer (L4 Q64 H1024 I4096) over T = 1600 keys: C3's shapes at B = 2."""
     from unirec_amd.user_qformer import UserQFormer

@@ -572,10 +572,11 @@ def add_bf16(a, b, out=None):
     return out
 
 
-def swiglu_fwd(gu, I):
+def swiglu_fwd(gu, I, out=None):
     lib = _lib.load()
     M = gu.numel() // (2 * I)
-    act = torch.empty((M, I), dtype=BF16, device=gu.device)
+    act = torch.empty((M, I), dtype=BF16, device=gu.device) if out is None else out
+    assert act.is_contiguous() and act.numel() == M * I and act.dtype == BF16
     check(lib.ur_swiglu_fwd(gu.data_ptr(), act.data_ptr(), M, I, _stream()), "ur_swiglu_fwd")
     return act
 

@@ -161,6 +161,7 @@ class Qwen3LoRAModel(nn.Module):
         self._bcomb = None             # block-diagonal LoRA B operands of the merged q|k|v and gate|up launches
         self._bits_stream = None       # side stream + planes of prefetch_lora_bits
         self._bits_pre = None
+        self.recompute_mlp = os.environ.get("UNIREC_RECOMPUTE_MLP", "0") == "1"   # drop gate|up and act after the forward, rebuild them in the backward
         self.keep_norm_outputs = True   # keep the two RMSNorm outputs per layer for the backward (memory for time); False recomputes them
         self.reset_parameters()
 
@@ -579,6 +580,12 @@ class Qwen3LoRAModel(nn.Module):
             else:
                 x3 = hip.gemm(act, fl["d"], residual=x2)
             L.update(rstd1=rstd1, qkv=qkv, actx=actx, att=att2, x2=x2, rstd2=rstd2, gu=gu, act=act)      # (qkv is None under the fused q/k-norm + RoPE epilogue)
+            if self.recompute_mlp and keep:
+                # memory for time: gate|up and act (2 x [M, 3I] bf16 over the stack: 67 GB at C4) are dropped and rebuilt in the
+                # backward by the very launch that made them (bit-identical: same kernel, same operands).
+                how = "pair" if (pack is not None and pair) else ("merged" if (pack is not None and bc_gu is not None and not fused) else ("plain" if pack is None else None))
+                if how is not None:
+                    L.update(gu=None, act=None, mlp_recompute=how)
             if self.keep_norm_outputs:       # 2 x [M,D] bf16 per layer (15 GB at C4) instead of two RMSNorm recomputes
                 L.update(h=h, h2=h2)
             if keep:
@@ -641,19 +648,34 @@ class Qwen3LoRAModel(nn.Module):
             drop = (bits, pdrop, r) if bits is not None else None
             return hip.gemm(dy, wT, R2=tb, S2=AT, drop=drop, swiglu_bwd=swiglu)
 
+        scratch = {}
         for i in reversed(range(len(fz["layers"]))):
             fl, L = fz["layers"][i], saved["layers"][i]
             lp = f"layers.{i}."
             x, x2, gu, qkv = L["x"], L["x2"], L["gu"], L["qkv"]
             # ---- MLP: x3 = x2 + down(silu(gate) * up)
             act = L["act"]
+            h2 = L["h2"] if "h2" in L else hip.rmsnorm_fwd(x2, fl["ln2"], eps)[0]          # kept, or recomputed
+            if L.get("mlp_recompute"):           # recompute_mlp: one [M, 2I] + [M, I] scratch pair serves every layer
+                if "gu" not in scratch:
+                    scratch["gu"] = torch.empty((M, 2 * I), dtype=BF16, device=dev)
+                    scratch["act"] = torch.empty((M, I), dtype=BF16, device=dev)
+                gu, act = scratch["gu"], scratch["act"]
+                how = L["mlp_recompute"]
+                if how == "pair":
+                    hip.gemm(h2, fl["guP"], out=gu, R2=L["t_gu"], S2=self._bcomb["guP"][i], swiglu_paired=act)
+                else:
+                    if how == "merged":
+                        hip.gemm(h2, fl["gu"], out=gu, R2=L["t_gu"], S2=self._bcomb["gu"][i])
+                    else:
+                        hip.gemm(h2, fl["gu"], out=gu)
+                    hip.swiglu_fwd(gu, I, out=act)
             dgu = torch.empty_like(gu)
             if pack is not None:
                 tb = lora_grads(dx, L["t_d"], act, [lp + "mlp.down_proj.lora_A.weight"], [(lp + "mlp.down_proj.lora_B.weight", 0, D)], L["bits_d"])
                 dx_gemm(dx, fl["dT"], tb, [lp + "mlp.down_proj.lora_A.weight"], L["bits_d"], swiglu=(gu, dgu))
             else:
                 hip.gemm(dx, fl["dT"], swiglu_bwd=(gu, dgu))
-            h2 = L["h2"] if "h2" in L else hip.rmsnorm_fwd(x2, fl["ln2"], eps)[0]          # kept, or recomputed
             if pack is not None:
                 a_names = [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"]
                 tb = lora_grads(dgu, L["t_gu"], h2, a_names, [(lp + "mlp.gate_proj.lora_B.weight", 0, I), (lp + "mlp.up_proj.lora_B.weight", I, I)], L["bits_gu"])
