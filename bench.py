@@ -140,6 +140,30 @@ def flops_per_step(args, B, cfg, dims):
     return qf_fwd * 3 + qwen
 
 
+def attn_executed_ratio(am, S, qblk=128, kt=64):
+    """Executed / algorithmic FLOPs of the causal head_dim-128 attention launches for the 0/1 attention mask `am` [B, S]
+    (csrc/attn.hip).  Forward and dQ: a workgroup owns 128 queries and sweeps the 64-key tiles from the sequence's first tile
+    holding a valid key (first_valid_tile) up to its diagonal, 2 (forward) / 3 (dQ) contractions per tile.  dK/dV: a workgroup
+    owns 128 keys -- skipped whole when none is valid -- and sweeps the 64-query tiles from its diagonal to S, 4 contractions.
+    Algorithmic: S^2 / 2 query-key pairs per head x 2 contractions forward, 5 backward (bench convention: 2.5 x forward)."""
+    valid = am.to("cpu").bool()
+    B = valid.shape[0]
+    nqb, nkb = (S + qblk - 1) // qblk, (S + qblk - 1) // qblk
+    pairs_q = pairs_k = 0.0
+    for b in range(B):
+        nz = torch.nonzero(valid[b])
+        t0 = (int(nz[0]) // kt) if nz.numel() else (S + kt - 1) // kt
+        for qb in range(nqb):
+            tiles = max(0, (min(S, (qb + 1) * qblk) + kt - 1) // kt - t0)
+            pairs_q += tiles * kt * qblk
+        for kb in range(nkb):
+            if bool(valid[b, kb * qblk:(kb + 1) * qblk].any()):
+                q0 = ((kb * qblk) // kt) * kt
+                pairs_k += ((S - q0 + kt - 1) // kt) * kt * qblk
+    alg = B * S * S / 2.0
+    return {"fwd": pairs_q / alg, "bwd": (3.0 * pairs_q + 4.0 * pairs_k) / (5.0 * alg)}
+
+
 def _cpu_threads(args):
     try:
         avail = len(os.sched_getaffinity(0))
@@ -539,12 +563,12 @@ def main():
         # largest launch of the family, the merged gate|up forward (M=131072, N=6144, K=1024).
         traffic, tnote = None, "no PMC summary found"
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_gemm_pmc.json")))["launches"]["gate|up fwd"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r3_gemm_pmc.json")))["launches"]["gate|up fwd"]
             if B * args.seq == pm["M"]:
                 traffic = pm["hbm_bytes"]
                 tnote = (f"gate|up forward launch (N=6144, K=1024): fabric reads {pm['fabric_read_bytes']} (x{pm['read_ratio']} of A+W; FETCH_SIZE "
                          f"counts Infinity-Cache hits too) + writes {pm['write_bytes']} vs algorithmic {pm['algorithmic_bytes']} (x{pm['ratio']}); "
-                         f"profiles/r2_gemm_pmc.json")
+                         f"profiles/r3_gemm_pmc.json")
         except Exception:
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
@@ -567,6 +591,12 @@ def main():
                 att[kind][0] += e0.elapsed_time(e1); att[kind][1] += f; att[kind][2] += 1
         attn = {k: {"launches": v[2], "avg_launch_ms": round(v[0] / max(v[2], 1), 4), "ms_per_step": round(v[0] / args.steps, 2),
                     "tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 1), "frac_of_peak": round(v[1] / max(v[0], 1e-9) / 1e9 / 2500.0, 4)} for k, v in att.items()}
+        # ... and on the EXECUTED FLOPs: what the kernels issue for this batch's masks (whole 64-key tiles incl. the masked half of
+        # the diagonal ones, minus the leading all-padding key tiles they skip) -- the honest MFMA utilisation of the kernels
+        ex = attn_executed_ratio(batch["attention_mask"], args.seq)
+        for k in ("fwd", "bwd"):
+            attn[k]["executed_over_algorithmic"] = round(ex[k], 4)
+            attn[k]["frac_of_peak_executed"] = round(attn[k]["frac_of_peak"] * ex[k], 4)
         attn["kernels"] = "attn_fwd_kernel<128,true,4>; attn_bwd_dq_kernel<128,true,4> + attn_bwd_dkv2_kernel<true> (one ur_attn_bwd call)"
         fl = flops_per_step(args, B, cfg, dims)
         out = {"metric": f"user-sequences/sec joint fwd+bwd (Qwen3-0.6B+LoRA, hist={args.hist})", "value": round(world * B * args.steps / dt, 3),
