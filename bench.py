@@ -296,6 +296,7 @@ def run_stage(args):
     if rank == 0:
         print(json.dumps(out), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
+        dp.close_native_comms()
         torch.distributed.destroy_process_group()
 
 
@@ -425,6 +426,10 @@ def _comm_info(world):
     d = torch.distributed
     if d.is_available() and d.is_initialized():
         be = d.get_backend()
+        from unirec_amd import dp as _dp
+        if _dp.use_native_comm() and _dp._native:          # UNIREC_DP_COMM=native: the buckets went through the library's communicator
+            c = next(iter(_dp._native.values()))
+            return {"backend": "rccl (native ur_comm_*; rendezvous over torch.distributed " + be + ")", "ranks": c.world, "allreduce_launches": c.launches}
         return {"backend": "rccl (torch.distributed nccl)" if be == "nccl" else be, "ranks": d.get_world_size()}
     return {"backend": None, "ranks": 1}
 
@@ -637,6 +642,7 @@ def main():
             out["stages"] = stages
         print(json.dumps(out), flush=True)
     if dist_on:
+        dp.close_native_comms()
         torch.distributed.destroy_process_group()
 
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 5
+#define UR_ABI_VERSION 6
 
 int ur_version(void);
 const char* ur_last_error(void);
@@ -398,6 +398,33 @@ int ur_swiglu_bwd(const void* dact, const void* gu, void* dgu, int32_t M, int32_
 int ur_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Gradient all-reduce of the data-parallel step (SURVEY 8(b) communicator calls, 8(e)).
+ * The reference trains on ONE device (training/train_item_individual_token_joint.py:755-773 hands the model to the HF
+ * Trainer; training/item_qformer_training.py:105-125 and training/user_qformer_training.py:170-208 are plain single-process
+ * loops), so these replace nothing: they are the north-star's pure data parallelism -- one process per GPU, an in-place SUM
+ * all-reduce per gradient bucket over RCCL / xGMI, overlapped with the backward.
+ *   ur_comm_unique_id      rank 0 makes the 128-byte RCCL id and hands it to every rank by any channel
+ *                          (unirec_amd.dp: torch.distributed broadcast_object_list / the launcher's store).
+ *   ur_comm_init           collective over all `world` ranks: RCCL communicator + ONE library-owned side stream + two events
+ *                          on `device`.  world = 1 is valid (the all-reduce is then the identity).
+ *   ur_comm_allreduce_async  buf (device, `count` elements of dtype, in place) was written on producer_stream: the side stream
+ *                          waits for that stream's work up to this call, then reduces.  Calls queue in order on the side
+ *                          stream; every rank must issue the same sequence of (count, dtype).  No host synchronisation.
+ *   ur_comm_wait           consumer_stream waits for every all-reduce queued so far (event fence, no host sync).  buf must
+ *                          stay allocated and untouched by other streams between the two calls.
+ *   ur_comm_destroy        synchronises the side stream, frees communicator, stream and events.  NULL is a no-op.
+ * Errors: < 0 invalid argument (-2: RCCL could not be loaded -- it is resolved with dlopen at the first ur_comm_* call, so
+ * the library itself does not depend on it), 1..999 HIP error codes, 1000 + ncclResult_t for RCCL failures. */
+#define UR_COMM_ID_BYTES 128
+#define UR_COMM_F32 0
+#define UR_COMM_BF16 1
+int ur_comm_unique_id(void* id_out);
+int ur_comm_init(void** comm_out, int32_t rank, int32_t world, const void* unique_id, int32_t device);
+int ur_comm_allreduce_async(void* comm, void* buf, int64_t count, int32_t dtype, void* producer_stream);
+int ur_comm_wait(void* comm, void* consumer_stream);
+int ur_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

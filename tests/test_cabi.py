@@ -44,6 +44,12 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     rc = lib.ur_gemm(ctypes.byref(a), None, 0, None)
     assert rc < 0 and b"multiples of 8" in lib.ur_last_error()
     assert lib.ur_layernorm_fwd(None, 1, None, None, None, None, None, None, None, 4, 12, 1e-5, 0.0, 0, 0.0, 0, 0, None) < 0
+    # communicator entry points: argument checks precede any RCCL / HIP call
+    h = ctypes.c_void_p()
+    assert lib.ur_comm_init(ctypes.byref(h), 3, 2, ctypes.create_string_buffer(128), 0) < 0 and b"outside a world" in lib.ur_last_error()
+    assert lib.ur_comm_allreduce_async(None, None, 4, 0, None) < 0 and b"not a communicator" in lib.ur_last_error()
+    assert lib.ur_comm_wait(None, None) < 0
+    assert lib.ur_comm_destroy(None) == 0
 
 
 def test_product_path_has_no_oracle_import():

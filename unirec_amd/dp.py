@@ -102,11 +102,109 @@ def launch_ranks(n, script, argv, extra_env=None):
     return subprocess.run(cmd, env=env).returncode
 
 
+class NativeComm:
+    """The library's own RCCL communicator (include/unirec_hip.h: ur_comm_*): in-place SUM all-reduces queued on ONE
+    library-owned side stream, fenced with events against the producing / consuming torch streams -- no host
+    synchronisation, no torch.distributed call on the data path.  torch.distributed (any backend) is only the channel that
+    hands rank 0's 128-byte RCCL id to the other ranks; one rank needs no channel at all."""
+
+    _DTYPES = {torch.float32: 0, torch.bfloat16: 1}
+
+    def __init__(self, rank, world, device, unique_id):
+        import ctypes
+        from . import _lib
+        self._lib = _lib.load()
+        self._check = _lib.check
+        self.rank, self.world = int(rank), int(world)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("NativeComm: RCCL reduces device buffers; pass a cuda device")
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        if len(unique_id) != 128:
+            raise ValueError("NativeComm: the RCCL unique id is 128 bytes")
+        handle = ctypes.c_void_p()
+        idbuf = (ctypes.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._check(self._lib.ur_comm_init(ctypes.byref(handle), self.rank, self.world, idbuf, index), "ur_comm_init")
+        self._handle = handle
+        self.launches = 0
+
+    @staticmethod
+    def new_unique_id():
+        import ctypes
+        from . import _lib
+        buf = (ctypes.c_char * 128)()
+        _lib.check(_lib.load().ur_comm_unique_id(buf), "ur_comm_unique_id")
+        return bytes(buf)
+
+    @classmethod
+    def from_env(cls, device, group=None):
+        """Rank / world of the initialised process group (or a world of one without a group); rank 0 creates the id and
+        broadcast_object_list carries it (works on gloo and nccl groups alike)."""
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            rank, world = 0, 1
+        box = [cls.new_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, device, box[0])
+
+    def all_reduce_(self, t, stream=None):
+        """Queue the in-place sum of `t` (contiguous f32 / bf16 device tensor, written on `stream` -- default: torch's
+        current stream) on the communicator's side stream."""
+        if not t.is_contiguous() or t.device != self.device or t.dtype not in self._DTYPES:
+            raise ValueError(f"NativeComm.all_reduce_: contiguous f32/bf16 tensor on {self.device} expected, got {t.dtype} on {t.device}")
+        st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        self._check(self._lib.ur_comm_allreduce_async(self._handle, t.data_ptr(), t.numel(), self._DTYPES[t.dtype], st), "ur_comm_allreduce_async")
+        self.launches += 1
+        return self
+
+    def wait(self, stream=None):
+        """`stream` (default: torch's current stream) waits for every all-reduce queued so far."""
+        st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        self._check(self._lib.ur_comm_wait(self._handle, st), "ur_comm_wait")
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            h, self._handle = self._handle, None
+            self._check(self._lib.ur_comm_destroy(h), "ur_comm_destroy")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_native = {}
+
+
+def native_comm(device, group=None):
+    """The process's NativeComm for `device` (created on first use: a collective -- every rank must reach it)."""
+    key = (torch.device(device).index, id(group))
+    if key not in _native:
+        _native[key] = NativeComm.from_env(device, group)
+    return _native[key]
+
+
+def close_native_comms():
+    for c in _native.values():
+        c.close()
+    _native.clear()
+
+
+def use_native_comm():
+    """UNIREC_DP_COMM=native: the bucket all-reduces go through ur_comm_* instead of torch.distributed's nccl group."""
+    return os.environ.get("UNIREC_DP_COMM", "torch") == "native"
+
+
 class GradBuckets:
     """Contiguous buckets over one flat gradient buffer, reduced as they become ready."""
 
-    def __init__(self, flat_grad, boundaries, group=None):
-        """boundaries: ascending element offsets [0, ..., numel]; bucket i = [b[i], b[i+1])."""
+    def __init__(self, flat_grad, boundaries, group=None, comm=None):
+        """boundaries: ascending element offsets [0, ..., numel]; bucket i = [b[i], b[i+1]).  comm: a NativeComm to reduce
+        through (default: torch.distributed's group, or the process's native communicator under UNIREC_DP_COMM=native)."""
         self.flat = flat_grad
         self.bounds = list(boundaries)
         self.group = group
@@ -115,6 +213,11 @@ class GradBuckets:
         self.hold = False          # True while a non-final micro-batch runs its backward: hooks accumulate, nothing is sent
         self.enabled = dist.is_available() and dist.is_initialized() and (
             dist.get_world_size(group) > 1 or os.environ.get("UNIREC_DP_FORCE") == "1")
+        self.comm = comm
+        if comm is not None:
+            self.enabled = True
+        elif self.enabled and use_native_comm() and flat_grad.is_cuda:
+            self.comm = native_comm(flat_grad.device, group)
 
     @property
     def n(self):
@@ -134,7 +237,9 @@ class GradBuckets:
         if self.stash is not None:
             self.flat[lo:hi].add_(self.stash[lo:hi])
             self.stash[lo:hi].zero_()
-        if self.enabled:
+        if self.enabled and self.comm is not None:
+            self.comm.all_reduce_(self.flat[lo:hi])
+        elif self.enabled:
             self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def begin_micro_batch(self, last):
@@ -148,6 +253,8 @@ class GradBuckets:
             self.ready(i)
 
     def wait(self):
+        if self.comm is not None and self.enabled:
+            self.comm.wait()
         for w in self.pending:
             w.wait()
         self.pending = []
