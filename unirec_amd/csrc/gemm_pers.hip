@@ -725,7 +725,16 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
 int gemm_pers_launch(GemmP p, hipStream_t st) {
   p.gm = p.M / BM; p.gn = p.N / BN;
   p.gcw = 0;
-  if (p.gn >= 16 && (p.gm % 8) == 0 && p.gn > 4 && (p.gn % 4) == 0) p.gcw = 4;     // column chunks on wide launches (gemm.hip)
+  {
+    // column chunks on wide launches (gemm.hip): an XCD's 32 concurrent tiles cover (32 / cw) tile rows x cw tile columns and
+    // every A row panel crosses the fabric gn / cw times.  UR_PERS_CW = n (lab) overrides the width where it divides gn.
+    // Measured (gate|up, gn = 24, K = 1024; same process, interleaved): cw 6 1.448 ms, 12 1.482, 2 1.496, 4 1.507, row-major
+    // 1.528, 8 1.535 -- the order moves the launch by +-3 % although the fabric reads differ x2.5 between them; q|k|v (gn 16):
+    // 4 and 8 equal, 2 and row-major 1-2 % slower.
+    static const int env_cw = [] { const char* e = getenv("UR_PERS_CW"); return e ? atoi(e) : -1; }();
+    const int cw = env_cw >= 0 ? env_cw : ((p.gn % 6) == 0 && p.gn >= 24 ? 6 : 4);
+    if (cw > 0 && p.gn >= 16 && (p.gm % 8) == 0 && p.gn > cw && (p.gn % cw) == 0) p.gcw = cw;
+  }
   const bool drop = p.drop_bits != nullptr && p.K2 > 0;
   {
     static const int env_st = [] { const char* e = getenv("UR_PERS_STAGGER"); return e ? atoi(e) : 0; }();      // lab: cycles per start step; 0 = off (default)
