@@ -50,6 +50,21 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ char* uniform_wptr(char* p) { return const_cast<char*>(uniform_ptr(p)); }
+// Epilogue accesses name the GLOBAL address space: a pointer rebuilt from scalar halves (uniform_ptr) or read out of the
+// by-value argument struct is a generic pointer to hipcc, which then emits FLAT loads / stores -- and the wait-count pass answers
+// any pending FLAT access with s_waitcnt vmcnt(0) lgkmcnt(0) instead of the exact in-order count (no load could stay in flight
+// across a batch of stores).  global_load / global_store get exact counts.
+template <int W> struct raw_words { typedef uint32_t type __attribute__((ext_vector_type(W))); };
+template <> struct raw_words<1> { typedef uint32_t type; };
+template <class T> __device__ __forceinline__ T ld_g(const void* p) {
+  typedef typename raw_words<sizeof(T) / 4>::type raw_t;                   // (HIP's uint4 / float4 classes do not copy out of an address space)
+  const raw_t r = *(const __attribute__((address_space(1))) raw_t*)(p);
+  return __builtin_bit_cast(T, r);
+}
+template <class T> __device__ __forceinline__ void st_g(void* p, const T& v) {
+  typedef typename raw_words<sizeof(T) / 4>::type raw_t;
+  *(__attribute__((address_space(1))) raw_t*)(p) = __builtin_bit_cast(raw_t, v);
+}
 
 // XCD-aware tile order of gemm.hip, as a function of the (virtual) block id: ids equal mod 8 share an XCD
 // n / d for n * d < 2^32 by one scalar multiply-high: magic = ceil(2^32 / d) (host, TileOrder)
@@ -353,15 +368,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const char* ub = uniform_ptr(reinterpret_cast<const char*>(p.S2 + (long)(n0 + (i >> 1) * 128 + wc * 32 + (i & 1) * 16) * p.lds2 + a * 16));
-          s2[i] = *reinterpret_cast<const bf16x4*>(ub + lo_s2);
+          s2[i] = ld_g<bf16x4>(ub + lo_s2);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const long mb = m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16;
           const char* ub = uniform_ptr(reinterpret_cast<const char*>(p.R2 + mb * p.ldr2 + a * 16));
-          r2[j] = *reinterpret_cast<const bf16x4*>(ub + lo_r2);
+          r2[j] = ld_g<bf16x4>(ub + lo_r2);
           const char* fb = uniform_ptr(reinterpret_cast<const char*>(p.drop_bits + (long)a * p.drop_bits_stride + mb * p.drop_bits_ld + ((n0 + wc * 32) >> 3)));
-          fl[j] = make_uint2(*reinterpret_cast<const uint32_t*>(fb + lo_fl), *reinterpret_cast<const uint32_t*>(fb + lo_fl + 16));
+          fl[j] = make_uint2(ld_g<uint32_t>(fb + lo_fl), ld_g<uint32_t>(fb + lo_fl + 16));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -405,9 +420,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
 #pragma unroll
         for (int e = 0; e < 4; ++e) aq[e] = pack_bf2(silu_f(bf_lo(gq[e])) * bf_lo(uq[e]), silu_f(bf_hi(gq[e])) * bf_hi(uq[e]));
         const u32x4_t vg = {gq[0], gq[1], gq[2], gq[3]}, vu = {uq[0], uq[1], uq[2], uq[3]}, va = {aq[0], aq[1], aq[2], aq[3]};
-        *reinterpret_cast<u32x4_t*>(Cb + m * p.ldc + f0) = vg;
-        *reinterpret_cast<u32x4_t*>(Cb + m * p.ldc + p.sp_I + f0) = vu;
-        *reinterpret_cast<u32x4_t*>(p.sp_act + m * p.sp_ldact + f0) = va;
+        st_g<u32x4_t>(Cb + m * p.ldc + f0, vg);
+        st_g<u32x4_t>(Cb + m * p.ldc + p.sp_I + f0, vu);
+        st_g<u32x4_t>(p.sp_act + m * p.sp_ldact + f0, va);
       }
     } else
     if constexpr (EPI == 3) {
@@ -429,10 +444,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
         // pos0 + wr*64 + l15) advanced by the angle-addition theorem: + 16 positions per row block, + 80 across the two row halves
         // (table rows 16 and 80 are cos / sin of exactly those steps).
         const int prow0 = pos0 + wr * 64 + el15;
-        const float4 w0 = *reinterpret_cast<const float4*>(wgt + dq0), w1 = *reinterpret_cast<const float4*>(wgt + 64 + dq0);
-        const float4 c_0 = *reinterpret_cast<const float4*>(p.qk_cos + (long)prow0 * 64 + dq0), s_0 = *reinterpret_cast<const float4*>(p.qk_sin + (long)prow0 * 64 + dq0);
-        const float4 c16 = *reinterpret_cast<const float4*>(p.qk_cos + 16 * 64 + dq0), s16 = *reinterpret_cast<const float4*>(p.qk_sin + 16 * 64 + dq0);
-        const float4 c80 = *reinterpret_cast<const float4*>(p.qk_cos + 80 * 64 + dq0), s80 = *reinterpret_cast<const float4*>(p.qk_sin + 80 * 64 + dq0);
+        const float4 w0 = ld_g<float4>(wgt + dq0), w1 = ld_g<float4>(wgt + 64 + dq0);
+        const float4 c_0 = ld_g<float4>(p.qk_cos + (long)prow0 * 64 + dq0), s_0 = ld_g<float4>(p.qk_sin + (long)prow0 * 64 + dq0);
+        const float4 c16 = ld_g<float4>(p.qk_cos + 16 * 64 + dq0), s16 = ld_g<float4>(p.qk_sin + 16 * 64 + dq0);
+        const float4 c80 = ld_g<float4>(p.qk_cos + 80 * 64 + dq0), s80 = ld_g<float4>(p.qk_sin + 80 * 64 + dq0);
 #pragma unroll
         for (int sh = 0; sh < 2; ++sh)
 #pragma unroll
@@ -474,7 +489,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             swap16(a0, b0); swap16(a1, b1);
             const long m = m0 + row;
             const u32x4_t v = {a0, a1, b0, b1};
-            *reinterpret_cast<u32x4_t*>(outb + m * ldo + c0 + sh * 128 + ocol) = v;
+            st_g<u32x4_t>(outb + m * ldo + c0 + sh * 128 + ocol, v);
             if (wc == 0 && eg4 == 0) p.qk_rstd[m * nheads + head0 + sh] = rs;
           }
           // the next row block's angles: + 16 positions, or + 80 from the last block of the first row half to the first of the second
@@ -498,7 +513,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             char* base = uniform_wptr(reinterpret_cast<char*>(p.qk_v) +
                                       ((long)(m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16) * p.qk_ldv + (n0 - qkc) + sh * 128 + wc * 32) * 2);
             const u32x4_t v = {a0, a1, b0, b1};
-            *reinterpret_cast<u32x4_t*>(base + loff) = v;
+            st_g<u32x4_t>(base + loff, v);
           }
       }
     } else
@@ -522,9 +537,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
 #if UR_PERS_ABLATE == 1
             asm volatile("" :: "v"(v), "v"(base + loff));
 #elif UR_PERS_ABLATE == 4
-            *reinterpret_cast<u32x4_t*>(base + loff) = v;
+            st_g<u32x4_t>(base + loff, v);
 #else
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(base + loff));
+            __builtin_nontemporal_store(v, (__attribute__((address_space(1))) u32x4_t*)(base + loff));
 #endif
           }
       } else if constexpr (EPI == 2 || EPI == 5) {
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
         for (int sh = 0; sh < 2; ++sh) {
           float bsa[4] = {0.f, 0.f, 0.f, 0.f}, bsb[4] = {0.f, 0.f, 0.f, 0.f};
           if (p.bias) {
-            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0 + sh * 128 + wc * 32 + nq4), b1 = *reinterpret_cast<const float4*>(p.bias + n0 + sh * 128 + wc * 32 + 16 + nq4);
+            const float4 b0 = ld_g<float4>(p.bias + n0 + sh * 128 + wc * 32 + nq4), b1 = ld_g<float4>(p.bias + n0 + sh * 128 + wc * 32 + 16 + nq4);
             bsa[0] = b0.x; bsa[1] = b0.y; bsa[2] = b0.z; bsa[3] = b0.w; bsb[0] = b1.x; bsb[1] = b1.y; bsb[2] = b1.z; bsb[3] = b1.w;
           }
 #pragma unroll
@@ -548,8 +563,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
 #pragma unroll
               for (int jj = 0; jj < 4; ++jj) {
                 const char* rbase = uniform_ptr(reinterpret_cast<const char*>(p.res + (long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldres + n0 + sh * 128 + wc * 32));
-                ra[jj] = *reinterpret_cast<const uint2*>(rbase + loff_r);
-                rb[jj] = *reinterpret_cast<const uint2*>(rbase + loff_r + 32);
+                ra[jj] = ld_g<uint2>(rbase + loff_r);
+                rb[jj] = ld_g<uint2>(rbase + loff_r + 32);
               }
             }
 #pragma unroll
@@ -567,80 +582,66 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
               swap16(a0, b0); swap16(a1, b1);
               char* cb = uniform_wptr(reinterpret_cast<char*>(p.C) + ((long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldc + n0 + sh * 128 + wc * 32) * 2);
               const u32x4_t o = {a0, a1, b0, b1};
-              *reinterpret_cast<u32x4_t*>(cb + loff_c) = o;
+              st_g<u32x4_t>(cb + loff_c, o);
             }
           }
         }
       } else {
-        // Every load of a batch is issued BEFORE the batch's first store: hipcc waits vmcnt(0) for a load that follows stores
-        // (the LDS-DMA stream is in flight), i.e. for those stores' acknowledgements too -- one ~1 us round trip per batch.
-        // A quarter tile per batch (residual: 4 pieces = 16 registers, SwiGLU backward gate + up: 8 pieces = 32; bigger batches
-        // spill 30-120 registers beside the accumulators and the next tile's R fragments).
-        const uint32_t loff_c = (uint32_t)((el15 * p.ldc + cs) * 2), loff_res = (uint32_t)((el15 * p.ldres + cs) * 2);
+        // ---- SwiGLU backward (EPI 1; no bias / residual: gemm_pers_eligible).  vmcnt counts loads and stores in issue order, so a
+        // load issued AFTER a batch of stores cannot be waited for without those stores' acknowledgements: four quarter-tile
+        // batches of {8 loads, wait, math, 8 stores} exposed one load latency + one store round trip each (~28 us per tile
+        // beside a 23 us K loop at K = 1024).  Software pipeline instead: quarter q + 1's gate / up pieces are issued BEFORE
+        // quarter q's stores, into the second of two 32-register buffers; the wait for quarter q's pieces then leaves the 8
+        // stores of q - 1 and the 8 loads of q + 1 in flight (hipcc counts them: vmcnt(16)).
+        static_assert(EPI == 1, "the remaining epilogue is the SwiGLU backward");
+        __builtin_amdgcn_sched_barrier(0);       // (behind the masked LoRA epilogue: its uniform bases are dead before these are made)
+        int em0 = __builtin_amdgcn_readfirstlane(m0), en0 = __builtin_amdgcn_readfirstlane(n0);
+        asm volatile("" : "+s"(em0), "+s"(en0));
+        uint4 gw[2][4], uw[2][4];
+        // every address = uniform base (scalar registers) + ONE 32-bit lane offset per tensor
+        const uint32_t loff_g = (uint32_t)((el15 * p.sw_ldgu + cs) * 2), loff_d = (uint32_t)((el15 * p.sw_lddgu + cs) * 2);
+        const long up_g = (long)p.sw_I * 2;                                  // bytes from a row's gate half to its up half
+        auto load_quarter = [&](int q, uint4 (&g)[4], uint4 (&u)[4]) {
 #pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-          const int ncol = n0 + sh * 128 + wc * 32 + cs;
-          float bs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          if (p.bias) {
-            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + ncol), b1 = *reinterpret_cast<const float4*>(p.bias + ncol + 4);
-            bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
+          for (int jj = 0; jj < 4; ++jj) {
+            const char* gb = uniform_ptr(reinterpret_cast<const char*>(p.sw_gu + (long)(em0 + (q & 1) * 128 + wr * 64 + jj * 16) * p.sw_ldgu + en0 + (q >> 1) * 128 + wc * 32));
+            g[jj] = ld_g<uint4>(gb + loff_g);
+            u[jj] = ld_g<uint4>(gb + up_g + loff_g);
           }
-          uint4 rwa[8], gwa[8], uwa[8];
+        };
+        load_quarter(0, gw[0], uw[0]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (EPI == 2 && p.res && (j & 3) == 0) {
+        for (int q = 0; q < 4; ++q) {
+          if (q + 1 < 4) load_quarter(q + 1, gw[(q + 1) & 1], uw[(q + 1) & 1]);
+          const int sh = q >> 1, rh = q & 1;
 #pragma unroll
-              for (int jj = j; jj < j + 4; ++jj) {      // uniform base (scalar registers) + ONE 32-bit lane offset per tensor
-                const char* rb = uniform_ptr(reinterpret_cast<const char*>(p.res + (long)(m0 + (jj >> 2) * 128 + wr * 64 + (jj & 3) * 16) * p.ldres + n0 + sh * 128 + wc * 32));
-                rwa[jj] = *reinterpret_cast<const uint4*>(rb + loff_res);
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * rh + jj;
+            char* db = uniform_wptr(reinterpret_cast<char*>(p.sw_dgu + (long)(em0 + rh * 128 + wr * 64 + jj * 16) * p.sw_lddgu + en0 + sh * 128 + wc * 32));
+            f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float x = a[e], y = b[e]; swap16f(x, y); a[e] = x; b[e] = y; }
+            const float v[8] = {a[0] * alpha, a[1] * alpha, a[2] * alpha, a[3] * alpha, b[0] * alpha, b[1] * alpha, b[2] * alpha, b[3] * alpha};
+            // d(act) = v (f32, unrounded): dgate = v u silu'(g), dup = v silu(g)   (elementwise.hip: swiglu_bwd_kernel)
+            const uint4 gq4 = gw[q & 1][jj], uq4 = uw[q & 1][jj];
+            const uint32_t gq[4] = {gq4.x, gq4.y, gq4.z, gq4.w}, uq[4] = {uq4.x, uq4.y, uq4.z, uq4.w};
+            uint32_t og[4], ou[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float dgv[2], duv[2];
+#pragma unroll
+              for (int hh = 0; hh < 2; ++hh) {
+                const float gg = hh ? bf_hi(gq[e]) : bf_lo(gq[e]), uu = hh ? bf_hi(uq[e]) : bf_lo(uq[e]);
+                const float d = v[2 * e + hh];
+                const float sg = 1.0f / (1.0f + __expf(-gg));
+                duv[hh] = d * (gg * sg);
+                dgv[hh] = d * uu * (sg * (1.0f + gg * (1.0f - sg)));
               }
+              og[e] = pack_bf2(dgv[0], dgv[1]); ou[e] = pack_bf2(duv[0], duv[1]);
             }
-            if (EPI == 1 && (j & 3) == 0) {
-#pragma unroll
-              for (int jj = j; jj < j + 4; ++jj) {
-                const long m = m0 + (jj >> 2) * 128 + wr * 64 + (jj & 3) * 16 + el15;
-                gwa[jj] = *reinterpret_cast<const uint4*>(p.sw_gu + m * p.sw_ldgu + ncol);
-                uwa[jj] = *reinterpret_cast<const uint4*>(p.sw_gu + m * p.sw_ldgu + p.sw_I + ncol);
-              }
-            }
-            {
-              const long m = m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16 + el15;
-              f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { float x = a[e], y = b[e]; swap16f(x, y); a[e] = x; b[e] = y; }
-              float v[8] = {a[0] * alpha + bs[0], a[1] * alpha + bs[1], a[2] * alpha + bs[2], a[3] * alpha + bs[3],
-                            b[0] * alpha + bs[4], b[1] * alpha + bs[5], b[2] * alpha + bs[6], b[3] * alpha + bs[7]};
-              if (EPI == 2) {
-                if (p.res) {
-                  const uint32_t w[4] = {rwa[j].x, rwa[j].y, rwa[j].z, rwa[j].w};
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
-                }
-                const u32x4_t o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-                char* cb = uniform_wptr(reinterpret_cast<char*>(p.C) + ((long)(m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16) * p.ldc + n0 + sh * 128 + wc * 32) * 2);
-                *reinterpret_cast<u32x4_t*>(cb + loff_c) = o;
-              } else {
-                // d(act) = v (f32, unrounded): dgate = v u silu'(g), dup = v silu(g)   (elementwise.hip: swiglu_bwd_kernel)
-                const uint32_t gq[4] = {gwa[j].x, gwa[j].y, gwa[j].z, gwa[j].w}, uq[4] = {uwa[j].x, uwa[j].y, uwa[j].z, uwa[j].w};
-                uint32_t og[4], ou[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  float dgv[2], duv[2];
-#pragma unroll
-                  for (int hh = 0; hh < 2; ++hh) {
-                    const float gg = hh ? bf_hi(gq[e]) : bf_lo(gq[e]), uu = hh ? bf_hi(uq[e]) : bf_lo(uq[e]);
-                    const float d = v[2 * e + hh];
-                    const float sg = 1.0f / (1.0f + __expf(-gg));
-                    duv[hh] = d * (gg * sg);
-                    dgv[hh] = d * uu * (sg * (1.0f + gg * (1.0f - sg)));
-                  }
-                  og[e] = pack_bf2(dgv[0], dgv[1]); ou[e] = pack_bf2(duv[0], duv[1]);
-                }
-                const u32x4_t vg = {og[0], og[1], og[2], og[3]}, vu = {ou[0], ou[1], ou[2], ou[3]};
-                *reinterpret_cast<u32x4_t*>(p.sw_dgu + m * p.sw_lddgu + ncol) = vg;
-                *reinterpret_cast<u32x4_t*>(p.sw_dgu + m * p.sw_lddgu + p.sw_I + ncol) = vu;
-              }
-            }
+            const u32x4_t vg = {og[0], og[1], og[2], og[3]}, vu = {ou[0], ou[1], ou[2], ou[3]};
+            st_g<u32x4_t>(db + loff_d, vg);
+            st_g<u32x4_t>(db + up_g + loff_d, vu);
           }
         }
       }
