@@ -549,41 +549,48 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
         // costs 8 more live registers per row block; hipcc spilled 16-25 registers around it, some inside the K tiles.)
         const int nq4 = eg4 * 4;
         const uint32_t loff_c = (uint32_t)((el15 * p.ldc + cs) * 2), loff_r = (uint32_t)((el15 * p.ldres + nq4) * 2);
-#pragma unroll
-        for (int sh = 0; sh < 2; ++sh) {
-          float bsa[4] = {0.f, 0.f, 0.f, 0.f}, bsb[4] = {0.f, 0.f, 0.f, 0.f};
-          if (p.bias) {
+        // Software pipeline over the four quarter tiles q = 2 sh + rh (see the SwiGLU-backward branch below): the residual
+        // pieces (and, per column half, the bias) of quarter q + 1 are issued BEFORE quarter q's stores -- a load issued after
+        // stores cannot be waited for without their acknowledgements (vmcnt counts both, in order).
+        uint2 ra[2][4], rb[2][4];
+        float bsa[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, bsb[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        auto load_quarter = [&](int q) {
+          const int sh = q >> 1, rh = q & 1;
+          if ((q & 1) == 0 && p.bias) {
             const float4 b0 = ld_g<float4>(p.bias + n0 + sh * 128 + wc * 32 + nq4), b1 = ld_g<float4>(p.bias + n0 + sh * 128 + wc * 32 + 16 + nq4);
-            bsa[0] = b0.x; bsa[1] = b0.y; bsa[2] = b0.z; bsa[3] = b0.w; bsb[0] = b1.x; bsb[1] = b1.y; bsb[2] = b1.z; bsb[3] = b1.w;
+            bsa[sh][0] = b0.x; bsa[sh][1] = b0.y; bsa[sh][2] = b0.z; bsa[sh][3] = b0.w; bsb[sh][0] = b1.x; bsb[sh][1] = b1.y; bsb[sh][2] = b1.z; bsb[sh][3] = b1.w;
           }
-#pragma unroll
-          for (int rh = 0; rh < 2; ++rh) {
-            uint2 ra[4], rb[4];
-            if constexpr (RES) {
-#pragma unroll
-              for (int jj = 0; jj < 4; ++jj) {
-                const char* rbase = uniform_ptr(reinterpret_cast<const char*>(p.res + (long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldres + n0 + sh * 128 + wc * 32));
-                ra[jj] = ld_g<uint2>(rbase + loff_r);
-                rb[jj] = ld_g<uint2>(rbase + loff_r + 32);
-              }
-            }
+          if constexpr (RES) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-              const int j = 4 * rh + jj;
-              const f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
-              float va[4], vb[4];
-#pragma unroll
-              for (int e = 0; e < 4; ++e) { va[e] = a[e] * alpha + bsa[e]; vb[e] = b[e] * alpha + bsb[e]; }
-              if constexpr (RES) {
-                va[0] += bf_lo(ra[jj].x); va[1] += bf_hi(ra[jj].x); va[2] += bf_lo(ra[jj].y); va[3] += bf_hi(ra[jj].y);
-                vb[0] += bf_lo(rb[jj].x); vb[1] += bf_hi(rb[jj].x); vb[2] += bf_lo(rb[jj].y); vb[3] += bf_hi(rb[jj].y);
-              }
-              uint32_t a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]), b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
-              swap16(a0, b0); swap16(a1, b1);
-              char* cb = uniform_wptr(reinterpret_cast<char*>(p.C) + ((long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldc + n0 + sh * 128 + wc * 32) * 2);
-              const u32x4_t o = {a0, a1, b0, b1};
-              st_g<u32x4_t>(cb + loff_c, o);
+              const char* rbase = uniform_ptr(reinterpret_cast<const char*>(p.res + (long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldres + n0 + sh * 128 + wc * 32));
+              ra[q & 1][jj] = ld_g<uint2>(rbase + loff_r);
+              rb[q & 1][jj] = ld_g<uint2>(rbase + loff_r + 32);
             }
+          }
+        };
+        load_quarter(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q + 1 < 4) load_quarter(q + 1);
+          const int sh = q >> 1, rh = q & 1;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * rh + jj;
+            const f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
+            float va[4], vb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { va[e] = a[e] * alpha + bsa[sh][e]; vb[e] = b[e] * alpha + bsb[sh][e]; }
+            if constexpr (RES) {
+              const uint2 xa = ra[q & 1][jj], xb = rb[q & 1][jj];
+              va[0] += bf_lo(xa.x); va[1] += bf_hi(xa.x); va[2] += bf_lo(xa.y); va[3] += bf_hi(xa.y);
+              vb[0] += bf_lo(xb.x); vb[1] += bf_hi(xb.x); vb[2] += bf_lo(xb.y); vb[3] += bf_hi(xb.y);
+            }
+            uint32_t a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]), b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
+            swap16(a0, b0); swap16(a1, b1);
+            char* cb = uniform_wptr(reinterpret_cast<char*>(p.C) + ((long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldc + n0 + sh * 128 + wc * 32) * 2);
+            const u32x4_t o = {a0, a1, b0, b1};
+            st_g<u32x4_t>(cb + loff_c, o);
           }
         }
       } else {
