@@ -86,7 +86,7 @@ __global__ void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t*
     un8(ld_stream(dact + m * I + c), d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float sg = 1.0f / (1.0f + __expf(-g[e]));
+      const float sg = sigmoid_f(g[e]);
       const float si = g[e] * sg;
       du[e] = d[e] * si;
       dg[e] = d[e] * u[e] * (sg * (1.0f + g[e] * (1.0f - sg)));

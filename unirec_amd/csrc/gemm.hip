@@ -789,7 +789,7 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
                 for (int hh = 0; hh < 2; ++hh) {
                   const float gg = hh ? bf_hi(gw[k][e]) : bf_lo(gw[k][e]), uu = hh ? bf_hi(uw[k][e]) : bf_lo(uw[k][e]);
                   const float d = v[2 * e + hh];
-                  const float sg = 1.0f / (1.0f + __expf(-gg));
+                  const float sg = sigmoid_f(gg);
                   duv[hh] = d * (gg * sg);
                   dgv[hh] = d * uu * (sg * (1.0f + gg * (1.0f - sg)));
                 }

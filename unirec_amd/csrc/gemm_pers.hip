@@ -640,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
               for (int hh = 0; hh < 2; ++hh) {
                 const float gg = hh ? bf_hi(gq[e]) : bf_lo(gq[e]), uu = hh ? bf_hi(uq[e]) : bf_lo(uq[e]);
                 const float d = v[2 * e + hh];
-                const float sg = 1.0f / (1.0f + __expf(-gg));
+                const float sg = sigmoid_f(gg);
                 duv[hh] = d * (gg * sg);
                 dgv[hh] = d * uu * (sg * (1.0f + gg * (1.0f - sg)));
               }
