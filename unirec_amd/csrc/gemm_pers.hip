@@ -32,6 +32,9 @@ using urgemm::uniform_ptr;
 #ifndef UR_PERS_JOIN
 #define UR_PERS_JOIN 0            // lab: 1 = the two wave groups re-join for EVERY epilogue (measured neutral for the plain one: the CU's store rate under load, ~17 B/clk, is the limit either way)
 #endif
+#ifndef UR_PERS_EPI_WAIT
+#define UR_PERS_EPI_WAIT 0        // lab: 1 = the epilogue starts with s_waitcnt vmcnt(0): the next tile's two prefetched K tiles have landed before the first C store
+#endif
 #ifndef UR_PERS_STAMPS
 #define UR_PERS_STAMPS 0          // lab builds only: n > 0 = waves 0 and 4 of every workgroup log s_memtime around their n-th output tile (ur_lab_pers_stamps)
 #endif
@@ -346,6 +349,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
     constexpr bool JOIN = UR_PERS_JOIN || DROP || EPI == 3;      // (EPI 3: its row sums cross the waves through LDS behind a workgroup barrier)
     if (JOIN && wr == 0) __builtin_amdgcn_s_barrier();
     UR_PSTAMP(6);
+#if UR_PERS_EPI_WAIT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     // ================= epilogue, from the accumulators (no LDS, no barrier) =================
     __builtin_amdgcn_sched_barrier(0);      // nothing of the epilogue (its loads!) is scheduled up into the last K tile's phases
     // Lane constants of the epilogue are derived from an opaque copy of the lane id EVERY tile: hoisted out of the tile loop they
