@@ -127,8 +127,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
   // epilogues take as long (in-kernel stamps: 3.85 k cycles per wave group either way), and the de-phasing costs the operand
   // panels their L2 sharing: CUs that read the same A / W panel a few K tiles apart no longer hit the lines their neighbours
   // fetched (rocprofv3 FETCH_SIZE of the N = 1024 launches x1.5 of A + W in lockstep, x2.9-4.3 staggered).  See DESIGN.md 11.
-  if (p.stagger > 0) {
-    const long long until = (long long)__builtin_readcyclecounter() + (long long)((blockIdx.x >> 3) & 15) * p.stagger;
+  if (p.stagger != 0) {
+    // p.stagger < 0 (UR_PERS_STAGGER_XCD): whole XCDs are de-phased instead (ids equal mod 8 share an XCD and its L2): the 32
+    // workgroups of an XCD stay in lockstep on their shared panels, the eight XCDs reach their epilogues 1/8 period apart
+    const int steps = p.stagger < 0 ? (int)(blockIdx.x & 7) : (int)((blockIdx.x >> 3) & 15);
+    const long long until = (long long)__builtin_readcyclecounter() + (long long)steps * (p.stagger < 0 ? -p.stagger : p.stagger);
     while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(8);
   }
   // ---- producer: where the K tile that is fetched next comes from (scalars + one lane offset per operand) ----
@@ -752,7 +755,8 @@ int gemm_pers_launch(GemmP p, hipStream_t st) {
   const bool drop = p.drop_bits != nullptr && p.K2 > 0;
   {
     static const int env_st = [] { const char* e = getenv("UR_PERS_STAGGER"); return e ? atoi(e) : 0; }();      // lab: cycles per start step; 0 = off (default)
-    p.stagger = env_st > 0 ? env_st : 0;
+    static const int env_sx = [] { const char* e = getenv("UR_PERS_STAGGER_XCD"); return e ? atoi(e) : 0; }();  // lab: cycles per XCD step
+    p.stagger = env_sx > 0 ? -env_sx : (env_st > 0 ? env_st : 0);
   }
   const int mode = drop ? 2 : (p.K2 > 0 ? 1 : 0);
   const int epi = p.sp_act ? 4 : (p.qk_q ? 3 : (p.sw_mode == 1 ? 1 : (p.res ? 2 : (p.bias ? 5 : 0))));
