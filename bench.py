@@ -553,15 +553,21 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: forward projection GEMM gemm_kernel<RK=1,SK=1,bf16> -----
         tot_ms, tot_fl, n = 0.0, 0.0, 0
+        pl_ms, pl_fl, pl_n = 0.0, 0.0, 0
         all_ms, all_fl = 0.0, 0.0
         for (e0, e1, rk, sk, f32, M, N, K, split, epi) in prof:
             ms = e0.elapsed_time(e1)
             all_ms += ms; all_fl += 2.0 * M * N * K
-            # exactly the launches ur_gemm dispatches to gemm_kernel<RK=1,SK=1,bf16,256,256,2,4,EPI=0> (gemm.hip: launch()); the
-            # down-projection dX launches that carry the SwiGLU backward in their epilogue are another instantiation (EPI=1: an
-            # HBM-bound elementwise pass rides on them) and are counted under all_gemm only
-            if epi == 0 and rk and sk and not f32 and M >= 256 and N >= 256 and (-(-M // 256)) * (-(-N // 256)) * max(split, 1) >= 256:
+            # The family of rounds 1-2: every K-contiguous bf16 projection launch on 256x256 tiles (forward q|k|v, o, gate|up, down
+            # and the frozen-weight dX launches), whatever rides in its epilogue now -- q/k-norm + RoPE (3) and the SwiGLU forward (4)
+            # are counted with their GEMM FLOPs only, so fusing work into a launch can only LOWER this number.  The down-projection
+            # dX launch that carries the SwiGLU backward (1: 3.2 GB of gate|up / dgate|dup traffic ride on it) stays under all_gemm
+            # only, as in rounds 1-2.  Tile rule = csrc/gemm.hip launch() / csrc/gemm_pers.hip gemm_pers_eligible().
+            tiles = (-(-M // 256)) * (-(-N // 256)) * max(split, 1)
+            if epi in (0, 3, 4) and rk and sk and not f32 and M >= 256 and N >= 256 and tiles >= (128 if epi else 256):
                 tot_ms += ms; tot_fl += 2.0 * M * N * K; n += 1
+                if epi == 0:
+                    pl_ms += ms; pl_fl += 2.0 * M * N * K; pl_n += 1
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
         # HBM-side bytes of one launch from the separate rocprofv3 --pmc passes (profiles/r2_gemm_pmc.json: FETCH_SIZE x2 +
         # WRITE_SIZE, the MI355X_MICROARCH corrections); bench.py itself cannot collect PMC counters.  Reported for the
@@ -577,8 +583,11 @@ def main():
         except Exception:
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-                "traffic": traffic, "kernel": "gemm_pers_kernel<EPI 0|2, MODE> + gemm_kernel<true,true,false,256,256,2,4,0> (K-contiguous 256x256 projection GEMM: forward + "
-                          "frozen-weight dX; the persistent kernel takes the launches csrc/gemm_pers.hip:gemm_pers_eligible accepts)",
+                "traffic": traffic, "kernel": "gemm_pers_kernel<EPI 0|2|3|4|5, MODE> + gemm_kernel<true,true,false,256,256,2,4,0> (K-contiguous 256x256 projection GEMM: forward + "
+                          "frozen-weight dX; the persistent kernel takes the launches csrc/gemm_pers.hip:gemm_pers_eligible accepts; launches with the q/k-norm + RoPE or "
+                          "SwiGLU-forward epilogue are counted with their GEMM FLOPs only)",
+                "plain_epilogue_launches": {"launches": pl_n, "avg_launch_ms": round(pl_ms / max(pl_n, 1), 4),
+                                            "tflops": round(pl_fl / max(pl_ms, 1e-9) / 1e9, 1), "frac": round(pl_fl / max(pl_ms, 1e-9) / 1e9 / 2500.0, 4)},
                 "traffic_note": tnote,
                 "launches": n, "avg_launch_ms": round(tot_ms / max(n, 1), 4),
                 "all_gemm_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 1) if all_ms > 0 else 0.0,

@@ -62,7 +62,7 @@ def test_shard_range_partitions_the_global_batch():
 
 
 def _worker(rank, world, port, tmp):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    os.environ.update(GLOO_SOCKET_IFNAME="lo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     r, w, _ = dp.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
     torch.set_num_threads(1)

@@ -29,10 +29,21 @@ def _launch(outdir, world, Bg, dropout, mode=None):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   UNIREC_DP_BACKEND="gloo", OMP_NUM_THREADS="2")
+                   UNIREC_DP_BACKEND="gloo", OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo")      # loopback: the box's hostname may not resolve
         procs.append(subprocess.Popen([sys.executable, WORKER, str(outdir), str(Bg), str(dropout)] + ([mode] if mode else []), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=240)[0])
+    except subprocess.TimeoutExpired:
+        # a rank that never returns (rendezvous or a collective that the other rank left) must fail the test with both ranks'
+        # output, not stall the whole run: end exactly the processes started here
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        tails = [p.communicate()[0][-2000:] for p in procs]
+        raise AssertionError(f"a rank did not finish within 240 s (world {world}, port {port}):\n" + "\n-----\n".join(tails))
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o[-3000:]
     return [torch.load(os.path.join(outdir, f"rank{r}.pt")) for r in range(world)]
