@@ -89,7 +89,7 @@ typedef struct {
    * accumulators in the STANDARD feature order, qkr_v [M, N - nq_cols - nk_cols] the plain projection, qkr_rstd
    * [M, (nq_cols + nk_cols) / 128] f32 the 1 / rms of every (token, head) -- what ur_qknorm_rope_bwd_roped needs instead of
    * the raw q, k, which are never stored.  Position of row m = m % qkr_S; cos / sin tables [S, 64] f32 (ur_rope_table).
-   * Runs on the persistent kernel only (M, N multiples of 256, K of 64, >= 512 tiles, S a multiple of 256, nq / nk columns multiples
+   * Runs on the persistent kernel only (M, N multiples of 256, K of 64, >= 128 tiles, S a multiple of 256, nq / nk columns multiples
    * of 256, no other epilogue): ur_gemm_qkrope_supported tells; ur_gemm fails loudly otherwise. */
   void* qkr_q; int64_t qkr_ldq; void* qkr_k; int64_t qkr_ldk; void* qkr_v; int64_t qkr_ldv;
   float* qkr_rstd;
@@ -111,7 +111,7 @@ int ur_gemm_qkrope_supported(const ur_gemm_args* a);
 int ur_qkrope_perm(int c);
 int64_t ur_gemm_workspace_bytes(const ur_gemm_args* a);
 int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, void* stream);
-/* Launches with K-contiguous operands, bf16 output, M, N multiples of 256, K a multiple of 64 (>= 256), >= 512 output tiles and
+/* Launches with K-contiguous operands, bf16 output, M, N multiples of 256, K a multiple of 64 (>= 256), >= 128 output tiles and
  * a plain / bias / residual / masked-LoRA / SwiGLU-backward epilogue run on the persistent kernel (csrc/gemm_pers.hip: one
  * workgroup per CU walks its tiles, the LDS-DMA ring never drains, epilogue from registers) -- bit-identical to the generic
  * kernel.  ur_gemm_persistent_mode(0) keeps every launch on the generic kernel, (1) enables the persistent one, (-1) returns

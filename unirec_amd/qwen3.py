@@ -107,7 +107,7 @@ _MERGE_PROJ = os.environ.get("UNIREC_MERGE_PROJ", "1") != "0"
 # UNIREC_FUSE_NORM_LORA=0 (lab): RMSNorm forward and the q|k|v / gate|up adapters' down projection as two kernels again
 _FUSE_NORM_LORA = os.environ.get("UNIREC_FUSE_NORM_LORA", "1") != "0"
 # UNIREC_FUSE_QK_ROPE=0 (lab): q/k-norm + RoPE as their own pass over the raw q|k|v again (the fused form needs the persistent GEMM:
-# >= 512 output tiles, S >= 256, head_dim 128; smaller launches take the separate pass anyway)
+# >= 128 output tiles, S >= 256, head_dim 128; smaller launches take the separate pass anyway)
 _FUSE_QK_ROPE = os.environ.get("UNIREC_FUSE_QK_ROPE", "1") != "0"
 # UNIREC_FUSE_SWIGLU_GEMM=0 (lab): SwiGLU forward as its own pass over gate|up again (the fused form rides in the merged gate|up launch on
 # the persistent GEMM: interleaved weight rows put gate and up of a feature into one lane; the down adapter's t = dropout(act) A^T is
