@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include "common.cuh"
 #include "unirec_hip.h"
+#include "gen/attn_fwd_c128_asm.h"
 
 namespace {
 
@@ -1956,6 +1957,150 @@ int launch_tiny(const AttnP& p, bool bwd, hipStream_t st) {
 }
 
 // ================================================================================================
+// Causal head_dim-128 forward, hand-scheduled: the key-tile loop is ONE generated inline-asm block (tools/asmgen/attn_fwd.py ->
+// gen/attn_fwd_c128_asm.h; emulated and hazard-checked on the CPU by tests/test_asmgen_attn_fwd.py).  A workgroup = 4 waves = 256
+// query rows of one (batch, query head); a wave owns 64 rows and the whole register file of its SIMD (one wave per SIMD), so every
+// K / V fragment read from LDS feeds two MFMAs; q is pre-scaled by scale*log2e here and the running maximum enters the S chain as its
+// C operand, so a score costs one v_exp_f32, one v_add_f32, half a v_max3 and half a v_cvt_pk.  Replaces the SDPA call of
+// transformers modeling_qwen3.py:185-208 behind /root/reference/training/train_item_individual_token_joint.py:173-177 for Sq == Sk,
+// Sk % 64 == 0, Sk <= 4096; other shapes keep attn_fwd_kernel.
+// LDS: K ring 4 x 16 KiB | V ring 4 x 16 KiB | key bias f32[Sk] (0 / -inf) | key-state words.
+namespace c128 {
+constexpr int VBASE_LDS = 65536, BIAS_LDS = 131072, WORDS_LDS = BIAS_LDS + 16384, LDS_BYTES = WORDS_LDS + 64 * 8;
+constexpr int MAX_SK = 4096;
+typedef __attribute__((ext_vector_type(32))) float f32x32;
+typedef __attribute__((ext_vector_type(32))) int i32x32;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+}  // namespace c128
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_fwd_c128_kernel(AttnP p) {
+  using namespace c128;
+  using C = Cfg<128>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
+  const BlockMap bm = block_map<true>((p.Sq + 255) / 256, p.rep, p.nkv, p.B);
+  const int x = bm.x, hq = bm.head, b = bm.b, kvh = hq / p.rep;
+  const int ntiles = p.Sk / KT;
+  const int tend = min(ntiles, 4 * x + 4);
+  const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
+  const uint32_t lds0 = lds_off(smem);
+
+  // key bias table + per-tile state words
+  float* bias = reinterpret_cast<float*>(smem + BIAS_LDS);
+  unsigned long long* words = reinterpret_cast<unsigned long long*>(smem + WORDS_LDS);
+  for (int t = wave; t < tend; t += 4) {
+    const int key = t * KT + lane;
+    const bool ok = km == nullptr || km[key] != 0;
+    bias[key] = ok ? 0.f : NEG_INF;
+    const unsigned long long wv = __ballot(ok);
+    if (lane == 0) words[t] = wv;
+  }
+  __syncthreads();
+  int tfirst = 0;
+  unsigned long long maskbits = 0ull;
+  for (int t = 0; t < tend; ++t) {
+    const unsigned long long wv = words[t];
+    if (wv == 0ull && tfirst == t) ++tfirst;
+    if (wv != ~0ull) maskbits |= 1ull << t;
+  }
+  tfirst = __builtin_amdgcn_readfirstlane(tfirst);
+  const uint32_t mb_lo = __builtin_amdgcn_readfirstlane((uint32_t)maskbits), mb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(maskbits >> 32));
+
+  const int q0 = 256 * x + 64 * wave;
+  f32x32 o0, o1, o2, o3;
+  f32x4 ml;
+  if (tfirst < tend) {
+    // Q fragments, pre-scaled: element j of lane half h of k-step ks = q[row][16 ks + 8 h + j] * scale * log2(e), rounded to bf16 once more
+    const float c = p.scale * LOG2E;
+    i32x32 qv0, qv1;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int row = q0 + 32 * qb + l31;
+      const bool ok = row < p.Sq;
+      const bf16_t* qrow = p.q + ((long)b * p.Sq + (ok ? row : 0)) * p.ldq + (long)hq * 128;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x8 f = g_frag(qrow, ks, lane, ok);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t wv = pack_bf2(bf2f((bf16_t)f[2 * j]) * c, bf2f((bf16_t)f[2 * j + 1]) * c);
+          if (qb == 0) qv0[4 * ks + j] = (int)wv; else qv1[4 * ks + j] = (int)wv;
+        }
+      }
+    }
+    // lane-constant LDS addresses (tile-relative swizzled offsets; the ring slot is an immediate in the generated code)
+    i32x8 ka, tatb;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) ka[ks] = (int)(lds0 + C::off(l31, 2 * ks + h));
+    {
+      const int g16 = (lane >> 4) & 1, i = lane & 15;
+      const int row = 4 * h + (i >> 2), sub8 = 8 * (i & 1);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int ch = 4 * dt + 2 * g16 + ((i & 3) >> 1);
+        tatb[dt] = (int)(lds0 + VBASE_LDS + C::off(row, ch) + sub8);
+        tatb[4 + dt] = (int)(lds0 + VBASE_LDS + C::off(row + 8, ch) + sub8);
+      }
+    }
+    i32x2 voff, bd;
+    {
+      const int row = 4 * wave + (lane >> 4), pos = lane & 15;
+      const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+      voff[0] = (int)((uint32_t)(row * p.ldk + (pos ^ sw) * 8) * 2u);
+      voff[1] = (int)((uint32_t)(row * p.ldv + (pos ^ sw) * 8) * 2u);
+    }
+    bd[0] = (int)(lds0 + BIAS_LDS + 16 * h);
+    bd[1] = l31 - 4 * h;
+    const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * 128;
+    const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * 128;
+    const uint32_t kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)kb), kb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)kb >> 32));
+    const uint32_t vb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)vb), vb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)vb >> 32));
+    const int k16b = __builtin_amdgcn_readfirstlane((int)(p.ldk * 32)), v16b = __builtin_amdgcn_readfirstlane((int)(p.ldv * 32));
+    const int tlast = __builtin_amdgcn_readfirstlane(q0 < p.Sq ? min(4 * x + wave, ntiles - 1) : -1);
+    const int tend_s = __builtin_amdgcn_readfirstlane(tend);
+    const uint32_t waveb = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
+    asm volatile(
+        "s_mov_b32 s36, %[kbl]\n\ts_mov_b32 s37, %[kbh]\n\ts_mov_b32 s38, %[vbl]\n\ts_mov_b32 s39, %[vbh]\n\t"
+        "s_mov_b32 s40, %[k16]\n\ts_mov_b32 s41, %[v16]\n\ts_mov_b32 s43, %[tend]\n\ts_mov_b32 s44, %[tlast]\n\t"
+        "s_mov_b32 s45, %[tfirst]\n\ts_mov_b32 s46, %[mbl]\n\ts_mov_b32 s47, %[mbh]\n\ts_mov_b32 s57, %[waveb]\n\t"
+        UR_ATTN_FWD_C128_ASM
+        : "=&{a[0:31]}"(o0), "=&{a[32:63]}"(o1), "=&{a[64:95]}"(o2), "=&{a[96:127]}"(o3), "=&{v[192:195]}"(ml)
+        : "{a[128:159]}"(qv0), "{a[160:191]}"(qv1), "{v[176:183]}"(ka), "{v[184:191]}"(tatb), "{v[204:205]}"(voff), "{v[208:209]}"(bd),
+          [kbl] "s"(kb_lo), [kbh] "s"(kb_hi), [vbl] "s"(vb_lo), [vbh] "s"(vb_hi), [k16] "s"(k16b), [v16] "s"(v16b), [tend] "s"(tend_s),
+          [tlast] "s"(tlast), [tfirst] "s"(tfirst), [mbl] "s"(mb_lo), [mbh] "s"(mb_hi), [waveb] "s"(waveb)
+        : UR_ATTN_FWD_C128_CLOBBERS);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { o0[i] = 0.f; o1[i] = 0.f; o2[i] = 0.f; o3[i] = 0.f; }
+    ml = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // epilogue: the two lane halves of a query hold the row sums of complementary key halves
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int row = q0 + 32 * qb + l31;
+    const bool ok = row < p.Sq;
+    float l = ml[2 + qb];
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    f32x16 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int idx = 16 * (dt & 1) + r;
+        acc[dt][r] = qb == 0 ? (dt < 2 ? o0[idx] : o1[idx]) : (dt < 2 ? o2[idx] : o3[idx]);
+      }
+    store_T<128>(p.o + ((long)b * p.Sq + (ok ? row : 0)) * p.ldo + (long)hq * 128, acc, inv, lane, ok);
+    if (ok && h == 0) {
+      float* st = p.stats + (((long)b * p.nq + hq) * p.Sq + row) * 2;
+      st[0] = ml[qb] * (1.0f / LOG2E);        // running maximum in natural-log units of the scaled scores (the backward's convention)
+      st[1] = inv;
+    }
+  }
+}
+
+// ================================================================================================
 template <int HD> constexpr int fwd_smem() { return 4 * Cfg<HD>::TILE + MAX_KTILES * 16; }
 template <int HD> constexpr int dkv_smem() { return 2 * (2 * Cfg<HD>::TILE + 3 * KT * (int)sizeof(float)); }
 
@@ -1989,6 +2134,8 @@ int fill(AttnP& p, const ur_attn_args* a) {
   return 0;
 }
 
+// test / lab switch, read on every call: UR_ATTN_C128=0 sends the causal head_dim-128 forward back to attn_fwd_kernel
+inline bool fwd_c128_enabled() { const char* e = getenv("UR_ATTN_C128"); return !(e && e[0] == '0'); }
 inline bool fwd_gq2_enabled() { static const bool on = [] { const char* e = getenv("UR_FWD_GQ2"); return e && e[0] == '1'; }(); return on; }
 template <int HD, bool CAUSAL, int NW>
 int launch_fwd(const AttnP& p, hipStream_t st) {
@@ -1999,6 +2146,17 @@ int launch_fwd(const AttnP& p, hipStream_t st) {
       dim3 grid(ur_cdiv(p.Sq, 128) * (p.nq / 2) * p.B);
       hipLaunchKernelGGL((attn_fwd_kernel<128, true, 8, true>), grid, dim3(512), fwd_smem<128>(), st, p);
       UR_CHECK_LAUNCH("ur_attn_fwd(gq2)");
+      return 0;
+    }
+  }
+  if constexpr (HD == 128 && CAUSAL && NW == 4) {
+    if (p.Sq == p.Sk && (p.Sk % KT) == 0 && p.Sk >= 128 && p.Sk <= c128::MAX_SK && fwd_c128_enabled() &&
+        p.ldk * 2L * p.Sk < (1L << 31) && p.ldv * 2L * p.Sk < (1L << 31)) {
+      static std::atomic<bool> once_c{false};
+      if (!once_c) { int rc = set_smem(&attn_fwd_c128_kernel, c128::LDS_BYTES, "ur_attn_fwd(c128)"); if (rc) return rc; once_c = true; }
+      dim3 grid(ur_cdiv(p.Sq, 256) * p.nq * p.B);
+      hipLaunchKernelGGL(attn_fwd_c128_kernel, grid, dim3(256), c128::LDS_BYTES, st, p);
+      UR_CHECK_LAUNCH("ur_attn_fwd(c128)");
       return 0;
     }
   }
