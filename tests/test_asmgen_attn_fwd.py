@@ -51,8 +51,9 @@ def _case(prog, S, x, pad=0, holes=False, spike=None, amp=1.0, seed=0, nq=2, nkv
 
 def test_first_block_all_four_waves(prog):
     c = _case(prog, 256, 0)
-    # wave w sweeps w + 1 tiles: 32 MFMAs for its first tile's S, 64 per steady tile, 56 + 24 for the diagonal tile and its P V
-    assert [d["mfma"] for d in c] == [48, 112, 176, 240]
+    # wave w sweeps w + 1 tiles: 32 MFMAs for its first tile's S (24 when it is the diagonal tile), 72 per steady tile, 64 for the
+    # diagonal tile and 30 for the P V + row sums that follow it
+    assert [d["mfma"] for d in c] == [54, 126, 198, 270]
 
 
 def test_second_block_full_pipeline(prog):

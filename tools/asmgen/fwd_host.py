@@ -96,8 +96,8 @@ def run_block(q, k, v, kmask, x, hq, rep, scale, prog=None, check=True):
             w.R[G.TB(dt)] = TB[dt]
         row, pos = 4 * wave + (lane >> 4), lane & 15
         sw = np.array([swz(int(r)) for r in row])
-        w.R[G.VOFFK] = ((row * ldk + (pos ^ sw) * 8) * 2).astype(np.uint32)
-        w.R[G.VOFFV] = ((row * ldv + (pos ^ sw) * 8) * 2).astype(np.uint32)
+        w.R[G.VOFFK0] = ((row * ldk + (pos ^ sw) * 8) * 2).astype(np.uint32)
+        w.R[G.VOFFV0] = ((row * ldv + (pos ^ sw) * 8) * 2).astype(np.uint32)
         w.R[G.BIASADDR] = (G.BIAS_LDS + 16 * h).astype(np.uint32)
         w.R[G.DIAGX] = (l31 - 4 * h).astype(np.int32).view(np.uint32)
         tlast = min(4 * x + wave, ntiles - 1) if q0 < S else -1
@@ -115,10 +115,9 @@ def run_block(q, k, v, kmask, x, hq, rep, scale, prog=None, check=True):
     O = np.zeros((256, 128), np.float32)
     mm, ll = np.zeros(256, np.float32), np.zeros(256, np.float32)
     for w in wg.waves:
-        L = w.R[G.L_(0):G.L_(0) + 2].view(np.float32)
         M = w.R[G.M_(0):G.M_(0) + 2].view(np.float32)
         for qb in range(2):
-            lt = L[qb] + L[qb][lane ^ 32]
+            lt = w.R[G.LA(qb, 0)].view(np.float32)          # every register of the row-sum tile holds the complete sum
             inv = np.where(lt > 0, 1.0 / np.where(lt > 0, lt, 1.0), 0.0).astype(np.float32)
             for dt in range(4):
                 for r in range(16):

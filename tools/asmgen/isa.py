@@ -57,11 +57,12 @@ def rrange(r, n):
 
 class I:
     """one instruction.  rd / wr: register ids read / written (for the hazard and wait checks); fn(wave): emulation."""
-    __slots__ = ("text", "kind", "rd", "wr", "fn", "cost", "srcc", "target", "note", "region")
+    __slots__ = ("text", "kind", "rd", "wr", "fn", "cost", "srcc", "target", "note", "region", "tag")
 
     def __init__(self, text, kind, rd=(), wr=(), fn=None, cost=4, srcc=(), target=None, note=None):
         self.text, self.kind, self.rd, self.wr, self.fn = text, kind, tuple(rd), tuple(wr), fn
         self.cost, self.srcc, self.target, self.note = cost, tuple(srcc), target, note
+        self.tag = None
         self.region = None         # "begin" / "end": a forward branch and its label around a conditionally executed block (cond_block)
 
     def __repr__(self):
@@ -497,6 +498,26 @@ def s_waitcnt(vmcnt=None, lgkmcnt=None):
     return I("s_waitcnt " + " ".join(parts), "wait", (), (), fn, 1, note=(vmcnt, lgkmcnt))
 
 
+def s_memtime_wait(d):
+    """lab: s_memtime into s[d:d+1] and the wait that makes it usable (drains the LDS reads in flight as well)"""
+    def fn(w):
+        w.sset64(d, w.step * 4)
+        w.wait(None, 0)
+    return I("s_memtime %s\ns_waitcnt lgkmcnt(0)" % rrange(d, 2), "wait", (), (d, d + 1), fn, 8, note=(None, 0))
+
+
+def s_sub_u32(d, x, y):
+    return salu2("s_sub_u32", d, x, y, lambda p, q, w: p - q, lambda p, q, r: int(p < q))
+
+
+def global_store_dword_s(vdata, voff, sbase, imm):
+    """mem[s[sbase:sbase+1] + v[voff] + imm] = v[vdata]  (emulator: recorded in wave.stores)"""
+    def fn(w):
+        w.stores = getattr(w, "stores", [])
+        w.stores.append((w.s64(sbase) + int(w.R[voff, 0]) + imm, int(w.R[vdata, 0])))
+    return I("global_store_dword %s, %s, %s offset:%d" % (rname(voff), rname(vdata), rrange(sbase, 2), imm), "vmem_st", (vdata, voff, sbase, sbase + 1), (), fn, 4)
+
+
 def s_barrier():
     return I("s_barrier", "barrier", (), (), None, 1)
 
@@ -527,7 +548,7 @@ class HazardError(Exception):
 
 MFMA_RESULT_WAIT = 14      # wait states between an MFMA and a non-MFMA read/write of its result (8-pass XDL: 12 are required)
 VALU_TO_MFMA_WAIT = 3      # vector write -> MFMA operand read (2 required)
-TRANS_TO_VALU_WAIT = 2     # v_exp_f32 result -> non-transcendental vector read (1 required)
+TRANS_TO_VALU_WAIT = 1     # v_exp_f32 result -> non-transcendental vector read
 PERMLANE_WAIT = 3          # vector write -> v_permlane32_swap operand (2 required), and back
 M0_TO_DMA_WAIT = 1
 SRCC_WAR_WAIT = 20         # MFMA srcC read -> vector write of those registers
@@ -665,7 +686,7 @@ class Program:
                 t = "%s%s:" % (it.target, suffix)
             elif it.kind == "branch":
                 t = t.replace(it.target, it.target + suffix)
-            out.append(t)
+            out.extend(x.strip() for x in t.split("\n"))
         return out
 
     def stats(self):
@@ -758,15 +779,25 @@ class Tracker:
         self.step, self.lastw, self.lastc, self.m0_step = 1000, {}, {}, -100
 
 
+LANDED_AFTER = 16          # wait states after which an LDS read is taken to have landed: a counted wait placed for one fragment also covers such older-than-that successors (fewer s_waitcnt in the stream)
+
+
 def fix_hazards(seq, entry_lgkm=()):
     """straight-line instruction list -> the same list with s_nop / s_waitcnt lgkmcnt(n) inserted where the rules ask for them.
     entry_lgkm: destination-register tuples of the LDS reads that may still be outstanding on entry (oldest first).
     Conditionally executed blocks (cond_block) are fixed as if taken, then the tracker returns to its state at the branch."""
     import copy
     t = Tracker()
-    q = [tuple(x) for x in entry_lgkm]
+    q = [(tuple(x), t.step - 1000) for x in entry_lgkm]
     out = []
     saved = None
+
+    def wait_keep(keep):
+        wi = s_waitcnt(lgkmcnt=min(keep, 15))
+        out.append(wi)
+        track(t, wi)
+        del q[:len(q) - min(keep, 15)]
+
     for it in seq:
         k = it.kind
         if it.region == "begin":
@@ -786,13 +817,12 @@ def fix_hazards(seq, entry_lgkm=()):
         if k == "wait" and it.note[1] is not None:
             del q[:max(0, len(q) - it.note[1])]
         regs = set(it.rd) | set(it.wr)
-        idx = [i for i, dst in enumerate(q) if regs & set(dst)]
+        idx = [i for i, (dst, _) in enumerate(q) if regs & set(dst)]
         if idx:
-            keep = len(q) - 1 - max(idx)
-            wi = s_waitcnt(lgkmcnt=min(keep, 15))
-            out.append(wi)
-            track(t, wi)
-            del q[:max(idx) + 1]
+            last = max(idx)
+            while last + 1 < len(q) and t.step - q[last + 1][1] >= LANDED_AFTER:
+                last += 1
+            wait_keep(len(q) - 1 - last)
         n, _ = missing_wait_states(t, it)
         while n > 0:
             m = min(n, 8)
@@ -802,14 +832,11 @@ def fix_hazards(seq, entry_lgkm=()):
             n -= m
         if k == "lds":
             if len(q) >= 15:
-                wi = s_waitcnt(lgkmcnt=14)       # the 4-bit counter cannot express more: retire the oldest first
-                out.append(wi)
-                track(t, wi)
-                del q[:len(q) - 14]
-            q.append(tuple(it.wr))
+                wait_keep(14)            # the 4-bit counter cannot express more: retire the oldest first
+            q.append((tuple(it.wr), t.step))
         out.append(it)
         track(t, it)
-    return out, q
+    return out, [d for d, _ in q]
 
 
 def run_workgroup(prog, wg, init, max_steps=5_000_000, check=True):

@@ -25,7 +25,10 @@
 #include <cstdlib>
 #include "common.cuh"
 #include "unirec_hip.h"
-#include "gen/attn_fwd_c128_asm.h"
+#ifndef UR_ATTN_FWD_C128_HDR
+#define UR_ATTN_FWD_C128_HDR "gen/attn_fwd_c128_asm.h"      // lab builds point this at an ablated variant (tools/lab/c128_variants.sh)
+#endif
+#include UR_ATTN_FWD_C128_HDR
 
 namespace {
 
@@ -1972,131 +1975,240 @@ typedef __attribute__((ext_vector_type(32))) float f32x32;
 typedef __attribute__((ext_vector_type(32))) int i32x32;
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 }  // namespace c128
+#ifndef UR_C128_STAMPS
+#define UR_C128_STAMPS 0      // lab builds only (tools/lab/c128_variants.sh stamps): per-wave cycle accumulators of the generated loop + four stamps of the C++ part
+#endif
+#if UR_C128_STAMPS
+__device__ unsigned int g_c128_stamps[8192 * 4 * 32];
+#endif
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_fwd_c128_kernel(AttnP p) {
+// Persistent: the grid is one workgroup per CU; a work item = one (batch, query head) x one PAIR of query blocks (the heaviest
+// remaining and the lightest remaining: every item sweeps 4 nx + 4 key tiles, so a static round robin balances).  Item ids are dealt
+// so that the rep x nch items of a (batch, kv head) group run on ONE XCD at the same time (its K / V stay in that L2).
+struct C128Div { uint32_t m_pg, m_nch, m_nkv; };      // ceil(2^32 / d) of the item-decode divisors
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_fwd_c128_kernel(AttnP p, int nitems, int nch, C128Div dv) {
   using namespace c128;
   using C = Cfg<128>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
-  const BlockMap bm = block_map<true>((p.Sq + 255) / 256, p.rep, p.nkv, p.B);
-  const int x = bm.x, hq = bm.head, b = bm.b, kvh = hq / p.rep;
-  const int ntiles = p.Sk / KT;
-  const int tend = min(ntiles, 4 * x + 4);
-  const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
+  const int nx = (p.Sq + 255) / 256, ntiles = p.Sk / KT;
   const uint32_t lds0 = lds_off(smem);
-
-  // key bias table + per-tile state words
   float* bias = reinterpret_cast<float*>(smem + BIAS_LDS);
   unsigned long long* words = reinterpret_cast<unsigned long long*>(smem + WORDS_LDS);
-  for (int t = wave; t < tend; t += 4) {
-    const int key = t * KT + lane;
-    const bool ok = km == nullptr || km[key] != 0;
-    bias[key] = ok ? 0.f : NEG_INF;
-    const unsigned long long wv = __ballot(ok);
-    if (lane == 0) words[t] = wv;
-  }
-  __syncthreads();
-  int tfirst = 0;
-  unsigned long long maskbits = 0ull;
-  for (int t = 0; t < tend; ++t) {
-    const unsigned long long wv = words[t];
-    if (wv == 0ull && tfirst == t) ++tfirst;
-    if (wv != ~0ull) maskbits |= 1ull << t;
-  }
-  tfirst = __builtin_amdgcn_readfirstlane(tfirst);
-  const uint32_t mb_lo = __builtin_amdgcn_readfirstlane((uint32_t)maskbits), mb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(maskbits >> 32));
 
-  const int q0 = 256 * x + 64 * wave;
-  f32x32 o0, o1, o2, o3;
-  f32x4 ml;
-  if (tfirst < tend) {
-    // Q fragments, pre-scaled: element j of lane half h of k-step ks = q[row][16 ks + 8 h + j] * scale * log2(e), rounded to bf16 once more
-    const float c = p.scale * LOG2E;
-    i32x32 qv0, qv1;
+  // lane-constant LDS addresses (tile-relative swizzled offsets; the ring slot is an immediate in the generated code)
+  i32x8 ka, tatb;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) ka[ks] = (int)(lds0 + C::off(l31, 2 * ks + h));
+  {
+    const int g16 = (lane >> 4) & 1, i = lane & 15;
+    const int row = 4 * h + (i >> 2), sub8 = 8 * (i & 1);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int ch = 4 * dt + 2 * g16 + ((i & 3) >> 1);
+      tatb[dt] = (int)(lds0 + VBASE_LDS + C::off(row, ch) + sub8);
+      tatb[4 + dt] = (int)(lds0 + VBASE_LDS + C::off(row + 8, ch) + sub8);
+    }
+  }
+  i32x2 voff, bd;
+  {
+    const int row = 4 * wave + (lane >> 4), pos = lane & 15;
+    const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+    voff[0] = (int)((uint32_t)(row * p.ldk + (pos ^ sw) * 8) * 2u);
+    voff[1] = (int)((uint32_t)(row * p.ldv + (pos ^ sw) * 8) * 2u);
+  }
+  bd[0] = (int)(lds0 + BIAS_LDS + 16 * h);
+  bd[1] = l31 - 4 * h;
+  const int k16b = __builtin_amdgcn_readfirstlane((int)(p.ldk * 32)), v16b = __builtin_amdgcn_readfirstlane((int)(p.ldv * 32));
+  const uint32_t waveb = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
+  const float c = p.scale * LOG2E;
+  const int ngroups = p.nkv * p.B;
+  const uint32_t per_group = (uint32_t)(p.rep * nch);
+
+  // One query block = one pass of the generated loop.  The passes of this workgroup are software-pipelined: as soon as every wave
+  // has left the loop of block n, the q rows and the first K / V tiles of block n + 1 are requested, and their latencies run
+  // under the normalisation and the stores of block n.
+  struct Blk { int item, half, x, hq, b, tend, tfirst; uint32_t mb_lo, mb_hi, kb_lo, kb_hi, vb_lo, vb_hi; bool valid; };
+  // n / d for the small launch constants d (n * d < 2^32): one s_mul_hi_u32 against ceil(2^32 / d) instead of hipcc's ~30-instruction
+  // expansion of a 32-bit division -- the decode below ran 2200 cycles per block with plain '/' and '%'
+  auto udiv = [](uint32_t n, uint32_t magic, uint32_t d) { return d == 1u ? n : __umulhi(n, magic); };
+  auto decode = [&](int item, int half, Blk& d) {
+    d.valid = item < nitems;
+    d.item = item; d.half = half;
+    if (!d.valid) return;
+    uint32_t g, j;
+    if ((ngroups & 7) == 0) { const uint32_t slot = (uint32_t)item >> 3, gq = udiv(slot, dv.m_pg, per_group); g = gq * 8u + ((uint32_t)item & 7u); j = slot - gq * per_group; }
+    else { g = udiv((uint32_t)item, dv.m_pg, per_group); j = (uint32_t)item - g * per_group; }
+    const uint32_t hr = udiv(j, dv.m_nch, nch), ch = j - hr * nch;
+    const uint32_t bb = udiv(g, dv.m_nkv, p.nkv), kvh = g - bb * p.nkv;
+    d.hq = (int)(kvh * p.rep + hr); d.b = (int)bb;
+    d.x = half == 0 ? nx - 1 - (int)ch : (int)ch;
+    d.tend = __builtin_amdgcn_readfirstlane(min(ntiles, 4 * d.x + 4));
+    const bf16_t* kb = p.k + (long)d.b * p.Sk * p.ldk + (long)kvh * 128;
+    const bf16_t* vb = p.v + (long)d.b * p.Sk * p.ldv + (long)kvh * 128;
+    d.kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)kb); d.kb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)kb >> 32));
+    d.vb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)vb); d.vb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)vb >> 32));
+  };
+  // the block after (item, half): the second block of the pair (unless the pair is the single middle block), else the next item
+  auto advance = [&](const Blk& c, Blk& n) {
+    const int chc = c.half == 0 ? nx - 1 - c.x : c.x;
+    if (c.half == 0 && nx - 1 - chc != chc) decode(c.item, 1, n); else decode(c.item + (int)gridDim.x, 0, n);
+  };
+  // key state of a sample: bias table (0 / -inf per key) + one word per tile (only with a key mask).  Caller: every wave has left the loop.
+  auto key_state = [&](Blk& d) {
+    d.tfirst = 0; d.mb_lo = 0u; d.mb_hi = 0u;
+    const uint8_t* km = p.kmask ? p.kmask + (long)d.b * p.Sk : nullptr;
+    if (km != nullptr) {
+      for (int t = wave; t < ntiles; t += 4) {
+        const int key = t * KT + lane;
+        const bool ok = km[key] != 0;
+        bias[key] = ok ? 0.f : NEG_INF;
+        const unsigned long long wv = __ballot(ok);
+        if (lane == 0) words[t] = wv;
+      }
+      __syncthreads();
+      const unsigned long long wv = lane < ntiles ? words[lane] : ~0ull;
+      const unsigned long long anym = __ballot(lane < ntiles && wv != 0ull), partm = __ballot(lane < ntiles && wv != ~0ull);
+      d.tfirst = anym ? __builtin_ctzll(anym) : ntiles;
+      d.mb_lo = (uint32_t)partm; d.mb_hi = (uint32_t)(partm >> 32);
+    }
+    d.tfirst = __builtin_amdgcn_readfirstlane(d.tfirst);
+    d.mb_lo = __builtin_amdgcn_readfirstlane(d.mb_lo); d.mb_hi = __builtin_amdgcn_readfirstlane(d.mb_hi);
+  };
+  bf16x8 qf[2][8];
+  // q rows of this wave (two 32-row blocks) and the first tiles' LDS-DMA of block d.  Caller: the K / V rings are free.
+  auto request = [&](const Blk& d) {
+    // (qf is assigned on every path: a conditional assignment would keep its 64 registers alive across the generated loop)
+    const bool live = d.valid && d.tfirst < d.tend;
+    const int q0 = live ? 256 * d.x + 64 * wave : 0;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int row = q0 + 32 * qb + l31;
+      const bool ok = live && row < p.Sq;
+      const bf16_t* qrow = p.q + ((long)(live ? d.b : 0) * p.Sq + (ok ? row : 0)) * p.ldq + (long)(live ? d.hq : 0) * 128;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) qf[qb][ks] = g_frag(qrow, ks, lane, ok);
+    }
+    if (!live) return;
+    asm volatile(
+        "s_mov_b32 s36, %[kbl]\n\ts_mov_b32 s37, %[kbh]\n\ts_mov_b32 s38, %[vbl]\n\ts_mov_b32 s39, %[vbh]\n\t"
+        "s_mov_b32 s40, %[k16]\n\ts_mov_b32 s41, %[v16]\n\ts_mov_b32 s43, %[tend]\n\ts_mov_b32 s45, %[tfirst]\n\ts_mov_b32 s57, %[waveb]\n\t"
+        UR_ATTN_FWD_C128_DMA_ASM
+        :
+        : "{v[204:205]}"(voff), [kbl] "s"(d.kb_lo), [kbh] "s"(d.kb_hi), [vbl] "s"(d.vb_lo), [vbh] "s"(d.vb_hi), [k16] "s"(k16b), [v16] "s"(v16b),
+          [tend] "s"(d.tend), [tfirst] "s"(d.tfirst), [waveb] "s"(waveb)
+        : UR_ATTN_FWD_C128_DMA_CLOBBERS);
+  };
+
+  Blk cur, nxt;
+  decode((int)blockIdx.x, 0, cur);
+  if (cur.valid) { key_state(cur); __syncthreads(); request(cur); }
+  while (cur.valid) {
+    const int x = cur.x, hq = cur.hq, b = cur.b;
+    const int q0 = 256 * x + 64 * wave;
+#if UR_C128_STAMPS
+    const unsigned long long st0 = __builtin_readcyclecounter();
+    unsigned long long st1 = st0, st2 = st0;
+    unsigned int* dbg = g_c128_stamps + ((size_t)((cur.item * 2 + cur.half) & 8191) * 4 + wave) * 32;
+    unsigned long long sa = 0, sb = 0, sc = 0, sd = 0;
+#endif
+    f32x32 o0, o1, o2, o3, lsum;       // lsum: [qb][16], every register of a query block's tile = the row sum
+    c128::f32x2 mrow;
+    if (cur.tfirst < cur.tend) {
+      // element j of lane half h of k-step ks = q[row][16 ks + 8 h + j] * scale * log2(e), rounded to bf16 once more
+      i32x32 qv0, qv1;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          qv0[4 * ks + jj] = (int)pack_bf2(bf2f((bf16_t)qf[0][ks][2 * jj]) * c, bf2f((bf16_t)qf[0][ks][2 * jj + 1]) * c);
+          qv1[4 * ks + jj] = (int)pack_bf2(bf2f((bf16_t)qf[1][ks][2 * jj]) * c, bf2f((bf16_t)qf[1][ks][2 * jj + 1]) * c);
+        }
+      const int tlast = __builtin_amdgcn_readfirstlane(q0 < p.Sq ? min(4 * x + wave, ntiles - 1) : -1);
+#if UR_C128_STAMPS
+      const uint32_t db_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dbg), db_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)dbg >> 32));
+      st1 = __builtin_readcyclecounter();
+#endif
+      asm volatile(
+          "s_mov_b32 s36, %[kbl]\n\ts_mov_b32 s37, %[kbh]\n\ts_mov_b32 s38, %[vbl]\n\ts_mov_b32 s39, %[vbh]\n\t"
+          "s_mov_b32 s40, %[k16]\n\ts_mov_b32 s41, %[v16]\n\ts_mov_b32 s43, %[tend]\n\ts_mov_b32 s44, %[tlast]\n\t"
+          "s_mov_b32 s45, %[tfirst]\n\ts_mov_b32 s46, %[mbl]\n\ts_mov_b32 s47, %[mbh]\n\ts_mov_b32 s57, %[waveb]\n\t"
+#if UR_C128_STAMPS
+          "s_mov_b32 s72, %[dbl]\n\ts_mov_b32 s73, %[dbh]\n\t"
+#endif
+          UR_ATTN_FWD_C128_ASM
+          : "=&{a[0:31]}"(o0), "=&{a[32:63]}"(o1), "=&{a[64:95]}"(o2), "=&{a[96:127]}"(o3), "=&{a[192:223]}"(lsum), "=&{v[192:193]}"(mrow)
+          : "{a[128:159]}"(qv0), "{a[160:191]}"(qv1), "{v[176:183]}"(ka), "{v[184:191]}"(tatb), "{v[204:205]}"(voff), "{v[208:209]}"(bd),
+            [kbl] "s"(cur.kb_lo), [kbh] "s"(cur.kb_hi), [vbl] "s"(cur.vb_lo), [vbh] "s"(cur.vb_hi), [k16] "s"(k16b), [v16] "s"(v16b), [tend] "s"(cur.tend),
+            [tlast] "s"(tlast), [tfirst] "s"(cur.tfirst), [mbl] "s"(cur.mb_lo), [mbh] "s"(cur.mb_hi), [waveb] "s"(waveb)
+#if UR_C128_STAMPS
+            , [dbl] "s"(db_lo), [dbh] "s"(db_hi)
+#endif
+          : UR_ATTN_FWD_C128_CLOBBERS);
+#if UR_C128_STAMPS
+      st2 = __builtin_readcyclecounter();
+#endif
+    } else {
+#pragma unroll
+      for (int i = 0; i < 32; ++i) { o0[i] = 0.f; o1[i] = 0.f; o2[i] = 0.f; o3[i] = 0.f; lsum[i] = 0.f; }
+      mrow = c128::f32x2{0.f, 0.f};
+    }
+    // the next block: once every wave has left the loop, its key state is built; its q rows and first tiles are requested between
+    // the two halves of this block's epilogue (after the first half has freed its registers) and fly under the second half
+    advance(cur, nxt);
+#if UR_C128_STAMPS
+    sa = __builtin_readcyclecounter();
+#endif
+    __syncthreads();
+#if UR_C128_STAMPS
+    sb = __builtin_readcyclecounter();
+#endif
+    if (nxt.valid) {
+      if (nxt.item != cur.item) { key_state(nxt); if (p.kmask) __syncthreads(); }
+      else { nxt.tfirst = cur.tfirst; nxt.mb_lo = cur.mb_lo; nxt.mb_hi = cur.mb_hi; }
+    }
+    // epilogue (the row sums came off the matrix pipe: complete in every lane)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       const int row = q0 + 32 * qb + l31;
       const bool ok = row < p.Sq;
-      const bf16_t* qrow = p.q + ((long)b * p.Sq + (ok ? row : 0)) * p.ldq + (long)hq * 128;
+      const float l = lsum[16 * qb];
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      f32x16 acc[4];
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const bf16x8 f = g_frag(qrow, ks, lane, ok);
+      for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t wv = pack_bf2(bf2f((bf16_t)f[2 * j]) * c, bf2f((bf16_t)f[2 * j + 1]) * c);
-          if (qb == 0) qv0[4 * ks + j] = (int)wv; else qv1[4 * ks + j] = (int)wv;
+        for (int r = 0; r < 16; ++r) {
+          const int idx = 16 * (dt & 1) + r;
+          acc[dt][r] = qb == 0 ? (dt < 2 ? o0[idx] : o1[idx]) : (dt < 2 ? o2[idx] : o3[idx]);
         }
+      store_T<128>(p.o + ((long)b * p.Sq + (ok ? row : 0)) * p.ldo + (long)hq * 128, acc, inv, lane, ok);
+      if (ok && h == 0) {
+        float* st = p.stats + (((long)b * p.nq + hq) * p.Sq + row) * 2;
+        st[0] = mrow[qb] * (1.0f / LOG2E);        // running maximum in natural-log units of the scaled scores (the backward's convention)
+        st[1] = inv;
+      }
+      if (qb == 0) {
+        asm volatile("" ::: "memory");
+#if UR_C128_STAMPS
+        sc = __builtin_readcyclecounter();
+#endif
+        request(nxt);
+#if UR_C128_STAMPS
+        sd = __builtin_readcyclecounter();
+#endif
       }
     }
-    // lane-constant LDS addresses (tile-relative swizzled offsets; the ring slot is an immediate in the generated code)
-    i32x8 ka, tatb;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) ka[ks] = (int)(lds0 + C::off(l31, 2 * ks + h));
-    {
-      const int g16 = (lane >> 4) & 1, i = lane & 15;
-      const int row = 4 * h + (i >> 2), sub8 = 8 * (i & 1);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const int ch = 4 * dt + 2 * g16 + ((i & 3) >> 1);
-        tatb[dt] = (int)(lds0 + VBASE_LDS + C::off(row, ch) + sub8);
-        tatb[4 + dt] = (int)(lds0 + VBASE_LDS + C::off(row + 8, ch) + sub8);
-      }
+#if UR_C128_STAMPS
+    if (lane == 0) {
+      const unsigned long long st3 = __builtin_readcyclecounter();
+      dbg[12] = (unsigned int)(st1 - st0); dbg[13] = (unsigned int)(st2 - st1); dbg[14] = (unsigned int)(st3 - st2); dbg[15] = (unsigned int)x;
+      dbg[16] = (unsigned int)(sa - st2); dbg[17] = (unsigned int)(sb - sa); dbg[18] = (unsigned int)(sc - sb); dbg[19] = (unsigned int)(sd - sc); dbg[20] = (unsigned int)(st3 - sd);
     }
-    i32x2 voff, bd;
-    {
-      const int row = 4 * wave + (lane >> 4), pos = lane & 15;
-      const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
-      voff[0] = (int)((uint32_t)(row * p.ldk + (pos ^ sw) * 8) * 2u);
-      voff[1] = (int)((uint32_t)(row * p.ldv + (pos ^ sw) * 8) * 2u);
-    }
-    bd[0] = (int)(lds0 + BIAS_LDS + 16 * h);
-    bd[1] = l31 - 4 * h;
-    const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * 128;
-    const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * 128;
-    const uint32_t kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)kb), kb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)kb >> 32));
-    const uint32_t vb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)vb), vb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)vb >> 32));
-    const int k16b = __builtin_amdgcn_readfirstlane((int)(p.ldk * 32)), v16b = __builtin_amdgcn_readfirstlane((int)(p.ldv * 32));
-    const int tlast = __builtin_amdgcn_readfirstlane(q0 < p.Sq ? min(4 * x + wave, ntiles - 1) : -1);
-    const int tend_s = __builtin_amdgcn_readfirstlane(tend);
-    const uint32_t waveb = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
-    asm volatile(
-        "s_mov_b32 s36, %[kbl]\n\ts_mov_b32 s37, %[kbh]\n\ts_mov_b32 s38, %[vbl]\n\ts_mov_b32 s39, %[vbh]\n\t"
-        "s_mov_b32 s40, %[k16]\n\ts_mov_b32 s41, %[v16]\n\ts_mov_b32 s43, %[tend]\n\ts_mov_b32 s44, %[tlast]\n\t"
-        "s_mov_b32 s45, %[tfirst]\n\ts_mov_b32 s46, %[mbl]\n\ts_mov_b32 s47, %[mbh]\n\ts_mov_b32 s57, %[waveb]\n\t"
-        UR_ATTN_FWD_C128_ASM
-        : "=&{a[0:31]}"(o0), "=&{a[32:63]}"(o1), "=&{a[64:95]}"(o2), "=&{a[96:127]}"(o3), "=&{v[192:195]}"(ml)
-        : "{a[128:159]}"(qv0), "{a[160:191]}"(qv1), "{v[176:183]}"(ka), "{v[184:191]}"(tatb), "{v[204:205]}"(voff), "{v[208:209]}"(bd),
-          [kbl] "s"(kb_lo), [kbh] "s"(kb_hi), [vbl] "s"(vb_lo), [vbh] "s"(vb_hi), [k16] "s"(k16b), [v16] "s"(v16b), [tend] "s"(tend_s),
-          [tlast] "s"(tlast), [tfirst] "s"(tfirst), [mbl] "s"(mb_lo), [mbh] "s"(mb_hi), [waveb] "s"(waveb)
-        : UR_ATTN_FWD_C128_CLOBBERS);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 32; ++i) { o0[i] = 0.f; o1[i] = 0.f; o2[i] = 0.f; o3[i] = 0.f; }
-    ml = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  // epilogue: the two lane halves of a query hold the row sums of complementary key halves
-#pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
-    const int row = q0 + 32 * qb + l31;
-    const bool ok = row < p.Sq;
-    float l = ml[2 + qb];
-    l += __shfl_xor(l, 32, 64);
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
-    f32x16 acc[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int idx = 16 * (dt & 1) + r;
-        acc[dt][r] = qb == 0 ? (dt < 2 ? o0[idx] : o1[idx]) : (dt < 2 ? o2[idx] : o3[idx]);
-      }
-    store_T<128>(p.o + ((long)b * p.Sq + (ok ? row : 0)) * p.ldo + (long)hq * 128, acc, inv, lane, ok);
-    if (ok && h == 0) {
-      float* st = p.stats + (((long)b * p.nq + hq) * p.Sq + row) * 2;
-      st[0] = ml[qb] * (1.0f / LOG2E);        // running maximum in natural-log units of the scaled scores (the backward's convention)
-      st[1] = inv;
-    }
+#endif
+    cur = nxt;
   }
 }
 
@@ -2134,6 +2246,18 @@ int fill(AttnP& p, const ur_attn_args* a) {
   return 0;
 }
 
+// CUs of the current device (persistent grids), cached per device
+inline int device_cu_count() {
+  static std::atomic<int> cached[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  int n = cached[dev].load();
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return n;
+}
 // test / lab switch, read on every call: UR_ATTN_C128=0 sends the causal head_dim-128 forward back to attn_fwd_kernel
 inline bool fwd_c128_enabled() { const char* e = getenv("UR_ATTN_C128"); return !(e && e[0] == '0'); }
 inline bool fwd_gq2_enabled() { static const bool on = [] { const char* e = getenv("UR_FWD_GQ2"); return e && e[0] == '1'; }(); return on; }
@@ -2150,12 +2274,14 @@ int launch_fwd(const AttnP& p, hipStream_t st) {
     }
   }
   if constexpr (HD == 128 && CAUSAL && NW == 4) {
-    if (p.Sq == p.Sk && (p.Sk % KT) == 0 && p.Sk >= 128 && p.Sk <= c128::MAX_SK && fwd_c128_enabled() &&
+    if (p.Sq == p.Sk && (p.Sk % KT) == 0 && p.Sk >= 128 && p.Sk <= c128::MAX_SK && fwd_c128_enabled() && (long)p.nq * p.B * 8 < (1L << 24) &&
         p.ldk * 2L * p.Sk < (1L << 31) && p.ldv * 2L * p.Sk < (1L << 31)) {
       static std::atomic<bool> once_c{false};
       if (!once_c) { int rc = set_smem(&attn_fwd_c128_kernel, c128::LDS_BYTES, "ur_attn_fwd(c128)"); if (rc) return rc; once_c = true; }
-      dim3 grid(ur_cdiv(p.Sq, 256) * p.nq * p.B);
-      hipLaunchKernelGGL(attn_fwd_c128_kernel, grid, dim3(256), c128::LDS_BYTES, st, p);
+      const int nx = ur_cdiv(p.Sq, 256), nch = (nx + 1) / 2, nitems = p.nq * p.B * nch;
+      auto magic = [](uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); };
+      const C128Div dv{magic((uint32_t)(p.rep * nch)), magic((uint32_t)nch), magic((uint32_t)p.nkv)};
+      hipLaunchKernelGGL(attn_fwd_c128_kernel, dim3(std::min(nitems, device_cu_count())), dim3(256), c128::LDS_BYTES, st, p, nitems, nch, dv);
       UR_CHECK_LAUNCH("ur_attn_fwd(c128)");
       return 0;
     }
@@ -2229,6 +2355,11 @@ int do_dkv(const AttnP& p, int hd, bool causal, hipStream_t st) { UR_ATTN_DISPAT
 
 }  // namespace
 
+#if UR_C128_STAMPS
+extern "C" int ur_lab_c128_stamps(unsigned int* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_c128_stamps), sizeof(unsigned int) * n);   // 32 words per wave
+}
+#endif
 #if UR_DKV2_STAMPS
 extern "C" int ur_lab_attn_stamps(long long* host, int n) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), sizeof(long long) * n);
