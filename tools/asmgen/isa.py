@@ -638,8 +638,23 @@ class Workgroup:
                                   % (w.wid, b, w.nbar, ww.wid, self.lastread[b][ww.wid]))
         self.blk[b] = ("fly", w.wid)
 
+    def dma_issue_small(self, w, ad, n):
+        """a piece smaller than a block (row constants: several waves fill parts of one block)"""
+        b = ad // self.BLK
+        for ww in self.waves:
+            if self.lastread[b][ww.wid] >= w.nbar:
+                raise HazardError("wave %d issues LDS-DMA into block %d (epoch %d) that wave %d read in epoch %d: no barrier between"
+                                  % (w.wid, b, w.nbar, ww.wid, self.lastread[b][ww.wid]))
+        st = self.blk[b]
+        self.blk[b] = ("fly", w.wid, (st[2] if st is not None and st[0] == "fly" and len(st) > 2 else 0) + 1)
+        w.vm.append((ad, n))
+
     def dma_landed(self, w, ad, n):
         b = ad // self.BLK
+        st = self.blk[b]
+        if n < self.BLK and st is not None and st[0] == "fly" and len(st) > 2 and st[2] > 1:
+            self.blk[b] = ("fly", st[1], st[2] - 1)       # other pieces of the block are still in flight
+            return
         self.blk[b] = ("landed", w.nbar, w.wid)    # visible to other waves after the barrier the issuer reaches next
 
     def lds_read(self, w, ad, n):

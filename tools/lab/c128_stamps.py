@@ -10,8 +10,14 @@ nq, nkv, hd = 16, 8, 128
 g = torch.Generator().manual_seed(0)
 qkv = torch.randn(B, S, (nq + 2 * nkv) * hd, generator=g).cuda().to(torch.bfloat16)
 q = qkv[..., :nq * hd].view(B, S, nq, hd); k = qkv[..., nq * hd:(nq + nkv) * hd].view(B, S, nkv, hd); v = qkv[..., (nq + nkv) * hd:].view(B, S, nkv, hd)
+WHAT = os.environ.get("WHAT", "fwd")
+o, ctx = hip.attn_fwd(q, k, v, causal=True)
+dout = torch.randn(B, S, nq, hd, generator=g).cuda().to(torch.bfloat16)
 for _ in range(3):
-    hip.attn_fwd(q, k, v, causal=True)
+    if WHAT == "fwd":
+        hip.attn_fwd(q, k, v, causal=True)
+    else:
+        hip.attn_bwd(ctx, dout)
 torch.cuda.synchronize()
 lib = _lib.load()
 n = 8192 * 4 * 32
@@ -33,6 +39,8 @@ for w in range(4):
     print("    wave %d: barrier %.0f  half0 %.0f  request %.0f  half1 %.0f" % (w, a[:, w, 17].mean(), a[:, w, 18].mean(), a[:, w, 19].mean(), a[:, w, 20].mean()))
 for w in range(4):
     print(f"  wave {w}: STEADY per occurrence {a[:, w, 4].sum() / max(1, a[:, w, 5].sum()):7.0f}  ring wait per iteration {a[:, w, 0].sum() / max(1, a[:, w, 1].sum()):6.0f}  LAST {a[:, w, 6].sum() / max(1, a[:, w, 7].sum()):6.0f} EPI {a[:, w, 8].sum() / max(1, a[:, w, 9].sum()):6.0f}")
+if WHAT != "fwd":
+    print("  in-kernel clock over a block (shader cycles / 100 MHz ticks): %.0f MHz" % (100.0 * a[:, :, 21].sum() / max(1.0, a[:, :, 22].sum())))
 xs = a[:, 0, 15]
 for x in sorted(set(xs.astype(int))):
     m = xs == x

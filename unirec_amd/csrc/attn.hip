@@ -29,6 +29,14 @@
 #define UR_ATTN_FWD_C128_HDR "gen/attn_fwd_c128_asm.h"      // lab builds point this at an ablated variant (tools/lab/c128_variants.sh)
 #endif
 #include UR_ATTN_FWD_C128_HDR
+#ifndef UR_ATTN_DQ_C128_HDR
+#define UR_ATTN_DQ_C128_HDR "gen/attn_dq_c128_asm.h"
+#endif
+#include UR_ATTN_DQ_C128_HDR
+#ifndef UR_ATTN_DKV_C128_HDR
+#define UR_ATTN_DKV_C128_HDR "gen/attn_dkv_c128_asm.h"
+#endif
+#include UR_ATTN_DKV_C128_HDR
 
 namespace {
 
@@ -76,6 +84,8 @@ struct AttnP {
   // gradient of the RAW q projection
   const bf16_t* rp_raw; long rp_ldraw; const float* rp_w; const float* rp_cos; const float* rp_sin; float rp_eps;
   bf16_t* rp_draw; long rp_lddraw;
+  // hand-scheduled causal head_dim-128 backward (both kernels or neither): plane 1 of `delta` holds -LSE * log2(e) instead of -LSE / scale
+  int lse_log2;
 };
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -574,6 +584,74 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   }
 }
 
+// Store of a 32-query block's dQ^T accumulators (lane = query row, registers = head_dim), shared by both dQ kernels: plain bf16 rows, or
+// -- head_dim 128 with ur_attn_bwd_args.rope_* -- the q-norm + RoPE backward applied in registers first (dq leaves as the gradient of
+// the RAW q projection).
+template <int HD>
+__device__ __forceinline__ void dq_store_block(const AttnP& p, f32x16 (&dq)[Cfg<HD>::NDT], int b, int hq, int q, bool qok, int lane) {
+  const int h = lane >> 5;
+  if (HD == 128 && p.rp_raw != nullptr) {
+    // Qwen3Attention: q = rope(q_norm(q_raw)) (modeling_qwen3.py:59-64,107-170,244-252).  dq above is the gradient of the
+    // ROTATED, NORMED q; the lane holds half of its row (d = 32 dt + acc_row(r, h)), and the rotate-half partner d +- 64 is
+    // the same register of tile dt +- 2, so the whole chain back to the raw projection -- un-rotate, norm weight, RMS-norm
+    // backward with its two row sums (registers + one cross-half shuffle each) -- is lane-local.  Same arithmetic as
+    // qknorm_rope_kernel<128, true>; the 2 + 2 activation passes of writing dq and reading it back are gone.
+    const long qrow = (long)b * p.Sq + (qok ? q : 0);
+    const bf16_t* xr = p.rp_raw + qrow * p.rp_ldraw + (long)hq * HD;
+    const int pos = qok ? q : 0;
+    const float* cr = p.rp_cos + (long)pos * (HD / 2);
+    const float* sr = p.rp_sin + (long)pos * (HD / 2);
+    uint2 xp[4][4];
+    float ss = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        xp[dt][rq] = *reinterpret_cast<const uint2*>(xr + 32 * dt + 8 * rq + 4 * h);
+        const float x0 = bf_lo(xp[dt][rq].x), x1 = bf_hi(xp[dt][rq].x), x2 = bf_lo(xp[dt][rq].y), x3 = bf_hi(xp[dt][rq].y);
+        ss += x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
+      }
+    ss += __shfl_xor(ss, 32, 64);
+    const float rs = rsqrtf(ss / (float)HD + p.rp_eps);
+    float t = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int j = 32 * dt + 8 * rq + 4 * h;              // d of the first-half element; its partner is d + 64
+        const float4 c4 = *reinterpret_cast<const float4*>(cr + j), s4 = *reinterpret_cast<const float4*>(sr + j);
+        const float4 wa = *reinterpret_cast<const float4*>(p.rp_w + j), wb = *reinterpret_cast<const float4*>(p.rp_w + j + 64);
+        const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+        const float wA[4] = {wa.x, wa.y, wa.z, wa.w}, wB[4] = {wb.x, wb.y, wb.z, wb.w};
+        const float xA[4] = {bf_lo(xp[dt][rq].x), bf_hi(xp[dt][rq].x), bf_lo(xp[dt][rq].y), bf_hi(xp[dt][rq].y)};
+        const float xB[4] = {bf_lo(xp[dt + 2][rq].x), bf_hi(xp[dt + 2][rq].x), bf_lo(xp[dt + 2][rq].y), bf_hi(xp[dt + 2][rq].y)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * rq + e;
+          // the standalone kernel reads dq back as bf16: round here too, so both paths see the same upstream gradient
+          const float dA = bf2f(f2bf(dq[dt][r])), dB = bf2f(f2bf(dq[dt + 2][r]));
+          const float gA = (dA * cc[e] + dB * sn[e]) * wA[e];            // d <  64: dy c + dy[d+64] s
+          const float gB = (dB * cc[e] - dA * sn[e]) * wB[e];            // d >= 64: dy c - dy[d-64] s
+          t += gA * (xA[e] * rs) + gB * (xB[e] * rs);
+          dq[dt][r] = gA; dq[dt + 2][r] = gB;
+        }
+      }
+    t += __shfl_xor(t, 32, 64);
+    t /= (float)HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const float xv[4] = {bf_lo(xp[dt][rq].x), bf_hi(xp[dt][rq].x), bf_lo(xp[dt][rq].y), bf_hi(xp[dt][rq].y)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dq[dt][4 * rq + e] = rs * (dq[dt][4 * rq + e] - xv[e] * rs * t);
+      }
+    store_T<HD>(p.rp_draw + qrow * p.rp_lddraw + (long)hq * HD, dq, 1.0f, lane, qok);
+    return;
+  }
+  store_T<HD>(p.dq + ((long)b * p.Sq + (qok ? q : 0)) * p.lddq + (long)hq * HD, dq, 1.0f, lane, qok);
+}
+
 // ================================================================================================
 // dQ: same decomposition as forward.  dQ^T[d][q] += K^T[d][key] * dS^T[key][q]
 template <int HD, bool CAUSAL, int NW>
@@ -710,66 +788,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
     }
     __syncthreads();
   }
-  if (HD == 128 && p.rp_raw != nullptr) {
-    // Qwen3Attention: q = rope(q_norm(q_raw)) (modeling_qwen3.py:59-64,107-170,244-252).  dq above is the gradient of the
-    // ROTATED, NORMED q; the lane holds half of its row (d = 32 dt + acc_row(r, h)), and the rotate-half partner d +- 64 is
-    // the same register of tile dt +- 2, so the whole chain back to the raw projection -- un-rotate, norm weight, RMS-norm
-    // backward with its two row sums (registers + one cross-half shuffle each) -- is lane-local.  Same arithmetic as
-    // qknorm_rope_kernel<128, true>; the 2 + 2 activation passes of writing dq and reading it back are gone.
-    const long qrow = (long)b * p.Sq + (qok ? q : 0);
-    const bf16_t* xr = p.rp_raw + qrow * p.rp_ldraw + (long)hq * HD;
-    const int pos = qok ? q : 0;
-    const float* cr = p.rp_cos + (long)pos * (HD / 2);
-    const float* sr = p.rp_sin + (long)pos * (HD / 2);
-    uint2 xp[4][4];
-    float ss = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        xp[dt][rq] = *reinterpret_cast<const uint2*>(xr + 32 * dt + 8 * rq + 4 * h);
-        const float x0 = bf_lo(xp[dt][rq].x), x1 = bf_hi(xp[dt][rq].x), x2 = bf_lo(xp[dt][rq].y), x3 = bf_hi(xp[dt][rq].y);
-        ss += x0 * x0 + x1 * x1 + x2 * x2 + x3 * x3;
-      }
-    ss += __shfl_xor(ss, 32, 64);
-    const float rs = rsqrtf(ss / (float)HD + p.rp_eps);
-    float t = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int j = 32 * dt + 8 * rq + 4 * h;              // d of the first-half element; its partner is d + 64
-        const float4 c4 = *reinterpret_cast<const float4*>(cr + j), s4 = *reinterpret_cast<const float4*>(sr + j);
-        const float4 wa = *reinterpret_cast<const float4*>(p.rp_w + j), wb = *reinterpret_cast<const float4*>(p.rp_w + j + 64);
-        const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
-        const float wA[4] = {wa.x, wa.y, wa.z, wa.w}, wB[4] = {wb.x, wb.y, wb.z, wb.w};
-        const float xA[4] = {bf_lo(xp[dt][rq].x), bf_hi(xp[dt][rq].x), bf_lo(xp[dt][rq].y), bf_hi(xp[dt][rq].y)};
-        const float xB[4] = {bf_lo(xp[dt + 2][rq].x), bf_hi(xp[dt + 2][rq].x), bf_lo(xp[dt + 2][rq].y), bf_hi(xp[dt + 2][rq].y)};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * rq + e;
-          // the standalone kernel reads dq back as bf16: round here too, so both paths see the same upstream gradient
-          const float dA = bf2f(f2bf(dq[dt][r])), dB = bf2f(f2bf(dq[dt + 2][r]));
-          const float gA = (dA * cc[e] + dB * sn[e]) * wA[e];            // d <  64: dy c + dy[d+64] s
-          const float gB = (dB * cc[e] - dA * sn[e]) * wB[e];            // d >= 64: dy c - dy[d-64] s
-          t += gA * (xA[e] * rs) + gB * (xB[e] * rs);
-          dq[dt][r] = gA; dq[dt + 2][r] = gB;
-        }
-      }
-    t += __shfl_xor(t, 32, 64);
-    t /= (float)HD;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const float xv[4] = {bf_lo(xp[dt][rq].x), bf_hi(xp[dt][rq].x), bf_lo(xp[dt][rq].y), bf_hi(xp[dt][rq].y)};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dq[dt][4 * rq + e] = rs * (dq[dt][4 * rq + e] - xv[e] * rs * t);
-      }
-    store_T<HD>(p.rp_draw + qrow * p.rp_lddraw + (long)hq * HD, dq, 1.0f, lane, qok);
-    return;
-  }
-  store_T<HD>(p.dq + ((long)b * p.Sq + (qok ? q : 0)) * p.lddq + (long)hq * HD, dq, 1.0f, lane, qok);
+  dq_store_block<HD>(p, dq, b, hq, q, qok, lane);
 }
 
 // ================================================================================================
@@ -2213,6 +2232,299 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // ================================================================================================
+// Causal head_dim-128 backward dQ, hand-scheduled (tools/asmgen/attn_dq.py -> gen/attn_dq_c128_asm.h; CPU-emulated by
+// tests/test_asmgen_attn_dq.py).  Same decomposition and persistent item loop as attn_fwd_c128_kernel; per 64-key tile and wave
+// 96 MFMAs (S, dP, dQ) with every K / V fragment feeding two of them.  The C++ part loads q (pre-scaled by scale*log2e), dO and O of
+// the wave's 64 rows, forms the row constants delta = sum_d dO O and LSE2 = (m + ln l) log2e from the forward's statistics, and
+// publishes -delta and -LSE/scale for the dK/dV kernel exactly as attn_bwd_dq_kernel does.
+// LDS: K ring 4 x 16 KiB | V ring 4 x 16 KiB | key-state words.
+namespace c128 { constexpr int DQ_WORDS_LDS = 131072, DQ_LDS_BYTES = DQ_WORDS_LDS + 64 * 8; }
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dq_c128_kernel(AttnP p, int nitems, int nch, C128Div dv) {
+  using namespace c128;
+  using C = Cfg<128>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
+  const int nx = (p.Sq + 255) / 256, ntiles = p.Sk / KT;
+  const uint32_t lds0 = lds_off(smem);
+  unsigned long long* words = reinterpret_cast<unsigned long long*>(smem + DQ_WORDS_LDS);
+  i32x2 kava, dw, voff;
+  i32x8 tatb;
+  kava[0] = (int)(lds0 + C::off(l31, h));
+  kava[1] = kava[0] + VBASE_LDS;
+  {
+    const int g16 = (lane >> 4) & 1, i = lane & 15;
+    const int row = 4 * h + (i >> 2), sub8 = 8 * (i & 1);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int ch = 4 * dt + 2 * g16 + ((i & 3) >> 1);
+      tatb[dt] = (int)(lds0 + C::off(row, ch) + sub8);
+      tatb[4 + dt] = (int)(lds0 + C::off(row + 8, ch) + sub8);
+    }
+  }
+  {
+    const int row = 4 * wave + (lane >> 4), pos = lane & 15;
+    const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+    voff[0] = (int)((uint32_t)(row * p.ldk + (pos ^ sw) * 8) * 2u);
+    voff[1] = (int)((uint32_t)(row * p.ldv + (pos ^ sw) * 8) * 2u);
+  }
+  dw[0] = l31 - 4 * h;
+  dw[1] = (int)(lds0 + DQ_WORDS_LDS);
+  const int k16b = __builtin_amdgcn_readfirstlane((int)(p.ldk * 32)), v16b = __builtin_amdgcn_readfirstlane((int)(p.ldv * 32));
+  const uint32_t waveb = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
+  const float c = p.scale * LOG2E;
+  const int ngroups = p.nkv * p.B;
+  const uint32_t per_group = (uint32_t)(p.rep * nch);
+  const long nrows = (long)p.B * p.nq * p.Sq;
+  auto udiv = [](uint32_t n, uint32_t magic, uint32_t d) { return d == 1u ? n : __umulhi(n, magic); };
+
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    uint32_t g, j;
+    if ((ngroups & 7) == 0) { const uint32_t slot = (uint32_t)item >> 3, gq = udiv(slot, dv.m_pg, per_group); g = gq * 8u + ((uint32_t)item & 7u); j = slot - gq * per_group; }
+    else { g = udiv((uint32_t)item, dv.m_pg, per_group); j = (uint32_t)item - g * per_group; }
+    const uint32_t hr = udiv(j, dv.m_nch, nch), ch = j - hr * nch;
+    const uint32_t bb = udiv(g, dv.m_nkv, p.nkv), kvh = g - bb * p.nkv;
+    const int hq = (int)(kvh * p.rep + hr), b = (int)bb;
+    const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
+    const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * 128;
+    const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * 128;
+    const uint32_t kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)kb), kb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)kb >> 32));
+    const uint32_t vb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)vb), vb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)vb >> 32));
+    int tfirst = 0;
+    uint32_t mb_lo = 0u, mb_hi = 0u;
+    if (km != nullptr) {
+      __syncthreads();                       // every wave has left the previous item's loop: the words table is free
+      for (int t = wave; t < ntiles; t += 4) {
+        const unsigned long long wv = __ballot(km[t * KT + lane] != 0);
+        if (lane == 0) words[t] = wv;
+      }
+      __syncthreads();
+      const unsigned long long wv = lane < ntiles ? words[lane] : ~0ull;
+      const unsigned long long anym = __ballot(lane < ntiles && wv != 0ull), partm = __ballot(lane < ntiles && wv != ~0ull);
+      tfirst = anym ? __builtin_ctzll(anym) : ntiles;
+      mb_lo = (uint32_t)partm; mb_hi = (uint32_t)(partm >> 32);
+    }
+    tfirst = __builtin_amdgcn_readfirstlane(tfirst);
+    mb_lo = __builtin_amdgcn_readfirstlane(mb_lo); mb_hi = __builtin_amdgcn_readfirstlane(mb_hi);
+
+    for (int half = 0; half < 2; ++half) {
+      const int x = half == 0 ? nx - 1 - (int)ch : (int)ch;
+      if (half == 1 && x == nx - 1 - (int)ch) break;
+      const int tend = __builtin_amdgcn_readfirstlane(min(ntiles, 4 * x + 4));
+      const int q0 = 256 * x + 64 * wave;
+      // rows of this wave: q, dO, O fragments; delta and the forward's statistics
+      bf16x8 qf[2][8], dof[2][8];
+      f32x4 ld;                       // LSE2[qb 0, 1], delta[qb 0, 1]
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int row = q0 + 32 * qb + l31;
+        const bool ok = row < p.Sq;
+        const long qtok = (long)b * p.Sq + (ok ? row : 0);
+        float dlt = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          qf[qb][ks] = g_frag(p.q + qtok * p.ldq + (long)hq * 128, ks, lane, ok);
+          dof[qb][ks] = g_frag(p.dout + qtok * p.lddo + (long)hq * 128, ks, lane, ok);
+          const bf16x8 of = g_frag(p.o + qtok * p.ldo + (long)hq * 128, ks, lane, ok);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dlt = fmaf(bf2f((bf16_t)dof[qb][ks][e]), bf2f((bf16_t)of[e]), dlt);
+        }
+        dlt += __shfl_xor(dlt, 32, 64);
+        const long srow = ((long)b * p.nq + hq) * p.Sq + (ok ? row : 0);
+        const float m = p.stats[srow * 2], inv = ok ? p.stats[srow * 2 + 1] : 0.f;
+        const float lse = m - __logf(inv);                 // natural log of the row's normaliser, scaled scores
+        if (ok && h == 0) {
+          float* ws = const_cast<float*>(p.delta);
+          ws[srow] = -dlt;
+          ws[nrows + srow] = (inv > 0.f) ? (p.lse_log2 ? -lse * LOG2E : -lse / p.scale) : NEG_INF;
+        }
+        ld[qb] = (inv > 0.f) ? lse * LOG2E : __builtin_huge_valf();
+        ld[2 + qb] = dlt;
+      }
+      f32x32 d0, d1, d2, d3;
+#if UR_C128_STAMPS
+      unsigned int* dbg = g_c128_stamps + ((size_t)((item * 2 + half) & 8191) * 4 + wave) * 32;
+      const uint32_t db_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dbg), db_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)dbg >> 32));
+      const unsigned long long st1 = __builtin_readcyclecounter(), sr1 = wall_clock64();
+      unsigned long long st2 = st1;
+#endif
+      __syncthreads();                     // every wave has left the previous loop: the K / V rings are free
+      if (tfirst < tend) {
+        const int tlast = __builtin_amdgcn_readfirstlane(q0 < p.Sq ? min(4 * x + wave, ntiles - 1) : -1);
+        asm volatile(
+            "s_mov_b32 s36, %[kbl]\n\ts_mov_b32 s37, %[kbh]\n\ts_mov_b32 s38, %[vbl]\n\ts_mov_b32 s39, %[vbh]\n\t"
+            "s_mov_b32 s40, %[k16]\n\ts_mov_b32 s41, %[v16]\n\ts_mov_b32 s43, %[tend]\n\ts_mov_b32 s45, %[tfirst]\n\ts_mov_b32 s57, %[waveb]\n\t"
+            UR_ATTN_DQ_C128_DMA_ASM
+            :
+            : "{v[12:13]}"(voff), [kbl] "s"(kb_lo), [kbh] "s"(kb_hi), [vbl] "s"(vb_lo), [vbh] "s"(vb_hi), [k16] "s"(k16b), [v16] "s"(v16b),
+              [tend] "s"(tend), [tfirst] "s"(tfirst), [waveb] "s"(waveb)
+            : UR_ATTN_DQ_C128_DMA_CLOBBERS);
+        i32x32 qv0, qv1, dov0, dov1;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            qv0[4 * ks + jj] = (int)pack_bf2(bf2f((bf16_t)qf[0][ks][2 * jj]) * c, bf2f((bf16_t)qf[0][ks][2 * jj + 1]) * c);
+            qv1[4 * ks + jj] = (int)pack_bf2(bf2f((bf16_t)qf[1][ks][2 * jj]) * c, bf2f((bf16_t)qf[1][ks][2 * jj + 1]) * c);
+            dov0[4 * ks + jj] = (int)((uint32_t)(uint16_t)dof[0][ks][2 * jj] | ((uint32_t)(uint16_t)dof[0][ks][2 * jj + 1] << 16));
+            dov1[4 * ks + jj] = (int)((uint32_t)(uint16_t)dof[1][ks][2 * jj] | ((uint32_t)(uint16_t)dof[1][ks][2 * jj + 1] << 16));
+          }
+        asm volatile(
+            "s_mov_b32 s36, %[kbl]\n\ts_mov_b32 s37, %[kbh]\n\ts_mov_b32 s38, %[vbl]\n\ts_mov_b32 s39, %[vbh]\n\t"
+            "s_mov_b32 s40, %[k16]\n\ts_mov_b32 s41, %[v16]\n\ts_mov_b32 s43, %[tend]\n\ts_mov_b32 s44, %[tlast]\n\t"
+            "s_mov_b32 s45, %[tfirst]\n\ts_mov_b32 s46, %[mbl]\n\ts_mov_b32 s47, %[mbh]\n\ts_mov_b32 s57, %[waveb]\n\t"
+#if UR_C128_STAMPS
+            "s_mov_b32 s72, %[dbl]\n\ts_mov_b32 s73, %[dbh]\n\t"
+#endif
+            UR_ATTN_DQ_C128_ASM
+            : "=&{a[0:31]}"(d0), "=&{a[32:63]}"(d1), "=&{a[64:95]}"(d2), "=&{a[96:127]}"(d3)
+            : "{a[128:159]}"(qv0), "{a[160:191]}"(qv1), "{a[192:223]}"(dov0), "{a[224:255]}"(dov1), "{v[240:241]}"(kava), "{v[242:249]}"(tatb),
+              "{v[250:253]}"(ld), "{v[8:9]}"(dw), "{v[12:13]}"(voff),
+              [kbl] "s"(kb_lo), [kbh] "s"(kb_hi), [vbl] "s"(vb_lo), [vbh] "s"(vb_hi), [k16] "s"(k16b), [v16] "s"(v16b), [tend] "s"(tend),
+              [tlast] "s"(tlast), [tfirst] "s"(tfirst), [mbl] "s"(mb_lo), [mbh] "s"(mb_hi), [waveb] "s"(waveb)
+#if UR_C128_STAMPS
+              , [dbl] "s"(db_lo), [dbh] "s"(db_hi)
+#endif
+            : UR_ATTN_DQ_C128_CLOBBERS);
+#if UR_C128_STAMPS
+        st2 = __builtin_readcyclecounter();
+#endif
+      } else {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { d0[i] = 0.f; d1[i] = 0.f; d2[i] = 0.f; d3[i] = 0.f; }
+      }
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int row = q0 + 32 * qb + l31;
+        const bool ok = row < p.Sq;
+        f32x16 acc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int idx = 16 * (dt & 1) + r;
+            acc[dt][r] = (qb == 0 ? (dt < 2 ? d0[idx] : d1[idx]) : (dt < 2 ? d2[idx] : d3[idx])) * p.scale;
+          }
+        dq_store_block<128>(p, acc, b, hq, row, ok, lane);
+      }
+#if UR_C128_STAMPS
+      if (lane == 0) {
+        const unsigned long long st3 = __builtin_readcyclecounter(), sr3 = wall_clock64();
+        dbg[12] = 0; dbg[13] = (unsigned int)(st2 - st1); dbg[14] = (unsigned int)(st3 - st2); dbg[15] = (unsigned int)x;
+        dbg[21] = (unsigned int)(st3 - st1); dbg[22] = (unsigned int)(sr3 - sr1);      // shader cycles and 100 MHz ticks of the same span: the clock
+      }
+#endif
+    }
+  }
+}
+
+// ================================================================================================
+// Causal head_dim-128 backward dK / dV, hand-scheduled (tools/asmgen/attn_dkv.py -> gen/attn_dkv_c128_asm.h; CPU-emulated by
+// tests/test_asmgen_attn_dkv.py).  A workgroup = 128 keys of one (batch, kv head), one wave per SIMD, 32 keys per wave (key = MFMA lane);
+// per 64-query tile 64 MFMAs in the order X_a X_b Y_a Y_b with the vector work of a half in the gaps of the following block; Q / dO
+// tiles and the row constants (-delta, -LSE2 from attn_bwd_dq_c128_kernel) arrive by LDS-DMA three tiles ahead.  k is pre-scaled by
+// scale*log2e here, so P = exp2(S') is one instruction per score.  Padded keys are zeroed at the store (their lanes never mix).
+// LDS: 4 ring slots x (1 KiB row constants | Q tile 16 KiB | dO tile 16 KiB).
+namespace c128 { constexpr int DKV_SLOT = 33792, DKV_LDS_BYTES = 4 * DKV_SLOT, DKV_HIGH = 2 * DKV_SLOT; }
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv_c128_kernel(AttnP p) {
+  using namespace c128;
+  using C = Cfg<128>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
+  const BlockMap bm = block_map<false>(p.Sk / 128, 1, p.nkv, p.B);
+  const int kvh = bm.head, b = bm.b, xk = bm.x;
+  const int kb = 128 * xk + 32 * wave;
+  const int key = kb + l31;
+  const long ktok = (long)b * p.Sk + key;
+  const uint32_t lds0 = lds_off(smem);
+  const bool kvalid = p.kmask == nullptr || p.kmask[(long)b * p.Sk + key] != 0;
+  f32x16 dk[4], dv[4];
+  // causal (SDPA) semantics: a key block without a single valid key (left padding) has P = 0 everywhere: dK = dV = 0
+  if (p.kmask != nullptr && !__syncthreads_or(kvalid ? 1 : 0)) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
+    store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 0.f, lane, true);
+    store_T<128>(p.dv + ktok * p.lddv + (long)kvh * 128, dv, 0.f, lane, true);
+    return;
+  }
+  // K~ = k * scale * log2(e) (rounded to bf16 once more) and V fragments of this lane's key
+  const float c = p.scale * LOG2E;
+  i32x32 kv_, vv_;
+  {
+    const bf16_t* krow = p.k + ktok * p.ldk + (long)kvh * 128;
+    const bf16_t* vrow = p.v + ktok * p.ldv + (long)kvh * 128;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const bf16x8 kf = g_frag(krow, ks, lane, true), vf = g_frag(vrow, ks, lane, true);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        kv_[4 * ks + jj] = (int)pack_bf2(bf2f((bf16_t)kf[2 * jj]) * c, bf2f((bf16_t)kf[2 * jj + 1]) * c);
+        vv_[4 * ks + jj] = (int)((uint32_t)(uint16_t)vf[2 * jj] | ((uint32_t)(uint16_t)vf[2 * jj + 1] << 16));
+      }
+    }
+  }
+  i32x2 ra, ca, voff;
+  i32x8 ta, tb;
+  ra[0] = (int)(lds0 + C::off(l31, h)); ra[1] = ra[0] + DKV_HIGH;
+  ca[0] = (int)(lds0 + 16 * h); ca[1] = ca[0] + DKV_HIGH;
+  {
+    const int g16 = (lane >> 4) & 1, i = lane & 15;
+    const int row = 4 * h + (i >> 2), sub8 = 8 * (i & 1);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int ch = 4 * dt + 2 * g16 + ((i & 3) >> 1);
+      ta[dt] = (int)(lds0 + C::off(row, ch) + sub8); ta[4 + dt] = ta[dt] + DKV_HIGH;
+      tb[dt] = (int)(lds0 + C::off(row + 8, ch) + sub8); tb[4 + dt] = tb[dt] + DKV_HIGH;
+    }
+  }
+  {
+    const int row = 4 * wave + (lane >> 4), pos = lane & 15;
+    const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+    voff[0] = (int)((uint32_t)(row * p.ldq + (pos ^ sw) * 8) * 2u);
+    voff[1] = (int)((uint32_t)(row * p.lddo + (pos ^ sw) * 8) * 2u);
+  }
+  const int voffc = 4 * lane, xdiag = l31 - 4 * h;
+  const int hq0 = kvh * p.rep;
+  const bf16_t* qb = p.q + (long)b * p.Sq * p.ldq + (long)hq0 * 128;
+  const bf16_t* dob = p.dout + (long)b * p.Sq * p.lddo + (long)hq0 * 128;
+  const float* wsb = p.delta + ((long)b * p.nq + hq0) * p.Sq;
+  const long nrows = (long)p.B * p.nq * p.Sq;
+  auto sgpr64 = [](const void* ptr) { return (unsigned long long)(uintptr_t)ptr; };
+  const unsigned long long qb_s = sgpr64(qb), dob_s = sgpr64(dob), wsb_s = sgpr64(wsb);
+  const uint32_t qb_lo = __builtin_amdgcn_readfirstlane((uint32_t)qb_s), qb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(qb_s >> 32));
+  const uint32_t do_lo = __builtin_amdgcn_readfirstlane((uint32_t)dob_s), do_hi = __builtin_amdgcn_readfirstlane((uint32_t)(dob_s >> 32));
+  const uint32_t ws_lo = __builtin_amdgcn_readfirstlane((uint32_t)wsb_s), ws_hi = __builtin_amdgcn_readfirstlane((uint32_t)(wsb_s >> 32));
+  const int q16b = __builtin_amdgcn_readfirstlane((int)(p.ldq * 32)), d16b = __builtin_amdgcn_readfirstlane((int)(p.lddo * 32));
+  const int qstart = 128 * xk, ntot = __builtin_amdgcn_readfirstlane(((p.Sq - qstart) / KT) * p.rep);
+  const int kb_s = __builtin_amdgcn_readfirstlane(kb), sq = __builtin_amdgcn_readfirstlane(p.Sq);
+  const uint32_t wsel = __builtin_amdgcn_readfirstlane((wave & 1) ? 0u : (uint32_t)(nrows * 4));
+  const uint32_t cwave = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(wave & 1) * 256u), waveb = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
+  c128::f32x32 k0, k1, v0, v1;
+  asm volatile(
+      "s_mov_b32 s36, %[qbl]\n\ts_mov_b32 s37, %[qbh]\n\ts_mov_b32 s38, %[dol]\n\ts_mov_b32 s39, %[doh]\n\ts_mov_b32 s40, %[wsl]\n\ts_mov_b32 s41, %[wsh]\n\t"
+      "s_mov_b32 s42, %[q16]\n\ts_mov_b32 s43, %[d16]\n\ts_mov_b32 s45, %[ntot]\n\ts_mov_b32 s47, %[kb]\n\ts_mov_b32 s58, %[qstart]\n\t"
+      "s_mov_b32 s35, %[sq]\n\ts_lshl_b32 s60, %[sq], 2\n\ts_mov_b32 s34, %[wsel]\n\ts_mov_b32 s56, %[cwave]\n\ts_mov_b32 s57, %[waveb]\n\t"
+      UR_ATTN_DKV_C128_ASM
+      : "=&{a[0:31]}"(k0), "=&{a[32:63]}"(k1), "=&{a[64:95]}"(v0), "=&{a[96:127]}"(v1)
+      : "{a[128:159]}"(kv_), "{a[160:191]}"(vv_), "{v[8:9]}"(voff), "{v10}"(voffc), "{v[144:145]}"(ra), "{v[146:153]}"(ta), "{v[154:161]}"(tb),
+        "{v[162:163]}"(ca), "{v164}"(xdiag),
+        [qbl] "s"(qb_lo), [qbh] "s"(qb_hi), [dol] "s"(do_lo), [doh] "s"(do_hi), [wsl] "s"(ws_lo), [wsh] "s"(ws_hi), [q16] "s"(q16b), [d16] "s"(d16b),
+        [ntot] "s"(ntot), [kb] "s"(kb_s), [qstart] "s"(qstart), [sq] "s"(sq), [wsel] "s"(wsel), [cwave] "s"(cwave), [waveb] "s"(waveb)
+      : UR_ATTN_DKV_C128_CLOBBERS);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int idx = 16 * (dt & 1) + r;
+      dk[dt][r] = kvalid ? (dt < 2 ? k0[idx] : k1[idx]) * p.scale : 0.f;       // padded key: whatever its lane computed is dropped
+      dv[dt][r] = kvalid ? (dt < 2 ? v0[idx] : v1[idx]) : 0.f;
+    }
+  store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 1.0f, lane, true);
+  store_T<128>(p.dv + ktok * p.lddv + (long)kvh * 128, dv, 1.0f, lane, true);
+}
+
+// ================================================================================================
 template <int HD> constexpr int fwd_smem() { return 4 * Cfg<HD>::TILE + MAX_KTILES * 16; }
 template <int HD> constexpr int dkv_smem() { return 2 * (2 * Cfg<HD>::TILE + 3 * KT * (int)sizeof(float)); }
 
@@ -2246,6 +2558,8 @@ int fill(AttnP& p, const ur_attn_args* a) {
   return 0;
 }
 
+// the hand-scheduled causal head_dim-128 BACKWARD pair (dQ + dK/dV) runs together or not at all (they share the -LSE2 plane)
+inline bool c128_bwd_ok(const AttnP& p);
 // CUs of the current device (persistent grids), cached per device
 inline int device_cu_count() {
   static std::atomic<int> cached[16];
@@ -2295,6 +2609,18 @@ int launch_fwd(const AttnP& p, hipStream_t st) {
 }
 template <int HD, bool CAUSAL, int NW>
 int launch_dq(const AttnP& p, hipStream_t st) {
+  if constexpr (HD == 128 && CAUSAL && NW == 4) {
+    if (c128_bwd_ok(p)) {
+      static std::atomic<bool> once_c{false};
+      if (!once_c) { int rc = set_smem(&attn_bwd_dq_c128_kernel, c128::DQ_LDS_BYTES, "ur_attn_bwd(dq c128)"); if (rc) return rc; once_c = true; }
+      const int nx = ur_cdiv(p.Sq, 256), nch = (nx + 1) / 2, nitems = p.nq * p.B * nch;
+      auto magic = [](uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); };
+      const C128Div dv{magic((uint32_t)(p.rep * nch)), magic((uint32_t)nch), magic((uint32_t)p.nkv)};
+      hipLaunchKernelGGL(attn_bwd_dq_c128_kernel, dim3(std::min(nitems, device_cu_count())), dim3(256), c128::DQ_LDS_BYTES, st, p, nitems, nch, dv);
+      UR_CHECK_LAUNCH("ur_attn_bwd(dq c128)");
+      return 0;
+    }
+  }
   static std::atomic<bool> once{false};   // init-once flag: the call it guards is idempotent, the flag itself is race-free
   if (!once) { int rc = set_smem(&attn_bwd_dq_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_bwd(dq)"); if (rc) return rc; once = true; }
   dim3 grid(ur_cdiv(p.Sq, 32 * NW) * p.nq * p.B);
@@ -2321,6 +2647,15 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
     return 0;
   }
   dim3 grid(ur_cdiv(p.Sk, 32 * NW) * p.nkv * p.B);
+  if constexpr (HD == 128 && CAUSAL && NW == 4) {
+    if (c128_bwd_ok(p)) {
+      static std::atomic<bool> once_c{false};
+      if (!once_c) { int rc = set_smem(&attn_bwd_dkv_c128_kernel, c128::DKV_LDS_BYTES, "ur_attn_bwd(dkv c128)"); if (rc) return rc; once_c = true; }
+      hipLaunchKernelGGL(attn_bwd_dkv_c128_kernel, grid, dim3(256), c128::DKV_LDS_BYTES, st, p);
+      UR_CHECK_LAUNCH("ur_attn_bwd(dkv c128)");
+      return 0;
+    }
+  }
   if (HD == 128 && NW == 4 && p.drop_thr == 0) {
     constexpr int SM2 = 2 * (2 * Cfg<128>::TILE + 4 * KT * (int)sizeof(float));      // = NB buffers of attn_bwd_dkv2_kernel
     static std::atomic<bool> once2{false};
@@ -2336,6 +2671,11 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
   return 0;
 }
 
+inline bool c128_bwd_ok(const AttnP& p) {
+  return p.Sq == p.Sk && (p.Sk % 128) == 0 && p.Sk >= 128 && p.Sk <= c128::MAX_SK && fwd_c128_enabled() && (long)p.nq * p.B * 8 < (1L << 24) &&
+         p.ldk * 2L * p.Sk < (1L << 31) && p.ldv * 2L * p.Sk < (1L << 31) && p.ldq * 2L * p.Sq < (1L << 31) && p.lddo * 2L * p.Sq < (1L << 31) &&
+         p.drop_thr == 0 && (long)p.B * p.nq * p.Sq * 4 < (1L << 31);
+}
 inline int pick_nw(int S) { return S <= 32 ? 1 : (S <= 64 ? 2 : 4); }
 
 #define UR_ATTN_DISPATCH(HD_, CAUSAL_, NW_, FN, ...)                                      \
@@ -2397,6 +2737,7 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
   p.rp_raw = (const bf16_t*)g->rope_q_raw; p.rp_ldraw = g->rope_ldraw; p.rp_w = g->rope_q_weight; p.rp_cos = g->rope_cos; p.rp_sin = g->rope_sin;
   p.rp_eps = g->rope_eps; p.rp_draw = (bf16_t*)g->rope_dq_raw; p.rp_lddraw = g->rope_lddraw;
   hipStream_t st = (hipStream_t)stream;
+  p.lse_log2 = (a->head_dim == 128 && a->causal != 0 && c128_bwd_ok(p)) ? 1 : 0;
   if (tiny_shape(p, a->head_dim, a->causal != 0, true)) return launch_tiny(p, true, st);      // dQ, dK, dV in one kernel
   // the dQ kernel also computes the row constants (delta, -LSE/scale) and leaves them in `delta` for dK/dV
   rc = do_dq(p, a->head_dim, a->causal != 0, st);
