@@ -140,28 +140,30 @@ def flops_per_step(args, B, cfg, dims):
     return qf_fwd * 3 + qwen
 
 
-def attn_executed_ratio(am, S, qblk=128, kt=64):
-    """Executed / algorithmic FLOPs of the causal head_dim-128 attention launches for the 0/1 attention mask `am` [B, S]
-    (csrc/attn.hip).  Forward and dQ: a workgroup owns 128 queries and sweeps the 64-key tiles from the sequence's first tile
-    holding a valid key (first_valid_tile) up to its diagonal, 2 (forward) / 3 (dQ) contractions per tile.  dK/dV: a workgroup
-    owns 128 keys -- skipped whole when none is valid -- and sweeps the 64-query tiles from its diagonal to S, 4 contractions.
+def attn_executed_ratio(am, S, kt=64):
+    """Executed / algorithmic MFMA work of the causal head_dim-128 attention launches for the 0/1 attention mask `am` [B, S]
+    (csrc/attn.hip: attn_fwd_c128_kernel, attn_bwd_dq_c128_kernel, attn_bwd_dkv_c128_kernel; S a multiple of 128).
+    Forward and dQ: a wave owns 64 queries and sweeps the 64-key tiles from the sequence's first tile holding a valid key up to
+    its diagonal tile; per tile 72 MFMAs forward (S, P V and the 8 row-sum products: 2.25 contractions of 64 x 64 pairs) and 96
+    for dQ (3 contractions); the diagonal tile skips the quarter above the diagonal.  dK/dV: a workgroup owns 128 keys -- skipped
+    whole when none is valid -- and every wave sweeps all 64-query tiles from the block's first query to S, 4 contractions.
     Algorithmic: S^2 / 2 query-key pairs per head x 2 contractions forward, 5 backward (bench convention: 2.5 x forward)."""
     valid = am.to("cpu").bool()
     B = valid.shape[0]
-    nqb, nkb = (S + qblk - 1) // qblk, (S + qblk - 1) // qblk
+    ntiles = S // kt
     pairs_q = pairs_k = 0.0
     for b in range(B):
         nz = torch.nonzero(valid[b])
-        t0 = (int(nz[0]) // kt) if nz.numel() else (S + kt - 1) // kt
-        for qb in range(nqb):
-            tiles = max(0, (min(S, (qb + 1) * qblk) + kt - 1) // kt - t0)
-            pairs_q += tiles * kt * qblk
-        for kb in range(nkb):
-            if bool(valid[b, kb * qblk:(kb + 1) * qblk].any()):
-                q0 = ((kb * qblk) // kt) * kt
-                pairs_k += ((S - q0 + kt - 1) // kt) * kt * qblk
+        t0 = (int(nz[0]) // kt) if nz.numel() else ntiles
+        for w in range(S // 64):                       # wave w of the sequence: queries 64 w .. 64 w + 63, diagonal tile w
+            tiles = max(0, w + 1 - t0)
+            if tiles > 0:
+                pairs_q += (tiles - 0.25) * kt * 64
+        for kb in range(S // 128):
+            if bool(valid[b, kb * 128:(kb + 1) * 128].any()):
+                pairs_k += ((S - kb * 128) // kt) * kt * 128
     alg = B * S * S / 2.0
-    return {"fwd": pairs_q / alg, "bwd": (3.0 * pairs_q + 4.0 * pairs_k) / (5.0 * alg)}
+    return {"fwd": 2.25 * pairs_q / (2.0 * alg), "bwd": (3.0 * pairs_q + 4.0 * pairs_k) / (5.0 * alg)}
 
 
 def _cpu_threads(args):
@@ -611,7 +613,9 @@ def main():
         for k in ("fwd", "bwd"):
             attn[k]["executed_over_algorithmic"] = round(ex[k], 4)
             attn[k]["frac_of_peak_executed"] = round(attn[k]["frac_of_peak"] * ex[k], 4)
-        attn["kernels"] = "attn_fwd_kernel<128,true,4>; attn_bwd_dq_kernel<128,true,4> + attn_bwd_dkv2_kernel<true> (one ur_attn_bwd call)"
+        attn["kernels"] = ("attn_fwd_c128_kernel; attn_bwd_dq_c128_kernel + attn_bwd_dkv_c128_kernel (one ur_attn_bwd call): main loops "
+                           "generated by tools/asmgen (one wave per SIMD, hand-scheduled); executed_over_algorithmic counts the MFMAs they issue: "
+                           "forward incl. the row-sum products, backward 7 contractions for the 5 algorithmic ones (S and dP in both kernels)")
         fl = flops_per_step(args, B, cfg, dims)
         out = {"metric": f"user-sequences/sec joint fwd+bwd (Qwen3-0.6B+LoRA, hist={args.hist})", "value": round(world * B * args.steps / dt, 3),
                "unit": "user-sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -15,9 +15,9 @@ def test_floor_branch_checks_the_result_too():
 
 
 def test_attention_executed_ratio_counts_whole_tiles_and_skipped_padding():
-    """bench.py prints the attention fractions on executed FLOPs too: whole 64-key tiles (the masked half of the diagonal ones
-    included) minus the leading all-padding key tiles the kernels skip; the backward executes 7 contractions for the 5
-    algorithmic ones."""
+    """bench.py prints the attention fractions on executed MFMA work too: whole 64-key tiles per 64-query wave (three quarters of the
+    diagonal one) plus the forward's row-sum products, minus the leading all-padding key tiles the kernels skip; the backward
+    executes S and dP in both of its kernels."""
     import os
     import sys
     import torch
@@ -25,13 +25,16 @@ def test_attention_executed_ratio_counts_whole_tiles_and_skipped_padding():
     import bench
     S = 2048
     full = bench.attn_executed_ratio(torch.ones(2, S), S)
-    # 16 query blocks of 128: block qb sweeps 2 (qb + 1) tiles of 64 keys -> 128 * 64 * 272 pairs against S^2 / 2
-    assert abs(full["fwd"] - (128 * 64 * 272) / (S * S / 2)) < 1e-12 and abs(full["bwd"] - 7.0 / 5.0 * full["fwd"]) < 1e-12
+    # 32 waves of 64 queries: wave w sweeps w + 1 tiles of 64 keys, the last one at 3/4
+    pq = sum(w + 1 - 0.25 for w in range(32)) * 64 * 64
+    pk = sum((S - 128 * kb) // 64 for kb in range(16)) * 64 * 128
+    assert abs(full["fwd"] - 2.25 * pq / (2 * S * S / 2)) < 1e-12
+    assert abs(full["bwd"] - (3 * pq + 4 * pk) / (5 * S * S / 2)) < 1e-12
     am = torch.ones(1, S)
     am[0, :640] = 0                      # ten whole key tiles of left padding
     pad = bench.attn_executed_ratio(am, S)
     assert pad["fwd"] < full["fwd"] and pad["bwd"] < full["bwd"]
-    tiles = sum(max(0, 2 * (qb + 1) - 10) for qb in range(16))
-    assert abs(pad["fwd"] - tiles * 64 * 128 / (S * S / 2)) < 1e-12
+    pq = sum(max(0, w + 1 - 10) - 0.25 for w in range(32) if w + 1 > 10) * 64 * 64
+    assert abs(pad["fwd"] - 2.25 * pq / (2 * S * S / 2)) < 1e-12
     none = bench.attn_executed_ratio(torch.zeros(1, S), S)
     assert none["fwd"] == 0.0 and none["bwd"] == 0.0

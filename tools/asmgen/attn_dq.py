@@ -351,13 +351,25 @@ def common_scalars():
     return out
 
 
-def dma_prologue_code():
-    """first tiles' LDS-DMA: K(t0), V(t0), K(t0+1), V(t0+1), V(t0+2)   (ring slot = tile - t0; K runs two tiles ahead, V three)"""
-    out = [comment("---- prologue LDS-DMA")] + common_scalars() + [s_nop(3)]
-    for which, add in (("k", 0), ("v", 0), ("k", 1), ("v", 1), ("v", 2)):
-        out += dma_setup(kadd=add, vadd=add, base=TFIRST)[:5] if which == "k" else dma_setup(kadd=add, vadd=add, base=TFIRST)[5:]
+PROLOGUE_TILES = (("k", 0), ("v", 0), ("k", 1), ("v", 1), ("v", 2))      # issue order (ring slot = tile - t0; K runs two tiles ahead, V three)
+
+
+def prologue_pieces(tiles):
+    out = []
+    for which, add in tiles:
+        grp = dma_setup(kadd=add, vadd=add, base=TFIRST)[:5] if which == "k" else dma_setup(kadd=add, vadd=add, base=TFIRST)[5:]
         for j in (range(4) if which == "k" else range(4, 8)):
-            out += dma_piece(j, add, add)
+            out.append(grp + dma_piece(j, add, add))
+            grp = []
+    return out
+
+
+def dma_prologue_code():
+    """the FIRST tile's LDS-DMA K(t0), V(t0) as a statement of its own; the other prologue tiles ride between the initialisation
+    instructions of the main statement (see attn_fwd.dma_prologue_code)"""
+    out = [comment("---- prologue LDS-DMA")] + common_scalars() + [s_nop(3)]
+    for piece in prologue_pieces(PROLOGUE_TILES[:2]):
+        out += piece
     return out
 
 
@@ -365,10 +377,12 @@ def entry_code():
     out = [comment("---- entry of the main statement")]
     if STAMPS:
         out += [s_mov_b32(ACC(i), Lit(0)) for i in range(NACC)]
-    out += common_scalars() + [s_add_i32(TLASTP1, TLAST, Lit(1)), s_mov_b32(IT, TFIRST)]
-    for i in range(128):
-        out.append(v_accvgpr_write(a(i), Lit(0)))
-    out.append(v_mov_b32(NEGINF, Lit(0xFF800000)))
+    out += common_scalars() + [s_add_i32(TLASTP1, TLAST, Lit(1)), s_mov_b32(IT, TFIRST), s_nop(3)]
+    init = [v_accvgpr_write(a(i), Lit(0)) for i in range(128)] + [v_mov_b32(NEGINF, Lit(0xFF800000))]
+    pieces = prologue_pieces(PROLOGUE_TILES[2:])
+    step = max(1, len(init) // len(pieces))
+    for n, piece in enumerate(pieces):
+        out += piece + init[n * step:(n + 1) * step if n + 1 < len(pieces) else len(init)]
     return out
 
 
@@ -425,7 +439,7 @@ def build_program(with_dma_prologue=True):
             P.add(v_mov_b32(TMPA, ACC(i)), v_mov_b32(TMPB, Lit(0)), global_store_dword_s(TMPA, TMPB, DBGPTR, 4 * i))
         P.add(s_waitcnt(vmcnt=0, lgkmcnt=0), s_nop(15))
     else:
-        P.add(label("EXIT"), s_waitcnt(vmcnt=0, lgkmcnt=0), s_nop(15))
+        P.add(label("EXIT"), s_waitcnt(lgkmcnt=0), s_nop(15))      # (LDS-DMA still in flight: see attn_fwd.build_program)
     P.finalize()
     return P, bodies
 

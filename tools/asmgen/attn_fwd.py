@@ -499,14 +499,26 @@ def common_scalars():
     return out
 
 
-def dma_prologue_code():
-    """a statement of its own in the kernel (UR_ATTN_FWD_C128_DMA_ASM), issued before the C++ part scales q: the first tiles'
-    LDS-DMA K(t0), V(t0), K(t0+1), K(t0+2), V(t0+1) (tile indices clamped to tend-1; ring slot = tile - t0)"""
-    out = [comment("---- prologue LDS-DMA")] + common_scalars() + [s_nop(3)]
-    for which, add in (("k", 0), ("v", 0), ("k", 1), ("k", 2), ("v", 1)):
-        out += dma_setup(kadd=add, vadd=add, base=TFIRST)[:5] if which == "k" else dma_setup(kadd=add, vadd=add, base=TFIRST)[5:]
+PROLOGUE_TILES = (("k", 0), ("v", 0), ("k", 1), ("k", 2), ("v", 1))      # issue order (ring slot = tile - t0; tile indices clamped to tend-1)
+
+
+def prologue_pieces(tiles):
+    out = []
+    for which, add in tiles:
+        grp = dma_setup(kadd=add, vadd=add, base=TFIRST)[:5] if which == "k" else dma_setup(kadd=add, vadd=add, base=TFIRST)[5:]
         for j in (range(4) if which == "k" else range(4, 8)):
-            out += dma_piece(j, add, add)
+            out.append(grp + dma_piece(j, add, add))
+            grp = []
+    return out
+
+
+def dma_prologue_code():
+    """a statement of its own in the kernel (UR_ATTN_FWD_C128_DMA_ASM), issued before the C++ part scales q: the FIRST tile's
+    LDS-DMA K(t0), V(t0).  The other three tiles of the prologue are issued by the main statement between its initialisation
+    instructions (a burst of back-to-back pieces waits ~150 cycles per piece on the LDS-DMA path; vector work hides that)."""
+    out = [comment("---- prologue LDS-DMA")] + common_scalars() + [s_nop(3)]
+    for piece in prologue_pieces(PROLOGUE_TILES[:2]):
+        out += piece
     return out
 
 
@@ -514,17 +526,21 @@ def entry_code():
     out = [comment("---- entry of the main statement: scalars and state")]
     if STAMPS:
         out += [s_mov_b32(ACC(i), Lit(0)) for i in range(NACC)]
-    out += common_scalars() + [s_add_i32(TLASTP1, TLAST, Lit(1)), s_mov_b32(IT, TFIRST)]
-    for i in range(128):
-        out.append(v_accvgpr_write(a(i), Lit(0)))
+    out += common_scalars() + [s_add_i32(TLASTP1, TLAST, Lit(1)), s_mov_b32(IT, TFIRST), s_nop(3)]
+    init = [v_accvgpr_write(a(i), Lit(0)) for i in range(128)]
     for qb in range(2):
-        out += [v_mov_b32(M_(qb), Lit(0)), v_mov_b32(ALPHA(0, qb), Lit(1.0)), v_mov_b32(ALPHA(1, qb), Lit(1.0))]
+        init += [v_mov_b32(M_(qb), Lit(0)), v_mov_b32(ALPHA(0, qb), Lit(1.0)), v_mov_b32(ALPHA(1, qb), Lit(1.0))]
         for r in range(16):
-            out += [v_mov_b32(MNEG(qb, r), Lit(0)), v_accvgpr_write(LA(qb, r), Lit(0))]
+            init += [v_mov_b32(MNEG(qb, r), Lit(0)), v_accvgpr_write(LA(qb, r), Lit(0))]
     for j in range(4):
-        out.append(v_mov_b32(ONES(j), Lit(0x3F803F80)))
-    out += [v_mov_b32(NEGINF, Lit(0xFF800000)), v_mov_b32(THRV, Lit(float(THR))), s_mov_b32(PEND0, Lit(0)), s_mov_b32(PEND1, Lit(0)),
-            s_mov_b64(NOTINIT0, Lit(-1)), s_mov_b64(NOTINIT1, Lit(-1))]
+        init.append(v_mov_b32(ONES(j), Lit(0x3F803F80)))
+    init += [v_mov_b32(NEGINF, Lit(0xFF800000)), v_mov_b32(THRV, Lit(float(THR)))]
+    # the remaining prologue tiles' LDS-DMA pieces, one every ~20 initialisation instructions
+    pieces = prologue_pieces(PROLOGUE_TILES[2:])
+    step = max(1, len(init) // len(pieces))
+    for n, piece in enumerate(pieces):
+        out += piece + init[n * step:(n + 1) * step if n + 1 < len(pieces) else len(init)]
+    out += [s_mov_b32(PEND0, Lit(0)), s_mov_b32(PEND1, Lit(0)), s_mov_b64(NOTINIT0, Lit(-1)), s_mov_b64(NOTINIT1, Lit(-1))]
     return out
 
 
@@ -589,8 +605,9 @@ def build_program(with_dma_prologue=True):
     for site in range(2):
         P.add(fix_hazards(oresc_routine(site, sites))[0])
     P.add(label("TRAP"), I("s_trap 2", "salu", (), (), lambda w: (_ for _ in ()).throw(RuntimeError("TRAP reached")), 1))
-    # the compiler's code behind the statement reads O (v_accvgpr_read) and may end the wave: MFMA results need their wait states,
-    # and no LDS-DMA piece may still be in flight when the workgroup gives its LDS back
+    # the compiler's code behind the statement reads O (v_accvgpr_read): MFMA results need their wait states.  LDS-DMA pieces of the
+    # last iterations may still be in flight: vmcnt is in order, so the next block's first ring wait covers them, and the kernel
+    # drains them before it ends (attn.hip).
     if STAMPS:
         # every wave writes its NACC accumulators: DBGPTR already points at this wave's record
         P.add(label("EXIT"))
@@ -599,7 +616,7 @@ def build_program(with_dma_prologue=True):
         P.add(s_waitcnt(vmcnt=0, lgkmcnt=0), s_nop(15))
         P.finalize()
         return P, bodies
-    P.add(label("EXIT"), s_waitcnt(vmcnt=0, lgkmcnt=0), s_nop(15))
+    P.add(label("EXIT"), s_waitcnt(lgkmcnt=0), s_nop(15))
     P.finalize()
     return P, bodies
 

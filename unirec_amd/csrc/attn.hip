@@ -2229,6 +2229,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
     cur = nxt;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA pieces of the last loop iterations: landed before the workgroup gives its LDS back
 }
 
 // ================================================================================================
@@ -2416,6 +2417,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA pieces of the last loop iterations: landed before the workgroup gives its LDS back
 }
 
 // ================================================================================================
