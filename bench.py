@@ -429,7 +429,7 @@ def _comm_info(world):
     if d.is_available() and d.is_initialized():
         be = d.get_backend()
         from unirec_amd import dp as _dp
-        if _dp.use_native_comm() and _dp._native:          # UNIREC_DP_COMM=native: the buckets went through the library's communicator
+        if _dp._native:          # the buckets went through the library's own communicator (default for multi-rank RCCL runs; UNIREC_DP_COMM=torch opts out)
             c = next(iter(_dp._native.values()))
             return {"backend": "rccl (native ur_comm_*; rendezvous over torch.distributed " + be + ")", "ranks": c.world, "allreduce_launches": c.launches}
         return {"backend": "rccl (torch.distributed nccl)" if be == "nccl" else be, "ranks": d.get_world_size()}

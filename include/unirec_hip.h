@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 6
+#define UR_ABI_VERSION 7
 
 int ur_version(void);
 const char* ur_last_error(void);
@@ -412,9 +412,15 @@ int ur_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
  *   ur_comm_allreduce_async  buf (device, `count` elements of dtype, in place) was written on producer_stream: the side stream
  *                          waits for that stream's work up to this call, then reduces.  Calls queue in order on the side
  *                          stream; every rank must issue the same sequence of (count, dtype).  No host synchronisation.
- *   ur_comm_wait           consumer_stream waits for every all-reduce queued so far (event fence, no host sync).  buf must
- *                          stay allocated and untouched by other streams between the two calls.
+ *   ur_comm_ticket         number of all-reduces queued so far = the ticket of the last one (0: none yet).
+ *   ur_comm_wait_ticket    consumer_stream waits for the all-reduce with that ticket (and, the side stream being in order, every
+ *                          earlier one): a consumer can start on bucket k while k + 1 is still in flight.  The library keeps a
+ *                          ring of UR_COMM_RING completion events; a ticket older than the ring waits for the oldest one kept
+ *                          (later in stream order, so still correct).
+ *   ur_comm_wait           = ur_comm_wait_ticket(last ticket): consumer_stream waits for every all-reduce queued so far
+ *                          (event fence, no host sync).  buf must stay allocated and untouched by other streams until waited for.
  *   ur_comm_destroy        synchronises the side stream, frees communicator, stream and events.  NULL is a no-op.
+ * Every call selects the communicator's device for its own duration and restores the caller's.
  * Errors: < 0 invalid argument (-2: RCCL could not be loaded -- it is resolved with dlopen at the first ur_comm_* call, so
  * the library itself does not depend on it), 1..999 HIP error codes, 1000 + ncclResult_t for RCCL failures. */
 #define UR_COMM_ID_BYTES 128
@@ -423,6 +429,9 @@ int ur_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int ur_comm_unique_id(void* id_out);
 int ur_comm_init(void** comm_out, int32_t rank, int32_t world, const void* unique_id, int32_t device);
 int ur_comm_allreduce_async(void* comm, void* buf, int64_t count, int32_t dtype, void* producer_stream);
+#define UR_COMM_RING 64
+int64_t ur_comm_ticket(void* comm);
+int ur_comm_wait_ticket(void* comm, int64_t ticket, void* consumer_stream);
 int ur_comm_wait(void* comm, void* consumer_stream);
 int ur_comm_destroy(void* comm);
 

@@ -214,6 +214,11 @@ MID_STRIDE = 16
 # 2 layers of the 0.6B shape, B 2 x S 256, left padding.  lora_B ~ N(0, 0.05) so the adapter term is ~40 % of |W|.
 LORA = dict(kind="qwen_lora", seed=57, B=2, S=256, pad_side="left", lora_r=16, lora_alpha=32.0, lora_b_std=0.05,
             qwen=dict(D=1024, L=2, nq=16, nkv=8, hd=128, I=3072, vocab=64))
+# ... and the same at 4 x 512 = 2048 tokens: the q|k|v (N 4096) and gate|up (N 6144) launches then have >= 128 output tiles of 256 x 256,
+# i.e. they run on gemm_pers_kernel<3|4, 1> (fused q/k-norm + RoPE / SwiGLU epilogues with the LoRA K tile), which the 512-token case does not reach
+LORA_BIG = dict(kind="qwen_lora", seed=58, B=4, S=512, pad_side="left", lora_r=16, lora_alpha=32.0, lora_b_std=0.05,
+                qwen=dict(D=1024, L=2, nq=16, nkv=8, hd=128, I=3072, vocab=64))
+LORA_CASES = {"qwen_lora": LORA, "qwen_lora_big": LORA_BIG}
 LORA_PROJ = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
 # adapter gradients stored in full (the others by their norms): one of every projection kind, both layers touched
 LORA_FULL = ("layers.0.self_attn.q_proj", "layers.0.self_attn.v_proj", "layers.1.self_attn.o_proj", "layers.1.mlp.gate_proj", "layers.0.mlp.down_proj")

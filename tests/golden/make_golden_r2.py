@@ -16,10 +16,12 @@ make_golden.py, which this script imports):
                       0.6B shape, B 2 x S 256: pooled output, gradient w.r.t. inputs_embeds, and dA / dB of every adapter
                       derived from the merged weights' gradients dW' (peft is not installed; its call site is
                       training/train_item_individual_token_joint.py:121-131)
+  qwen_lora_big.npz   the same at B 4 x S 512 = 2048 tokens (cases.LORA_BIG): the size at which the product's q|k|v and gate|up launches run
+                      on the persistent GEMM with the fused q/k-norm + RoPE / SwiGLU epilogues and the LoRA K tile
   state_dict_shapes.json   key -> shape of the reference modules' state_dict (item default / Q=8 duplicate / C1 / C2,
                       UserQFormer default): the checkpoint-compatibility contract of SURVEY 8(b)
 
-Usage:  python tests/golden/make_golden_r2.py [qwen_mid qwen_deep user_mid item_mid joint_mid qwen_lora use_real shapes]
+Usage:  python tests/golden/make_golden_r2.py [qwen_mid qwen_deep user_mid item_mid joint_mid qwen_lora qwen_lora_big use_real shapes]
 """
 import json
 import os
@@ -176,11 +178,13 @@ def main():
             path = os.path.join(HERE, name + ".npz")
             np.savez_compressed(path, **{k: np.asarray(v) for k, v in res.items()})
             print(f"{name}: {len(res)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
-    if want("qwen_lora"):
-        res = gen_qwen_lora(cases.LORA)
-        path = os.path.join(HERE, "qwen_lora.npz")
+    for lname, lcase in cases.LORA_CASES.items():
+        if not want(lname):
+            continue
+        res = gen_qwen_lora(lcase)
+        path = os.path.join(HERE, lname + ".npz")
         np.savez_compressed(path, **{k: np.asarray(v) for k, v in res.items()})
-        print(f"qwen_lora: {len(res)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+        print(f"{lname}: {len(res)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
     if want("use_real"):
         res = gen_use_real()
         path = os.path.join(HERE, "use_real.npz")

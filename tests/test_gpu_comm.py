@@ -28,6 +28,13 @@ def comm():
     c.close()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_unique_ids_are_fresh_and_128_bytes():
     a, b = dp.NativeComm.new_unique_id(), dp.NativeComm.new_unique_id()
     assert len(a) == len(b) == 128 and a != b
@@ -72,6 +79,37 @@ def test_bucket_slices_reduce_in_place_and_zero_counts_are_accepted(comm):
     assert torch.equal(flat, ref) and comm.launches == 3        # the empty bucket [8, 8) sends nothing
 
 
+def test_tickets_fence_single_buckets(comm):
+    """every all-reduce has a ticket; a consumer stream can wait for ONE bucket (and what precedes it) while later ones are queued"""
+    lib = _lib.load()
+    t0 = comm.ticket()
+    flat = torch.arange(4096, dtype=torch.float32, device=DEV)
+    ref = flat.clone()
+    bk = dp.GradBuckets(flat, [0, 1024, 2048, 4096], comm=comm)
+    bk.ready_all()                                   # buckets 2, 1, 0 in backward order
+    assert comm.ticket() == t0 + 3 and bk.tickets == {2: t0 + 1, 1: t0 + 2, 0: t0 + 3}
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        bk.wait_bucket(2, side)                      # fences on the first queued bucket only
+        head = flat[2048:].clone()
+    bk.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(head, ref[2048:]) and torch.equal(flat, ref) and bk.tickets == {}
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.ur_comm_wait_ticket(comm._handle, comm.ticket() + 1, st) < 0 and b"ticket" in lib.ur_last_error()
+    assert lib.ur_comm_wait_ticket(comm._handle, 0, st) == 0
+    # more all-reduces than the ring holds: an old ticket still waits (for a later event of the same in-order stream)
+    x = torch.ones(8, device=DEV)
+    first = None
+    for i in range(70):
+        comm.all_reduce_(x)
+        first = first or comm.ticket()
+    comm.wait(ticket=first)
+    comm.wait()
+    torch.cuda.synchronize()
+    assert torch.equal(x, torch.ones(8, device=DEV))
+
+
 def test_error_paths_return_codes_and_messages(comm):
     lib = _lib.load()
     t = torch.zeros(16, dtype=torch.float32, device=DEV)
@@ -108,7 +146,7 @@ def test_joint_step_through_the_native_communicator_equals_the_plain_step():
     """bench.py's joint step with every bucket all-reduce going through ur_comm_* (one rank): same loss and parameter
     checksums as the step without any process group, and the line says which communicator ran."""
     plain = _bench()
-    native = _bench(env={"UNIREC_DP_FORCE": "1", "UNIREC_DP_COMM": "native", "MASTER_PORT": "29519"})
+    native = _bench(env={"UNIREC_DP_FORCE": "1", "UNIREC_DP_COMM": "native", "MASTER_PORT": str(_free_port())})
     assert native["comm"]["backend"].startswith("rccl (native ur_comm_*") and native["comm"]["ranks"] == 1
     assert native["comm"]["allreduce_launches"] > 0
     assert native["loss"] == plain["loss"] and native["param_checksum"] == plain["param_checksum"]

@@ -30,9 +30,16 @@ def _bench(extra_args=(), env=None, timeout=600):
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_one_rank_rccl_step_equals_the_step_without_a_process_group():
     plain = _bench()
-    forced = _bench(env={"UNIREC_DP_FORCE": "1", "MASTER_PORT": "29517"})
+    forced = _bench(env={"UNIREC_DP_FORCE": "1", "MASTER_PORT": str(_free_port())})
     assert plain["comm"] == {"backend": None, "ranks": 1}
     assert forced["comm"] == {"backend": "rccl (torch.distributed nccl)", "ranks": 1}
     for d in (plain, forced):

@@ -38,12 +38,13 @@ def test_qwen3_mid_size(golden_dir, name):
     assert abs(gn - float(g["sdpa/grad_inputs_embeds_norm"])) <= 1e-3 * gn
 
 
-def test_lora_unmerged_matches_merged_transformers(golden_dir):
+@pytest.mark.parametrize("name", ["qwen_lora", "qwen_lora_big"])
+def test_lora_unmerged_matches_merged_transformers(golden_dir, name):
     """J4 pin: the oracle's UNMERGED LoRA (y = W x + (alpha / r) B A x, oracle/qwen3_ref.py:lora_linear) against the installed
     Qwen3Model run with merged weights W + (alpha / r) B A (tests/golden/make_golden_r2.py:gen_qwen_lora): pooled output,
     input gradient, and dA / dB of every adapter (full tensors for cases.LORA_FULL, norms for all 14 x 2)."""
-    case = cases.LORA
-    g = _load(golden_dir, "qwen_lora")
+    case = cases.LORA_CASES[name]
+    g = _load(golden_dir, name)
     qc = cases.qwen_cfg(case)
     qc.lora_r, qc.lora_alpha, qc.lora_dropout = case["lora_r"], case["lora_alpha"], 0.0
     sd = W.fill_state_dict(Q.qwen3_shapes(qc, lora=True), case["seed"] + 1, rules=cases.lora_weight_rules(case))

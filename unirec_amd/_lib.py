@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UNIREC_HIP_LIB selects another build of the SAME library (kernel A/B experiments); there is still no fallback.
 LIB_PATH = os.environ.get("UNIREC_HIP_LIB") or os.path.join(_HERE, "lib", "libunirec_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_void_p, c_int, c_i64, c_u64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
@@ -77,6 +77,8 @@ SIGNATURES = {
     "ur_comm_unique_id": (c_int, [c_void_p]),
     "ur_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_int, c_int, c_void_p, c_int]),
     "ur_comm_allreduce_async": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p]),
+    "ur_comm_ticket": (c_i64, [c_void_p]),
+    "ur_comm_wait_ticket": (c_int, [c_void_p, c_i64, c_void_p]),
     "ur_comm_wait": (c_int, [c_void_p, c_void_p]),
     "ur_comm_destroy": (c_int, [c_void_p]),
     "ur_gemm_workspace_bytes": (c_i64, [ctypes.POINTER(GemmArgs)]),

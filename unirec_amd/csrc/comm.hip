@@ -5,11 +5,14 @@
 // parallelism -- one process per GPU, a SUM all-reduce per gradient bucket over RCCL / xGMI, overlapped with the backward.
 //
 // Ownership and ordering (no host synchronisation anywhere):
-//   * the library owns the RCCL communicator, ONE side stream and two events; the caller owns every buffer;
+//   * the library owns the RCCL communicator, ONE side stream, a `ready` event and a ring of completion events; the caller owns every buffer;
 //   * ur_comm_allreduce_async(buf, producer_stream): records `ready` on the producer stream (the stream whose kernels wrote
 //     buf), makes the side stream wait for it, and queues an in-place sum all-reduce on the side stream.  Buckets queue in call
 //     order on that one stream -- the same order on every rank, which is what RCCL requires;
-//   * ur_comm_wait(consumer_stream): the consumer stream (the optimizer's) waits for everything queued so far.
+//   * ur_comm_wait(consumer_stream): the consumer stream (the optimizer's) waits for everything queued so far;
+//     ur_comm_wait_ticket(ticket, consumer_stream) for ONE bucket and everything before it (every all-reduce records its own event of
+//     a ring), so a consumer can start on the first buckets while the last are still on the wire;
+//   * every call runs on the communicator's device and restores the caller's current device.
 //   The buffer must stay allocated and untouched by other streams until a ur_comm_wait has been issued.
 //
 // RCCL is resolved at run time (dlopen of librccl.so.1, preferring the copy the process has already loaded -- PyTorch-ROCm
@@ -18,6 +21,7 @@
 #include "common.cuh"
 #include "unirec_hip.h"
 
+#include <algorithm>
 #include <dlfcn.h>
 #include <mutex>
 #include <rccl/rccl.h>
@@ -72,9 +76,19 @@ struct Comm {
   uint32_t magic = COMM_MAGIC;
   ncclComm_t comm = nullptr;
   hipStream_t side = nullptr;
-  hipEvent_t ready = nullptr, done = nullptr;
+  hipEvent_t ready = nullptr, done[UR_COMM_RING] = {};      // done[(ticket - 1) % UR_COMM_RING]: completion of the all-reduce with that ticket
   int rank = 0, world = 1, device = 0;
   long long queued = 0;
+};
+
+// the communicator's device for the duration of a call (a caller thread may have another one current)
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  explicit DeviceScope(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
 };
 
 Comm* as_comm(void* p) {
@@ -115,7 +129,12 @@ extern "C" int ur_comm_init(void** comm_out, int32_t rank, int32_t world, const 
   UR_REQUIRE(device >= 0, "%s: device %d", fn, device);
   const RcclApi* a = api();
   if (!a) UR_FAIL(-2, "%s: %s", fn, g_api.why);
-  UR_HIP_OK(hipSetDevice(device), "hipSetDevice");
+  DeviceScope scope(device);
+  {
+    int cur = -1;
+    UR_HIP_OK(hipGetDevice(&cur), "hipGetDevice");
+    UR_REQUIRE(cur == device, "%s: cannot select device %d", fn, device);
+  }
   Comm* c = new Comm();
   c->rank = rank; c->world = world; c->device = device;
   ncclUniqueId id;
@@ -127,9 +146,9 @@ extern "C" int ur_comm_init(void** comm_out, int32_t rank, int32_t world, const 
   }
   hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ready, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done, hipEventDisableTiming);
+  for (int i = 0; e == hipSuccess && i < UR_COMM_RING; ++i) e = hipEventCreateWithFlags(&c->done[i], hipEventDisableTiming);
   if (e != hipSuccess) {
-    if (c->done) (void)hipEventDestroy(c->done);
+    for (int i = 0; i < UR_COMM_RING; ++i) if (c->done[i]) (void)hipEventDestroy(c->done[i]);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->side) (void)hipStreamDestroy(c->side);
     a->CommDestroy(c->comm);
@@ -151,22 +170,38 @@ extern "C" int ur_comm_allreduce_async(void* comm, void* buf, int64_t count, int
   UR_REQUIRE((((uintptr_t)buf) & (dtype == UR_COMM_F32 ? 3 : 1)) == 0, "%s: buf is not aligned to its element size", fn);
   const RcclApi* a = api();
   if (!a) UR_FAIL(-2, "%s: %s", fn, g_api.why);
+  DeviceScope scope(c->device);
   hipStream_t prod = static_cast<hipStream_t>(producer_stream);
   UR_HIP_OK(hipEventRecord(c->ready, prod), "hipEventRecord(ready)");
   UR_HIP_OK(hipStreamWaitEvent(c->side, c->ready, 0), "hipStreamWaitEvent(side)");
   UR_RCCL_OK(a->AllReduce(buf, buf, (size_t)count, dtype == UR_COMM_F32 ? ncclFloat32 : ncclBfloat16, ncclSum, c->comm, c->side), "ncclAllReduce");
-  UR_HIP_OK(hipEventRecord(c->done, c->side), "hipEventRecord(done)");
+  UR_HIP_OK(hipEventRecord(c->done[c->queued % UR_COMM_RING], c->side), "hipEventRecord(done)");
   c->queued += 1;
   return 0;
 }
 
-extern "C" int ur_comm_wait(void* comm, void* consumer_stream) {
-  static const char* fn = "ur_comm_wait";
+extern "C" int64_t ur_comm_ticket(void* comm) {
+  Comm* c = as_comm(comm);
+  return c ? (int64_t)c->queued : -1;
+}
+
+extern "C" int ur_comm_wait_ticket(void* comm, int64_t ticket, void* consumer_stream) {
+  static const char* fn = "ur_comm_wait_ticket";
   Comm* c = as_comm(comm);
   UR_REQUIRE(c != nullptr, "%s: not a communicator from ur_comm_init", fn);
-  if (c->queued == 0) return 0;
-  UR_HIP_OK(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), c->done, 0), "hipStreamWaitEvent(consumer)");
+  UR_REQUIRE(ticket >= 0 && ticket <= c->queued, "%s: ticket %lld outside 0..%lld", fn, (long long)ticket, c->queued);
+  if (ticket == 0) return 0;
+  // an event that has left the ring was re-recorded by a LATER all-reduce of the same in-order stream: waiting for the oldest one kept covers it
+  const long long t = std::max<long long>(ticket, c->queued - UR_COMM_RING + 1);
+  DeviceScope scope(c->device);
+  UR_HIP_OK(hipStreamWaitEvent(static_cast<hipStream_t>(consumer_stream), c->done[(t - 1) % UR_COMM_RING], 0), "hipStreamWaitEvent(consumer)");
   return 0;
+}
+
+extern "C" int ur_comm_wait(void* comm, void* consumer_stream) {
+  Comm* c = as_comm(comm);
+  if (c == nullptr) UR_FAIL(-1, "ur_comm_wait: not a communicator from ur_comm_init");
+  return ur_comm_wait_ticket(comm, (int64_t)c->queued, consumer_stream);
 }
 
 extern "C" int ur_comm_destroy(void* comm) {
@@ -175,10 +210,11 @@ extern "C" int ur_comm_destroy(void* comm) {
   Comm* c = as_comm(comm);
   UR_REQUIRE(c != nullptr, "%s: not a communicator from ur_comm_init", fn);
   const RcclApi* a = api();
+  DeviceScope scope(c->device);
   hipError_t e = hipStreamSynchronize(c->side);          // tear-down only: nothing of ours may still be queued
   if (a && c->comm) a->CommDestroy(c->comm);
   (void)hipEventDestroy(c->ready);
-  (void)hipEventDestroy(c->done);
+  for (int i = 0; i < UR_COMM_RING; ++i) (void)hipEventDestroy(c->done[i]);
   (void)hipStreamDestroy(c->side);
   c->magic = 0;
   delete c;

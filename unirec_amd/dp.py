@@ -13,6 +13,7 @@ of the global minibatch and the only exchange is the gradient all-reduce:
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): few large messages, not many small ones.
 Works unchanged with backend "gloo" on CPU tensors (tests/test_dp_gloo.py).
 """
+import atexit
 import os
 
 import torch
@@ -160,21 +161,23 @@ class NativeComm:
         self.launches += 1
         return self
 
-    def wait(self, stream=None):
-        """`stream` (default: torch's current stream) waits for every all-reduce queued so far."""
+    def ticket(self):
+        """ticket of the last all-reduce queued (0: none yet); wait(ticket=...) fences on that one and everything before it"""
+        return int(self._lib.ur_comm_ticket(self._handle))
+
+    def wait(self, stream=None, ticket=None):
+        """`stream` (default: torch's current stream) waits for every all-reduce queued so far, or up to `ticket`."""
         st = (stream or torch.cuda.current_stream(self.device)).cuda_stream
-        self._check(self._lib.ur_comm_wait(self._handle, st), "ur_comm_wait")
+        if ticket is None:
+            self._check(self._lib.ur_comm_wait(self._handle, st), "ur_comm_wait")
+        else:
+            self._check(self._lib.ur_comm_wait_ticket(self._handle, int(ticket), st), "ur_comm_wait_ticket")
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
             h, self._handle = self._handle, None
             self._check(self._lib.ur_comm_destroy(h), "ur_comm_destroy")
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
 
 _native = {}
@@ -189,14 +192,29 @@ def native_comm(device, group=None):
 
 
 def close_native_comms():
-    for c in _native.values():
-        c.close()
+    for c in list(_native.values()):
+        try:
+            c.close()
+        except Exception:
+            pass
     _native.clear()
 
 
-def use_native_comm():
-    """UNIREC_DP_COMM=native: the bucket all-reduces go through ur_comm_* instead of torch.distributed's nccl group."""
-    return os.environ.get("UNIREC_DP_COMM", "torch") == "native"
+# communicators are torn down at interpreter exit, while HIP is still alive -- not from __del__ during module teardown
+atexit.register(close_native_comms)
+
+
+def use_native_comm(group=None):
+    """The bucket all-reduces of a multi-rank run go through the library's own communicator (ur_comm_*: the C-ABI path SURVEY 8(b)
+    names) whenever the process group runs on RCCL; UNIREC_DP_COMM=torch opts out (torch.distributed's all_reduce), =native forces
+    it (also for one rank: the launch path on a one-GPU box).  gloo groups (CPU rehearsals) always use torch.distributed."""
+    mode = os.environ.get("UNIREC_DP_COMM", "auto")
+    if mode in ("native", "torch"):
+        return mode == "native"
+    try:
+        return dist.get_world_size(group) > 1 and dist.get_backend(group) == "nccl"
+    except Exception:
+        return False
 
 
 class GradBuckets:
@@ -209,6 +227,7 @@ class GradBuckets:
         self.bounds = list(boundaries)
         self.group = group
         self.pending = []
+        self.tickets = {}          # native communicator: bucket index -> ticket of its all-reduce (wait_bucket)
         self.stash = None          # micro-batch accumulation: gradients of the earlier micro-batches of this step
         self.hold = False          # True while a non-final micro-batch runs its backward: hooks accumulate, nothing is sent
         self.enabled = dist.is_available() and dist.is_initialized() and (
@@ -216,7 +235,7 @@ class GradBuckets:
         self.comm = comm
         if comm is not None:
             self.enabled = True
-        elif self.enabled and use_native_comm() and flat_grad.is_cuda:
+        elif self.enabled and use_native_comm(group) and flat_grad.is_cuda:
             self.comm = native_comm(flat_grad.device, group)
 
     @property
@@ -239,6 +258,7 @@ class GradBuckets:
             self.stash[lo:hi].zero_()
         if self.enabled and self.comm is not None:
             self.comm.all_reduce_(self.flat[lo:hi])
+            self.tickets[i] = self.comm.ticket()
         elif self.enabled:
             self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -252,9 +272,17 @@ class GradBuckets:
         for i in reversed(range(self.n)):
             self.ready(i)
 
+    def wait_bucket(self, i, stream=None):
+        """the current stream waits for bucket i's all-reduce only (native communicator; otherwise for everything queued)"""
+        if self.comm is not None and self.enabled and i in self.tickets:
+            self.comm.wait(stream, ticket=self.tickets[i])
+        else:
+            self.wait()
+
     def wait(self):
         if self.comm is not None and self.enabled:
             self.comm.wait()
+            self.tickets = {}
         for w in self.pending:
             w.wait()
         self.pending = []

@@ -109,6 +109,7 @@ _FUSE_NORM_LORA = os.environ.get("UNIREC_FUSE_NORM_LORA", "1") != "0"
 # UNIREC_FUSE_QK_ROPE=0 (lab): q/k-norm + RoPE as their own pass over the raw q|k|v again (the fused form needs the persistent GEMM:
 # >= 128 output tiles, S >= 256, head_dim 128; smaller launches take the separate pass anyway)
 _FUSE_QK_ROPE = os.environ.get("UNIREC_FUSE_QK_ROPE", "1") != "0"
+_QK_FUSE_MAX_RATIO = 4.0      # largest |w_d| / |w_{d+64}| spread of a rotate-half pair of the q / k norm weights under which the fused epilogue is used
 # UNIREC_FUSE_SWIGLU_GEMM=0 (lab): SwiGLU forward as its own pass over gate|up again (the fused form rides in the merged gate|up launch on
 # the persistent GEMM: interleaved weight rows put gate and up of a feature into one lane; the down adapter's t = dropout(act) A^T is
 # then a lora_project pass over act)
@@ -285,10 +286,24 @@ class Qwen3LoRAModel(nn.Module):
                 "qn": a.q_norm.weight.detach().to(dev, F32).contiguous(), "kn": a.k_norm.weight.detach().to(dev, F32).contiguous(),
                 "ln1": lyr.input_layernorm.weight.detach().to(dev, F32).contiguous(),
                 "ln2": lyr.post_attention_layernorm.weight.detach().to(dev, F32).contiguous()})
-        # the fused epilogue's backward divides by the norm weights (x^ = R^T(o) / w)
-        fz["qk_norm_nonzero"] = all(bool((l["qn"] != 0).all()) and bool((l["kn"] != 0).all()) for l in fz["layers"])
+        # The fused epilogue's backward recovers the normalised rows from the bf16 roped outputs (x^ = R^T(o) / w): the rounding
+        # error of a rotate-half pair (d, d + 64) scales with the larger of its two entries and is divided by each one's own weight,
+        # i.e. it is amplified by max(|w_d|, |w_{d+64}|) / min(...).  Fuse only while that conditioning stays small; a checkpoint
+        # with widely spread norm weights takes the separate q/k-norm + RoPE pass (which keeps the raw q, k).
+        def well_conditioned(w):
+            a = w.abs().view(2, -1)
+            lo, hi = torch.minimum(a[0], a[1]), torch.maximum(a[0], a[1])
+            return bool((lo > 0).all()) and bool((hi <= _QK_FUSE_MAX_RATIO * lo).all())
+        fz["qk_norm_fusable"] = all(well_conditioned(l["qn"]) and well_conditioned(l["kn"]) for l in fz["layers"])
         self._frozen = fz
         return fz
+
+    def _swiglu_rows(self, I, device):
+        """hip.swiglu_pair_rows(I) on `device`, built once (a host -> device copy per forward would block the host on the stream)"""
+        key = (str(device), int(I))
+        if getattr(self, "_sp", None) is None or self._sp[0] != key:
+            self._sp = (key, hip.swiglu_pair_rows(I).to(device))
+        return self._sp[1]
 
     def _qk_row_perm(self, device):
         """Row order of the paired q|k|v operand: inside every q / k head tile column c holds feature qkrope_perm[c]; v rows stay."""
@@ -410,7 +425,7 @@ class Qwen3LoRAModel(nn.Module):
         torch._foreach_copy_(self._bcomb["dst"], self._bcomb["src"])
         rp = self._qk_row_perm(device) if _FUSE_QK_ROPE else None
         self._bcomb["qkvP"] = self._bcomb["qkv"].index_select(1, rp) if rp is not None else None      # rows paired like fz["qkvP"]
-        self._bcomb["guP"] = (self._bcomb["gu"].index_select(1, hip.swiglu_pair_rows(I).to(device)) if (_FUSE_SWIGLU_GEMM and I % 128 == 0) else None)
+        self._bcomb["guP"] = (self._bcomb["gu"].index_select(1, self._swiglu_rows(I, device)) if (_FUSE_SWIGLU_GEMM and I % 128 == 0) else None)
         return self._bcomb["qkv"], self._bcomb["gu"]
 
     def _lora_transposes(self, pack):
@@ -495,7 +510,7 @@ class Qwen3LoRAModel(nn.Module):
             lp = f"layers.{i}."
             L = {"x": x}
             # q/k-norm + RoPE inside the q|k|v launch (the raw q, k are never written or re-read) when the persistent GEMM takes it
-            fuse_rope = (_FUSE_QK_ROPE and hd == 128 and fl["qkvP"] is not None and fz["qk_norm_nonzero"] and (pack is None or bc_qkv is not None) and
+            fuse_rope = (_FUSE_QK_ROPE and hd == 128 and fl["qkvP"] is not None and fz["qk_norm_fusable"] and (pack is None or bc_qkv is not None) and
                          hip.gemm_qkrope_supported(M, NQ + 2 * NKV, D, 3 * r if pack is not None else 0, S, NQ, NKV, dev))
             qkv = None if fuse_rope else torch.empty((M, NQ + 2 * NKV), dtype=BF16, device=dev)
             if fuse_norm:      # RMSNorm + the q|k|v adapters' down projection in one pass over x (h is written once, never re-read by a projection kernel)
