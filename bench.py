@@ -166,6 +166,23 @@ def attn_executed_ratio(am, S, kt=64):
     return {"fwd": 2.25 * pairs_q / (2.0 * alg), "bwd": (3.0 * pairs_q + 4.0 * pairs_k) / (5.0 * alg)}
 
 
+def device_peaks():
+    """Peaks READ FROM THE DEVICE beside the datasheet ones: bf16 dense MFMA = CUs x max shader clock x 4096 FLOP per CU
+    and clock (4 SIMDs x one v_mfma_f32_32x32x16_bf16 = 32768 FLOP per 32 cycles); HBM from the memory clock and bus width."""
+    out = {"mfma_bf16_TFLOPs_spec": 2500.0, "hbm_GBps_spec": 8000.0}
+    try:
+        pr = torch.cuda.get_device_properties(0)
+        cus, khz = int(pr.multi_processor_count), int(getattr(pr, "clock_rate", 0))
+        out.update({"compute_units": cus, "max_shader_clock_MHz": round(khz / 1e3, 1),
+                    "mfma_bf16_TFLOPs_device": round(cus * khz * 1e3 * 4096 / 1e12, 1) if khz else None})
+        mk, bw = int(getattr(pr, "memory_clock_rate", 0)), int(getattr(pr, "memory_bus_width", 0))
+        if mk and bw:
+            out.update({"memory_clock_MHz": round(mk / 1e3, 1), "memory_bus_bits": bw, "hbm_GBps_device": round(2.0 * mk * 1e3 * bw / 8 / 1e9, 1)})
+    except Exception as e:                      # noqa: BLE001 -- the line must still print
+        out["error"] = str(e)
+    return out
+
+
 def _cpu_threads(args):
     try:
         avail = len(os.sched_getaffinity(0))
@@ -396,7 +413,7 @@ def measure_stage(args, rank, world, device):
                 print(f"M={k[0]:7d} N={k[1]:5d} K={k[2]:7d} rk={int(k[3])} sk={int(k[4])} f32={int(k[5])} split={k[6]:3d} epi={k[7]}: {n // args.steps:4d}/step x "
                       f"{ms / n * 1e3:7.1f} us = {ms / args.steps:6.2f} ms/step  {2.0 * k[0] * k[1] * k[2] * n / ms / 1e9:7.1f} TFLOP/s", file=sys.stderr)
         ach = g_fl / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
-        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
+        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None, "peak_device": device_peaks(),
                 "kernel": "gemm_kernel<...> (all MFMA GEMM launches of the stage)", "launches": len(prof),
                 "avg_launch_ms": round(g_ms / max(len(prof), 1), 4), "gemm_ms_per_step": round(g_ms / args.steps, 2),
                 "step_frac_of_peak": round(flops / (dt / args.steps) / 2.5e15, 4)}
@@ -534,6 +551,7 @@ def main():
     sync()
     hip.PROFILE = []
     hip.PROFILE_ATTN = []
+    hip.PROFILE_STREAM = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -541,6 +559,7 @@ def main():
     dt = time.perf_counter() - t0
     prof, hip.PROFILE = hip.PROFILE, None
     aprof, hip.PROFILE_ATTN = hip.PROFILE_ATTN, None
+    sprof, hip.PROFILE_STREAM = hip.PROFILE_STREAM, None
     if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -571,6 +590,17 @@ def main():
                 if epi == 0:
                     pl_ms += ms; pl_fl += 2.0 * M * N * K; pl_n += 1
         ach = tot_fl / (tot_ms * 1e-3) / 1e12 if tot_ms > 0 else 0.0
+        e1_ms = sum(e0.elapsed_time(e1) for (e0, e1, rk, sk, f32, M, N, K, split, epi) in prof if epi == 1)
+        e1_fl = sum(2.0 * M * N * K for (e0, e1, rk, sk, f32, M, N, K, split, epi) in prof if epi == 1)
+        e1_n = sum(1 for r_ in prof if r_[9] == 1)
+        peaks = device_peaks()
+        # HBM-bound families (hbm_fraction = algorithmic bytes / (time x peak bandwidth)), HIP events around every launch
+        fam = {}
+        for (e0, e1, family, nbytes) in sprof:
+            f_ = fam.setdefault(family, [0.0, 0, 0])
+            f_[0] += e0.elapsed_time(e1); f_[1] += nbytes; f_[2] += 1
+        streams = {k: {"launches": v[2], "ms_per_step": round(v[0] / args.steps, 3), "GB_per_s": round(v[1] / max(v[0], 1e-9) / 1e6, 1),
+                       "hbm_fraction": round(v[1] / max(v[0], 1e-9) / 1e6 / peaks["hbm_GBps_spec"], 4)} for k, v in sorted(fam.items())}
         # HBM-side bytes of one launch from the separate rocprofv3 --pmc passes (profiles/r2_gemm_pmc.json: FETCH_SIZE x2 +
         # WRITE_SIZE, the MI355X_MICROARCH corrections); bench.py itself cannot collect PMC counters.  Reported for the
         # largest launch of the family, the merged gate|up forward (M=131072, N=6144, K=1024).
@@ -585,7 +615,11 @@ def main():
         except Exception:
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
-                "traffic": traffic, "kernel": "gemm_pers_kernel<EPI 0|2|3|4|5, MODE> + gemm_kernel<true,true,false,256,256,2,4,0> (K-contiguous 256x256 projection GEMM: forward + "
+                "traffic": traffic, "peak_device": peaks,
+                "swiglu_backward_launch": {"launches": e1_n, "avg_launch_ms": round(e1_ms / max(e1_n, 1), 4), "tflops": round(e1_fl / max(e1_ms, 1e-9) / 1e9, 1),
+                                           "frac": round(e1_fl / max(e1_ms, 1e-9) / 1e9 / 2500.0, 4),
+                                           "note": "gemm_pers_kernel<1, 2>: the down-projection dX launch that carries the SwiGLU backward in its epilogue (outside `frac`, inside all_gemm_tflops)"},
+                "hbm_bound_families": streams, "kernel": "gemm_pers_kernel<EPI 0|2|3|4|5, MODE> + gemm_kernel<true,true,false,256,256,2,4,0> (K-contiguous 256x256 projection GEMM: forward + "
                           "frozen-weight dX; the persistent kernel takes the launches csrc/gemm_pers.hip:gemm_pers_eligible accepts; launches with the q/k-norm + RoPE or "
                           "SwiGLU-forward epilogue are counted with their GEMM FLOPs only)",
                 "plain_epilogue_launches": {"launches": pl_n, "avg_launch_ms": round(pl_ms / max(pl_n, 1), 4),

@@ -268,7 +268,7 @@ def test_gemm_swiglu_forward_epilogue(M, I, K):
 
 @pytest.mark.parametrize("p", [0.1, 0.2, 0.5])
 def test_dropout_counter_hash_statistics(p):
-    """The counter-based dropout generator (common.cuh ur_hash2: keyed 32-bit murmur finaliser): drop rate, independence
+    """The counter-based dropout generator (common.hip.h ur_hash2: keyed 32-bit murmur finaliser): drop rate, independence
     of neighbouring elements (along a row and across rows), and independence of the streams of neighbouring seeds and of
     seeds that differ only in their high word -- all within 5 sigma on 2^21 decisions."""
     M, H = 2048, 1024

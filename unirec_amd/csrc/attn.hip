@@ -23,7 +23,7 @@
 #include <algorithm>
 #include <type_traits>
 #include <cstdlib>
-#include "common.cuh"
+#include "common.hip.h"
 #include "unirec_hip.h"
 #ifndef UR_ATTN_FWD_C128_HDR
 #define UR_ATTN_FWD_C128_HDR "gen/attn_fwd_c128_asm.h"      // lab builds point this at an ablated variant (tools/lab/c128_variants.sh)
@@ -179,7 +179,7 @@ __device__ __forceinline__ bf16x8 row_frag(const char* tile, int r0, int s, int 
 }
 // transposed fragments: A[m = 32*dt + (lane&31)][k-element j] = X[r0 + 8*(j>>2) + 4*(lane>>5) + (j&3)][m]
 // for dt = 0..NDT-1 (16 rows r0..r0+15 of X; k order matches an accumulator tile used as the B operand).
-// Inline-asm ds_read_b64_tr_b16 batches (common.cuh: the builtin would drain the LDS-DMA prefetch).
+// Inline-asm ds_read_b64_tr_b16 batches (common.hip.h: the builtin would drain the LDS-DMA prefetch).
 template <int HD>
 __device__ __forceinline__ void tr_frags(bf16x8 (&f)[Cfg<HD>::NDT], const char* tile, int r0, int lane) {
   const int h = lane >> 5, g16 = (lane >> 4) & 1, i = lane & 15;
@@ -2576,7 +2576,7 @@ inline int device_cu_count() {
 }
 // test / lab switch, read on every call: UR_ATTN_C128=0 sends the causal head_dim-128 forward back to attn_fwd_kernel
 inline bool fwd_c128_enabled() { const char* e = getenv("UR_ATTN_C128"); return !(e && e[0] == '0'); }
-inline bool fwd_gq2_enabled() { static const bool on = [] { const char* e = getenv("UR_FWD_GQ2"); return e && e[0] == '1'; }(); return on; }
+inline bool fwd_gq2_enabled() { static const bool on = ur_lab_int("UR_FWD_GQ2", 0) == 1; return on; }
 template <int HD, bool CAUSAL, int NW>
 int launch_fwd(const AttnP& p, hipStream_t st) {
   if constexpr (HD == 128 && CAUSAL && NW == 4) {

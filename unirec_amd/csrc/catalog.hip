@@ -11,7 +11,7 @@
 //                       evaluation over pool = all items); the catalogue is read once per 16 users.
 //   ur_rank_of_index  : rank_b = 1 + #{n : s_bn > s_b,gt_b}  (:416-417: position of the positive in the descending
 //                       argsort; ties resolved for the positive, as ur_mrr_rank).
-#include "common.cuh"
+#include "common.hip.h"
 #include "unirec_hip.h"
 
 namespace {

@@ -18,7 +18,7 @@
 // RCCL is resolved at run time (dlopen of librccl.so.1, preferring the copy the process has already loaded -- PyTorch-ROCm
 // ships one): the library itself loads, and every other entry point works, on a box without RCCL; ur_comm_* then fail with a
 // message instead of the loader failing.
-#include "common.cuh"
+#include "common.hip.h"
 #include "unirec_hip.h"
 
 #include <algorithm>

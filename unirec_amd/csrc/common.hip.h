@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <atomic>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 
@@ -16,6 +17,21 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define UR_WAVE 64
+
+// Lab knobs (tools/lab): experiment switches read from the environment and the kernel branches behind them exist only in builds
+// made with -DUR_LAB=1 (tools/lab/lib_variant.sh ... -DUR_LAB=1); the product library compiles them out.
+#ifndef UR_LAB
+#define UR_LAB 0
+#endif
+static inline int ur_lab_int(const char* name, int dflt) {
+#if UR_LAB
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
 
 // ---- error plumbing (C ABI: 0 ok, <0 invalid argument, >0 HIP error code) -------------------
 extern thread_local char g_ur_err[512];

@@ -1,5 +1,5 @@
 // HBM-bound element-wise kernels: casts, adds, SwiGLU, fused AdamW.  16-byte accesses, grid-stride.
-#include "common.cuh"
+#include "common.hip.h"
 #include "unirec_hip.h"
 
 thread_local char g_ur_err[512] = {0};

@@ -22,9 +22,9 @@
 // transpose); both images are bank-conflict-free.
 #include <cstdlib>
 #include <type_traits>
-#include "common.cuh"
+#include "common.hip.h"
 #include "unirec_hip.h"
-#include "gemm_common.cuh"
+#include "gemm_common.hip.h"
 
 using urgemm::GemmP;
 using urgemm::uniform_ptr;
@@ -253,11 +253,13 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   // De-phase the CUs: every tile of a launch takes the same time, so the 256 workgroups of a round reach their epilogues
   // together and 32 MiB of C leave for HBM at once (an epilogue of ~10 k cycles, most of it write back-pressure) while HBM
   // idles during the main loops.  The launch's FIRST wave of workgroups starts in 8 groups `stagger` cycles apart; the
-  // offsets then persist from round to round.
+  // offsets then persist from round to round.  (Lab builds only; measured neutral: DESIGN / docs/lab_notes.md.)
+#if UR_LAB
   if (p.stagger > 0 && blockIdx.x < 256 && blockIdx.z == 0) {
     const long long until = (long long)__builtin_readcyclecounter() + (long long)((blockIdx.x >> 3) & 7) * p.stagger;
     while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(16);
   }
+#endif
   UR_STAMP(0);
 
   int kbeg = z * p.ksplit_len;
@@ -867,7 +869,7 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
     // (tools/kernel_bench.py gemm_step), while launches of <= 12 column tiles still lose 1-3 %.  Inside the joint step,
     // alternating same-box runs: chunks of 4 on the two wide launches only 516.6 vs 517.0 ms (nothing), chunks of 4 wherever
     // they divide 551.8 vs 545.8 ms (+1.1 %) -- the plain order stays the default (UR_GEMM_CW = n: lab).
-    static const int env_cw = [] { const char* e = getenv("UR_GEMM_CW"); return e ? atoi(e) : -1; }();
+    static const int env_cw = ur_lab_int("UR_GEMM_CW", -1);
     p.gcw = 0;
     // default: chunks of 4 on launches of >= 16 column tiles (the merged q|k|v and gate|up forwards) -- time-neutral inside the
     // step, but the fabric reads of those launches drop from x8.7 / x21 of A + W to what profiles/r2_gemm_pmc.json lists
@@ -875,7 +877,7 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
     if (cw > 0 && BM == 256 && (p.gm % 8) == 0 && p.gn > cw && (p.gn % cw) == 0) p.gcw = cw;
   }
   {
-    static const int env_st = [] { const char* e = getenv("UR_GEMM_STAGGER"); return e ? atoi(e) : 0; }();     // lab
+    static const int env_st = ur_lab_int("UR_GEMM_STAGGER", 0);     // lab
     p.stagger = (BM == 256 && p.gm * p.gn >= 1024) ? env_st : 0;
   }
   dim3 grid(p.gm * p.gn, 1, splits);
@@ -900,7 +902,7 @@ int launch(const GemmP& p, int splits, hipStream_t st) {
       return launch_cfg<true, true, false, 128, 128, 2, 2, 2>(p, splits, st);
     }
   }
-  static const bool force128 = [] { const char* e = getenv("UR_GEMM_FORCE128"); return e && e[0] == '1'; }();      // lab: 128x128 tiles (2 workgroups per CU) everywhere
+  static const bool force128 = ur_lab_int("UR_GEMM_FORCE128", 0) == 1;      // lab: 128x128 tiles (2 workgroups per CU) everywhere
   if (p.M >= 256 && p.N >= 256 && big_wgs >= 256 && !force128) return launch_cfg<RK, SK, OUTF32, 256, 256, 2, 4>(p, splits, st);
   return launch_cfg<RK, SK, OUTF32, 128, 128, 2, 2>(p, splits, st);
 }

@@ -1,6 +1,6 @@
 // Shared between gemm.hip (generic tiles) and gemm_pers.hip (persistent 256x256 projection kernel).
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace urgemm {
 

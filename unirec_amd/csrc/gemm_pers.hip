@@ -19,7 +19,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <type_traits>
-#include "gemm_common.cuh"
+#include "gemm_common.hip.h"
 #include "unirec_hip.h"
 
 namespace {
@@ -127,6 +127,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
   // epilogues take as long (in-kernel stamps: 3.85 k cycles per wave group either way), and the de-phasing costs the operand
   // panels their L2 sharing: CUs that read the same A / W panel a few K tiles apart no longer hit the lines their neighbours
   // fetched (rocprofv3 FETCH_SIZE of the N = 1024 launches x1.5 of A + W in lockstep, x2.9-4.3 staggered).  See DESIGN.md 11.
+#if UR_LAB
   if (p.stagger != 0) {
     // p.stagger < 0 (UR_PERS_STAGGER_XCD): whole XCDs are de-phased instead (ids equal mod 8 share an XCD and its L2): the 32
     // workgroups of an XCD stay in lockstep on their shared panels, the eight XCDs reach their epilogues 1/8 period apart
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
     const long long until = (long long)__builtin_readcyclecounter() + (long long)steps * (p.stagger < 0 ? -p.stagger : p.stagger);
     while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(8);
   }
+#endif
   // ---- producer: where the K tile that is fetched next comes from (scalars + one lane offset per operand) ----
   int vid = blockIdx.x, m0, n0;                            // current output tile
   { int bm, bn; tile_coords(ord, vid, bm, bn); m0 = bm * BM; n0 = bn * BN; }
@@ -690,7 +692,7 @@ int launch_pers(const GemmP& p, hipStream_t st) {
     return n > 0 ? n : 8;
   }();
   const int ntiles = p.gm * p.gn;
-  static const int env_grid = [] { const char* e = getenv("UR_PERS_GRID"); return e ? atoi(e) : 0; }();      // lab: fewer workgroups (a multiple of 8)
+  static const int env_grid = ur_lab_int("UR_PERS_GRID", 0);      // lab: fewer workgroups (a multiple of 8)
   const int cap = (env_grid >= 8 && env_grid < ncu) ? env_grid - env_grid % 8 : ncu;
   const int grid = ntiles < cap ? ntiles : cap;
   auto magic = [](int d) { return (uint32_t)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
@@ -715,7 +717,7 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
   const int mode = set >= 0 ? set : env_mode;
   if (!mode || !rk || !sk || outf32 || splits > 1) return false;
   if ((p.M % BM) || (p.N % BN) || (p.K % BK) || p.K < 4 * BK) return false;
-  static const int min_tiles = [] { const char* e = getenv("UR_PERS_MIN_TILES"); return e ? atoi(e) : 128; }();      // lab; default 128: half a round already gains from the register epilogue (C2 item stage 21.66 -> 21.05 ms; 256 and 512 equal within noise, user stage unchanged)
+  static const int min_tiles = ur_lab_int("UR_PERS_MIN_TILES", 128);      // lab; default 128: half a round already gains from the register epilogue (C2 item stage 21.66 -> 21.05 ms; 256 and 512 equal within noise, user stage unchanged)
   if ((long)(p.M / BM) * (p.N / BN) < min_tiles) return false;
   if ((long)(p.M / BM) * (p.N / BN) >= (1L << 20) || p.N / BN >= (1 << 12) || p.M / BM >= (1 << 15)) return false;      // fdiv: n * d < 2^32
   if (p.gelu_out || p.aux || p.sw_mode == 2) return false;
@@ -725,7 +727,7 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
     // measured (tools/lab/gemm_pers_ab.py, C4 shapes; profiles/r3_gemm_pers_ab.txt): with the masked LoRA epilogue the persistent
     // kernel wins at K = 1024 (+5 %, +17 % with the SwiGLU backward epilogue), is even at K = 4096 (+1 %) and loses 1.5 % at
     // K = 6144 (8 long tiles per CU: nothing to hide, and the joined epilogue costs two barrier intervals)
-    static const int kmax = [] { const char* e = getenv("UR_PERS_DROP_KMAX"); return e ? atoi(e) : 4096; }();
+    static const int kmax = ur_lab_int("UR_PERS_DROP_KMAX", 4096);
     if (p.K > kmax) return false;
   }
   if (p.sw_mode == 1 && (p.bias || p.res)) return false;
@@ -748,14 +750,14 @@ int gemm_pers_launch(GemmP p, hipStream_t st) {
     // Measured (gate|up, gn = 24, K = 1024; same process, interleaved): cw 6 1.448 ms, 12 1.482, 2 1.496, 4 1.507, row-major
     // 1.528, 8 1.535 -- the order moves the launch by +-3 % although the fabric reads differ x2.5 between them; q|k|v (gn 16):
     // 4 and 8 equal, 2 and row-major 1-2 % slower.
-    static const int env_cw = [] { const char* e = getenv("UR_PERS_CW"); return e ? atoi(e) : -1; }();
+    static const int env_cw = ur_lab_int("UR_PERS_CW", -1);
     const int cw = env_cw >= 0 ? env_cw : ((p.gn % 6) == 0 && p.gn >= 24 ? 6 : 4);
     if (cw > 0 && p.gn >= 16 && (p.gm % 8) == 0 && p.gn > cw && (p.gn % cw) == 0) p.gcw = cw;
   }
   const bool drop = p.drop_bits != nullptr && p.K2 > 0;
   {
-    static const int env_st = [] { const char* e = getenv("UR_PERS_STAGGER"); return e ? atoi(e) : 0; }();      // lab: cycles per start step; 0 = off (default)
-    static const int env_sx = [] { const char* e = getenv("UR_PERS_STAGGER_XCD"); return e ? atoi(e) : 0; }();  // lab: cycles per XCD step
+    static const int env_st = ur_lab_int("UR_PERS_STAGGER", 0);      // lab: cycles per start step; 0 = off (default)
+    static const int env_sx = ur_lab_int("UR_PERS_STAGGER_XCD", 0);  // lab: cycles per XCD step
     p.stagger = env_sx > 0 ? -env_sx : (env_st > 0 ? env_st : 0);
   }
   const int mode = drop ? 2 : (p.K2 > 0 ? 1 : 0);

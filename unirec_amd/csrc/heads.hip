@@ -4,7 +4,7 @@
 //   QFormerLoss (training/item_qformer_training.py:49-56): masked MSE / #valid fields + TripletMargin
 //   eval metrics (evaluation/evaluate_item_qformer.py:75-92): masked MSE + cosine sum over valid fields
 //   MSE loss of the user Q-Former (training/user_qformer_training.py:193,209)
-#include "common.cuh"
+#include "common.hip.h"
 #include "unirec_hip.h"
 
 namespace {

@@ -20,7 +20,7 @@
 // a 16-byte bf16x8 fragment keeps its elements in 32-bit pairs, so a byte expands to four pair masks with
 // one shift/and + one packed arithmetic shift each.
 #include <type_traits>
-#include "common.cuh"
+#include "common.hip.h"
 #include "unirec_hip.h"
 
 namespace {

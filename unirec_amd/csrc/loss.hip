@@ -2,7 +2,7 @@
 // element is read ONCE -> HBM-bound), InfoNCE loss forward/backward, MRR rank and
 // deterministic top-K.  training/train_item_individual_token_joint.py:331-352 (InfoNCELoss.forward),
 // :392-419 (MRREvaluator._compute_batch_mrr).  All arithmetic f32.  gfx950 only.
-#include "common.cuh"
+#include "common.hip.h"
 #include "unirec_hip.h"
 
 namespace {

@@ -1,6 +1,6 @@
 // LayerNorm / RMSNorm forward+backward and batch reductions (HBM-bound, one wave per row,
 // 16-byte vector loads, wave-shuffle row reductions, f32 statistics).  gfx950 only.
-#include "common.cuh"
+#include "common.hip.h"
 #include "unirec_hip.h"
 
 namespace {

@@ -1,6 +1,6 @@
 // Qwen3-side HBM-bound kernels: RoPE table, fused per-head q/k RMSNorm + RoPE (fwd/bwd), embedding
 // gather fused with Q-Former token injection (fwd/bwd), mean pooling (fwd/bwd).  gfx950 only.
-#include "common.cuh"
+#include "common.hip.h"
 #include "unirec_hip.h"
 
 namespace {

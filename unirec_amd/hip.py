@@ -37,7 +37,33 @@ _ws_cache = {}
 # Optional live kernel timing (bench.py roofline leg): when PROFILE is a list, every ur_gemm launch is
 # bracketed by HIP events recorded on the launching (current) stream and logged with its shape.
 PROFILE = None
+PROFILE_STREAM = None   # bench.py: list of (event0, event1, family, algorithmic bytes) around the HBM-bound launches wrapped by _stream_family
 PROFILE_ATTN = None     # bench.py: list of (event0, event1, 'fwd' | 'bwd', B, Sq, Sk, nq, head_dim, causal) around every attention launch
+
+
+def _stream_family(family, nbytes):
+    """Decorator for a wrapper of an HBM-bound launch: when PROFILE_STREAM is a list (bench.py's roofline leg) HIP events on the
+    launching stream bracket the call and (events, family, ALGORITHMIC bytes = every operand read / written once) is appended.
+    nbytes(result, *args, **kwargs) -> bytes."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            if PROFILE_STREAM is None:
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            PROFILE_STREAM.append((e0, e1, family, int(nbytes(r, *a, **k))))
+            return r
+        return wrapped
+    return deco
+
+
+def _nb(*ts):
+    return sum(t.numel() * t.element_size() for t in ts if t is not None and hasattr(t, "numel"))
 
 
 def workspace(nbytes, device, tag="default"):
@@ -220,6 +246,8 @@ def gemm_qkv_rope(R, S, qw, kw, cos, sin, Sseq, nq_cols, nk_cols, eps, R2=None, 
     return outs
 
 
+@_stream_family("qknorm_rope_bwd", lambda r, dq_out, dk_out, q_r, k_r, rstd, qw, kw, cos, sin, dqkv_raw, S, nq, nkv, hd:
+                3 * (_nb(k_r) if dq_out is None else _nb(q_r, k_r)))      # gradient in, roped output in, raw gradient out
 def qknorm_rope_bwd_roped(dq_out, dk_out, q_r, k_r, rstd, qw, kw, cos, sin, dqkv_raw, S, nq, nkv, hd):
     """Backward of the fused q|k|v epilogue: dq|dk raw into dqkv_raw[:, :(nq+nkv)*hd] from the ROPED forward outputs + rstd."""
     lib = _lib.load()
@@ -241,6 +269,7 @@ def lora_bits_ld(W):
     return int(_lib.load().ur_lora_bits_ld(int(W)))
 
 
+@_stream_family("lora_bits", lambda r, *a, **k: _nb(r))
 def lora_dropout_bits(seed, p, M, W, nad, device, out=None, row0=0):
     """Dropped-flag bit planes uint8 [nad, M, ur_lora_bits_ld(W)] of nad adapters that share an [M, W] input.  row0: rows that
     precede row 0 in the global minibatch (a data-parallel rank draws the flags of ITS rows)."""
@@ -275,6 +304,11 @@ def _lora_args(X, cols, shared, bits, alpha):
     return a
 
 
+def _cols_bytes(X, cols):
+    return X.shape[0] * 2 * (X.shape[1] if cols is None else sum(w for _, w in cols))
+
+
+@_stream_family("lora_project", lambda r, X, U, cols=None, alpha=1.0, bits=None, out=None: _cols_bytes(X, cols) + _nb(r) + (_nb(bits) if bits is not None else 0))
 def lora_project(X, U, cols=None, alpha=1.0, bits=None, out=None):
     """P[m, 16a+j] = alpha * sum_w keep_a(m,w) X[m, c0_a+w] U_a[j,w].  U: list of bf16 [16, width_a] matrices.
     cols=None: the adapters share all of X's columns (optionally with dropout bit planes `bits`);
@@ -295,6 +329,7 @@ def lora_project(X, U, cols=None, alpha=1.0, bits=None, out=None):
     return out
 
 
+@_stream_family("swiglu_lora", lambda r, gu, I, U, alpha=1.0, bits=None: _nb(gu) + _nb(*r) + (_nb(bits) if bits is not None else 0))
 def swiglu_lora_fwd(gu, I, U, alpha=1.0, bits=None):
     """SwiGLU forward + the down_proj adapter's down projection in one pass over gu [M, 2I]: -> (act bf16 [M, I], t bf16 [M, 16])."""
     lib = _lib.load()
@@ -311,6 +346,7 @@ def swiglu_lora_fwd(gu, I, U, alpha=1.0, bits=None):
     return act, t
 
 
+@_stream_family("rms_lora", lambda r, x, w, eps, U, alpha=1.0, bits=None: _nb(x) + _nb(*r) + (_nb(bits) if bits is not None else 0))
 def rmsnorm_lora_fwd(x, w, eps, U, alpha=1.0, bits=None):
     """RMSNorm forward + the down projection of the 2 or 3 adapters that read the normalised activation, one pass over x:
     -> (h bf16 like x, rstd f32 [M], t bf16 [M, 16 len(U)]).  D must be 1024."""
@@ -332,6 +368,8 @@ def rmsnorm_lora_fwd(x, w, eps, U, alpha=1.0, bits=None):
     return out, rstd, t
 
 
+@_stream_family("lora_reduce", lambda r, X, V, out, cols=None, nad=None, alpha=1.0, bits=None, transposed=False:
+                _cols_bytes(X, cols) + X.shape[0] * 2 * 16 * (len(cols) if cols is not None else int(nad)) + (_nb(bits) if bits is not None else 0))
 def lora_reduce(X, V, out, cols=None, nad=None, alpha=1.0, bits=None, transposed=False):
     """G_a[j,w] = alpha * sum_m V[m,16a+j] keep_a(m,w) X[m, c0_a+w] into the dense f32 tensor `out`
     ([16 nad, W] for shared columns, or [sum width, 16] with transposed=True for per-adapter column ranges)."""
@@ -418,6 +456,7 @@ def rmsnorm_fwd(x, w, eps):
     return out, rstd
 
 
+@_stream_family("rms_bwd", lambda r, dout, x, w, rstd, add=None: _nb(dout, x, r, add))
 def rmsnorm_bwd(dout, x, w, rstd, add=None):
     lib = _lib.load()
     D = x.shape[-1]
@@ -589,6 +628,7 @@ def swiglu_bwd(dact, gu, I):
     return dgu
 
 
+@_stream_family("adamw", lambda r, param, grad, exp_avg, exp_avg_sq, *a, **k: 2 * _nb(param, exp_avg, exp_avg_sq) + _nb(grad))
 def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     lib = _lib.load()
     check(lib.ur_adamw_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), lr,
@@ -672,6 +712,7 @@ def mean_pool_bwd(dout, S):
 
 
 # ---- ranking head --------------------------------------------------------------------------------
+@_stream_family("J6_candidate_scores", lambda r, user, pos, neg: _nb(user, pos, neg) + _nb(*r))
 def cosine_scores(user, pos, neg):
     """user [B,D], pos [B,D], neg [B,N,D] f32 -> (scores [B,1+N], cand_inv_norm [B,1+N])."""
     lib = _lib.load()
@@ -770,6 +811,7 @@ def rank_of_index(scores, gt_index):
     return rank
 
 
+@_stream_family("lora_bgrad", lambda r, dy, t, Bt, cols, gB, alpha=1.0, out=None: _cols_bytes(dy, cols) + 2 * dy.shape[0] * 2 * 16 * len(cols))
 def lora_bgrad(dy, t, Bt, cols, gB, alpha=1.0, out=None):
     """One pass over dy: returns tb [M, 16 nad] = alpha * dy_a B_a (Bt: list of B_a^T [16, width_a]) and fills
     gB [sum width, 16] f32 with dB_a = dy_a^T t_a (adapter a owns columns cols[a] of dy, t holds t_a at columns 16a)."""

@@ -82,46 +82,39 @@ class ItemEncoder:
                 "number_encoders/mathematical_encoder_1024d_normalized.pth) are upstream of the MI355X hot path and their weights are "
                 "not available here.  Pass backend=<object with encode_text_batch / encode_image_batch / encode_number_batch> or "
                 "field_cache=<item_id -> {field: vector} | PackedFieldStore> to ItemEncoder.")
-        if modality_type in ("text", "category"):
-            return np.asarray(b.encode_text_batch(data_batch), dtype=np.float32)
-        if modality_type == "image":
-            return np.asarray(b.encode_image_batch(data_batch), dtype=np.float32)
-        if modality_type == "number":
-            return np.asarray(b.encode_number_batch(data_batch), dtype=np.float32)
-        raise ValueError(f"Unknown modality type: {modality_type}")
+        if modality_type not in self._BACKEND_METHOD:
+            raise ValueError(f"Unknown modality type: {modality_type}")
+        return np.asarray(getattr(b, self._BACKEND_METHOD[modality_type])(data_batch), dtype=np.float32)
+
+    # modality (third entry of a FIELD_MAPPING value) -> the backend method that embeds a batch of raw field values
+    _BACKEND_METHOD = {"text": "encode_text_batch", "category": "encode_text_batch", "image": "encode_image_batch", "number": "encode_number_batch"}
 
     # ---- reference surface ------------------------------------------------------------------------------------
     def encode_batch_by_field(self, samples: List[Dict[str, Any]], fields_to_encode: List[str]) -> Dict[str, np.ndarray]:
-        """:359-389 -- {field: np.float32 [B, embedding_dim]}; a field absent from FIELD_MAPPING is all zeros (with the
-        reference's warning), an empty batch gives empty arrays."""
+        """Contract of models/item_encoder_pure_value.py:359-389: {field: float array [B, embedding_dim]}; a field that FIELD_MAPPING does
+        not know is all zeros (and is reported once per call), an unknown modality raises ValueError, an empty batch gives empty arrays.
+        Columns come from the field cache when there is one, else from the backend's method for the field's modality."""
         if not samples:
-            return {field: np.array([]) for field in fields_to_encode}
-        if self.backend is not None and self.field_cache is None and hasattr(self.backend, "encode_batch_by_field"):
-            return self.backend.encode_batch_by_field(samples, fields_to_encode)
-        field_batches = {field: [s.get(field, "") for s in samples] for field in fields_to_encode}
-        encoded = {}
-        for field_name in fields_to_encode:
-            info = self.field_mapping.get(field_name)
-            if not info:
-                print(f"Warning: Field '{field_name}' not in field_mapping. Skipping.")
-                encoded[field_name] = np.zeros((len(samples), self.embedding_dim))
-                continue
-            modality_type = info[2]
-            if modality_type not in ("text", "category", "image", "number"):
-                raise ValueError(f"Unknown modality type: {modality_type}")
-            encoded[field_name] = self._encode_modality(modality_type, field_name, field_batches[field_name], samples)
-        return encoded
+            return {name: np.array([]) for name in fields_to_encode}
+        b = self.backend
+        if b is not None and self.field_cache is None and hasattr(b, "encode_batch_by_field"):
+            return b.encode_batch_by_field(samples, fields_to_encode)          # a backend that batches by field itself
+        modality = {name: (self.field_mapping[name][2] if self.field_mapping.get(name) else None) for name in fields_to_encode}
+        bad = [m for m in modality.values() if m is not None and m not in self._BACKEND_METHOD]
+        if bad:
+            raise ValueError(f"Unknown modality type: {bad[0]}")
+        for name in (n for n, m in modality.items() if m is None):
+            print(f"Warning: Field '{name}' not in field_mapping. Skipping.")
+        zeros = np.zeros((len(samples), self.embedding_dim))
+        return {name: zeros.copy() if m is None else self._encode_modality(m, name, [s.get(name, "") for s in samples], samples)
+                for name, m in modality.items()}
 
     def encode_batch(self, samples: List[Dict[str, Any]]) -> List[Dict[str, np.ndarray]]:
-        """:391-409"""
+        """Contract of :391-409: the per-field columns of encode_batch_by_field over every mapped field, regrouped per sample."""
         if not samples:
             return []
-        by_field = self.encode_batch_by_field(samples, list(self.field_mapping.keys()))
-        results = [{} for _ in range(len(samples))]
-        for field_name, embeddings in by_field.items():
-            for i, embedding in enumerate(embeddings):
-                results[i][field_name] = embedding
-        return results
+        columns = self.encode_batch_by_field(samples, list(self.field_mapping.keys()))
+        return [{name: col[i] for name, col in columns.items()} for i in range(len(samples))]
 
     def get_embedding_dimensions(self) -> Dict[str, int]:
         """every field vector is 1024-d whatever its modality (CLIP's 768 are zero-padded, :163,257)."""
