@@ -168,16 +168,33 @@ def attn_executed_ratio(am, S, kt=64):
 
 def device_peaks():
     """Peaks READ FROM THE DEVICE beside the datasheet ones: bf16 dense MFMA = CUs x max shader clock x 4096 FLOP per CU
-    and clock (4 SIMDs x one v_mfma_f32_32x32x16_bf16 = 32768 FLOP per 32 cycles); HBM from the memory clock and bus width."""
+    and clock (4 SIMDs x one v_mfma_f32_32x32x16_bf16 = 32768 FLOP per 32 cycles).  CU count from the HIP device properties, the
+    maximum shader clock from `rocminfo` (torch does not expose it on ROCm), else from sysfs pp_dpm_sclk."""
     out = {"mfma_bf16_TFLOPs_spec": 2500.0, "hbm_GBps_spec": 8000.0}
     try:
-        pr = torch.cuda.get_device_properties(0)
-        cus, khz = int(pr.multi_processor_count), int(getattr(pr, "clock_rate", 0))
-        out.update({"compute_units": cus, "max_shader_clock_MHz": round(khz / 1e3, 1),
-                    "mfma_bf16_TFLOPs_device": round(cus * khz * 1e3 * 4096 / 1e12, 1) if khz else None})
-        mk, bw = int(getattr(pr, "memory_clock_rate", 0)), int(getattr(pr, "memory_bus_width", 0))
-        if mk and bw:
-            out.update({"memory_clock_MHz": round(mk / 1e3, 1), "memory_bus_bits": bw, "hbm_GBps_device": round(2.0 * mk * 1e3 * bw / 8 / 1e9, 1)})
+        cus = int(torch.cuda.get_device_properties(0).multi_processor_count)
+        mhz, src = 0.0, None
+        try:
+            import re
+            import subprocess
+            txt = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=30).stdout
+            for blk in txt.split("Agent ")[1:]:
+                if "Device Type:             GPU" in blk or re.search(r"Device Type:\s+GPU", blk):
+                    m = re.search(r"Max Clock Freq\. \(MHz\):\s+(\d+)", blk)
+                    if m:
+                        mhz, src = float(m.group(1)), "rocminfo"
+                        break
+        except Exception:                       # noqa: BLE001
+            pass
+        if not mhz:
+            import glob
+            for f in glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk"):
+                vals = [float(x.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()) for x in open(f).read().strip().splitlines() if ":" in x]
+                if vals:
+                    mhz, src = max(vals), "pp_dpm_sclk"
+                    break
+        out.update({"compute_units": cus, "max_shader_clock_MHz": mhz or None, "clock_source": src,
+                    "mfma_bf16_TFLOPs_device": round(cus * mhz * 1e6 * 4096 / 1e12, 1) if mhz else None})
     except Exception as e:                      # noqa: BLE001 -- the line must still print
         out["error"] = str(e)
     return out
