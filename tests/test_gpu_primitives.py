@@ -386,6 +386,34 @@ def test_lora_kernels_with_dropout_bits(M, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,cols", [(200, [(0, 64)]), (1024, [(0, 128), (128, 64), (256, 192)]), (4100, [(64, 256), (320, 128)]),
+                                    (3000, [(0, 2048), (2048, 1024), (3072, 1024)]), (88000 + 200, [(0, 256), (256, 128), (384, 64)])])
+def test_lora_bgrad_ring_kernel(M, cols):
+    """Widths that are multiples of 64 take the LDS-DMA ring kernel (csrc/lora.hip: lora_bgrad_ring_kernel): tb = s * dy_a B_a and
+    dB_a = dy_a^T t_a against fp32 products of the same bf16 inputs; ragged token counts (partial 512-token block, partial
+    256-token tile), column ranges that do not start at 0, ld != width; deterministic.  The last case has enough tokens for the
+    1024-token blocks (one block per CU at least)."""
+    from unirec_amd import hip
+    g = torch.Generator().manual_seed(M)
+    r = 16
+    Wt = max(c0 + n for c0, n in cols)
+    dy = torch.randn(M, Wt + 8, generator=g).to(DEV).to(torch.bfloat16)[:, :Wt]
+    B = [(torch.randn(n, r, generator=g) * 0.2).to(DEV).to(torch.bfloat16) for _, n in cols]
+    t = torch.randn(M, len(cols) * r, generator=g).to(DEV).to(torch.bfloat16)
+    ntot = sum(n for _, n in cols)
+    gB = torch.full((ntot, r), float("nan"), device=DEV)
+    tb = hip.lora_bgrad(dy, t, [hip.transpose_bf16(b) for b in B], cols, gB, alpha=0.5).float()
+    want_tb = torch.cat([0.5 * dy[:, c0:c0 + n].float() @ B[a].float() for a, (c0, n) in enumerate(cols)], 1)
+    want_gB = torch.cat([dy[:, c0:c0 + n].float().t() @ t[:, a * r:(a + 1) * r].float() for a, (c0, n) in enumerate(cols)], 0)
+    # tb is rounded to bf16 once (2^-9 relative); dB is an f32 sum of exact bf16 x bf16 products
+    assert (tb - want_tb).abs().max().item() <= 6e-3 * want_tb.abs().max().item() + 1e-3
+    assert (gB - want_gB).abs().max().item() <= 1e-4 * want_gB.abs().max().item() + 1e-3
+    gB2 = torch.empty_like(gB)
+    tb2 = hip.lora_bgrad(dy, t, [hip.transpose_bf16(b) for b in B], cols, gB2, alpha=0.5).float()
+    assert torch.equal(gB, gB2) and torch.equal(tb, tb2)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M", [200, 4100])
 def test_lora_kernels_on_column_ranges(M):
     """Adapters that own column ranges of one activation (backward): tb_a = s * dy_a B_a (ur_lora_project, no

@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--S", type=int, default=2048)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--only", default="", help="comma list of kinds (f, r, d, s) to run")
     ap.add_argument("--plain", action="store_true", help="no LoRA terms / epilogues: the bare GEMMs")
     ap.add_argument("--ksweep", action="store_true", help="plain GEMM, N = 4096, K = 256 .. 4096: per-K-tile and fixed cost per output tile of both kernels")
     a = ap.parse_args()
@@ -63,6 +64,8 @@ def main():
     g = torch.Generator().manual_seed(0)
     ops = []
     for (N, K, kind, name, nad) in SHAPES:
+        if a.only and kind not in a.only.split(","):
+            continue
         R = torch.randn(M, K, generator=g).cuda().to(torch.bfloat16)
         W = (torch.randn(N, K, generator=g) * 0.05).cuda().to(torch.bfloat16)
         kw = {}

@@ -2563,17 +2563,7 @@ int fill(AttnP& p, const ur_attn_args* a) {
 // the hand-scheduled causal head_dim-128 BACKWARD pair (dQ + dK/dV) runs together or not at all (they share the -LSE2 plane)
 inline bool c128_bwd_ok(const AttnP& p);
 // CUs of the current device (persistent grids), cached per device
-inline int device_cu_count() {
-  static std::atomic<int> cached[16];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-  int n = cached[dev].load();
-  if (n == 0) {
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    cached[dev] = n;
-  }
-  return n;
-}
+inline int device_cu_count() { return ur_device_cu_count(); }
 // test / lab switch, read on every call: UR_ATTN_C128=0 sends the causal head_dim-128 forward back to attn_fwd_kernel
 inline bool fwd_c128_enabled() { const char* e = getenv("UR_ATTN_C128"); return !(e && e[0] == '0'); }
 inline bool fwd_gq2_enabled() { static const bool on = ur_lab_int("UR_FWD_GQ2", 0) == 1; return on; }
@@ -2581,8 +2571,8 @@ template <int HD, bool CAUSAL, int NW>
 int launch_fwd(const AttnP& p, hipStream_t st) {
   if constexpr (HD == 128 && CAUSAL && NW == 4) {
     if (p.rep == 2 && fwd_gq2_enabled()) {
-      static std::atomic<bool> once8{false};
-      if (!once8) { int rc = set_smem(&attn_fwd_kernel<128, true, 8, true>, fwd_smem<128>(), "ur_attn_fwd(gq2)"); if (rc) return rc; once8 = true; }
+      static std::atomic<uint64_t> once8{0};   // per device
+      if (ur_first_on_device(once8)) { int rc = set_smem(&attn_fwd_kernel<128, true, 8, true>, fwd_smem<128>(), "ur_attn_fwd(gq2)"); if (rc) return rc; }
       dim3 grid(ur_cdiv(p.Sq, 128) * (p.nq / 2) * p.B);
       hipLaunchKernelGGL((attn_fwd_kernel<128, true, 8, true>), grid, dim3(512), fwd_smem<128>(), st, p);
       UR_CHECK_LAUNCH("ur_attn_fwd(gq2)");
@@ -2592,8 +2582,8 @@ int launch_fwd(const AttnP& p, hipStream_t st) {
   if constexpr (HD == 128 && CAUSAL && NW == 4) {
     if (p.Sq == p.Sk && (p.Sk % KT) == 0 && p.Sk >= 128 && p.Sk <= c128::MAX_SK && fwd_c128_enabled() && (long)p.nq * p.B * 8 < (1L << 24) &&
         p.ldk * 2L * p.Sk < (1L << 31) && p.ldv * 2L * p.Sk < (1L << 31)) {
-      static std::atomic<bool> once_c{false};
-      if (!once_c) { int rc = set_smem(&attn_fwd_c128_kernel, c128::LDS_BYTES, "ur_attn_fwd(c128)"); if (rc) return rc; once_c = true; }
+      static std::atomic<uint64_t> once_c{0};   // per device
+      if (ur_first_on_device(once_c)) { int rc = set_smem(&attn_fwd_c128_kernel, c128::LDS_BYTES, "ur_attn_fwd(c128)"); if (rc) return rc; }
       const int nx = ur_cdiv(p.Sq, 256), nch = (nx + 1) / 2, nitems = p.nq * p.B * nch;
       auto magic = [](uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); };
       const C128Div dv{magic((uint32_t)(p.rep * nch)), magic((uint32_t)nch), magic((uint32_t)p.nkv)};
@@ -2602,8 +2592,8 @@ int launch_fwd(const AttnP& p, hipStream_t st) {
       return 0;
     }
   }
-  static std::atomic<bool> once{false};   // init-once flag: the call it guards is idempotent, the flag itself is race-free
-  if (!once) { int rc = set_smem(&attn_fwd_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_fwd"); if (rc) return rc; once = true; }
+  static std::atomic<uint64_t> once{0};   // per device
+  if (ur_first_on_device(once)) { int rc = set_smem(&attn_fwd_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_fwd"); if (rc) return rc; }
   dim3 grid(ur_cdiv(p.Sq, 32 * NW) * p.nq * p.B);
   hipLaunchKernelGGL((attn_fwd_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), fwd_smem<HD>(), st, p);
   UR_CHECK_LAUNCH("ur_attn_fwd");
@@ -2613,8 +2603,8 @@ template <int HD, bool CAUSAL, int NW>
 int launch_dq(const AttnP& p, hipStream_t st) {
   if constexpr (HD == 128 && CAUSAL && NW == 4) {
     if (c128_bwd_ok(p)) {
-      static std::atomic<bool> once_c{false};
-      if (!once_c) { int rc = set_smem(&attn_bwd_dq_c128_kernel, c128::DQ_LDS_BYTES, "ur_attn_bwd(dq c128)"); if (rc) return rc; once_c = true; }
+      static std::atomic<uint64_t> once_c{0};   // per device
+      if (ur_first_on_device(once_c)) { int rc = set_smem(&attn_bwd_dq_c128_kernel, c128::DQ_LDS_BYTES, "ur_attn_bwd(dq c128)"); if (rc) return rc; }
       const int nx = ur_cdiv(p.Sq, 256), nch = (nx + 1) / 2, nitems = p.nq * p.B * nch;
       auto magic = [](uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); };
       const C128Div dv{magic((uint32_t)(p.rep * nch)), magic((uint32_t)nch), magic((uint32_t)p.nkv)};
@@ -2623,8 +2613,8 @@ int launch_dq(const AttnP& p, hipStream_t st) {
       return 0;
     }
   }
-  static std::atomic<bool> once{false};   // init-once flag: the call it guards is idempotent, the flag itself is race-free
-  if (!once) { int rc = set_smem(&attn_bwd_dq_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_bwd(dq)"); if (rc) return rc; once = true; }
+  static std::atomic<uint64_t> once{0};   // per device
+  if (ur_first_on_device(once)) { int rc = set_smem(&attn_bwd_dq_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_bwd(dq)"); if (rc) return rc; }
   dim3 grid(ur_cdiv(p.Sq, 32 * NW) * p.nq * p.B);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), fwd_smem<HD>(), st, p);
   UR_CHECK_LAUNCH("ur_attn_bwd(dq)");
@@ -2651,8 +2641,8 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
   dim3 grid(ur_cdiv(p.Sk, 32 * NW) * p.nkv * p.B);
   if constexpr (HD == 128 && CAUSAL && NW == 4) {
     if (c128_bwd_ok(p)) {
-      static std::atomic<bool> once_c{false};
-      if (!once_c) { int rc = set_smem(&attn_bwd_dkv_c128_kernel, c128::DKV_LDS_BYTES, "ur_attn_bwd(dkv c128)"); if (rc) return rc; once_c = true; }
+      static std::atomic<uint64_t> once_c{0};   // per device
+      if (ur_first_on_device(once_c)) { int rc = set_smem(&attn_bwd_dkv_c128_kernel, c128::DKV_LDS_BYTES, "ur_attn_bwd(dkv c128)"); if (rc) return rc; }
       hipLaunchKernelGGL(attn_bwd_dkv_c128_kernel, grid, dim3(256), c128::DKV_LDS_BYTES, st, p);
       UR_CHECK_LAUNCH("ur_attn_bwd(dkv c128)");
       return 0;
@@ -2660,14 +2650,14 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
   }
   if (HD == 128 && NW == 4 && p.drop_thr == 0) {
     constexpr int SM2 = 2 * (2 * Cfg<128>::TILE + 4 * KT * (int)sizeof(float));      // = NB buffers of attn_bwd_dkv2_kernel
-    static std::atomic<bool> once2{false};
-    if (!once2) { int rc = set_smem(&attn_bwd_dkv2_kernel<CAUSAL>, SM2, "ur_attn_bwd(dkv2)"); if (rc) return rc; once2 = true; }
+    static std::atomic<uint64_t> once2{0};   // per device
+    if (ur_first_on_device(once2)) { int rc = set_smem(&attn_bwd_dkv2_kernel<CAUSAL>, SM2, "ur_attn_bwd(dkv2)"); if (rc) return rc; }
     hipLaunchKernelGGL((attn_bwd_dkv2_kernel<CAUSAL>), grid, dim3(256), SM2, st, p);
     UR_CHECK_LAUNCH("ur_attn_bwd(dkv2)");
     return 0;
   }
-  static std::atomic<bool> once{false};   // init-once flag: the call it guards is idempotent, the flag itself is race-free
-  if (!once) { int rc = set_smem(&attn_bwd_dkv_kernel<HD, CAUSAL, NW>, dkv_smem<HD>(), "ur_attn_bwd(dkv)"); if (rc) return rc; once = true; }
+  static std::atomic<uint64_t> once{0};   // per device
+  if (ur_first_on_device(once)) { int rc = set_smem(&attn_bwd_dkv_kernel<HD, CAUSAL, NW>, dkv_smem<HD>(), "ur_attn_bwd(dkv)"); if (rc) return rc; }
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), dkv_smem<HD>(), st, p);
   UR_CHECK_LAUNCH("ur_attn_bwd(dkv)");
   return 0;

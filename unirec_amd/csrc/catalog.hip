@@ -215,11 +215,10 @@ extern "C" int ur_catalog_scores(const float* user, const float* catalog, float*
   rpb = (rpb + 3) / 4 * 4;
   blocks_x = (N + rpb - 1) / rpb;
   const size_t smem = (size_t)CU_USERS * D * sizeof(float);
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_set{0};   // per device
+  if (ur_first_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_scores_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CU_USERS * 2048 * 4);
     if (e != hipSuccess) UR_FAIL((int)e, "ur_catalog_scores: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    attr_set = true;
   }
   hipLaunchKernelGGL(catalog_scores_kernel, dim3((unsigned)blocks_x, (unsigned)ub), dim3(256), smem, st, user, user_inv_norm, catalog,
                      cat_inv_norm, scores, (int)B, (long)N, (int)D, (long)rpb);

@@ -33,6 +33,31 @@ static inline int ur_lab_int(const char* name, int dflt) {
 #endif
 }
 
+// ---- per-device once flags -------------------------------------------------------------------------
+// hipFuncSetAttribute and the CU count are properties of (function, DEVICE): a process that drives several GPUs needs them per
+// device.  Bit d of the mask = done on device d (the guarded calls are idempotent: a race only repeats one).
+static inline int ur_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev;
+}
+static inline bool ur_first_on_device(std::atomic<uint64_t>& mask) {
+  const uint64_t bit = 1ull << (ur_current_device() & 63);
+  if (mask.load(std::memory_order_relaxed) & bit) return false;
+  mask.fetch_or(bit, std::memory_order_relaxed);
+  return true;
+}
+static inline int ur_device_cu_count() {
+  static std::atomic<int> cached[64];
+  const int dev = ur_current_device() & 63;
+  int n = cached[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
+
 // ---- error plumbing (C ABI: 0 ok, <0 invalid argument, >0 HIP error code) -------------------
 extern thread_local char g_ur_err[512];
 #define UR_FAIL(code, ...)                                   \

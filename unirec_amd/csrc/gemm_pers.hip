@@ -678,19 +678,15 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
 
 template <int EPI, int MODE>
 int launch_pers(const GemmP& p, hipStream_t st) {
-  static std::atomic<bool> attr_set{false};
+  static std::atomic<uint64_t> attr_set{0};   // per device
   constexpr int SMEM = 2 * STAGE + (EPI == 3 ? 2 * 256 * 4 * (int)sizeof(float) : 0);
-  if (!attr_set) {
+  if (ur_first_on_device(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<EPI, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) UR_FAIL((int)e, "ur_gemm(persistent): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
-    attr_set = true;
   }
-  static const int ncu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount; }
-    n -= n % 8;                    // ids equal mod 8 share an XCD: the stride of the tile walk must keep that
-    return n > 0 ? n : 8;
-  }();
+  int ncu = ur_device_cu_count();
+  ncu -= ncu % 8;                  // ids equal mod 8 share an XCD: the stride of the tile walk must keep that
+  if (ncu <= 0) ncu = 8;
   const int ntiles = p.gm * p.gn;
   static const int env_grid = ur_lab_int("UR_PERS_GRID", 0);      // lab: fewer workgroups (a multiple of 8)
   const int cap = (env_grid >= 8 && env_grid < ncu) ? env_grid - env_grid % 8 : ncu;

@@ -734,6 +734,166 @@ __global__ __launch_bounds__(256, 2) void lora_bgrad_kernel(BgradP p) {
   }
 }
 
+// ---- the same products with dy streamed through an LDS-DMA ring ------------------------------------------------------------
+// grid: x = block of 512 tokens, y = adapter entry (every width a multiple of 64).  The block's stream is a sequence of stages
+// (column chunk c, token tile t): [256 tokens x 64 columns] of dy (32 KiB, rows of 128 bytes, 16-byte chunks swizzled by
+// sw16) + the [16 x 64] chunk of B^T, fetched by global_load_lds three stages ahead of their use (no registers, no LDS write
+// instructions; 96 KiB in flight per CU).  One barrier per stage makes the tile visible to the four waves, which then split it
+// TWO ways: tokens for tb (wave w: tokens 64 w .. + 63 of the tile as MFMA column operands, all 64 columns), columns for dB
+// (wave w: columns 16 w .. + 15 as hardware-transposed operands, all 256 tokens) -- the dB partial of a column is complete
+// inside one wave, so it leaves straight from the accumulators after the block's last token tile: no cross-wave sum.
+__device__ __forceinline__ const char* bg_uniform_ptr(const char* p) {          // (gemm_common.hip.h: uniform_ptr)
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
+constexpr int B2_TILE = 256, B2_NST = 4;
+constexpr int B2_XS = B2_TILE * 128, B2_STAGE = B2_XS + 2048;                   // dy tile + B^T chunk
+constexpr int b2_smem(int nt) { return B2_NST * B2_STAGE + (nt > 2 ? 0 : nt * B2_TILE * 32); }   // + t [tokens][16] (prologue staging; NT 4: inside the ring)
+template <int B2_NT>
+__global__ __launch_bounds__(256) void lora_bgrad_ring_kernel(BgradP p) {
+  constexpr int B2_TOK = B2_NT * B2_TILE;
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int e = blockIdx.y;
+  const int W = p.width[e], col0 = p.col0[e];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = l15 >> 2, pp = lane & 3;
+  const int tok0 = blockIdx.x * B2_TOK;
+  const int nch = W / 64, nst = nch * B2_NT;
+  char* tstage = B2_NT > 2 ? smem : smem + B2_NST * B2_STAGE;       // (NT 4: 32 KiB inside the ring, before the first stage is issued)
+
+  // ---- producer: this wave's 8 pieces (8 rows x 128 B each) of a stage's dy tile + one piece of its B^T chunk ----
+  // every address = uniform base (scalar registers) + ONE 32-bit lane offset; only the launch's last token block clamps rows per lane
+  const int prow = lane >> 3;                                 // row within a piece; rows 8 i .. of the tile: sw16(row) = prow ^ 4 (i & 1)
+  const int wpar = wave & 1;
+  const uint32_t xlane = (uint32_t)((prow * p.ldx + (((lane & 7) ^ prow ^ (4 * wpar)) * 8)) * 2);
+  const uint32_t ulane = (uint32_t)((prow * p.ldu[e] + (((lane & 7) ^ prow ^ (4 * wpar)) * 8)) * 2);
+  const char* ubase = reinterpret_cast<const char*>(p.U[e] + (long)(8 * wpar) * p.ldu[e]);
+  const bool full = tok0 + B2_TOK <= p.M;                     // uniform
+  auto issue = [&](int s) {
+    const int c = s / B2_NT, t = s - c * B2_NT;
+    char* st = smem + (s & (B2_NST - 1)) * B2_STAGE;
+    if (full) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int piece = 4 * i + wave;                       // rows 8 piece .. + 7
+        const char* ub = bg_uniform_ptr(reinterpret_cast<const char*>(p.X + (long)(tok0 + t * B2_TILE + 8 * piece) * p.ldx + col0 + 64 * c));
+        __builtin_amdgcn_global_load_lds((gbl_void*)(ub + xlane), (lds_void*)(st + piece * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int piece = 4 * i + wave;
+        const int m = min(tok0 + t * B2_TILE + 8 * piece + prow, p.M - 1);
+        const char* src = reinterpret_cast<const char*>(p.X + (long)m * p.ldx + col0 + 64 * c + (((lane & 7) ^ prow ^ (4 * wpar)) * 8));
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(st + piece * 1024), 16, 0, 0);
+      }
+    }
+    const char* uu = bg_uniform_ptr(ubase + 128 * c);
+    __builtin_amdgcn_global_load_lds((gbl_void*)(uu + ulane), (lds_void*)(st + B2_XS + wpar * 1024), 16, 0, 0);
+  };
+
+  // ---- t^T fragments of the block's 512 tokens (MFMA row operand of the dB product), staged once through LDS ----
+  bf16x8 tT[B2_NT][8];
+  {
+#pragma unroll
+    for (int i = 0; i < 2 * B2_NT; ++i) {
+      const int pi = tid + 256 * i, r = pi >> 1, part2 = pi & 1;
+      const int m = tok0 + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < p.M) v = *reinterpret_cast<const uint4*>(p.V + (long)m * p.ldv + 16 * e + 8 * part2);
+      *reinterpret_cast<uint4*>(tstage + r * 32 + part2 * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < B2_NT; ++t)
+#pragma unroll
+      for (int k = 0; k < 8; k += 4) {
+        bf16x8 f[4];
+        uint32_t a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { a[i] = lds_off(tstage) + (256 * t + 32 * (k + i) + 8 * g + q) * 32 + pp * 8; b[i] = a[i] + 4 * 32; }
+        tr_read(f, a, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tT[t][k + i] = f[i];
+      }
+  }
+  if (B2_NT > 2) __syncthreads();                 // the staging area is ring space
+  const int npro = min(B2_NST - 1, nst);
+  for (int s = 0; s < npro; ++s) issue(s);
+
+  f32x4 tb[B2_NT][4];
+#pragma unroll
+  for (int t = 0; t < B2_NT; ++t)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) tb[t][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float* slab = p.slabs + (long)blockIdx.x * p.total + p.goff[e];
+  // lane constants of the consumers
+  const uint32_t xrd0 = (uint32_t)((64 * wave + l15) * 128);             // row of row block 0; chunk position (4 s2 + g) ^ sw16(l15)
+  const int swl = sw16(l15);
+  uint32_t tra[8], trb[8];                                                // transposed reads of k-step k: rows 32 k + 8 g + q (+ 4)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ka = 32 * k + 8 * g + q, swk = sw16(ka), c0 = 2 * wave + (pp >> 1);
+    tra[k] = (uint32_t)(ka * 128 + ((pp & 1) << 3) + ((c0 ^ swk) << 4));
+    trb[k] = (uint32_t)((ka + 4) * 128 + ((pp & 1) << 3) + ((c0 ^ swk ^ 4) << 4));
+  }
+
+  int s = 0;
+  for (int c = 0; c < nch; ++c) {
+    f32x4 db = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < B2_NT; ++t, ++s) {
+      // stage s has landed (this wave's pieces: the stages issued after it may be in flight), then everyone's
+      const int later = min(nst, s + B2_NST - 1) - (s + 1);
+      if (later >= 2) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      else if (later == 1) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // (every wave has finished stage s - 1: its slot takes stage s + 3)
+      if (s + B2_NST - 1 < nst) issue(s + B2_NST - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const char* st = smem + (s & (B2_NST - 1)) * B2_STAGE;
+      bf16x8 uf[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) uf[s2] = *reinterpret_cast<const bf16x8*>(st + B2_XS + l15 * 128 + (((4 * s2 + g) ^ swl) << 4));
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 xf = *reinterpret_cast<const bf16x8*>(st + xrd0 + rb * 2048 + (((4 * s2 + g) ^ swl) << 4));
+          tb[t][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[s2], xf, tb[t][rb], 0, 0, 0);
+        }
+      const uint32_t sb = lds_off(st);
+#pragma unroll
+      for (int k = 0; k < 8; k += 4) {
+        bf16x8 f[4];
+        const uint32_t a[4] = {sb + tra[k], sb + tra[k + 1], sb + tra[k + 2], sb + tra[k + 3]};
+        const uint32_t b[4] = {sb + trb[k], sb + trb[k + 1], sb + trb[k + 2], sb + trb[k + 3]};
+        tr_read(f, a, b);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) db = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT[t][k + i], f[i], db, 0, 0, 0);     // D[j = 4g+e][w = l15]
+      }
+    }
+    *reinterpret_cast<float4*>(slab + (long)(64 * c + 16 * wave + l15) * 16 + 4 * g) = make_float4(db[0], db[1], db[2], db[3]);
+  }
+  // tb: lane holds rows j = 4 g .. + 3 of token l15
+#pragma unroll
+  for (int t = 0; t < B2_NT; ++t)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+      const int m = tok0 + t * B2_TILE + 64 * wave + 16 * rb + l15;
+      if (m < p.M)
+        *reinterpret_cast<uint2*>(p.P + (long)m * p.ldp + 16 * e + 4 * g) =
+            make_uint2(pack_bf2(tb[t][rb][0] * p.alpha, tb[t][rb][1] * p.alpha), pack_bf2(tb[t][rb][2] * p.alpha, tb[t][rb][3] * p.alpha));
+    }
+}
+
 // out = sum over `splits` slabs of total4 float4 each: 1024 threads = 64 float4 x 16 groups of slabs (a thread per
 // element walking 256 slabs serially took 64 us for 64 K floats)
 __global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict__ ws, float* __restrict__ out, long total4, int splits) {
@@ -998,14 +1158,23 @@ extern "C" int ur_lora_bgrad(const ur_lora_args* a, void* workspace, int64_t wor
   p.V = (const bf16_t*)a->V; p.ldv = a->ldv;
   p.P = (bf16_t*)a->P; p.ldp = a->ldp;
   p.slabs = (float*)workspace; p.total = total; p.alpha = a->alpha;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) {
-    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&lora_bgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, BG_SMEM);
+  // every width a multiple of 64 (the decoder's are): dy goes through the LDS-DMA ring, in blocks of 1024 tokens where that still
+  // gives every CU a block (half the slabs), else 512; ragged widths keep the register-staged kernel
+  bool ring = true;
+  for (int e = 0; e < a->nad; ++e) ring = ring && (a->width[e] % 64) == 0;
+  const int kind = !ring ? 0 : ((long)ur_cdiv(a->M, 1024) * a->nad >= ur_device_cu_count() ? 2 : 1);
+  const void* fn = kind == 0 ? reinterpret_cast<const void*>(&lora_bgrad_kernel)
+                 : kind == 1 ? reinterpret_cast<const void*>(&lora_bgrad_ring_kernel<2>) : reinterpret_cast<const void*>(&lora_bgrad_ring_kernel<4>);
+  const int smem = kind == 0 ? BG_SMEM : b2_smem(kind == 1 ? 2 : 4);
+  static std::atomic<uint64_t> attr_set[3];      // per device, per kernel
+  if (ur_first_on_device(attr_set[kind])) {
+    hipError_t er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (er != hipSuccess) UR_FAIL((int)er, "ur_lora_bgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(er));
-    attr_set = true;
   }
-  const int nblk = ur_cdiv(a->M, BG_TOK);
-  hipLaunchKernelGGL(lora_bgrad_kernel, dim3(nblk, a->nad), dim3(256), BG_SMEM, st, p);
+  const int nblk = ur_cdiv(a->M, kind == 2 ? 1024 : BG_TOK);
+  if (kind == 2) hipLaunchKernelGGL(lora_bgrad_ring_kernel<4>, dim3(nblk, a->nad), dim3(256), smem, st, p);
+  else if (kind == 1) hipLaunchKernelGGL(lora_bgrad_ring_kernel<2>, dim3(nblk, a->nad), dim3(256), smem, st, p);
+  else hipLaunchKernelGGL(lora_bgrad_kernel, dim3(nblk, a->nad), dim3(256), BG_SMEM, st, p);
   UR_CHECK_LAUNCH("ur_lora_bgrad");
   const long total4 = total / 4;
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)((total4 + 63) / 64)), dim3(1024), 0, st, (const float*)workspace, (float*)a->G, total4, nblk);
