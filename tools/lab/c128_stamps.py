@@ -34,9 +34,15 @@ for i, nm in enumerate(names):
     cyc, cnt = a[:, :, 2 * i], a[:, :, 2 * i + 1]
     print(f"  {nm:10s} total {cyc.mean():10.0f}  count {cnt.mean():6.2f}  per occurrence {cyc.sum() / max(1, cnt.sum()):8.0f}")
 print(f"  C++ prologue {a[:, :, 12].mean():8.0f}   asm block {tot_asm:9.0f}   C++ epilogue {a[:, :, 14].mean():8.0f}")
-print("  after the loop: advance %.0f | barrier %.0f | key state + epilogue half 0 %.0f | request (q loads + DMA statement) %.0f | epilogue half 1 %.0f" % tuple(a[:, :, 16 + i].mean() for i in range(5)))
-for w in range(4):
-    print("    wave %d: barrier %.0f  half0 %.0f  request %.0f  half1 %.0f" % (w, a[:, w, 17].mean(), a[:, w, 18].mean(), a[:, w, 19].mean(), a[:, w, 20].mean()))
+if WHAT == "fwd":
+    print("  after the loop: advance %.0f | barrier %.0f | key state + epilogue half 0 %.0f | request (q loads + DMA statement) %.0f | epilogue half 1 %.0f" % tuple(a[:, :, 16 + i].mean() for i in range(5)))
+    for w in range(4):
+        print("    wave %d: barrier %.0f  half0 %.0f  request %.0f  half1 %.0f" % (w, a[:, w, 17].mean(), a[:, w, 18].mean(), a[:, w, 19].mean(), a[:, w, 20].mean()))
+else:
+    print("  (dQ: 'C++ prologue' = row loads + delta of this block; 'asm block' = pack + loop)")
+    print("  after the loop: advance %.0f | barrier %.0f | key state + request (DMA statement) %.0f | dQ stores %.0f" % tuple(a[:, :, 16 + i].mean() for i in range(4)))
+    for w in range(4):
+        print("    wave %d: loads %.0f  asm %.0f  barrier %.0f  request %.0f  stores %.0f" % (w, a[:, w, 12].mean(), a[:, w, 13].mean(), a[:, w, 17].mean(), a[:, w, 18].mean(), a[:, w, 19].mean()))
 for w in range(4):
     print(f"  wave {w}: STEADY per occurrence {a[:, w, 4].sum() / max(1, a[:, w, 5].sum()):7.0f}  ring wait per iteration {a[:, w, 0].sum() / max(1, a[:, w, 1].sum()):6.0f}  LAST {a[:, w, 6].sum() / max(1, a[:, w, 7].sum()):6.0f} EPI {a[:, w, 8].sum() / max(1, a[:, w, 9].sum()):6.0f}")
 if WHAT != "fwd":

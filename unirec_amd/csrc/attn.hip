@@ -2239,6 +2239,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // the wave's 64 rows, forms the row constants delta = sum_d dO O and LSE2 = (m + ln l) log2e from the forward's statistics, and
 // publishes -delta and -LSE/scale for the dK/dV kernel exactly as attn_bwd_dq_kernel does.
 // LDS: K ring 4 x 16 KiB | V ring 4 x 16 KiB | key-state words.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 namespace c128 { constexpr int DQ_WORDS_LDS = 131072, DQ_LDS_BYTES = DQ_WORDS_LDS + 64 * 8; }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dq_c128_kernel(AttnP p, int nitems, int nch, C128Div dv) {
@@ -2279,22 +2283,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const long nrows = (long)p.B * p.nq * p.Sq;
   auto udiv = [](uint32_t n, uint32_t magic, uint32_t d) { return d == 1u ? n : __umulhi(n, magic); };
 
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  // One query block = one pass of the generated loop, software-pipelined as in the forward: as soon as every wave has left the loop
+  // of block n, the first K / V tiles of block n + 1 are requested, and their latency runs under block n's epilogue (dQ stores) and
+  // block n + 1's row loads.
+  struct Blk { int item, half, x, hq, b, tend, tfirst; uint32_t mb_lo, mb_hi, kb_lo, kb_hi, vb_lo, vb_hi; bool valid; };
+  auto decode = [&](int item, int half, Blk& d) {
+    d.valid = item < nitems;
+    d.item = item; d.half = half;
+    if (!d.valid) return;
     uint32_t g, j;
     if ((ngroups & 7) == 0) { const uint32_t slot = (uint32_t)item >> 3, gq = udiv(slot, dv.m_pg, per_group); g = gq * 8u + ((uint32_t)item & 7u); j = slot - gq * per_group; }
     else { g = udiv((uint32_t)item, dv.m_pg, per_group); j = (uint32_t)item - g * per_group; }
     const uint32_t hr = udiv(j, dv.m_nch, nch), ch = j - hr * nch;
     const uint32_t bb = udiv(g, dv.m_nkv, p.nkv), kvh = g - bb * p.nkv;
-    const int hq = (int)(kvh * p.rep + hr), b = (int)bb;
-    const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
-    const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * 128;
-    const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * 128;
-    const uint32_t kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)kb), kb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)kb >> 32));
-    const uint32_t vb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)vb), vb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)vb >> 32));
-    int tfirst = 0;
-    uint32_t mb_lo = 0u, mb_hi = 0u;
+    d.hq = (int)(kvh * p.rep + hr); d.b = (int)bb;
+    d.x = half == 0 ? nx - 1 - (int)ch : (int)ch;
+    d.tend = __builtin_amdgcn_readfirstlane(min(ntiles, 4 * d.x + 4));
+    const bf16_t* kb = p.k + (long)d.b * p.Sk * p.ldk + (long)kvh * 128;
+    const bf16_t* vb = p.v + (long)d.b * p.Sk * p.ldv + (long)kvh * 128;
+    d.kb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)kb); d.kb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)kb >> 32));
+    d.vb_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)vb); d.vb_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)vb >> 32));
+  };
+  auto advance = [&](const Blk& c, Blk& n) {
+    const int chc = c.half == 0 ? nx - 1 - c.x : c.x;
+    if (c.half == 0 && nx - 1 - chc != chc) decode(c.item, 1, n); else decode(c.item + (int)gridDim.x, 0, n);
+  };
+  // key state of a sample: one word per tile (only with a key mask).  Caller: every wave has left the loop.
+  auto key_state = [&](Blk& d) {
+    d.tfirst = 0; d.mb_lo = 0u; d.mb_hi = 0u;
+    const uint8_t* km = p.kmask ? p.kmask + (long)d.b * p.Sk : nullptr;
     if (km != nullptr) {
-      __syncthreads();                       // every wave has left the previous item's loop: the words table is free
       for (int t = wave; t < ntiles; t += 4) {
         const unsigned long long wv = __ballot(km[t * KT + lane] != 0);
         if (lane == 0) words[t] = wv;
@@ -2302,64 +2320,152 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __syncthreads();
       const unsigned long long wv = lane < ntiles ? words[lane] : ~0ull;
       const unsigned long long anym = __ballot(lane < ntiles && wv != 0ull), partm = __ballot(lane < ntiles && wv != ~0ull);
-      tfirst = anym ? __builtin_ctzll(anym) : ntiles;
-      mb_lo = (uint32_t)partm; mb_hi = (uint32_t)(partm >> 32);
+      d.tfirst = anym ? __builtin_ctzll(anym) : ntiles;
+      d.mb_lo = (uint32_t)partm; d.mb_hi = (uint32_t)(partm >> 32);
     }
-    tfirst = __builtin_amdgcn_readfirstlane(tfirst);
-    mb_lo = __builtin_amdgcn_readfirstlane(mb_lo); mb_hi = __builtin_amdgcn_readfirstlane(mb_hi);
+    d.tfirst = __builtin_amdgcn_readfirstlane(d.tfirst);
+    d.mb_lo = __builtin_amdgcn_readfirstlane(d.mb_lo); d.mb_hi = __builtin_amdgcn_readfirstlane(d.mb_hi);
+  };
+  // the first tiles' LDS-DMA of block d.  Caller: the K / V rings are free.
+  auto request = [&](const Blk& d) {
+    if (!(d.valid && d.tfirst < d.tend)) return;
+    asm volatile(
+        "s_mov_b32 s36, %[kbl]\n\ts_mov_b32 s37, %[kbh]\n\ts_mov_b32 s38, %[vbl]\n\ts_mov_b32 s39, %[vbh]\n\t"
+        "s_mov_b32 s40, %[k16]\n\ts_mov_b32 s41, %[v16]\n\ts_mov_b32 s43, %[tend]\n\ts_mov_b32 s45, %[tfirst]\n\ts_mov_b32 s57, %[waveb]\n\t"
+        UR_ATTN_DQ_C128_DMA_ASM
+        :
+        : "{v[12:13]}"(voff), [kbl] "s"(d.kb_lo), [kbh] "s"(d.kb_hi), [vbl] "s"(d.vb_lo), [vbh] "s"(d.vb_hi), [k16] "s"(k16b), [v16] "s"(v16b),
+          [tend] "s"(d.tend), [tfirst] "s"(d.tfirst), [waveb] "s"(waveb)
+        : UR_ATTN_DQ_C128_DMA_CLOBBERS);
+  };
 
-    for (int half = 0; half < 2; ++half) {
-      const int x = half == 0 ? nx - 1 - (int)ch : (int)ch;
-      if (half == 1 && x == nx - 1 - (int)ch) break;
-      const int tend = __builtin_amdgcn_readfirstlane(min(ntiles, 4 * x + 4));
+  Blk cur, nxt;
+  decode((int)blockIdx.x, 0, cur);
+  if (cur.valid) { key_state(cur); __syncthreads(); request(cur); }
+  while (cur.valid) {
+    const int x = cur.x, hq = cur.hq, b = cur.b, tend = cur.tend, tfirst = cur.tfirst;
+    // Lane-derived values of the C++ parts are rebuilt from an opaque copy of the lane id EVERY block: hoisted out of this loop they
+    // would have to survive the generated statement, which leaves the compiler 8 vector registers -- it spilled ~100 of them to
+    // scratch and reloaded each behind an s_waitcnt vmcnt(0) in the middle of the row loads and the dQ stores
+    int lane_b = lane;
+    asm volatile("" : "+v"(lane_b));
+    const int lane = lane_b, h = lane >> 5, l31 = lane & 31;
+#if UR_C128_STAMPS
+    const unsigned long long st0 = __builtin_readcyclecounter();
+    unsigned long long sa = 0, sb = 0, sc = 0;
+#endif
+    {
       const int q0 = 256 * x + 64 * wave;
-      // rows of this wave: q, dO, O fragments; delta and the forward's statistics
+      // Rows of this wave: q, dO, O; delta = sum_d dO O and the forward's statistics.  The MFMA fragment layout (lane = row) would
+      // fetch 32 rows x 32 bytes per load instruction -- the texture path then spends ~24 k cycles per block on the 48 loads of a
+      // wave.  The rows are read COALESCED instead (instruction i: rows 4 i .. + 3, 16 lanes x 16 bytes per row), delta is reduced
+      // in that layout, and q / dO turn into fragments through the ring slots the first-tile request leaves free (K / V slots 1..3:
+      // 12 KiB per wave in each ring; rows >= Sq read the last row -- their LSE2 = +inf zeroes every probability).
       bf16x8 qf[2][8], dof[2][8];
       f32x4 ld;                       // LSE2[qb 0, 1], delta[qb 0, 1]
+      {
+        const int r4 = lane >> 4, c16 = lane & 15;
+        char* stA = smem + 16384 + wave * 12288;
+        char* stB = smem + VBASE_LDS + 16384 + wave * 12288;
+        float* rowc = reinterpret_cast<float*>(stA + 8192);       // [0, 64): delta, [64, 128): LSE2 of the wave's rows
+        // every address = uniform base of the (batch, head) + a 32-bit lane offset (row stride x row + chunk)
+        const bf16_t* qbase = p.q + (long)b * p.Sq * p.ldq + (long)hq * 128;
+        const bf16_t* dobase = p.dout + (long)b * p.Sq * p.lddo + (long)hq * 128;
+        const bf16_t* obase = p.o + (long)b * p.Sq * p.ldo + (long)hq * 128;
+        auto ubase = [](const bf16_t* ptr) {
+          const uint64_t v = reinterpret_cast<uint64_t>(ptr);
+          uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+          asm volatile("" : "+s"(lo), "+s"(hi));
+          return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+        };
+        const char* qb8 = ubase(qbase); const char* dob8 = ubase(dobase); const char* ob8 = ubase(obase);
+        typedef uint32_t raw4_t __attribute__((ext_vector_type(4)));
+        auto ldrow = [&](const char* base8, long ld, int i) {
+          const uint32_t off = (uint32_t)min(q0 + 4 * i + r4, p.Sq - 1) * (uint32_t)(ld * 2) + (uint32_t)(16 * c16);
+          const raw4_t r = *(const __attribute__((address_space(1))) raw4_t*)(base8 + off);      // global_load ... s[base] (not FLAT)
+          return make_uint4(r[0], r[1], r[2], r[3]);
+        };
+        uint4 qr[16], dr[16], ovr[16];
+        float dl[16];
+        // all rows requested in consumption order (q, dO, O, this lane's row statistics: loads return in order); q turns into
+        // fragments while the rest flies
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
-        const int row = q0 + 32 * qb + l31;
+        for (int i = 0; i < 16; ++i) qr[i] = ldrow(qb8, p.ldq, i);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dr[i] = ldrow(dob8, p.lddo, i);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ovr[i] = ldrow(ob8, p.ldo, i);
+        const int rl = 4 * c16 + r4, row = q0 + rl;             // this lane's row of the wave's 64 (delta / LSE bookkeeping)
         const bool ok = row < p.Sq;
-        const long qtok = (long)b * p.Sq + (ok ? row : 0);
-        float dlt = 0.f;
+        const long srow = ((long)b * p.nq + hq) * p.Sq + (ok ? row : 0);
+        const float st_m = p.stats[srow * 2], st_inv = p.stats[srow * 2 + 1];
+        __builtin_amdgcn_sched_barrier(0);
+        // q: rows 0..31 through stA, rows 32..63 through stB (tile layout of the K ring: Cfg<128>::off)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<uint4*>((i < 8 ? stA : stB) + C::off(4 * (i & 7) + r4, c16)) = qr[i];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-          qf[qb][ks] = g_frag(p.q + qtok * p.ldq + (long)hq * 128, ks, lane, ok);
-          dof[qb][ks] = g_frag(p.dout + qtok * p.lddo + (long)hq * 128, ks, lane, ok);
-          const bf16x8 of = g_frag(p.o + qtok * p.ldo + (long)hq * 128, ks, lane, ok);
+          qf[0][ks] = *reinterpret_cast<const bf16x8*>(stA + C::off(l31, 2 * ks + h));
+          qf[1][ks] = *reinterpret_cast<const bf16x8*>(stB + C::off(l31, 2 * ks + h));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) dlt = fmaf(bf2f((bf16_t)dof[qb][ks][e]), bf2f((bf16_t)of[e]), dlt);
+          for (int i = 0; i < 16; ++i) {
+            const uint32_t dw4[4] = {dr[i].x, dr[i].y, dr[i].z, dr[i].w}, ow4[4] = {ovr[i].x, ovr[i].y, ovr[i].z, ovr[i].w};
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+            float acc = 0.f;                     // v_dot2c_f32_bf16: two bf16 products per instruction, f32 accumulation
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2_t, dw4[e]), __builtin_bit_cast(bf2_t, ow4[e]), acc, false);
+            dl[i] = acc;
+          }
         }
-        dlt += __shfl_xor(dlt, 32, 64);
-        const long srow = ((long)b * p.nq + hq) * p.Sq + (ok ? row : 0);
-        const float m = p.stats[srow * 2], inv = ok ? p.stats[srow * 2 + 1] : 0.f;
-        const float lse = m - __logf(inv);                 // natural log of the row's normaliser, scaled scores
-        if (ok && h == 0) {
-          float* ws = const_cast<float*>(p.delta);
-          ws[srow] = -dlt;
-          ws[nrows + srow] = (inv > 0.f) ? (p.lse_log2 ? -lse * LOG2E : -lse / p.scale) : NEG_INF;
+        // sum over the 16 lanes of a row (one DPP row): quad swaps, then the mirrored half and the mirrored row (the partial sums are
+        // uniform within what has been summed already, so a mirror reaches the other half); lane c16 keeps the total of dl[c16]
+        float mine = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float v = dl[i];
+          v += dpp_f32<0xB1>(v);        // quad_perm [1, 0, 3, 2]
+          v += dpp_f32<0x4E>(v);        // quad_perm [2, 3, 0, 1]
+          v += dpp_f32<0x141>(v);       // row_half_mirror
+          v += dpp_f32<0x140>(v);       // row_mirror
+          mine = c16 == i ? v : mine;
         }
-        ld[qb] = (inv > 0.f) ? lse * LOG2E : __builtin_huge_valf();
-        ld[2 + qb] = dlt;
+        dl[0] = mine;
+        {
+          const float dlt = dl[0];
+          const float m = st_m, inv = ok ? st_inv : 0.f;
+          const float lse = m - __logf(inv);                 // natural log of the row's normaliser, scaled scores
+          if (ok) {
+            float* ws = const_cast<float*>(p.delta);
+            ws[srow] = -dlt;
+            ws[nrows + srow] = (inv > 0.f) ? (p.lse_log2 ? -lse * LOG2E : -lse / p.scale) : NEG_INF;
+          }
+          rowc[rl] = dlt;
+          rowc[64 + rl] = (inv > 0.f) ? lse * LOG2E : __builtin_huge_valf();
+        }
+        // dO through the same areas (the wave's LDS operations execute in order: its q fragment reads precede these writes)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<uint4*>((i < 8 ? stA : stB) + C::off(4 * (i & 7) + r4, c16)) = dr[i];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          dof[0][ks] = *reinterpret_cast<const bf16x8*>(stA + C::off(l31, 2 * ks + h));
+          dof[1][ks] = *reinterpret_cast<const bf16x8*>(stB + C::off(l31, 2 * ks + h));
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) { ld[qb] = rowc[64 + 32 * qb + l31]; ld[2 + qb] = rowc[32 * qb + l31]; }
       }
       f32x32 d0, d1, d2, d3;
+      advance(cur, nxt);              // scalar work: its results wait in scalar registers / spill lanes while the loop runs
 #if UR_C128_STAMPS
-      unsigned int* dbg = g_c128_stamps + ((size_t)((item * 2 + half) & 8191) * 4 + wave) * 32;
+      unsigned int* dbg = g_c128_stamps + ((size_t)((cur.item * 2 + cur.half) & 8191) * 4 + wave) * 32;
       const uint32_t db_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dbg), db_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)dbg >> 32));
       const unsigned long long st1 = __builtin_readcyclecounter(), sr1 = wall_clock64();
       unsigned long long st2 = st1;
 #endif
-      __syncthreads();                     // every wave has left the previous loop: the K / V rings are free
       if (tfirst < tend) {
         const int tlast = __builtin_amdgcn_readfirstlane(q0 < p.Sq ? min(4 * x + wave, ntiles - 1) : -1);
-        asm volatile(
-            "s_mov_b32 s36, %[kbl]\n\ts_mov_b32 s37, %[kbh]\n\ts_mov_b32 s38, %[vbl]\n\ts_mov_b32 s39, %[vbh]\n\t"
-            "s_mov_b32 s40, %[k16]\n\ts_mov_b32 s41, %[v16]\n\ts_mov_b32 s43, %[tend]\n\ts_mov_b32 s45, %[tfirst]\n\ts_mov_b32 s57, %[waveb]\n\t"
-            UR_ATTN_DQ_C128_DMA_ASM
-            :
-            : "{v[12:13]}"(voff), [kbl] "s"(kb_lo), [kbh] "s"(kb_hi), [vbl] "s"(vb_lo), [vbh] "s"(vb_hi), [k16] "s"(k16b), [v16] "s"(v16b),
-              [tend] "s"(tend), [tfirst] "s"(tfirst), [waveb] "s"(waveb)
-            : UR_ATTN_DQ_C128_DMA_CLOBBERS);
         i32x32 qv0, qv1, dov0, dov1;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
@@ -2370,6 +2476,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             dov0[4 * ks + jj] = (int)((uint32_t)(uint16_t)dof[0][ks][2 * jj] | ((uint32_t)(uint16_t)dof[0][ks][2 * jj + 1] << 16));
             dov1[4 * ks + jj] = (int)((uint32_t)(uint16_t)dof[1][ks][2 * jj] | ((uint32_t)(uint16_t)dof[1][ks][2 * jj + 1] << 16));
           }
+        __syncthreads();        // the statement's entry LDS-DMA fills ring slots 1 and 2: every wave is done with its staging area there
         asm volatile(
             "s_mov_b32 s36, %[kbl]\n\ts_mov_b32 s37, %[kbh]\n\ts_mov_b32 s38, %[vbl]\n\ts_mov_b32 s39, %[vbh]\n\t"
             "s_mov_b32 s40, %[k16]\n\ts_mov_b32 s41, %[v16]\n\ts_mov_b32 s43, %[tend]\n\ts_mov_b32 s44, %[tlast]\n\t"
@@ -2381,8 +2488,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             : "=&{a[0:31]}"(d0), "=&{a[32:63]}"(d1), "=&{a[64:95]}"(d2), "=&{a[96:127]}"(d3)
             : "{a[128:159]}"(qv0), "{a[160:191]}"(qv1), "{a[192:223]}"(dov0), "{a[224:255]}"(dov1), "{v[240:241]}"(kava), "{v[242:249]}"(tatb),
               "{v[250:253]}"(ld), "{v[8:9]}"(dw), "{v[12:13]}"(voff),
-              [kbl] "s"(kb_lo), [kbh] "s"(kb_hi), [vbl] "s"(vb_lo), [vbh] "s"(vb_hi), [k16] "s"(k16b), [v16] "s"(v16b), [tend] "s"(tend),
-              [tlast] "s"(tlast), [tfirst] "s"(tfirst), [mbl] "s"(mb_lo), [mbh] "s"(mb_hi), [waveb] "s"(waveb)
+              [kbl] "s"(cur.kb_lo), [kbh] "s"(cur.kb_hi), [vbl] "s"(cur.vb_lo), [vbh] "s"(cur.vb_hi), [k16] "s"(k16b), [v16] "s"(v16b), [tend] "s"(tend),
+              [tlast] "s"(tlast), [tfirst] "s"(tfirst), [mbl] "s"(cur.mb_lo), [mbh] "s"(cur.mb_hi), [waveb] "s"(waveb)
 #if UR_C128_STAMPS
               , [dbl] "s"(db_lo), [dbh] "s"(db_hi)
 #endif
@@ -2394,6 +2501,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
         for (int i = 0; i < 32; ++i) { d0[i] = 0.f; d1[i] = 0.f; d2[i] = 0.f; d3[i] = 0.f; }
       }
+      // the next block (decoded before the loop): once every wave has left the loop its key state is built and its first tiles are requested
+#if UR_C128_STAMPS
+      sa = __builtin_readcyclecounter();
+#endif
+      __syncthreads();
+#if UR_C128_STAMPS
+      sb = __builtin_readcyclecounter();
+#endif
+      if (nxt.valid) {
+        if (nxt.item != cur.item) { key_state(nxt); if (p.kmask) __syncthreads(); }
+        else { nxt.tfirst = cur.tfirst; nxt.mb_lo = cur.mb_lo; nxt.mb_hi = cur.mb_hi; }
+      }
+      request(nxt);
+#if UR_C128_STAMPS
+      sc = __builtin_readcyclecounter();
+#endif
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const int row = q0 + 32 * qb + l31;
@@ -2411,11 +2534,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #if UR_C128_STAMPS
       if (lane == 0) {
         const unsigned long long st3 = __builtin_readcyclecounter(), sr3 = wall_clock64();
-        dbg[12] = 0; dbg[13] = (unsigned int)(st2 - st1); dbg[14] = (unsigned int)(st3 - st2); dbg[15] = (unsigned int)x;
+        dbg[12] = (unsigned int)(st1 - st0); dbg[13] = (unsigned int)(st2 - st1); dbg[14] = (unsigned int)(st3 - st2); dbg[15] = (unsigned int)x;
+        dbg[16] = (unsigned int)(sa - st2); dbg[17] = (unsigned int)(sb - sa); dbg[18] = (unsigned int)(sc - sb); dbg[19] = (unsigned int)(st3 - sc); dbg[20] = 0;
         dbg[21] = (unsigned int)(st3 - st1); dbg[22] = (unsigned int)(sr3 - sr1);      // shader cycles and 100 MHz ticks of the same span: the clock
       }
 #endif
     }
+    cur = nxt;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA pieces of the last loop iterations: landed before the workgroup gives its LDS back
 }
