@@ -2135,6 +2135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #endif
     f32x32 o0, o1, o2, o3, lsum;       // lsum: [qb][16], every register of a query block's tile = the row sum
     c128::f32x2 mrow;
+    advance(cur, nxt);                 // scalar work: its results wait in scalar registers / spill lanes while the loop runs
     if (cur.tfirst < cur.tend) {
       // element j of lane half h of k-step ks = q[row][16 ks + 8 h + j] * scale * log2(e), rounded to bf16 once more
       i32x32 qv0, qv1;
@@ -2174,9 +2175,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int i = 0; i < 32; ++i) { o0[i] = 0.f; o1[i] = 0.f; o2[i] = 0.f; o3[i] = 0.f; lsum[i] = 0.f; }
       mrow = c128::f32x2{0.f, 0.f};
     }
-    // the next block: once every wave has left the loop, its key state is built; its q rows and first tiles are requested between
-    // the two halves of this block's epilogue (after the first half has freed its registers) and fly under the second half
-    advance(cur, nxt);
+    // the next block (decoded before the loop): once every wave has left the loop, its key state is built; its q rows and first tiles
+    // are requested between the two halves of this block's epilogue (after the first half has freed its registers) and fly under the second half
 #if UR_C128_STAMPS
     sa = __builtin_readcyclecounter();
 #endif
