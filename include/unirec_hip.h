@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 7
+#define UR_ABI_VERSION 8
 
 int ur_version(void);
 const char* ur_last_error(void);
@@ -246,6 +246,12 @@ typedef struct {
   const void* rope_q_raw; int64_t rope_ldraw;
   const float* rope_q_weight; const float* rope_cos; const float* rope_sin; float rope_eps;
   void* rope_dq_raw; int64_t rope_lddraw;
+  /* rope_rstd != NULL (with rope_q_raw): the forward ran q-norm + RoPE as the q|k|v GEMM's epilogue (ur_gemm_args.qkr_*) and the raw
+   * projection was never stored.  rope_q_raw then holds the ROPED, normed q (that epilogue's qkr_q: the q of ur_attn_args), the
+   * normalised row is recovered by rotating back (x^ = R^T(q) / weight; non-zero norm weights) and 1 / rms of (token m, head h) is
+   * rope_rstd[m * rope_rstd_ld + rope_rstd_h0 + h] (qkr_rstd); rope_eps is not used.  Same arithmetic as
+   * ur_qknorm_rope_bwd_roped on the q heads. */
+  const float* rope_rstd; int64_t rope_rstd_ld; int32_t rope_rstd_h0;
 } ur_attn_bwd_args;
 int ur_attn_fwd(const ur_attn_args* a, void* stream);
 int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, void* stream);
@@ -271,6 +277,12 @@ int ur_qknorm_rope_bwd(const void* dq_out, const void* dk_out, const void* qkv_r
 int ur_qknorm_rope_bwd_roped(const void* dq_out, const void* dk_out, const void* q_roped, int64_t ldq, const void* k_roped, int64_t ldk,
                              const float* rstd, const float* q_norm_w, const float* k_norm_w, const float* cos_tab, const float* sin_tab,
                              void* dqkv_raw, int64_t lddraw, int64_t M, int32_t S, int32_t nq, int32_t nkv, int32_t head_dim, void* stream);
+/* The k heads alone (nq = 0 above would lose the row-constant layout): the q heads' backward rode in the dQ kernel
+ * (ur_attn_bwd_args.rope_rstd).  dk_out [M, nkv*hd] dense, k_roped [M, >= nkv*hd], 1 / rms of (m, k head h) = rstd[m * rstd_ld + rstd_h0 + h],
+ * dk_raw [M, >= nkv*hd] (row stride lddraw) receives the gradient of the raw k projection. */
+int ur_qknorm_rope_bwd_roped_k(const void* dk_out, const void* k_roped, int64_t ldk, const float* rstd, int64_t rstd_ld, int32_t rstd_h0,
+                               const float* k_norm_w, const float* cos_tab, const float* sin_tab, void* dk_raw, int64_t lddraw,
+                               int64_t M, int32_t S, int32_t nkv, int32_t head_dim, void* stream);
 
 /* Embedding gather fused with Q-Former token injection --
  * training/train_item_individual_token_joint.py:143 (embed) and :160-171 (triple python loop with a

@@ -236,6 +236,54 @@ def test_dq_kernel_carries_qnorm_rope_backward(S, mask_kind):
     assert (a - bq).norm() / a.norm() < 3e-3
 
 
+@pytest.mark.parametrize("S,mask_kind", [(130, "none"), (512, "left"), (200, "rand"), (1024, "left")])
+def test_dq_kernel_carries_qnorm_rope_backward_from_roped_q(S, mask_kind):
+    """ur_attn_bwd with rope_rstd: the forward ran q/k-norm + RoPE as the q|k|v GEMM's epilogue, so only the ROPED q and 1 / rms exist.
+    The dQ kernel's store recovers the normalised row from its own q operand and writes the gradient of the raw projection; against
+    the two-kernel path (dQ, then ur_qknorm_rope_bwd_roped) on the same inputs, and the k-only stand-alone kernel against the k
+    columns of the full one (same kernel, same inputs: bit for bit).  S 512 / 1024 run the generated kernels, 130 / 200 the generic."""
+    B, nq, nkv, hd, eps = 2, 4, 2, 128, 1e-6
+    NQ, NKV = nq * hd, nkv * hd
+    M = B * S
+    qkv = _randn((M, NQ + 2 * NKV), S).contiguous()
+    g = torch.Generator(device="cpu").manual_seed(S)
+    qw = (1.0 + 0.1 * torch.randn(hd, generator=g)).to(DEV)
+    kw = (1.0 + 0.1 * torch.randn(hd, generator=g)).to(DEV)
+    cos, sin = hip.rope_table(S, hd, 1e6, DEV)
+    q_r, k_r = hip.qknorm_rope_fwd(qkv, qw, kw, cos, sin, S, nq, nkv, hd, eps)
+    rstd = torch.rsqrt(qkv[:, :NQ + NKV].float().view(M, nq + nkv, hd).pow(2).mean(-1) + eps).contiguous()
+    km = None
+    if mask_kind != "none":
+        km = torch.ones((B, S), dtype=torch.uint8)
+        if mask_kind == "left":
+            km[1, :70] = 0
+        else:
+            km = (torch.rand((B, S), generator=g) < 0.8).to(torch.uint8); km[:, 0] = 1
+        km = km.to(DEV)
+    v4 = qkv[:, NQ + NKV:].view(B, S, nkv, hd)
+    o, ctx = hip.attn_fwd(q_r.view(B, S, nq, hd), k_r.view(B, S, nkv, hd), v4, causal=True, key_mask=km)
+    dout = _randn((B, S, nq, hd), S + 3)
+    d0 = torch.zeros_like(qkv)
+    dq_r = torch.empty((M, NQ), dtype=torch.bfloat16, device=DEV); dk_r = torch.empty((M, NKV), dtype=torch.bfloat16, device=DEV)
+    hip.attn_bwd(ctx, dout, dq=dq_r.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd), dv=d0[:, NQ + NKV:].view(B, S, nkv, hd))
+    hip.qknorm_rope_bwd_roped(dq_r, dk_r, q_r, k_r, rstd, qw, kw, cos, sin, d0, S, nq, nkv, hd)
+    d1 = torch.zeros_like(qkv)
+    dk2 = torch.empty_like(dk_r)
+    hip.attn_bwd(ctx, dout, dk=dk2.view(B, S, nkv, hd), dv=d1[:, NQ + NKV:].view(B, S, nkv, hd), rope_q=(q_r, qw, cos, sin, eps, d1[:, :NQ]),
+                 rope_rstd=(rstd, 0))
+    hip.qknorm_rope_bwd_roped_k(dk2, k_r, rstd, nq, kw, cos, sin, d1[:, NQ:NQ + NKV], S, nkv, hd)
+    torch.cuda.synchronize()
+    assert torch.equal(dk_r, dk2) and torch.equal(d0[:, NQ:], d1[:, NQ:])
+    a, bq = d0[:, :NQ].float(), d1[:, :NQ].float()
+    assert torch.isfinite(bq).all() and a.abs().max() > 0
+    assert (a - bq).abs().max() <= 2e-2 * a.abs().max()
+    assert (a - bq).norm() / a.norm() < 3e-3
+    # and against the raw-projection backward (the reference chain): to the tolerance of the roped recovery
+    d2 = torch.zeros_like(qkv)
+    hip.qknorm_rope_bwd(dq_r, dk_r, qkv, qw, kw, cos, sin, d2, S, nq, nkv, hd, eps)
+    assert (d2[:, :NQ].float() - bq).norm() / d2[:, :NQ].float().norm() < 1e-2
+
+
 @pytest.mark.parametrize("spike_key,gain", [(200, 6.0), (31, 3.0), (449, 12.0), (64, 1.5)])
 def test_deferred_max_rescale_is_exact_when_forced(spike_key, gain):
     """The forward defers the running-maximum update while the maximum grows by less than 2^6: a rare, data-dependent

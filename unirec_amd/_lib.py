@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UNIREC_HIP_LIB selects another build of the SAME library (kernel A/B experiments); there is still no fallback.
 LIB_PATH = os.environ.get("UNIREC_HIP_LIB") or os.path.join(_HERE, "lib", "libunirec_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_void_p, c_int, c_i64, c_u64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
@@ -66,7 +66,8 @@ class AttnBwdArgs(ctypes.Structure):
     _fields_ = [("dout", c_void_p), ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
                 ("lddo", c_i64), ("lddq", c_i64), ("lddk", c_i64), ("lddv", c_i64), ("delta", c_void_p),
                 ("rope_q_raw", c_void_p), ("rope_ldraw", c_i64), ("rope_q_weight", c_void_p), ("rope_cos", c_void_p),
-                ("rope_sin", c_void_p), ("rope_eps", c_float), ("rope_dq_raw", c_void_p), ("rope_lddraw", c_i64)]
+                ("rope_sin", c_void_p), ("rope_eps", c_float), ("rope_dq_raw", c_void_p), ("rope_lddraw", c_i64),
+                ("rope_rstd", c_void_p), ("rope_rstd_ld", c_i64), ("rope_rstd_h0", c_int)]
 
 
 # name -> (restype, argtypes).  Every symbol include/unirec_hip.h declares must appear here
@@ -114,6 +115,8 @@ SIGNATURES = {
                                    c_i64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ur_qknorm_rope_bwd_roped": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_int, c_void_p]),
+    "ur_qknorm_rope_bwd_roped_k": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_i64,
+                                           c_i64, c_int, c_int, c_int, c_void_p]),
     "ur_embed_inject_fwd": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ur_inject_bwd": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ur_user_sequence_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_u64,

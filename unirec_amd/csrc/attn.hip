@@ -84,6 +84,7 @@ struct AttnP {
   // gradient of the RAW q projection
   const bf16_t* rp_raw; long rp_ldraw; const float* rp_w; const float* rp_cos; const float* rp_sin; float rp_eps;
   bf16_t* rp_draw; long rp_lddraw;
+  const float* rp_rstd; long rp_rstd_ld; int rp_rstd_h0;      // non-null: rp_raw is the ROPED, normed q and 1 / rms comes from the forward (ur_attn_bwd_args.rope_rstd)
   // hand-scheduled causal head_dim-128 backward (both kernels or neither): plane 1 of `delta` holds -LSE * log2(e) instead of -LSE / scale
   int lse_log2;
 };
@@ -602,6 +603,48 @@ __device__ __forceinline__ void dq_store_block(const AttnP& p, f32x16 (&dq)[Cfg<
     const float* cr = p.rp_cos + (long)pos * (HD / 2);
     const float* sr = p.rp_sin + (long)pos * (HD / 2);
     uint2 xp[4][4];
+    if (p.rp_rstd != nullptr) {
+      // the forward ran as the q|k|v GEMM's epilogue: xp holds the ROPED, normed q; x^ = R^T(q) / w (qknorm_rope_bwd_roped_kernel)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) xp[dt][rq] = *reinterpret_cast<const uint2*>(xr + 32 * dt + 8 * rq + 4 * h);
+      const float rs = p.rp_rstd[qrow * p.rp_rstd_ld + p.rp_rstd_h0 + hq];
+      float xh[4][16];
+      float t = 0.f;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int j = 32 * dt + 8 * rq + 4 * h;
+          const float4 c4 = *reinterpret_cast<const float4*>(cr + j), s4 = *reinterpret_cast<const float4*>(sr + j);
+          const float4 wa = *reinterpret_cast<const float4*>(p.rp_w + j), wb = *reinterpret_cast<const float4*>(p.rp_w + j + 64);
+          const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+          const float wA[4] = {wa.x, wa.y, wa.z, wa.w}, wB[4] = {wb.x, wb.y, wb.z, wb.w};
+          const float oA[4] = {bf_lo(xp[dt][rq].x), bf_hi(xp[dt][rq].x), bf_lo(xp[dt][rq].y), bf_hi(xp[dt][rq].y)};
+          const float oB[4] = {bf_lo(xp[dt + 2][rq].x), bf_hi(xp[dt + 2][rq].x), bf_lo(xp[dt + 2][rq].y), bf_hi(xp[dt + 2][rq].y)};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * rq + e;
+            const float hA = (oA[e] * cc[e] + oB[e] * sn[e]) * __builtin_amdgcn_rcpf(wA[e]);      // forward: o = xn c -+ partner(xn) s
+            const float hB = (oB[e] * cc[e] - oA[e] * sn[e]) * __builtin_amdgcn_rcpf(wB[e]);
+            const float dA = bf2f(f2bf(dq[dt][r])), dB = bf2f(f2bf(dq[dt + 2][r]));               // (the standalone kernel reads dq back as bf16)
+            const float gA = (dA * cc[e] + dB * sn[e]) * wA[e];
+            const float gB = (dB * cc[e] - dA * sn[e]) * wB[e];
+            t += gA * hA + gB * hB;
+            dq[dt][r] = gA; dq[dt + 2][r] = gB;
+            xh[dt][r] = hA; xh[dt + 2][r] = hB;
+          }
+        }
+      t += __shfl_xor(t, 32, 64);
+      t /= (float)HD;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[dt][r] = rs * (dq[dt][r] - xh[dt][r] * t);
+      store_T<HD>(p.rp_draw + qrow * p.rp_lddraw + (long)hq * HD, dq, 1.0f, lane, qok);
+      return;
+    }
     float ss = 0.f;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -2845,6 +2888,8 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
                UR_ALIGNED16(g->rope_q_weight) && UR_ALIGNED16(g->rope_cos) && UR_ALIGNED16(g->rope_sin) && (g->rope_ldraw % 8) == 0 &&
                (g->rope_lddraw % 8) == 0 && g->rope_ldraw >= (int64_t)a->nq * a->head_dim && g->rope_lddraw >= (int64_t)a->nq * a->head_dim,
                "ur_attn_bwd: bad q-norm / RoPE operands (16-byte aligned, row strides %% 8 == 0)");
+    UR_REQUIRE(g->rope_rstd == nullptr || (g->rope_rstd_h0 >= 0 && g->rope_rstd_ld >= (int64_t)g->rope_rstd_h0 + a->nq),
+               "ur_attn_bwd: rope_rstd needs rope_rstd_ld >= rope_rstd_h0 + nq");
   }
   UR_REQUIRE(UR_ALIGNED16(g->dout) && UR_ALIGNED16(a->o) && (g->lddo % 8) == 0 && (a->ldo % 8) == 0, "ur_attn_bwd: dout/o need 16-byte aligned rows");
   UR_REQUIRE((g->dq == nullptr || (g->lddq % 4) == 0) && (g->lddk % 4) == 0 && (g->lddv % 4) == 0 && ((uintptr_t)g->dq & 7) == 0 && ((uintptr_t)g->dk & 7) == 0 &&
@@ -2853,6 +2898,7 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
   p.lddo = g->lddo; p.lddq = g->lddq; p.lddk = g->lddk; p.lddv = g->lddv;
   p.rp_raw = (const bf16_t*)g->rope_q_raw; p.rp_ldraw = g->rope_ldraw; p.rp_w = g->rope_q_weight; p.rp_cos = g->rope_cos; p.rp_sin = g->rope_sin;
   p.rp_eps = g->rope_eps; p.rp_draw = (bf16_t*)g->rope_dq_raw; p.rp_lddraw = g->rope_lddraw;
+  p.rp_rstd = g->rope_q_raw ? g->rope_rstd : nullptr; p.rp_rstd_ld = g->rope_rstd_ld; p.rp_rstd_h0 = g->rope_rstd_h0;
   hipStream_t st = (hipStream_t)stream;
   p.lse_log2 = (a->head_dim == 128 && a->causal != 0 && c128_bwd_ok(p)) ? 1 : 0;
   if (tiny_shape(p, a->head_dim, a->causal != 0, true)) return launch_tiny(p, true, st);      // dQ, dK, dV in one kernel

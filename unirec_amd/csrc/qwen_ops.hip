@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_roped_kernel(const bf16_t
                                                                     const bf16_t* __restrict__ qr, long ldqr, const bf16_t* __restrict__ kr, long ldkr,
                                                                     const float* __restrict__ rstd, const float* __restrict__ qw, const float* __restrict__ kw,
                                                                     const float* __restrict__ cs, const float* __restrict__ sn,
-                                                                    bf16_t* __restrict__ draw, long lddraw, long M, int S, int nq, int nkv) {
+                                                                    bf16_t* __restrict__ draw, long lddraw, long M, int S, int nq, int nkv,
+                                                                    long rstd_ld, int rstd_h0) {
   constexpr int LPH = HD / 8, HALF = HD / 2;
   const int lane = threadIdx.x & 63;
   const int li = lane % LPH;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_bwd_roped_kernel(const bf16_t
         const bool isq = hh < nq;
         orr[u] = *reinterpret_cast<const uint4*>((isq ? qr + m * ldqr + (long)hh * HD : kr + m * ldkr + (long)(hh - nq) * HD) + li * 8);
         dyr[u] = *reinterpret_cast<const uint4*>((isq ? dqo + m * (long)nq * HD + (long)hh * HD : dko + m * (long)nkv * HD + (long)(hh - nq) * HD) + li * 8);
-        rsv[u] = rstd[m * nh + hh];
+        rsv[u] = rstd[m * rstd_ld + rstd_h0 + hh];
       }
 #pragma unroll
       for (int u = 0; u < UH; ++u) {
@@ -430,8 +431,28 @@ extern "C" int ur_qknorm_rope_bwd_roped(const void* dq_out, const void* dk_out, 
   const int grid = grid_cap(((long)M + tpb - 1) / tpb, 256 * 16);
   hipLaunchKernelGGL((qknorm_rope_bwd_roped_kernel<128>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dq_out, (const bf16_t*)dk_out,
                      (const bf16_t*)q_roped, (long)ldq, (const bf16_t*)k_roped, (long)ldk, rstd, q_norm_w, k_norm_w, cos_tab, sin_tab,
-                     (bf16_t*)dqkv_raw, (long)lddraw, (long)M, S, nq, nkv);
+                     (bf16_t*)dqkv_raw, (long)lddraw, (long)M, S, nq, nkv, (long)(nq + nkv), 0);
   UR_CHECK_LAUNCH("ur_qknorm_rope_bwd_roped");
+  return 0;
+}
+
+extern "C" int ur_qknorm_rope_bwd_roped_k(const void* dk_out, const void* k_roped, int64_t ldk, const float* rstd, int64_t rstd_ld, int32_t rstd_h0,
+                                          const float* k_norm_w, const float* cos_tab, const float* sin_tab, void* dk_raw, int64_t lddraw,
+                                          int64_t M, int32_t S, int32_t nkv, int32_t head_dim, void* stream) {
+  UR_REQUIRE(head_dim == 128, "ur_qknorm_rope_bwd_roped_k: head_dim must be 128 (the q|k|v epilogue it pairs with)");
+  UR_REQUIRE(dk_out && k_roped && rstd && k_norm_w && cos_tab && sin_tab && dk_raw && M >= 0 && S > 0 && nkv > 0 && rstd_h0 >= 0 && rstd_ld >= rstd_h0 + nkv,
+             "ur_qknorm_rope_bwd_roped_k: null / bad argument");
+  UR_REQUIRE((ldk % 8) == 0 && (lddraw % 8) == 0 && ldk >= (int64_t)nkv * head_dim && lddraw >= (int64_t)nkv * head_dim && UR_ALIGNED16(dk_out) &&
+             UR_ALIGNED16(k_roped) && UR_ALIGNED16(k_norm_w) && UR_ALIGNED16(cos_tab) && UR_ALIGNED16(sin_tab) && UR_ALIGNED16(dk_raw),
+             "ur_qknorm_rope_bwd_roped_k: alignment / stride");
+  if (M == 0) return 0;
+  const int tpb = 256 / (head_dim / 8);
+  const int grid = grid_cap(((long)M + tpb - 1) / tpb, 256 * 16);
+  // (nq = 0: every head of the kernel's walk is a k head; the q operands are never dereferenced)
+  hipLaunchKernelGGL((qknorm_rope_bwd_roped_kernel<128>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dk_out, (const bf16_t*)dk_out,
+                     (const bf16_t*)k_roped, (long)ldk, (const bf16_t*)k_roped, (long)ldk, rstd, k_norm_w, k_norm_w, cos_tab, sin_tab,
+                     (bf16_t*)dk_raw, (long)lddraw, (long)M, S, 0, nkv, (long)rstd_ld, (int)rstd_h0);
+  UR_CHECK_LAUNCH("ur_qknorm_rope_bwd_roped_k");
   return 0;
 }
 

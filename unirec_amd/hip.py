@@ -258,6 +258,18 @@ def qknorm_rope_bwd_roped(dq_out, dk_out, q_r, k_r, rstd, qw, kw, cos, sin, dqkv
     return dqkv_raw
 
 
+@_stream_family("qknorm_rope_bwd", lambda r, dk_out, k_r, rstd, h0, kw, cos, sin, dk_raw, S, nkv, hd: 3 * _nb(dk_out))      # gradient in, roped k in, raw gradient out
+def qknorm_rope_bwd_roped_k(dk_out, k_r, rstd, h0, kw, cos, sin, dk_raw, S, nkv, hd):
+    """The k heads of qknorm_rope_bwd_roped alone (the q heads rode in the dQ kernel: attn_bwd(..., rope_rstd=...)): dk_raw [M, >= nkv*hd]
+    view receives the gradient of the raw k projection; 1 / rms of (m, k head h) = rstd[m, h0 + h]."""
+    lib = _lib.load()
+    M = k_r.shape[0]
+    check(lib.ur_qknorm_rope_bwd_roped_k(dk_out.data_ptr(), k_r.data_ptr(), k_r.stride(0), rstd.data_ptr(), rstd.stride(0), int(h0), kw.data_ptr(),
+                                         cos.data_ptr(), sin.data_ptr(), dk_raw.data_ptr(), dk_raw.stride(0), M, S, nkv, hd, _stream()),
+          "ur_qknorm_rope_bwd_roped_k")
+    return dk_raw
+
+
 def gemm_persistent_mode(mode):
     """0 = generic GEMM kernel only, 1 = persistent kernel where eligible, -1 = default; returns the previous setting
     (ur_gemm_persistent_mode, include/unirec_hip.h)."""
@@ -511,10 +523,12 @@ def attn_fwd(q, k, v, *, causal, key_mask=None, scale=None, dropout_p=0.0, seed=
     return out, ctx
 
 
-def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None):
+def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None, rope_rstd=None):
     """dout [B,Sq,nq,hd] -> (dq, dk, dv); outputs may be strided views into a fused gradient buffer.
     rope_q = (q_raw [M, >= nq*hd] view, q_norm_weight f32 [hd], cos, sin, eps, dq_raw [M, >= nq*hd] view): the dQ kernel carries
-    the q-norm + RoPE backward and writes the gradient of the RAW q projection into dq_raw; no dq is produced (returns None)."""
+    the q-norm + RoPE backward and writes the gradient of the RAW q projection into dq_raw; no dq is produced (returns None).
+    rope_rstd = (rstd f32 [M, nh], first q head's column): the forward ran q-norm + RoPE in the q|k|v GEMM epilogue -- rope_q[0]
+    is then the ROPED q (the attention's own q) and 1 / rms comes from rstd (ur_attn_bwd_args.rope_rstd)."""
     lib = _lib.load()
     q, k, v, _ = ctx.keep
     if dq is None and rope_q is None:
@@ -533,6 +547,10 @@ def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None):
         g.rope_q_raw, g.rope_ldraw, g.rope_q_weight = q_raw.data_ptr(), q_raw.stride(0), qw.data_ptr()
         g.rope_cos, g.rope_sin, g.rope_eps = cos.data_ptr(), sin.data_ptr(), float(eps)
         g.rope_dq_raw, g.rope_lddraw = dq_raw.data_ptr(), dq_raw.stride(0)
+        if rope_rstd is not None:
+            rstd, h0 = rope_rstd
+            _need(rstd, F32, "rope_rstd")
+            g.rope_rstd, g.rope_rstd_ld, g.rope_rstd_h0 = rstd.data_ptr(), rstd.stride(0), int(h0)
     g.delta = delta.data_ptr()
     if PROFILE_ATTN is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -707,8 +707,14 @@ class Qwen3LoRAModel(nn.Module):
                 datt = hip.gemm(dx2, fl["oT"])
             dqkv = torch.empty((M, NQ + 2 * NKV), dtype=BF16, device=dev)
             dk_r = torch.empty((M, NKV), dtype=BF16, device=dev)
-            if "rstd_qk" in L:
-                # the forward ran q/k-norm + RoPE in the q|k|v launch: no raw q, k exist; the rows are recovered from the roped outputs
+            if "rstd_qk" in L and hd == 128 and os.environ.get("UNIREC_ROPE_BWD_FUSED", "1") != "0":
+                # the forward ran q/k-norm + RoPE in the q|k|v launch: no raw q, k exist; the rows are recovered from the roped outputs.
+                # The q heads' backward rides in the dQ kernel's store (its lanes own whole rows of q_r, which it has just read as
+                # its q operand): dq never makes the round trip through HBM; the stand-alone kernel keeps the k heads.
+                hip.attn_bwd(L["actx"], datt.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd), dv=dqkv[:, NQ + NKV:].view(B, S, nkv, hd),
+                             rope_q=(L["q_r"], fl["qn"], cos, sin, eps, dqkv[:, :NQ]), rope_rstd=(L["rstd_qk"], 0))
+                hip.qknorm_rope_bwd_roped_k(dk_r, L["k_r"], L["rstd_qk"], nq, fl["kn"], cos, sin, dqkv[:, NQ:NQ + NKV], S, nkv, hd)
+            elif "rstd_qk" in L:
                 dq_r = torch.empty((M, NQ), dtype=BF16, device=dev)
                 hip.attn_bwd(L["actx"], datt.view(B, S, nq, hd), dq=dq_r.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd),
                              dv=dqkv[:, NQ + NKV:].view(B, S, nkv, hd))
