@@ -145,8 +145,18 @@ typedef struct {
   void* P; int64_t ldp;                   /* project: bf16 [M, >= 16 nad] */
   const void* V; int64_t ldv;             /* reduce: bf16 [M, >= 16 nad] */
   void* G; int32_t g_transposed;          /* reduce: f32, dense */
+  /* reduce only, optional: the TOKEN-packed copy of the dropped flags (ur_lora_bits_transpose).  With it (and M, the token split and
+   * every width multiples of 128 / 64) ur_lora_reduce streams X through an LDS-DMA ring and masks the transposed fragments in
+   * registers; without it the register-staged kernel runs.  Same flags, same result up to the order of the f32 token sum. */
+  const void* drop_bits_t; int64_t bits_t_ld; int64_t bits_t_stride;
 } ur_lora_args;
 int64_t ur_lora_bits_ld(int32_t W);
+/* Token-packed flags: plane a at bits_t + a*bits_t_stride (32-bit words), token group tg = m / 32 at + tg*bits_t_ld, column c at + c:
+ * byte g of the word = tokens 32 tg + 8 g .. + 7 of column c, bit i (i<4) = token 8g+2i dropped, bit 4+i = token 8g+2i+1 dropped (the
+ * pair order of a transposed bf16x8 fragment).  bits_t_ld = ur_lora_bits_t_ld(W) = W rounded up to 4 words; M % 32 == 0. */
+int64_t ur_lora_bits_t_ld(int32_t W);
+int ur_lora_bits_transpose(const uint8_t* bits, int64_t bits_ld, int64_t bits_stride, int32_t M, int32_t W, int32_t nad,
+                           uint32_t* bits_t, int64_t bits_t_ld, int64_t bits_t_stride, void* stream);
 /* row0: rows that precede row 0 of this call in the GLOBAL minibatch (row m draws the flags of global row row0 + m) */
 int ur_lora_dropout_bits(uint64_t seed, float p, int32_t M, int32_t W, int32_t nad, uint8_t* bits, int64_t bits_ld,
                          int64_t bits_stride, int64_t row0, void* stream);

@@ -386,6 +386,55 @@ def test_lora_kernels_with_dropout_bits(M, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,K,nad,p", [(1024, 128, 1, 0.3), (4096, 1024, 3, 0.1), (2048, 192, 2, 0.5), (8192, 2048, 1, 0.1), (1024, 256, 4, 0.2), (1024, 128, 2, 0.0)])
+def test_lora_reduce_ring_kernel(M, K, nad, p):
+    """Token counts / widths that are multiples of 128 / 64 take the LDS-DMA ring kernel (csrc/lora.hip: lora_reduce_ring_kernel): dA_a =
+    tb_a^T dropout_a(x) with the TOKEN-packed flags (ur_lora_bits_transpose) masking the transposed fragments, against an f32 product of
+    the same bf16 inputs and the same flags, and against the register-staged kernel (no bits_t: same flags, other summation order);
+    the unpacked transposed flags equal the row planes bit for bit; deterministic.  p = 0: the unmasked instantiation."""
+    from unirec_amd import hip
+    g = torch.Generator().manual_seed(M + K + nad)
+    r = 16
+    x = torch.randn(M, K + 8, generator=g).to(DEV).to(torch.bfloat16)[:, :K]
+    tb = torch.randn(M, nad * r, generator=g).to(DEV).to(torch.bfloat16)
+    bits = hip.lora_dropout_bits(77 + nad, p, M, K, nad, DEV) if p > 0 else None
+    keep = hip.lora_bits_to_keep(bits, K).float() if p > 0 else torch.ones((nad, M, K), device=DEV)
+    bt = hip.lora_bits_transpose(bits, K) if p > 0 else None
+    if p > 0:
+        # word (tg, c): byte g = tokens 32 tg + 8 g .. + 7, bit i (i < 4) = token 8g + 2i, bit 4 + i = token 8g + 2i + 1
+        w = bt[:, :, :K].to(torch.int64) & 0xffffffff
+        pos = torch.tensor([8 * (rr >> 3) + ((rr & 7) >> 1) + 4 * (rr & 1) for rr in range(32)], device=DEV)
+        dropped_t = ((w.unsqueeze(-1) >> pos) & 1).permute(0, 1, 3, 2).reshape(nad, M, K)
+        assert torch.equal(dropped_t.float(), 1.0 - keep)
+    gA = torch.full((nad * r, K), float("nan"), device=DEV)
+    hip.lora_reduce(x, tb, gA, nad=nad, alpha=1.0 / (1 - p), bits=bits, bits_t=bt)
+    want = torch.cat([tb[:, a * r:(a + 1) * r].float().t() @ (x.float() * keep[a] / (1 - p)) for a in range(nad)], 0)
+    assert (gA - want).abs().max().item() <= 1e-4 * want.abs().max().item() + 2e-3
+    old = torch.empty_like(gA)
+    hip.lora_reduce(x, tb, old, nad=nad, alpha=1.0 / (1 - p), bits=bits)
+    assert (gA - old).abs().max().item() <= 1e-4 * want.abs().max().item() + 2e-3
+    again = torch.empty_like(gA)
+    hip.lora_reduce(x, tb, again, nad=nad, alpha=1.0 / (1 - p), bits=bits, bits_t=bt)
+    assert torch.equal(gA, again)
+
+
+@pytest.mark.gpu
+def test_lora_reduce_ring_kernel_on_column_ranges():
+    """dB_a = dy_a^T t_a over per-adapter column ranges (shared = 0, transposed output, no dropout) through the ring kernel."""
+    from unirec_amd import hip
+    g = torch.Generator().manual_seed(9)
+    M, r = 2048, 16
+    cols = [(0, 256), (256, 128), (384, 64)]
+    Wt = 448
+    dy = torch.randn(M, Wt + 8, generator=g).to(DEV).to(torch.bfloat16)[:, :Wt]
+    t = torch.randn(M, 3 * r, generator=g).to(DEV).to(torch.bfloat16)
+    gB = torch.full((Wt, r), float("nan"), device=DEV)
+    hip.lora_reduce(dy, t, gB, cols=cols, transposed=True)
+    want = torch.cat([dy[:, c0:c0 + n].float().t() @ t[:, a * r:(a + 1) * r].float() for a, (c0, n) in enumerate(cols)], 0)
+    assert (gB - want).abs().max().item() <= 1e-4 * want.abs().max().item() + 2e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("M,cols", [(200, [(0, 64)]), (1024, [(0, 128), (128, 64), (256, 192)]), (4100, [(64, 256), (320, 128)]),
                                     (3000, [(0, 2048), (2048, 1024), (3072, 1024)]), (88000 + 200, [(0, 256), (256, 128), (384, 64)])])
 def test_lora_bgrad_ring_kernel(M, cols):

@@ -30,3 +30,18 @@ for name, N, nad in (("o_proj x=att (N=2048)", 2048, 1), ("down x=act (N=3072)",
     print(f"lora_project {name}: {ms*1e3:7.1f} us  {x.numel()*2/ms/1e9:6.2f} TB/s")
     ms = timeit(lambda: hip.lora_reduce(x, tb, gA, nad=1, bits=bits))
     print(f"lora_reduce  {name}: {ms*1e3:7.1f} us  {x.numel()*2/ms/1e9:6.2f} TB/s")
+    bt = hip.lora_bits_transpose(bits, N)
+    ms = timeit(lambda: hip.lora_reduce(x, tb, gA, nad=1, bits=bits, bits_t=bt))
+    print(f"lora_reduce  {name} (ring, token-packed flags): {ms*1e3:7.1f} us  {x.numel()*2/ms/1e9:6.2f} TB/s")
+    ms = timeit(lambda: hip.lora_bits_transpose(bits, N, out=bt))
+    print(f"  lora_bits_transpose: {ms*1e3:7.1f} us")
+for name, nad in (("q|k|v x=h (N=1024, 3 masks)", 3), ("gate|up x=h2 (N=1024, 2 masks)", 2)):
+    x = torch.randn(M, 1024, generator=g).cuda().to(torch.bfloat16)
+    bits = hip.lora_dropout_bits(1, 0.1, M, 1024, nad, "cuda")
+    tb = torch.randn(M, r * nad, generator=g).cuda().to(torch.bfloat16)
+    gA = torch.empty(r * nad, 1024, device="cuda")
+    ms = timeit(lambda: hip.lora_reduce(x, tb, gA, nad=nad, bits=bits))
+    print(f"lora_reduce  {name}: {ms*1e3:7.1f} us  {x.numel()*2/ms/1e9:6.2f} TB/s")
+    bt = hip.lora_bits_transpose(bits, 1024)
+    ms = timeit(lambda: hip.lora_reduce(x, tb, gA, nad=nad, bits=bits, bits_t=bt))
+    print(f"lora_reduce  {name} (ring, token-packed flags): {ms*1e3:7.1f} us  {x.numel()*2/ms/1e9:6.2f} TB/s")

@@ -49,7 +49,8 @@ class LoraArgs(ctypes.Structure):
                 ("U", c_void_p * 4), ("ldu", c_i64 * 4),
                 ("P", c_void_p), ("ldp", c_i64),
                 ("V", c_void_p), ("ldv", c_i64),
-                ("G", c_void_p), ("g_transposed", c_int)]
+                ("G", c_void_p), ("g_transposed", c_int),
+                ("drop_bits_t", c_void_p), ("bits_t_ld", c_i64), ("bits_t_stride", c_i64)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -90,6 +91,8 @@ SIGNATURES = {
     "ur_qkrope_perm": (c_int, [c_int]),
     "ur_lora_bits_ld": (c_i64, [c_int]),
     "ur_lora_dropout_bits": (c_int, [c_u64, c_float, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_i64, c_void_p]),
+    "ur_lora_bits_t_ld": (c_i64, [c_int]),
+    "ur_lora_bits_transpose": (c_int, [c_void_p, c_i64, c_i64, c_int, c_int, c_int, c_void_p, c_i64, c_i64, c_void_p]),
     "ur_lora_project": (c_int, [ctypes.POINTER(LoraArgs), c_void_p]),
     "ur_swiglu_lora_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(LoraArgs), c_void_p]),
     "ur_rmsnorm_lora_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, ctypes.POINTER(LoraArgs), c_void_p]),

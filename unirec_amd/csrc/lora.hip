@@ -455,12 +455,19 @@ __global__ __launch_bounds__(256, 4) void swiglu_lora_kernel(SwiLoraP p) {
   }
 }
 
+__device__ __forceinline__ const char* bg_uniform_ptr(const char* p) {          // (gemm_common.hip.h: uniform_ptr)
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
 // ---- token-reduction products --------------------------------------------------------------------
 struct RedP {
   const bf16_t* X; long ldx; int M;
   int col0[4], width[4]; long goff[4];
   const bf16_t* V; long ldv;
   const uint8_t* bits; long bits_ld, bits_stride;
+  const uint32_t* bits_t; long bt_ld, bt_stride;       // token-packed flags (ring kernel)
   float* out; int transposed;
   int tok_per_block;
   float alpha;
@@ -585,6 +592,173 @@ __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
       if (w < W) *reinterpret_cast<float4*>(ge + (long)l15 * W + w) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
+}
+
+// ---- the token reduction with X streamed through an LDS-DMA ring --------------------------------------------------------
+// Same grid and output as lora_reduce_kernel (x = 64-column block, y = token split, z = entry).  A stage = 128 tokens: the raw
+// [128 x 64] piece of X (16 KiB, the f64sw pair swizzle of lora_reduce_kernel applied on the SOURCE side of the LDS-DMA), the NAD
+// [128 x 16] tiles of V and -- MASKED -- the token-packed flag words of the stage ([4 token groups x 64 columns] per adapter,
+// ur_lora_bits_transpose), all fetched three stages ahead of their use.  One barrier per stage; wave w owns columns 16 w .. + 15:
+// per 32-token step it reads the transposed X fragment ONCE, masks a copy per adapter in registers (the flag byte of its column
+// and 8 tokens: drop_apply) and feeds NAD MFMAs.  No masked LDS copies, no global load between the barriers.
+constexpr int R2_TOK = 128, R2_XS = R2_TOK * 128, R2_VS = R2_TOK * 32;
+// ring depth: 4 stages and one workgroup per CU for a single adapter; two or more adapters (their flag expansion and MFMA chains make the
+// consumer the longer side) run 2 stages and TWO workgroups per CU, one's loads under the other's chains (measured: 104 -> 86 us for 3 adapters)
+constexpr int r2_nst(int nad) { return nad == 1 ? 4 : 2; }
+template <int NAD, bool MASKED> constexpr int r2_stage() { return R2_XS + NAD * R2_VS + (MASKED ? NAD * 1024 : 0); }
+template <int NAD, bool MASKED>
+__global__ __launch_bounds__(256) void lora_reduce_ring_kernel(RedP p) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+  constexpr int STAGE = r2_stage<NAD, MASKED>(), NP = 4 + NAD + (MASKED ? 1 : 0);      // LDS-DMA instructions per wave and stage
+  constexpr int R2_NST = r2_nst(NAD);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int e0 = blockIdx.z;
+  const int W = p.width[e0], col0 = p.col0[e0];
+  const int cb = blockIdx.x * 64;
+  if (cb >= W) return;                                   // uniform per block
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = l15 >> 2, pp = lane & 3;
+  const int tbeg = blockIdx.y * p.tok_per_block, tend = min(p.M, tbeg + p.tok_per_block);
+  const int nst = (tend - tbeg) / R2_TOK;                 // (host: M and the split are multiples of 128)
+
+  // ---- producer ----
+  const int prow = lane >> 3, pos = lane & 7, wpar = wave & 1;
+  // X piece = rows 8 piece .. + 7 (piece = 4 i + wave): f64sw(row) = bit 1 of prow | (piece & 1) << 1; LDS position pos holds
+  // source chunk ((pos >> 1) ^ f64sw) << 1 | (pos & 1)
+  const int fsw = ((prow >> 1) & 1) | (wpar << 1);
+  const uint32_t xlane = (uint32_t)((prow * p.ldx + ((((pos >> 1) ^ fsw) << 1) | (pos & 1)) * 8) * 2);
+  const uint32_t vlane = (uint32_t)(((lane >> 1) * p.ldv + 8 * (lane & 1)) * 2);
+  const int am = wave < NAD ? wave : NAD - 1;             // this wave's flag piece (waves >= NAD repeat the last adapter's: same bytes)
+  const uint32_t mlane = (uint32_t)(((lane >> 4) * p.bt_ld + 4 * (lane & 15)) * 4);
+  auto issue = [&](int s) {
+    char* st = smem + (s & (R2_NST - 1)) * STAGE;
+    const long t0 = tbeg + (long)s * R2_TOK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int piece = 4 * i + wave;
+      const char* ub = bg_uniform_ptr(reinterpret_cast<const char*>(p.X + (t0 + 8 * piece) * p.ldx + col0 + cb));
+      __builtin_amdgcn_global_load_lds((gbl_void*)(ub + xlane), (lds_void*)(st + piece * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int a = 0; a < NAD; ++a) {
+      const char* ub = bg_uniform_ptr(reinterpret_cast<const char*>(p.V + (t0 + 32 * wave) * p.ldv + 16 * (e0 + a)));
+      __builtin_amdgcn_global_load_lds((gbl_void*)(ub + vlane), (lds_void*)(st + R2_XS + a * R2_VS + wave * 1024), 16, 0, 0);
+    }
+    if (MASKED) {
+      const char* ub = bg_uniform_ptr(reinterpret_cast<const char*>(p.bits_t + (long)am * p.bt_stride + (t0 >> 5) * p.bt_ld + cb));
+      __builtin_amdgcn_global_load_lds((gbl_void*)(ub + mlane), (lds_void*)(st + R2_XS + NAD * R2_VS + am * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[NAD];
+#pragma unroll
+  for (int a = 0; a < NAD; ++a) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int npro = min(R2_NST - 1, nst);
+  for (int s = 0; s < npro; ++s) issue(s);
+  // lane constants of the consumer: transposed reads of step ks at rows ka = 32 ks + 8 g + q (+ 4)
+  uint32_t xo[4], vo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int ka = 32 * ks + 8 * g + q;
+    xo[ks] = (uint32_t)(ka * 128 + ((wave ^ f64sw(ka)) << 5) + pp * 8);
+    vo[ks] = (uint32_t)(R2_XS + ka * 32 + pp * 8);
+  }
+  const uint32_t mo = (uint32_t)(R2_XS + NAD * R2_VS + (16 * wave + l15) * 4);
+
+  for (int s = 0; s < nst; ++s) {
+    const int later = min(nst, s + R2_NST - 1) - (s + 1);      // stages issued after stage s (at most R2_NST - 2)
+    if (R2_NST > 3 && later >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP) : "memory");
+    else if (R2_NST > 2 && later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + R2_NST - 1 < nst) issue(s + R2_NST - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const char* st = smem + (s & (R2_NST - 1)) * STAGE;
+    const uint32_t sb = lds_off(st);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 xf, vf[NAD];
+      if constexpr (NAD == 1) {
+        bf16x8 f[2];
+        const uint32_t a[2] = {sb + xo[ks], sb + vo[ks]}, b[2] = {sb + xo[ks] + 4 * 128, sb + vo[ks] + 4 * 32};
+        tr_read(f, a, b);
+        xf = f[0]; vf[0] = f[1];
+      } else {
+        bf16x8 f[4];
+        uint32_t a[4], b[4];
+        a[0] = sb + xo[ks]; b[0] = a[0] + 4 * 128;
+#pragma unroll
+        for (int i = 1; i < 4; ++i) { const int ad = i - 1 < NAD ? i - 1 : NAD - 1; a[i] = sb + vo[ks] + ad * R2_VS; b[i] = a[i] + 4 * 32; }
+        tr_read(f, a, b);
+        xf = f[0];
+#pragma unroll
+        for (int ad = 0; ad < NAD && ad < 3; ++ad) vf[ad] = f[1 + ad];
+        if constexpr (NAD == 4) {
+          bf16x8 f2[2];
+          const uint32_t a2[2] = {sb + vo[ks] + 3 * R2_VS, sb + vo[ks] + 3 * R2_VS}, b2[2] = {a2[0] + 4 * 32, a2[0] + 4 * 32};
+          tr_read(f2, a2, b2);
+          vf[3] = f2[0];
+        }
+      }
+#pragma unroll
+      for (int ad = 0; ad < NAD; ++ad) {
+        bf16x8 xm = xf;
+        if (MASKED) {
+          const uint32_t wd = *reinterpret_cast<const uint32_t*>(st + mo + ad * 1024 + ks * 256);
+          xm = __builtin_bit_cast(bf16x8, drop_apply(__builtin_bit_cast(uint4, xf), (wd >> (8 * g)) & 0xffu));
+        }
+        const bf16x8 fa = p.transposed ? vf[ad] : xm, fb = p.transposed ? xm : vf[ad];
+        acc[ad] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc[ad], 0, 0, 0);
+      }
+    }
+  }
+  // partial (or final) result of this token range, dense layout: entry e at goff[e], [16][W] or [W][16]
+  long total = 0;
+  {
+    const int ne = gridDim.z > 1 ? (int)gridDim.z : NAD;
+    total = p.goff[ne - 1] + 16L * p.width[gridDim.z > 1 ? ne - 1 : 0];
+  }
+  float* base = p.out + (long)blockIdx.y * total;
+#pragma unroll
+  for (int a = 0; a < NAD; ++a) {
+    float* ge = base + p.goff[e0 + a];
+    const f32x4 v = acc[a] * p.alpha;
+    if (p.transposed) {            // D[j = 4g+e][w = l15]  ->  G[w][j]
+      const int w = cb + 16 * wave + l15;
+      *reinterpret_cast<float4*>(ge + (long)w * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {                       // D[w = 4g+e][j = l15]  ->  G[j][w]
+      const int w = cb + 16 * wave + 4 * g;
+      *reinterpret_cast<float4*>(ge + (long)l15 * W + w) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// token-packed flag words from the row planes: thread = (adapter, 32-token group, 8-column byte)
+__global__ __launch_bounds__(256) void lora_bits_transpose_kernel(const uint8_t* __restrict__ bits, long bits_ld, long bits_stride, int M, int W, int nad,
+                                                                  uint32_t* __restrict__ bt, long bt_ld, long bt_stride) {
+  const int noct = (W + 7) / 8;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long per = (long)(M / 32) * noct;
+  if (idx >= per * nad) return;
+  const int a = (int)(idx / per);
+  const long r = idx - (long)a * per;
+  const int tg = (int)(r / noct), o = (int)(r - (long)tg * noct);
+  const uint8_t* src = bits + (long)a * bits_stride + (long)(32 * tg) * bits_ld + o;
+  uint32_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 8
+  for (int rr = 0; rr < 32; ++rr) {
+    const uint32_t b = src[(long)rr * bits_ld];
+    const int db = 8 * (rr >> 3) + ((rr & 7) >> 1) + 4 * (rr & 1);        // token rr of the group -> bit of the word
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] |= ((b >> ((j >> 1) + 4 * (j & 1))) & 1u) << db;      // column j of the byte
+  }
+  uint32_t* dst = bt + (long)a * bt_stride + (long)tg * bt_ld + 8 * o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (8 * o + j < (int)bt_ld) dst[j] = out[j];
 }
 
 // ---- backward of the B side in ONE pass over dy: tb = alpha * dy_e B_e (column reduction) and the partial
@@ -742,12 +916,6 @@ __global__ __launch_bounds__(256, 2) void lora_bgrad_kernel(BgradP p) {
 // TWO ways: tokens for tb (wave w: tokens 64 w .. + 63 of the tile as MFMA column operands, all 64 columns), columns for dB
 // (wave w: columns 16 w .. + 15 as hardware-transposed operands, all 256 tokens) -- the dB partial of a column is complete
 // inside one wave, so it leaves straight from the accumulators after the block's last token tile: no cross-wave sum.
-__device__ __forceinline__ const char* bg_uniform_ptr(const char* p) {          // (gemm_common.hip.h: uniform_ptr)
-  const uint64_t v = reinterpret_cast<uint64_t>(p);
-  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  asm volatile("" : "+s"(lo), "+s"(hi));
-  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
-}
 constexpr int B2_TILE = 256, B2_NST = 4;
 constexpr int B2_XS = B2_TILE * 128, B2_STAGE = B2_XS + 2048;                   // dy tile + B^T chunk
 constexpr int b2_smem(int nt) { return B2_NST * B2_STAGE + (nt > 2 ? 0 : nt * B2_TILE * 32); }   // + t [tokens][16] (prologue staging; NT 4: inside the ring)
@@ -1042,13 +1210,39 @@ extern "C" int ur_swiglu_lora_fwd(const void* gu, void* act, int32_t M, int32_t 
   return 0;
 }
 
+// the ring kernel takes launches whose token count and every width are multiples of 128 / 64 and, under dropout, come with the
+// token-packed flags; (the split below is then a multiple of 128 tokens by construction)
+static inline bool lora_reduce_ring_ok(const ur_lora_args* a) {
+  if ((a->M % 128) != 0 || a->M < 128) return false;
+  const int ne = a->shared ? 1 : a->nad;
+  for (int e = 0; e < ne; ++e)
+    if ((a->width[e] % 64) != 0) return false;
+  if (a->drop_bits != nullptr) {
+    if (a->drop_bits_t == nullptr || (a->bits_t_ld % 4) != 0 || a->bits_t_ld < a->width[0] || !UR_ALIGNED16(a->drop_bits_t) || (a->bits_t_stride % 4) != 0) return false;
+  }
+  return true;
+}
+template <int NAD, bool MASKED>
+static int launch_reduce_ring(const RedP& p, dim3 grid, hipStream_t st) {
+  constexpr int SMEM = r2_nst(NAD) * r2_stage<NAD, MASKED>();
+  static std::atomic<uint64_t> attr_set{0};      // per device
+  if (ur_first_on_device(attr_set)) {
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&lora_reduce_ring_kernel<NAD, MASKED>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (er != hipSuccess) UR_FAIL((int)er, "ur_lora_reduce: hipFuncSetAttribute failed: %s", hipGetErrorString(er));
+  }
+  hipLaunchKernelGGL((lora_reduce_ring_kernel<NAD, MASKED>), grid, dim3(256), SMEM, st, p);
+  return 0;
+}
 static inline int lora_reduce_splits(const ur_lora_args* a) {
   int wmax = 0;
   const int ne = a->shared ? 1 : a->nad;
   for (int e = 0; e < ne; ++e) wmax = a->width[e] > wmax ? a->width[e] : wmax;
   const long colblocks = (long)ur_cdiv(wmax, 64) * ne;
   const int tiles = ur_cdiv(a->M, 128);
-  long want = (2048 + colblocks - 1) / colblocks;          // ~8 blocks per CU
+  // ~8 blocks per CU for the register-staged kernel; the ring kernel runs one workgroup per CU: 2 rounds of them
+  // ring: two rounds of the workgroups a CU holds (one for a single adapter, two otherwise), never a partial third
+  const long ring_wg = (a->shared && a->nad > 1 ? 4L : 2L) * ur_device_cu_count();
+  long want = lora_reduce_ring_ok(a) ? ring_wg / colblocks : (2048L + colblocks - 1) / colblocks;
   if (want < 1) want = 1;
   if (want > tiles) want = tiles;
   if (want > 256) want = 256;
@@ -1059,6 +1253,21 @@ static inline int64_t lora_reduce_total(const ur_lora_args* a) {
   int64_t t = 0;
   for (int e = 0; e < a->nad; ++e) t += 16LL * a->width[a->shared ? 0 : e];
   return t;
+}
+
+extern "C" int64_t ur_lora_bits_t_ld(int32_t W) { return ((int64_t)W + 3) / 4 * 4; }
+
+extern "C" int ur_lora_bits_transpose(const uint8_t* bits, int64_t bits_ld, int64_t bits_stride, int32_t M, int32_t W, int32_t nad,
+                                      uint32_t* bits_t, int64_t bits_t_ld, int64_t bits_t_stride, void* stream) {
+  UR_REQUIRE(bits && bits_t && M >= 0 && (M % 32) == 0 && W > 0 && nad >= 1 && nad <= 4, "ur_lora_bits_transpose: bad argument (M %% 32 == 0, 1 <= nad <= 4)");
+  UR_REQUIRE(bits_ld * 8 >= W && bits_t_ld >= W && (bits_t_ld % 4) == 0 && UR_ALIGNED16(bits_t) && (bits_t_stride % 4) == 0 &&
+             bits_t_stride >= (int64_t)(M / 32) * bits_t_ld, "ur_lora_bits_transpose: row / plane strides");
+  if (M == 0) return 0;
+  const long n = (long)(M / 32) * ((W + 7) / 8) * nad;
+  hipLaunchKernelGGL(lora_bits_transpose_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bits, (long)bits_ld, (long)bits_stride,
+                     (int)M, (int)W, (int)nad, bits_t, (long)bits_t_ld, (long)bits_t_stride);
+  UR_CHECK_LAUNCH("ur_lora_bits_transpose");
+  return 0;
 }
 
 extern "C" int64_t ur_lora_reduce_workspace_bytes(const ur_lora_args* a) {
@@ -1094,12 +1303,25 @@ extern "C" int ur_lora_reduce(const ur_lora_args* a, void* workspace, int64_t wo
   }
   p.V = (const bf16_t*)a->V; p.ldv = a->ldv;
   p.bits = (const uint8_t*)a->drop_bits; p.bits_ld = a->bits_ld; p.bits_stride = a->bits_stride;
+  p.bits_t = (const uint32_t*)a->drop_bits_t; p.bt_ld = a->bits_t_ld; p.bt_stride = a->bits_t_stride;
   p.out = splits > 1 ? (float*)workspace : (float*)a->G;
   p.transposed = a->g_transposed ? 1 : 0;
   const int tiles = ur_cdiv(a->M, 128);
   p.tok_per_block = ur_cdiv(tiles, splits) * 128;
   p.alpha = a->alpha;
   const bool masked = a->drop_bits != nullptr;
+  if (lora_reduce_ring_ok(a)) {
+    // X through the LDS-DMA ring (one workgroup per CU: the splits above were sized for it)
+    const bool per_entry = !a->shared || a->nad == 1;
+    dim3 grid(ur_cdiv(wmax, 64), splits, per_entry ? a->nad : 1);
+    const int nad_k = per_entry ? 1 : a->nad;
+    int rc = 0;
+#define UR_RING(NAD, MK) rc = launch_reduce_ring<NAD, MK>(p, grid, st)
+    if (masked) { if (nad_k == 1) UR_RING(1, true); else if (nad_k == 2) UR_RING(2, true); else if (nad_k == 3) UR_RING(3, true); else UR_RING(4, true); }
+    else { if (nad_k == 1) UR_RING(1, false); else if (nad_k == 2) UR_RING(2, false); else if (nad_k == 3) UR_RING(3, false); else UR_RING(4, false); }
+#undef UR_RING
+    if (rc) return rc;
+  } else
   if (!a->shared || a->nad == 1) {
     dim3 grid(ur_cdiv(wmax, 64), splits, a->nad);
     if (masked) hipLaunchKernelGGL((lora_reduce_kernel<1, true>), grid, dim3(256), 0, st, p);

@@ -281,6 +281,10 @@ def lora_bits_ld(W):
     return int(_lib.load().ur_lora_bits_ld(int(W)))
 
 
+def lora_bits_t_ld(W):
+    return int(_lib.load().ur_lora_bits_t_ld(int(W)))
+
+
 @_stream_family("lora_bits", lambda r, *a, **k: _nb(r))
 def lora_dropout_bits(seed, p, M, W, nad, device, out=None, row0=0):
     """Dropped-flag bit planes uint8 [nad, M, ur_lora_bits_ld(W)] of nad adapters that share an [M, W] input.  row0: rows that
@@ -291,6 +295,20 @@ def lora_dropout_bits(seed, p, M, W, nad, device, out=None, row0=0):
     check(lib.ur_lora_dropout_bits(int(seed), float(p), int(M), int(W), int(nad), bits.data_ptr(), ld, bits.stride(0), int(row0), _stream()),
           "ur_lora_dropout_bits")
     return bits
+
+
+def lora_bits_transpose(bits, W, out=None):
+    """Token-packed copy int32 [nad, M / 32, ur_lora_bits_t_ld(W)] of the dropped-flag planes (ur_lora_bits_transpose): what the token
+    reduction (lora_reduce(..., bits_t=...)) masks its transposed fragments with.  M % 32 == 0."""
+    lib = _lib.load()
+    nad, M, ld = bits.shape
+    if M % 32:
+        raise ValueError("lora_bits_transpose: M must be a multiple of 32")
+    ldt = int(lib.ur_lora_bits_t_ld(int(W)))
+    bt = torch.empty((nad, M // 32, ldt), dtype=torch.int32, device=bits.device) if out is None else out
+    check(lib.ur_lora_bits_transpose(bits.data_ptr(), ld, bits.stride(0), int(M), int(W), int(nad), bt.data_ptr(), ldt, bt.stride(0), _stream()),
+          "ur_lora_bits_transpose")
+    return bt
 
 
 def lora_bits_to_keep(bits, W):
@@ -380,11 +398,12 @@ def rmsnorm_lora_fwd(x, w, eps, U, alpha=1.0, bits=None):
     return out, rstd, t
 
 
-@_stream_family("lora_reduce", lambda r, X, V, out, cols=None, nad=None, alpha=1.0, bits=None, transposed=False:
+@_stream_family("lora_reduce", lambda r, X, V, out, cols=None, nad=None, alpha=1.0, bits=None, transposed=False, bits_t=None:
                 _cols_bytes(X, cols) + X.shape[0] * 2 * 16 * (len(cols) if cols is not None else int(nad)) + (_nb(bits) if bits is not None else 0))
-def lora_reduce(X, V, out, cols=None, nad=None, alpha=1.0, bits=None, transposed=False):
+def lora_reduce(X, V, out, cols=None, nad=None, alpha=1.0, bits=None, transposed=False, bits_t=None):
     """G_a[j,w] = alpha * sum_m V[m,16a+j] keep_a(m,w) X[m, c0_a+w] into the dense f32 tensor `out`
-    ([16 nad, W] for shared columns, or [sum width, 16] with transposed=True for per-adapter column ranges)."""
+    ([16 nad, W] for shared columns, or [sum width, 16] with transposed=True for per-adapter column ranges).
+    bits_t: lora_bits_transpose(bits, W) -- with it the launch streams X through the LDS-DMA ring kernel."""
     lib = _lib.load()
     shared = cols is None
     if shared:
@@ -397,6 +416,10 @@ def lora_reduce(X, V, out, cols=None, nad=None, alpha=1.0, bits=None, transposed
         raise ValueError("lora_reduce: out has the wrong size")
     a.V, a.ldv = V.data_ptr(), V.stride(0)
     a.G, a.g_transposed = out.data_ptr(), int(transposed)
+    if bits is not None and bits_t is not None:
+        if bits_t.dtype != torch.int32 or bits_t.dim() != 3 or bits_t.shape[0] != bits.shape[0] or bits_t.shape[1] * 32 != X.shape[0] or bits_t.stride(2) != 1:
+            raise ValueError("lora_reduce: bits_t must be the int32 [nad, M / 32, ld] tensor of lora_bits_transpose")
+        a.drop_bits_t, a.bits_t_ld, a.bits_t_stride = bits_t.data_ptr(), bits_t.stride(1), bits_t.stride(0)
     wsb = lib.ur_lora_reduce_workspace_bytes(ctypes.byref(a))
     ws = workspace(wsb, X.device, "lora").data_ptr() if wsb else 0
     check(lib.ur_lora_reduce(ctypes.byref(a), ws, wsb, _stream()), "ur_lora_reduce")

@@ -394,13 +394,20 @@ class Qwen3LoRAModel(nn.Module):
         side, step = self._bits_stream, self._lora_step
         planes = {(i, g): torch.empty((nad, M, hip.lora_bits_ld(W)), dtype=torch.uint8, device=device)
                   for i in range(self.config.num_hidden_layers) for g, (W, nad) in enumerate(self._bits_groups())}
+        # token-packed copies for the backward's token reductions (hip.lora_reduce's ring kernel), made on the side stream as well
+        packed = {}
+        if M % 128 == 0:
+            packed = {(i, g): torch.empty((nad, M // 32, hip.lora_bits_t_ld(W)), dtype=torch.int32, device=device)
+                      for i in range(self.config.num_hidden_layers) for g, (W, nad) in enumerate(self._bits_groups()) if W % 64 == 0}
         side.wait_stream(main)
         with torch.cuda.stream(side):
             for (i, g), buf in planes.items():
                 W, nad = self._bits_groups()[g]
                 hip.lora_dropout_bits(self.lora_dropout_seed(step, i, g), p, M, W, nad, device, out=buf, row0=row0)
+                if (i, g) in packed:
+                    hip.lora_bits_transpose(buf, W, out=packed[(i, g)])
             ev = side.record_event()
-        self._bits_pre = {"step": step, "M": M, "planes": planes, "event": ev, "row0": int(row0)}
+        self._bits_pre = {"step": step, "M": M, "planes": planes, "packed": packed, "event": ev, "row0": int(row0)}
 
     def _lora_bcomb(self, pack, device):
         """Second-K-range operands of the merged projection launches: y[q|k|v] = h W^T + [t_q|t_k|t_v] Bc^T with
@@ -501,6 +508,7 @@ class Qwen3LoRAModel(nn.Module):
         pre, self._bits_pre = self._bits_pre, None
         if pre is not None and pdrop > 0.0 and pre["step"] == step and pre["M"] == M and pre["row0"] == row0 and pack is not None:
             torch.cuda.current_stream(dev).wait_event(pre["event"])      # planes prefetched on the side stream
+            saved["bits_t"] = pre.get("packed", {})                      # (layer, group) -> token-packed copy for the backward
             pre = pre["planes"]
         else:
             pre = None
@@ -631,8 +639,11 @@ class Qwen3LoRAModel(nn.Module):
         pdrop, step = saved["pdrop"], saved["step"]
         lt = self._lora_transposes(pack) if (pack is not None and r == 16) else None      # name(s) -> transposed bf16 operand
 
-        def lora_grads(dy, t, xin, a_names, b_specs, bits):
-            """dB_p = dy_p^T t_p ; tb = s * dy B ; dA_p = tb_p^T dropout_p(x).  Returns tb [M, len(b)*r] (bf16)."""
+        packed_bits = saved.get("bits_t", {})
+
+        def lora_grads(dy, t, xin, a_names, b_specs, bits, group=None):
+            """dB_p = dy_p^T t_p ; tb = s * dy B ; dA_p = tb_p^T dropout_p(x).  Returns tb [M, len(b)*r] (bf16).
+            group = (layer, adapter group): the key of the prefetched token-packed flags."""
             nb = len(b_specs)
             touched.extend([b for b, _, _ in b_specs] + list(a_names))
             if r != 16:           # generic tiles (no dropout: _lora_down refused it)
@@ -649,7 +660,10 @@ class Qwen3LoRAModel(nn.Module):
             gB = pack.fusedg(bnames) if nb > 1 else pack.g32(bnames[0])            # [sum n, r]: adapter ranges in order
             tb = hip.lora_bgrad(dy, t, [lt[b] for b in bnames], cols, gB, alpha=sc)     # dB and tb, dy read once
             gA = pack.fusedg(a_names) if len(a_names) > 1 else pack.g32(a_names[0])
-            hip.lora_reduce(xin, tb, gA, nad=len(a_names), alpha=1.0 / (1.0 - pdrop), bits=bits)
+            bits_t = packed_bits.get(group) if bits is not None else None
+            if bits is not None and bits_t is None and M % 128 == 0 and xin.shape[1] % 64 == 0:
+                bits_t = hip.lora_bits_transpose(bits, xin.shape[1])          # (no prefetch this step: made here)
+            hip.lora_reduce(xin, tb, gA, nad=len(a_names), alpha=1.0 / (1.0 - pdrop), bits=bits, bits_t=bits_t)
             return tb
 
         def dx_gemm(dy, wT, tb, a_names, bits, swiglu=None):
@@ -687,13 +701,13 @@ class Qwen3LoRAModel(nn.Module):
                     hip.swiglu_fwd(gu, I, out=act)
             dgu = torch.empty_like(gu)
             if pack is not None:
-                tb = lora_grads(dx, L["t_d"], act, [lp + "mlp.down_proj.lora_A.weight"], [(lp + "mlp.down_proj.lora_B.weight", 0, D)], L["bits_d"])
+                tb = lora_grads(dx, L["t_d"], act, [lp + "mlp.down_proj.lora_A.weight"], [(lp + "mlp.down_proj.lora_B.weight", 0, D)], L["bits_d"], group=(i, 3))
                 dx_gemm(dx, fl["dT"], tb, [lp + "mlp.down_proj.lora_A.weight"], L["bits_d"], swiglu=(gu, dgu))
             else:
                 hip.gemm(dx, fl["dT"], swiglu_bwd=(gu, dgu))
             if pack is not None:
                 a_names = [lp + "mlp.gate_proj.lora_A.weight", lp + "mlp.up_proj.lora_A.weight"]
-                tb = lora_grads(dgu, L["t_gu"], h2, a_names, [(lp + "mlp.gate_proj.lora_B.weight", 0, I), (lp + "mlp.up_proj.lora_B.weight", I, I)], L["bits_gu"])
+                tb = lora_grads(dgu, L["t_gu"], h2, a_names, [(lp + "mlp.gate_proj.lora_B.weight", 0, I), (lp + "mlp.up_proj.lora_B.weight", I, I)], L["bits_gu"], group=(i, 2))
                 dh2 = dx_gemm(dgu, fl["guT"], tb, a_names, L["bits_gu"])
             else:
                 dh2 = hip.gemm(dgu, fl["guT"])
@@ -701,7 +715,7 @@ class Qwen3LoRAModel(nn.Module):
             # ---- attention: x2 = x + o(attn)
             att = L["att"]
             if pack is not None:
-                tb = lora_grads(dx2, L["t_o"], att, [lp + "self_attn.o_proj.lora_A.weight"], [(lp + "self_attn.o_proj.lora_B.weight", 0, D)], L["bits_o"])
+                tb = lora_grads(dx2, L["t_o"], att, [lp + "self_attn.o_proj.lora_A.weight"], [(lp + "self_attn.o_proj.lora_B.weight", 0, D)], L["bits_o"], group=(i, 1))
                 datt = dx_gemm(dx2, fl["oT"], tb, [lp + "self_attn.o_proj.lora_A.weight"], L["bits_o"])
             else:
                 datt = hip.gemm(dx2, fl["oT"])
@@ -738,7 +752,7 @@ class Qwen3LoRAModel(nn.Module):
                 a_names = [lp + f"self_attn.{p}_proj.lora_A.weight" for p in "qkv"]
                 specs = [(lp + "self_attn.q_proj.lora_B.weight", 0, NQ), (lp + "self_attn.k_proj.lora_B.weight", NQ, NKV),
                          (lp + "self_attn.v_proj.lora_B.weight", NQ + NKV, NKV)]
-                tb = lora_grads(dqkv, L["t_qkv"], h, a_names, specs, L["bits_qkv"])
+                tb = lora_grads(dqkv, L["t_qkv"], h, a_names, specs, L["bits_qkv"], group=(i, 0))
                 dh = dx_gemm(dqkv, fl["qkvT"], tb, a_names, L["bits_qkv"])
             else:
                 dh = hip.gemm(dqkv, fl["qkvT"])
