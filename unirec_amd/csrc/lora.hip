@@ -134,6 +134,12 @@ __global__ void lora_bits_kernel(uint64_t seed, uint32_t thr15, int M, int W, in
   }
 }
 
+__device__ __forceinline__ const char* bg_uniform_ptr(const char* p) {          // (gemm_common.hip.h: uniform_ptr)
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
 // ---- column-reduction products -------------------------------------------------------------------
 struct ProjP {
   const bf16_t* X; long ldx; int M;
@@ -229,6 +235,127 @@ __global__ __launch_bounds__(256, 4) void lora_project_kernel(ProjP p) {
         *reinterpret_cast<uint2*>(p.P + (long)m * p.ldp + 16 * (y + a) + 4 * g) =
             make_uint2(pack_bf2(v[0] * p.alpha, v[1] * p.alpha), pack_bf2(v[2] * p.alpha, v[3] * p.alpha));
       }
+    }
+  }
+}
+
+// ---- the column reduction of ONE adapter with X streamed through an LDS-DMA ring ------------------------------------------------
+// grid: x = block of 256 tokens, y = entry (widths multiples of 64).  The block walks the entry's columns in chunks of 64: a stage =
+// the [256 x 64] piece of X (32 KiB, rows of 128 bytes, chunks swizzled by sw16 on the source side), the [16 x 64] chunk of U and
+// -- MASKED -- the 8 flag bytes of each row, fetched by global_load_lds three stages ahead (96 KiB in flight per CU); one barrier
+// per stage; wave w consumes tokens 64 w .. + 63 as MFMA column operands (the layout of lora_bgrad_ring_kernel's tb product).
+constexpr int P2_NST = 4, P2_XS = 256 * 128, P2_STAGE = P2_XS + 2048 + 2048, P2_SMEM = P2_NST * P2_STAGE;
+template <bool MASKED>
+__global__ __launch_bounds__(256) void lora_project_ring_kernel(ProjP p) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void gbl_void;
+  constexpr int NP = 8 + 1 + (MASKED ? 2 : 0);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int y = blockIdx.y;
+  const int W = p.width[y], col0 = p.col0[y];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tok0 = blockIdx.x * 256;
+  const int nch = W / 64;
+  const bool full = tok0 + 256 <= p.M;                        // uniform
+
+  // ---- producer ----
+  const int prow = lane >> 3, wpar = wave & 1;
+  // X piece = rows 8 piece .. + 7 (piece = 4 i + wave): sw16(row) = prow ^ 4 (wave & 1)
+  const int schunk = (lane & 7) ^ prow ^ (4 * wpar);
+  const uint32_t xlane = (uint32_t)((prow * p.ldx + schunk * 8) * 2);
+  const uint32_t ulane = (uint32_t)((prow * p.ldu[y] + schunk * 8) * 2);
+  const uint32_t blane = (uint32_t)((lane >> 1) * p.bits_ld + 4 * (lane & 1));
+  // The blocks walk the chunks in ROTATED orders (block b starts at chunk 5 b mod nch): in lockstep, every request in flight on the chip
+  // would address the same 128 bytes of a row, and with a power-of-two row stride (2048 columns) those fall onto a few memory
+  // channels (141 us against 160 us for the 1.5 x wider 3072-column input before the rotation).
+  const int rot = (int)((blockIdx.x * 5u) % (unsigned)nch);
+  auto issue = [&](int cs) {
+    char* st = smem + (cs & (P2_NST - 1)) * P2_STAGE;
+    const int c = cs + rot < nch ? cs + rot : cs + rot - nch;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int piece = 4 * i + wave;
+      if (full) {
+        const char* ub = bg_uniform_ptr(reinterpret_cast<const char*>(p.X + (long)(tok0 + 8 * piece) * p.ldx + col0 + 64 * c));
+        __builtin_amdgcn_global_load_lds((gbl_void*)(ub + xlane), (lds_void*)(st + piece * 1024), 16, 0, 0);
+      } else {
+        const int m = min(tok0 + 8 * piece + prow, p.M - 1);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(p.X + (long)m * p.ldx + col0 + 64 * c + schunk * 8), (lds_void*)(st + piece * 1024), 16, 0, 0);
+      }
+    }
+    {
+      const char* ub = bg_uniform_ptr(reinterpret_cast<const char*>(p.U[y] + (long)(8 * wpar) * p.ldu[y] + 64 * c));
+      __builtin_amdgcn_global_load_lds((gbl_void*)(ub + ulane), (lds_void*)(st + P2_XS + wpar * 1024), 16, 0, 0);
+    }
+    if (MASKED) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {            // this wave's own rows 64 wave + 32 i + (lane >> 1), 4 of the chunk's 8 flag bytes per lane
+        const int r0 = 64 * wave + 32 * i;
+        if (full) {
+          const char* ub = bg_uniform_ptr(reinterpret_cast<const char*>(p.bits + (long)(tok0 + r0) * p.bits_ld + 8 * c));
+          __builtin_amdgcn_global_load_lds((gbl_void*)(ub + blane), (lds_void*)(st + P2_XS + 2048 + r0 * 8), 4, 0, 0);
+        } else {
+          const int m = min(tok0 + r0 + (lane >> 1), p.M - 1);
+          __builtin_amdgcn_global_load_lds((gbl_void*)(p.bits + (long)m * p.bits_ld + 8 * c + 4 * (lane & 1)), (lds_void*)(st + P2_XS + 2048 + r0 * 8), 4, 0, 0);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int npro = min(P2_NST - 1, nch);
+  for (int c = 0; c < npro; ++c) issue(c);
+  const int swl = sw16(l15);
+  const uint32_t xrd = (uint32_t)((64 * wave + l15) * 128), urd = (uint32_t)(P2_XS + l15 * 128), brd = (uint32_t)(P2_XS + 2048 + (64 * wave + l15) * 8 + g);
+  for (int c = 0; c < nch; ++c) {
+    const int later = min(nch, c + P2_NST - 1) - (c + 1);
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NP) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (c + P2_NST - 1 < nch) issue(c + P2_NST - 1);          // (every wave has finished stage c - 1: its slot takes stage c + 3)
+    __builtin_amdgcn_sched_barrier(0);
+    // (LDS reads as asm: hipcc may answer a plain LDS load that could alias an LDS-DMA in flight with s_waitcnt vmcnt(0))
+    const uint32_t sb = lds_off(smem) + (uint32_t)((c & (P2_NST - 1)) * P2_STAGE);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      u32x4_t xv[4], uv;
+      uint32_t fb[4] = {0u, 0u, 0u, 0u};
+      const uint32_t sw = (uint32_t)(((4 * s2 + g) ^ swl) << 4);
+      const uint32_t ax = sb + xrd + sw, au = sb + urd + sw, ab = sb + brd + 4u * s2;
+      if (MASKED)
+        asm volatile("ds_read_b128 %0, %9\n\tds_read_b128 %1, %9 offset:2048\n\tds_read_b128 %2, %9 offset:4096\n\tds_read_b128 %3, %9 offset:6144\n\t"
+                     "ds_read_b128 %4, %10\n\t"
+                     "ds_read_u8 %5, %11\n\tds_read_u8 %6, %11 offset:128\n\tds_read_u8 %7, %11 offset:256\n\tds_read_u8 %8, %11 offset:384\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[2]), "=&v"(xv[3]), "=&v"(uv), "=&v"(fb[0]), "=&v"(fb[1]), "=&v"(fb[2]), "=&v"(fb[3])
+                     : "v"(ax), "v"(au), "v"(ab) : "memory");
+      else
+        asm volatile("ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:2048\n\tds_read_b128 %2, %5 offset:4096\n\tds_read_b128 %3, %5 offset:6144\n\t"
+                     "ds_read_b128 %4, %6\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(xv[0]), "=&v"(xv[1]), "=&v"(xv[2]), "=&v"(xv[3]), "=&v"(uv) : "v"(ax), "v"(au) : "memory");
+      const bf16x8 uf = __builtin_bit_cast(bf16x8, uv);
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+        uint4 x = make_uint4(xv[rb][0], xv[rb][1], xv[rb][2], xv[rb][3]);
+        if (MASKED) x = drop_apply(x, fb[rb]);
+        acc[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf, __builtin_bit_cast(bf16x8, x), acc[rb], 0, 0, 0);
+      }
+    }
+  }
+  // lane holds P[token l15][16 y + 4 g .. + 3]
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb) {
+    const int m = tok0 + 64 * wave + 16 * rb + l15;
+    if (m < p.M) {
+      const f32x4 v = acc[rb];
+      *reinterpret_cast<uint2*>(p.P + (long)m * p.ldp + 16 * y + 4 * g) =
+          make_uint2(pack_bf2(v[0] * p.alpha, v[1] * p.alpha), pack_bf2(v[2] * p.alpha, v[3] * p.alpha));
     }
   }
 }
@@ -455,12 +582,6 @@ __global__ __launch_bounds__(256, 4) void swiglu_lora_kernel(SwiLoraP p) {
   }
 }
 
-__device__ __forceinline__ const char* bg_uniform_ptr(const char* p) {          // (gemm_common.hip.h: uniform_ptr)
-  const uint64_t v = reinterpret_cast<uint64_t>(p);
-  uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  asm volatile("" : "+s"(lo), "+s"(hi));
-  return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
-}
 // ---- token-reduction products --------------------------------------------------------------------
 struct RedP {
   const bf16_t* X; long ldx; int M;
@@ -942,8 +1063,13 @@ __global__ __launch_bounds__(256) void lora_bgrad_ring_kernel(BgradP p) {
   const uint32_t ulane = (uint32_t)((prow * p.ldu[e] + (((lane & 7) ^ prow ^ (4 * wpar)) * 8)) * 2);
   const char* ubase = reinterpret_cast<const char*>(p.U[e] + (long)(8 * wpar) * p.ldu[e]);
   const bool full = tok0 + B2_TOK <= p.M;                     // uniform
+  // (the blocks walk the column chunks in rotated orders: see lora_project_ring_kernel -- in lockstep every request in flight would
+  // address the same 128 bytes of a row, which a power-of-two row stride puts onto a few memory channels)
+  const int rot = (int)(((blockIdx.x + 3u * blockIdx.y) * 5u) % (unsigned)nch);
+  auto chunk_of = [&](int cs) { return cs + rot < nch ? cs + rot : cs + rot - nch; };
   auto issue = [&](int s) {
-    const int c = s / B2_NT, t = s - c * B2_NT;
+    const int cs = s / B2_NT, t = s - cs * B2_NT;
+    const int c = chunk_of(cs);
     char* st = smem + (s & (B2_NST - 1)) * B2_STAGE;
     if (full) {
 #pragma unroll
@@ -1048,7 +1174,7 @@ __global__ __launch_bounds__(256) void lora_bgrad_ring_kernel(BgradP p) {
         for (int i = 0; i < 4; ++i) db = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT[t][k + i], f[i], db, 0, 0, 0);     // D[j = 4g+e][w = l15]
       }
     }
-    *reinterpret_cast<float4*>(slab + (long)(64 * c + 16 * wave + l15) * 16 + 4 * g) = make_float4(db[0], db[1], db[2], db[3]);
+    *reinterpret_cast<float4*>(slab + (long)(64 * chunk_of(c) + 16 * wave + l15) * 16 + 4 * g) = make_float4(db[0], db[1], db[2], db[3]);
   }
   // tb: lane holds rows j = 4 g .. + 3 of token l15
 #pragma unroll
@@ -1144,6 +1270,19 @@ extern "C" int ur_lora_project(const ur_lora_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const unsigned gx = (unsigned)ur_cdiv(a->M, 128);
   const bool masked = a->drop_bits != nullptr;
+  bool ring = !a->shared || a->nad == 1;           // one adapter per entry, every width a multiple of 64: wave-private LDS-DMA rings
+  for (int e = 0; ring && e < (a->shared ? 1 : a->nad); ++e) ring = (a->width[e] % 64) == 0;
+  if (ring) {
+    static std::atomic<uint64_t> attr_set[2];      // per device, per kernel
+    const void* fn = masked ? reinterpret_cast<const void*>(&lora_project_ring_kernel<true>) : reinterpret_cast<const void*>(&lora_project_ring_kernel<false>);
+    if (ur_first_on_device(attr_set[masked ? 1 : 0])) {
+      hipError_t er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P2_SMEM);
+      if (er != hipSuccess) UR_FAIL((int)er, "ur_lora_project: hipFuncSetAttribute failed: %s", hipGetErrorString(er));
+    }
+    dim3 grid((unsigned)ur_cdiv(a->M, 256), a->nad);
+    if (masked) hipLaunchKernelGGL((lora_project_ring_kernel<true>), grid, dim3(256), P2_SMEM, st, p);
+    else hipLaunchKernelGGL((lora_project_ring_kernel<false>), grid, dim3(256), P2_SMEM, st, p);
+  } else
   if (!a->shared || a->nad == 1) {
     dim3 grid(gx, a->nad);
     if (masked) hipLaunchKernelGGL((lora_project_kernel<1, true>), grid, dim3(256), 0, st, p);
