@@ -262,6 +262,12 @@ typedef struct {
    * rope_rstd[m * rope_rstd_ld + rope_rstd_h0 + h] (qkr_rstd); rope_eps is not used.  Same arithmetic as
    * ur_qknorm_rope_bwd_roped on the q heads. */
   const float* rope_rstd; int64_t rope_rstd_ld; int32_t rope_rstd_h0;
+  /* with rope_rstd, optional: the k heads as well.  rope_k = the ROPED, normed k (qkr_k: the k of ur_attn_args, row stride rope_ldk),
+   * rope_k_weight its norm weight, 1 / rms of (token m, k head h) = rope_rstd[m * rope_rstd_ld + rope_rstd_hk0 + h]; rope_dk_raw
+   * (row stride rope_lddkraw) receives the gradient of the RAW k projection.  The generated causal head_dim-128 dK/dV kernel applies it
+   * in its store (dk is then not written); other shapes write dk (dense [B*Sk, nkv*hd] required) and run ur_qknorm_rope_bwd_roped_k. */
+  const void* rope_k; int64_t rope_ldk; const float* rope_k_weight; int32_t rope_rstd_hk0;
+  void* rope_dk_raw; int64_t rope_lddkraw;
 } ur_attn_bwd_args;
 int ur_attn_fwd(const ur_attn_args* a, void* stream);
 int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, void* stream);

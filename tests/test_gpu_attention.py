@@ -278,6 +278,19 @@ def test_dq_kernel_carries_qnorm_rope_backward_from_roped_q(S, mask_kind):
     assert torch.isfinite(bq).all() and a.abs().max() > 0
     assert (a - bq).abs().max() <= 2e-2 * a.abs().max()
     assert (a - bq).norm() / a.norm() < 3e-3
+    # the k heads in the same call (rope_k): the dK/dV kernel's store where the generated kernel runs (S 512 / 1024), the stand-alone
+    # kernel inside ur_attn_bwd elsewhere (bit for bit then)
+    d3 = torch.zeros_like(qkv)
+    dk3 = torch.empty_like(dk_r)
+    hip.attn_bwd(ctx, dout, dk=dk3.view(B, S, nkv, hd), dv=d3[:, NQ + NKV:].view(B, S, nkv, hd), rope_q=(q_r, qw, cos, sin, eps, d3[:, :NQ]),
+                 rope_rstd=(rstd, 0), rope_k=(k_r, kw, nq, d3[:, NQ:NQ + NKV]))
+    torch.cuda.synchronize()
+    assert torch.equal(d3[:, :NQ], d1[:, :NQ]) and torch.equal(d3[:, NQ + NKV:], d1[:, NQ + NKV:])
+    ak, bk = d0[:, NQ:NQ + NKV].float(), d3[:, NQ:NQ + NKV].float()
+    if S % 128:
+        assert torch.equal(ak, bk)
+    assert torch.isfinite(bk).all() and ak.abs().max() > 0
+    assert (ak - bk).abs().max() <= 2e-2 * ak.abs().max() and (ak - bk).norm() / ak.norm() < 3e-3
     # and against the raw-projection backward (the reference chain): to the tolerance of the roped recovery
     d2 = torch.zeros_like(qkv)
     hip.qknorm_rope_bwd(dq_r, dk_r, qkv, qw, kw, cos, sin, d2, S, nq, nkv, hd, eps)

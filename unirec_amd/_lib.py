@@ -68,7 +68,9 @@ class AttnBwdArgs(ctypes.Structure):
                 ("lddo", c_i64), ("lddq", c_i64), ("lddk", c_i64), ("lddv", c_i64), ("delta", c_void_p),
                 ("rope_q_raw", c_void_p), ("rope_ldraw", c_i64), ("rope_q_weight", c_void_p), ("rope_cos", c_void_p),
                 ("rope_sin", c_void_p), ("rope_eps", c_float), ("rope_dq_raw", c_void_p), ("rope_lddraw", c_i64),
-                ("rope_rstd", c_void_p), ("rope_rstd_ld", c_i64), ("rope_rstd_h0", c_int)]
+                ("rope_rstd", c_void_p), ("rope_rstd_ld", c_i64), ("rope_rstd_h0", c_int),
+                ("rope_k", c_void_p), ("rope_ldk", c_i64), ("rope_k_weight", c_void_p), ("rope_rstd_hk0", c_int),
+                ("rope_dk_raw", c_void_p), ("rope_lddkraw", c_i64)]
 
 
 # name -> (restype, argtypes).  Every symbol include/unirec_hip.h declares must appear here

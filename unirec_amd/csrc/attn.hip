@@ -85,6 +85,8 @@ struct AttnP {
   const bf16_t* rp_raw; long rp_ldraw; const float* rp_w; const float* rp_cos; const float* rp_sin; float rp_eps;
   bf16_t* rp_draw; long rp_lddraw;
   const float* rp_rstd; long rp_rstd_ld; int rp_rstd_h0;      // non-null: rp_raw is the ROPED, normed q and 1 / rms comes from the forward (ur_attn_bwd_args.rope_rstd)
+  // the k heads' q/k-norm + RoPE backward in the dK/dV kernel's store (with rp_rstd): roped k, its norm weight, first k column of rstd, raw-gradient output
+  const bf16_t* rk_src; long rk_ld; const float* rk_w; int rk_rstd_h0; bf16_t* rk_dst; long rk_lddst;
   // hand-scheduled causal head_dim-128 backward (both kernels or neither): plane 1 of `delta` holds -LSE * log2(e) instead of -LSE / scale
   int lse_log2;
 };
@@ -585,6 +587,50 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   }
 }
 
+// q/k-norm + RoPE backward of one row from the ROPED, normed forward output (qknorm_rope_bwd_roped_kernel's arithmetic in the transposed
+// accumulator layout: the lane holds d = 32 dt + acc_row(r, h) of its row, the rotate-half partner d +- 64 is the same register of tile
+// dt +- 2).  x^ = R^T(o) / w, g = R^T(d) w, d_raw = rstd (g - x^ mean(g x^)).  d: gradient of the roped row in, of the raw projection out.
+template <int HD>
+__device__ __forceinline__ void rope_bwd_from_roped(f32x16 (&d)[Cfg<HD>::NDT], const bf16_t* orow, const float* w, const float* cr, const float* sr, float rs, int h) {
+  uint2 xp[4][4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) xp[dt][rq] = *reinterpret_cast<const uint2*>(orow + 32 * dt + 8 * rq + 4 * h);
+  float xh[4][16];
+  float t = 0.f;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int j = 32 * dt + 8 * rq + 4 * h;
+      const float4 c4 = *reinterpret_cast<const float4*>(cr + j), s4 = *reinterpret_cast<const float4*>(sr + j);
+      const float4 wa = *reinterpret_cast<const float4*>(w + j), wb = *reinterpret_cast<const float4*>(w + j + 64);
+      const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+      const float wA[4] = {wa.x, wa.y, wa.z, wa.w}, wB[4] = {wb.x, wb.y, wb.z, wb.w};
+      const float oA[4] = {bf_lo(xp[dt][rq].x), bf_hi(xp[dt][rq].x), bf_lo(xp[dt][rq].y), bf_hi(xp[dt][rq].y)};
+      const float oB[4] = {bf_lo(xp[dt + 2][rq].x), bf_hi(xp[dt + 2][rq].x), bf_lo(xp[dt + 2][rq].y), bf_hi(xp[dt + 2][rq].y)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * rq + e;
+        const float hA = (oA[e] * cc[e] + oB[e] * sn[e]) * __builtin_amdgcn_rcpf(wA[e]);      // forward: o = xn c -+ partner(xn) s
+        const float hB = (oB[e] * cc[e] - oA[e] * sn[e]) * __builtin_amdgcn_rcpf(wB[e]);
+        const float dA = bf2f(f2bf(d[dt][r])), dB = bf2f(f2bf(d[dt + 2][r]));                 // (the standalone kernel reads the gradient back as bf16)
+        const float gA = (dA * cc[e] + dB * sn[e]) * wA[e];
+        const float gB = (dB * cc[e] - dA * sn[e]) * wB[e];
+        t += gA * hA + gB * hB;
+        d[dt][r] = gA; d[dt + 2][r] = gB;
+        xh[dt][r] = hA; xh[dt + 2][r] = hB;
+      }
+    }
+  t += __shfl_xor(t, 32, 64);
+  t /= (float)HD;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[dt][r] = rs * (d[dt][r] - xh[dt][r] * t);
+}
+
 // Store of a 32-query block's dQ^T accumulators (lane = query row, registers = head_dim), shared by both dQ kernels: plain bf16 rows, or
 // -- head_dim 128 with ur_attn_bwd_args.rope_* -- the q-norm + RoPE backward applied in registers first (dq leaves as the gradient of
 // the RAW q projection).
@@ -604,44 +650,8 @@ __device__ __forceinline__ void dq_store_block(const AttnP& p, f32x16 (&dq)[Cfg<
     const float* sr = p.rp_sin + (long)pos * (HD / 2);
     uint2 xp[4][4];
     if (p.rp_rstd != nullptr) {
-      // the forward ran as the q|k|v GEMM's epilogue: xp holds the ROPED, normed q; x^ = R^T(q) / w (qknorm_rope_bwd_roped_kernel)
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) xp[dt][rq] = *reinterpret_cast<const uint2*>(xr + 32 * dt + 8 * rq + 4 * h);
-      const float rs = p.rp_rstd[qrow * p.rp_rstd_ld + p.rp_rstd_h0 + hq];
-      float xh[4][16];
-      float t = 0.f;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-          const int j = 32 * dt + 8 * rq + 4 * h;
-          const float4 c4 = *reinterpret_cast<const float4*>(cr + j), s4 = *reinterpret_cast<const float4*>(sr + j);
-          const float4 wa = *reinterpret_cast<const float4*>(p.rp_w + j), wb = *reinterpret_cast<const float4*>(p.rp_w + j + 64);
-          const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
-          const float wA[4] = {wa.x, wa.y, wa.z, wa.w}, wB[4] = {wb.x, wb.y, wb.z, wb.w};
-          const float oA[4] = {bf_lo(xp[dt][rq].x), bf_hi(xp[dt][rq].x), bf_lo(xp[dt][rq].y), bf_hi(xp[dt][rq].y)};
-          const float oB[4] = {bf_lo(xp[dt + 2][rq].x), bf_hi(xp[dt + 2][rq].x), bf_lo(xp[dt + 2][rq].y), bf_hi(xp[dt + 2][rq].y)};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int r = 4 * rq + e;
-            const float hA = (oA[e] * cc[e] + oB[e] * sn[e]) * __builtin_amdgcn_rcpf(wA[e]);      // forward: o = xn c -+ partner(xn) s
-            const float hB = (oB[e] * cc[e] - oA[e] * sn[e]) * __builtin_amdgcn_rcpf(wB[e]);
-            const float dA = bf2f(f2bf(dq[dt][r])), dB = bf2f(f2bf(dq[dt + 2][r]));               // (the standalone kernel reads dq back as bf16)
-            const float gA = (dA * cc[e] + dB * sn[e]) * wA[e];
-            const float gB = (dB * cc[e] - dA * sn[e]) * wB[e];
-            t += gA * hA + gB * hB;
-            dq[dt][r] = gA; dq[dt + 2][r] = gB;
-            xh[dt][r] = hA; xh[dt + 2][r] = hB;
-          }
-        }
-      t += __shfl_xor(t, 32, 64);
-      t /= (float)HD;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[dt][r] = rs * (dq[dt][r] - xh[dt][r] * t);
+      // the forward ran as the q|k|v GEMM's epilogue: rp_raw holds the ROPED, normed q
+      rope_bwd_from_roped<HD>(dq, xr, p.rp_w, cr, sr, p.rp_rstd[qrow * p.rp_rstd_ld + p.rp_rstd_h0 + hq], h);
       store_T<HD>(p.rp_draw + qrow * p.rp_lddraw + (long)hq * HD, dq, 1.0f, lane, qok);
       return;
     }
@@ -2614,7 +2624,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   if (p.kmask != nullptr && !__syncthreads_or(kvalid ? 1 : 0)) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
-    store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 0.f, lane, true);
+    if (p.rk_src != nullptr) store_T<128>(p.rk_dst + ktok * p.rk_lddst + (long)kvh * 128, dk, 0.f, lane, true);
+    else store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 0.f, lane, true);
     store_T<128>(p.dv + ktok * p.lddv + (long)kvh * 128, dv, 0.f, lane, true);
     return;
   }
@@ -2690,7 +2701,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       dk[dt][r] = kvalid ? (dt < 2 ? k0[idx] : k1[idx]) * p.scale : 0.f;       // padded key: whatever its lane computed is dropped
       dv[dt][r] = kvalid ? (dt < 2 ? v0[idx] : v1[idx]) : 0.f;
     }
-  store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 1.0f, lane, true);
+  if (p.rk_src != nullptr) {
+    // k = rope(k_norm(k_raw)) ran in the q|k|v GEMM's epilogue: the lane owns its key's whole row, so dK leaves as the gradient of the
+    // RAW k projection (the arithmetic of qknorm_rope_bwd_roped_kernel; a padded key's zero gradient stays zero)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int key_e = kb + (lane_e & 31);
+    const long krow = (long)b * p.Sk + key_e;
+    rope_bwd_from_roped<128>(dk, p.rk_src + krow * p.rk_ld + (long)kvh * 128, p.rk_w, p.rp_cos + (long)key_e * 64, p.rp_sin + (long)key_e * 64,
+                             p.rp_rstd[krow * p.rp_rstd_ld + p.rk_rstd_h0 + kvh], lane_e >> 5);
+    store_T<128>(p.rk_dst + krow * p.rk_lddst + (long)kvh * 128, dk, 1.0f, lane_e, true);
+  } else {
+    store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 1.0f, lane, true);
+  }
   store_T<128>(p.dv + ktok * p.lddv + (long)kvh * 128, dv, 1.0f, lane, true);
 }
 
@@ -2899,11 +2922,32 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
   p.rp_raw = (const bf16_t*)g->rope_q_raw; p.rp_ldraw = g->rope_ldraw; p.rp_w = g->rope_q_weight; p.rp_cos = g->rope_cos; p.rp_sin = g->rope_sin;
   p.rp_eps = g->rope_eps; p.rp_draw = (bf16_t*)g->rope_dq_raw; p.rp_lddraw = g->rope_lddraw;
   p.rp_rstd = g->rope_q_raw ? g->rope_rstd : nullptr; p.rp_rstd_ld = g->rope_rstd_ld; p.rp_rstd_h0 = g->rope_rstd_h0;
+  const bool rope_k = p.rp_rstd != nullptr && g->rope_k != nullptr;
+  p.rk_src = nullptr;
+  if (rope_k) {
+    UR_REQUIRE(g->rope_k_weight && g->rope_dk_raw && UR_ALIGNED16(g->rope_k) && UR_ALIGNED16(g->rope_dk_raw) && UR_ALIGNED16(g->rope_k_weight) &&
+               (g->rope_ldk % 8) == 0 && (g->rope_lddkraw % 8) == 0 && g->rope_ldk >= (int64_t)a->nkv * a->head_dim &&
+               g->rope_lddkraw >= (int64_t)a->nkv * a->head_dim && g->rope_rstd_hk0 >= 0 && g->rope_rstd_ld >= (int64_t)g->rope_rstd_hk0 + a->nkv,
+               "ur_attn_bwd: bad k-norm / RoPE operands (rope_k, rope_k_weight, rope_dk_raw; 16-byte aligned, row strides %% 8 == 0)");
+    p.rk_src = (const bf16_t*)g->rope_k; p.rk_ld = g->rope_ldk; p.rk_w = g->rope_k_weight; p.rk_rstd_h0 = g->rope_rstd_hk0;
+    p.rk_dst = (bf16_t*)g->rope_dk_raw; p.rk_lddst = g->rope_lddkraw;
+  }
   hipStream_t st = (hipStream_t)stream;
   p.lse_log2 = (a->head_dim == 128 && a->causal != 0 && c128_bwd_ok(p)) ? 1 : 0;
   if (tiny_shape(p, a->head_dim, a->causal != 0, true)) return launch_tiny(p, true, st);      // dQ, dK, dV in one kernel
   // the dQ kernel also computes the row constants (delta, -LSE/scale) and leaves them in `delta` for dK/dV
+  // (only the generated dK/dV kernel carries the k heads' backward in its store; on every other path dk is written roped and the
+  // stand-alone kernel turns it into the raw gradient here)
+  const bool rope_k_fused = rope_k && p.lse_log2 != 0;
+  if (rope_k && !rope_k_fused) p.rk_src = nullptr;
   rc = do_dq(p, a->head_dim, a->causal != 0, st);
   if (rc) return rc;
-  return do_dkv(p, a->head_dim, a->causal != 0, st);
+  rc = do_dkv(p, a->head_dim, a->causal != 0, st);
+  if (rc) return rc;
+  if (rope_k && !rope_k_fused) {
+    UR_REQUIRE(g->lddk == (int64_t)a->nkv * a->head_dim, "ur_attn_bwd: rope_k on this shape needs a dense dk [B*Sk, nkv*hd]");
+    return ur_qknorm_rope_bwd_roped_k(g->dk, g->rope_k, g->rope_ldk, g->rope_rstd, g->rope_rstd_ld, g->rope_rstd_hk0, g->rope_k_weight, g->rope_cos,
+                                      g->rope_sin, g->rope_dk_raw, g->rope_lddkraw, (int64_t)a->B * a->Sk, a->Sk, a->nkv, a->head_dim, stream);
+  }
+  return 0;
 }

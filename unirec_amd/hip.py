@@ -546,12 +546,15 @@ def attn_fwd(q, k, v, *, causal, key_mask=None, scale=None, dropout_p=0.0, seed=
     return out, ctx
 
 
-def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None, rope_rstd=None):
+def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None, rope_rstd=None, rope_k=None):
     """dout [B,Sq,nq,hd] -> (dq, dk, dv); outputs may be strided views into a fused gradient buffer.
     rope_q = (q_raw [M, >= nq*hd] view, q_norm_weight f32 [hd], cos, sin, eps, dq_raw [M, >= nq*hd] view): the dQ kernel carries
     the q-norm + RoPE backward and writes the gradient of the RAW q projection into dq_raw; no dq is produced (returns None).
     rope_rstd = (rstd f32 [M, nh], first q head's column): the forward ran q-norm + RoPE in the q|k|v GEMM epilogue -- rope_q[0]
-    is then the ROPED q (the attention's own q) and 1 / rms comes from rstd (ur_attn_bwd_args.rope_rstd)."""
+    is then the ROPED q (the attention's own q) and 1 / rms comes from rstd (ur_attn_bwd_args.rope_rstd).
+    rope_k = (k_r [M, >= nkv*hd] view, k_norm_weight, first k head's column of rstd, dk_raw [M, >= nkv*hd] view) with rope_rstd: the
+    k heads' backward too (in the dK/dV kernel's store where the generated kernel runs, else by the stand-alone kernel inside the call;
+    dk is scratch then)."""
     lib = _lib.load()
     q, k, v, _ = ctx.keep
     if dq is None and rope_q is None:
@@ -574,6 +577,10 @@ def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None, rope_rstd=None):
             rstd, h0 = rope_rstd
             _need(rstd, F32, "rope_rstd")
             g.rope_rstd, g.rope_rstd_ld, g.rope_rstd_h0 = rstd.data_ptr(), rstd.stride(0), int(h0)
+            if rope_k is not None:
+                k_r, kw, hk0, dk_raw = rope_k
+                g.rope_k, g.rope_ldk, g.rope_k_weight, g.rope_rstd_hk0 = k_r.data_ptr(), k_r.stride(0), kw.data_ptr(), int(hk0)
+                g.rope_dk_raw, g.rope_lddkraw = dk_raw.data_ptr(), dk_raw.stride(0)
     g.delta = delta.data_ptr()
     if PROFILE_ATTN is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -724,10 +724,14 @@ class Qwen3LoRAModel(nn.Module):
             if "rstd_qk" in L and hd == 128 and os.environ.get("UNIREC_ROPE_BWD_FUSED", "1") != "0":
                 # the forward ran q/k-norm + RoPE in the q|k|v launch: no raw q, k exist; the rows are recovered from the roped outputs.
                 # The q heads' backward rides in the dQ kernel's store (its lanes own whole rows of q_r, which it has just read as
-                # its q operand): dq never makes the round trip through HBM; the stand-alone kernel keeps the k heads.
+                # its q operand): dq never makes the round trip through HBM.
+                # (the k heads' likewise in the dK/dV kernel's store; dk_r is scratch for the shapes the generated kernels do not take)
+                k_in_call = os.environ.get("UNIREC_ROPE_K_FUSED", "1") != "0"      # test / lab switch: 0 = the k heads by a separate launch
                 hip.attn_bwd(L["actx"], datt.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd), dv=dqkv[:, NQ + NKV:].view(B, S, nkv, hd),
-                             rope_q=(L["q_r"], fl["qn"], cos, sin, eps, dqkv[:, :NQ]), rope_rstd=(L["rstd_qk"], 0))
-                hip.qknorm_rope_bwd_roped_k(dk_r, L["k_r"], L["rstd_qk"], nq, fl["kn"], cos, sin, dqkv[:, NQ:NQ + NKV], S, nkv, hd)
+                             rope_q=(L["q_r"], fl["qn"], cos, sin, eps, dqkv[:, :NQ]), rope_rstd=(L["rstd_qk"], 0),
+                             rope_k=(L["k_r"], fl["kn"], nq, dqkv[:, NQ:NQ + NKV]) if k_in_call else None)
+                if not k_in_call:
+                    hip.qknorm_rope_bwd_roped_k(dk_r, L["k_r"], L["rstd_qk"], nq, fl["kn"], cos, sin, dqkv[:, NQ:NQ + NKV], S, nkv, hd)
             elif "rstd_qk" in L:
                 dq_r = torch.empty((M, NQ), dtype=BF16, device=dev)
                 hip.attn_bwd(L["actx"], datt.view(B, S, nq, hd), dq=dq_r.view(B, S, nq, hd), dk=dk_r.view(B, S, nkv, hd),
