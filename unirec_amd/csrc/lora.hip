@@ -266,13 +266,12 @@ __global__ __launch_bounds__(256) void lora_project_ring_kernel(ProjP p) {
   const uint32_t xlane = (uint32_t)((prow * p.ldx + schunk * 8) * 2);
   const uint32_t ulane = (uint32_t)((prow * p.ldu[y] + schunk * 8) * 2);
   const uint32_t blane = (uint32_t)((lane >> 1) * p.bits_ld + 4 * (lane & 1));
-  // The blocks walk the chunks in ROTATED orders (block b starts at chunk 5 b mod nch): in lockstep, every request in flight on the chip
-  // would address the same 128 bytes of a row, and with a power-of-two row stride (2048 columns) those fall onto a few memory
-  // channels (141 us against 160 us for the 1.5 x wider 3072-column input before the rotation).
-  const int rot = (int)((blockIdx.x * 5u) % (unsigned)nch);
-  auto issue = [&](int cs) {
-    char* st = smem + (cs & (P2_NST - 1)) * P2_STAGE;
-    const int c = cs + rot < nch ? cs + rot : cs + rot - nch;
+  // (Every block walks the chunks in the SAME order: a token's sum must not depend on where its row sits in the batch -- the shard
+  // invariance the forward is tested for.  Measured cost: with a power-of-two row stride (2048 columns) the blocks, in lockstep, keep
+  // every request in flight on the same 128 bytes of a row, i.e. on a few memory channels -- 141 us against 104 us with the chunk
+  // order rotated per block, which the backward-only lora_bgrad_ring_kernel may do and this kernel may not.)
+  auto issue = [&](int c) {
+    char* st = smem + (c & (P2_NST - 1)) * P2_STAGE;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int piece = 4 * i + wave;

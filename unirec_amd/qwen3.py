@@ -401,13 +401,17 @@ class Qwen3LoRAModel(nn.Module):
                       for i in range(self.config.num_hidden_layers) for g, (W, nad) in enumerate(self._bits_groups()) if W % 64 == 0}
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            for (i, g), buf in planes.items():
-                W, nad = self._bits_groups()[g]
-                hip.lora_dropout_bits(self.lora_dropout_seed(step, i, g), p, M, W, nad, device, out=buf, row0=row0)
-                if (i, g) in packed:
-                    hip.lora_bits_transpose(buf, W, out=packed[(i, g)])
-            ev = side.record_event()
-        self._bits_pre = {"step": step, "M": M, "planes": planes, "packed": packed, "event": ev, "row0": int(row0)}
+            # one event per layer: the forward of layer i waits for ITS planes only, so the generator keeps running under the first
+            # layers of the decoder when the Q-Former's forward is shorter than it; the token-packed copies (backward only) come last
+            events = []
+            for i in range(self.config.num_hidden_layers):
+                for g, (W, nad) in enumerate(self._bits_groups()):
+                    hip.lora_dropout_bits(self.lora_dropout_seed(step, i, g), p, M, W, nad, device, out=planes[(i, g)], row0=row0)
+                events.append(side.record_event())
+            for (i, g), bt in packed.items():
+                hip.lora_bits_transpose(planes[(i, g)], self._bits_groups()[g][0], out=bt)
+            ev_t = side.record_event()
+        self._bits_pre = {"step": step, "M": M, "planes": planes, "packed": packed, "events": events, "event_t": ev_t, "row0": int(row0)}
 
     def _lora_bcomb(self, pack, device):
         """Second-K-range operands of the merged projection launches: y[q|k|v] = h W^T + [t_q|t_k|t_v] Bc^T with
@@ -507,16 +511,20 @@ class Qwen3LoRAModel(nn.Module):
         row0 = self.first_sample(B) * S                # token rows that precede this shard in the global minibatch
         pre, self._bits_pre = self._bits_pre, None
         if pre is not None and pdrop > 0.0 and pre["step"] == step and pre["M"] == M and pre["row0"] == row0 and pack is not None:
-            torch.cuda.current_stream(dev).wait_event(pre["event"])      # planes prefetched on the side stream
             saved["bits_t"] = pre.get("packed", {})                      # (layer, group) -> token-packed copy for the backward
+            saved["bits_t_event"] = pre["event_t"]
+            pre_events = pre["events"]                                   # planes prefetched on the side stream, one event per layer
             pre = pre["planes"]
         else:
-            pre = None
+            pre, pre_events = None, None
         bp = (lambda i, g: pre[(i, g)]) if pre is not None else (lambda i, g: None)
         fuse_norm = _FUSE_NORM_LORA and pack is not None and c.lora_r == 16 and D == 1024
         for i, fl in enumerate(fz["layers"]):
             lp = f"layers.{i}."
             L = {"x": x}
+            if pre_events is not None:
+                # (lab switch UNIREC_BITS_ONE_EVENT=1: wait for every layer's planes before the first layer, the former behaviour)
+                torch.cuda.current_stream(dev).wait_event(pre_events[-1] if (i == 0 and os.environ.get("UNIREC_BITS_ONE_EVENT") == "1") else pre_events[i])
             # q/k-norm + RoPE inside the q|k|v launch (the raw q, k are never written or re-read) when the persistent GEMM takes it
             fuse_rope = (_FUSE_QK_ROPE and hd == 128 and fl["qkvP"] is not None and fz["qk_norm_fusable"] and (pack is None or bc_qkv is not None) and
                          hip.gemm_qkrope_supported(M, NQ + 2 * NKV, D, 3 * r if pack is not None else 0, S, NQ, NKV, dev))
@@ -640,6 +648,8 @@ class Qwen3LoRAModel(nn.Module):
         lt = self._lora_transposes(pack) if (pack is not None and r == 16) else None      # name(s) -> transposed bf16 operand
 
         packed_bits = saved.get("bits_t", {})
+        if saved.get("bits_t_event") is not None:
+            torch.cuda.current_stream(dev).wait_event(saved["bits_t_event"])
 
         def lora_grads(dy, t, xin, a_names, b_specs, bits, group=None):
             """dB_p = dy_p^T t_p ; tb = s * dy B ; dA_p = tb_p^T dropout_p(x).  Returns tb [M, len(b)*r] (bf16).
