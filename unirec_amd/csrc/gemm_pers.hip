@@ -734,6 +734,11 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
                          (reinterpret_cast<uintptr_t>(p.sw_dgu) & 15))) return false;
   // 32-bit lane offsets
   if (p.lds * 16 >= (1L << 31) || p.ldr * 16 >= (1L << 31) || p.ldc * 32 >= (1L << 31)) return false;
+  // (every epilogue operand is addressed as uniform base + a 32-bit lane offset of at most 16 rows)
+  auto wide = [](long ld) { return ld * 32 >= (1L << 31); };
+  if ((p.res && wide(p.ldres)) || (p.sw_mode == 1 && (wide(p.sw_ldgu) || wide(p.sw_lddgu))) || (p.qk_q && (wide(p.qk_ldq) || wide(p.qk_ldk) || wide(p.qk_ldv))) ||
+      (p.sp_act && wide(p.sp_ldact)) || (p.drop_bits && (wide(p.drop_bits_ld) || wide(p.lds2) || wide(p.ldr2))))
+    return false;
   return true;
 }
 

@@ -260,7 +260,7 @@ class Qwen3LoRAModel(nn.Module):
         """bf16 operands of the frozen base weights, fused per layer: [q|k|v], o, [gate|up], down."""
         # keyed on EVERY frozen tensor (storage + in-place version): loading any of them after a forward has run must not
         # leave stale bf16 / transposed copies behind
-        key = (str(device),) + tuple((p.data_ptr(), p._version) for n, p in self.named_parameters() if ".lora_" not in n)
+        key = (str(device), _FUSE_QK_ROPE, _FUSE_SWIGLU_GEMM) + tuple((p.data_ptr(), p._version) for n, p in self.named_parameters() if ".lora_" not in n)
         if self._frozen is not None and self._frozen["key"] == key:
             return self._frozen
         fz = {"key": key, "layers": []}
@@ -278,9 +278,11 @@ class Qwen3LoRAModel(nn.Module):
             fz["layers"].append({
                 "qkv": c16(wqkv),
                 # q|k|v with the rows of every q / k head in the paired order of the fused q/k-norm + RoPE epilogue (hip.qkrope_perm)
-                "qkvP": c16(wqkv.to(dev)[rp]) if rp is not None else None,
+                # (only when that path can be selected at all: the duplicates cost ~0.6 GB at Qwen3-0.6B)
+                "qkvP": c16(wqkv.to(dev)[rp]) if (rp is not None and _FUSE_QK_ROPE) else None,
                 # gate|up with 128-row blocks of gate and up interleaved (hip.swiglu_pair_rows): the paired SwiGLU forward epilogue
-                "guP": c16(wgu.to(dev)[hip.swiglu_pair_rows(m.gate_proj.weight.shape[0]).to(dev)]) if m.gate_proj.weight.shape[0] % 128 == 0 else None, "o": c16(a.o_proj.weight), "gu": c16(wgu), "d": c16(m.down_proj.weight),
+                "guP": c16(wgu.to(dev)[self._swiglu_rows(m.gate_proj.weight.shape[0], dev)]) if (_FUSE_SWIGLU_GEMM and m.gate_proj.weight.shape[0] % 128 == 0) else None,
+                "o": c16(a.o_proj.weight), "gu": c16(wgu), "d": c16(m.down_proj.weight),
                 # frozen => one-time transposed copies, so every dX GEMM is K-contiguous on both operands
                 "qkvT": c16(wqkv.t()), "oT": c16(a.o_proj.weight.t()), "guT": c16(wgu.t()), "dT": c16(m.down_proj.weight.t()),
                 "qn": a.q_norm.weight.detach().to(dev, F32).contiguous(), "kn": a.k_norm.weight.detach().to(dev, F32).contiguous(),
@@ -559,7 +561,13 @@ class Qwen3LoRAModel(nn.Module):
             else:
                 q_r, k_r = hip.qknorm_rope_fwd(qkv, fl["qn"], fl["kn"], cos, sin, S, nq, nkv, hd, eps)
                 v4 = qkv[:, NQ + NKV:].view(B, S, nkv, hd)
-            att, actx = hip.attn_fwd(q_r.view(B, S, nq, hd), k_r.view(B, S, nkv, hd), v4, causal=True, key_mask=mask_u8)
+            # the attention output's rows are padded by 64 columns when their length is a power of two: the kernels that stream it
+            # in 128-byte column chunks (the o_proj adapter's projection and its token reduction) otherwise keep every request in
+            # flight on the same bytes of a 4 KiB-strided row, i.e. on a few memory channels (lora_project_ring_kernel: 141 -> 104 us)
+            att_out = None
+            if (NQ & (NQ - 1)) == 0 and NQ >= 1024 and os.environ.get("UNIREC_PAD_ATT", "1") != "0":
+                att_out = torch.empty((M, NQ + 64), dtype=BF16, device=dev)[:, :NQ].view(B, S, nq, hd)
+            att, actx = hip.attn_fwd(q_r.view(B, S, nq, hd), k_r.view(B, S, nkv, hd), v4, causal=True, key_mask=mask_u8, out=att_out)
             att2 = att.view(M, NQ)
             if pack is not None:
                 t_o, L["bits_o"] = self._lora_down(att2, [lp + "self_attn.o_proj.lora_A.weight"], pack, sc, self.lora_dropout_seed(step, i, 1), pdrop, bp(i, 1), row0=row0)
