@@ -419,6 +419,31 @@ def test_lora_reduce_ring_kernel(M, K, nad, p):
 
 
 @pytest.mark.gpu
+def test_lora_row_products_do_not_depend_on_the_row_position():
+    """Per-token outputs of the ring kernels (t of ur_lora_project, tb of ur_lora_bgrad) are bit-identical wherever the row sits in
+    the launch: the shard invariance of the forward and the per-sample invariance of the backward (full-size additivity test) rest on
+    it -- a chunk order that varies per workgroup (tried: rotated orders against memory-channel camping) breaks it."""
+    from unirec_amd import hip
+    g = torch.Generator().manual_seed(21)
+    M, K, r = 4096, 2048, 16
+    x = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    A = (torch.randn(r, K, generator=g) * 0.2).to(DEV).to(torch.bfloat16)
+    bits = hip.lora_dropout_bits(5, 0.1, M, K, 1, DEV)
+    full = hip.lora_project(x, [A], alpha=1.1, bits=bits)
+    for lo, hi in ((1024, 2048), (2304, 4096)):
+        part = hip.lora_project(x[lo:hi], [A], alpha=1.1, bits=bits[:, lo:hi])
+        assert torch.equal(part, full[lo:hi])
+    cols = [(0, 1024), (1024, 512), (1536, 512)]
+    Bt = [(torch.randn(r, n, generator=g) * 0.2).to(DEV).to(torch.bfloat16) for _, n in cols]
+    t = torch.randn(M, 3 * r, generator=g).to(DEV).to(torch.bfloat16)
+    gB = torch.empty(K, r, device=DEV)
+    tb = hip.lora_bgrad(x, t, Bt, cols, gB)
+    for lo, hi in ((1024, 2048), (2304, 4096)):
+        tbp = hip.lora_bgrad(x[lo:hi], t[lo:hi], Bt, cols, torch.empty_like(gB))
+        assert torch.equal(tbp, tb[lo:hi])
+
+
+@pytest.mark.gpu
 def test_lora_reduce_ring_kernel_on_column_ranges():
     """dB_a = dy_a^T t_a over per-adapter column ranges (shared = 0, transposed output, no dropout) through the ring kernel."""
     from unirec_amd import hip

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void lora_project_ring_kernel(ProjP p) {
   // (Every block walks the chunks in the SAME order: a token's sum must not depend on where its row sits in the batch -- the shard
   // invariance the forward is tested for.  Measured cost: with a power-of-two row stride (2048 columns) the blocks, in lockstep, keep
   // every request in flight on the same 128 bytes of a row, i.e. on a few memory channels -- 141 us against 104 us with the chunk
-  // order rotated per block, which the backward-only lora_bgrad_ring_kernel may do and this kernel may not.)
+  // order rotated per block, which a kernel whose sums must not depend on the row's position may not do.)
   auto issue = [&](int c) {
     char* st = smem + (c & (P2_NST - 1)) * P2_STAGE;
 #pragma unroll
@@ -1062,13 +1062,10 @@ __global__ __launch_bounds__(256) void lora_bgrad_ring_kernel(BgradP p) {
   const uint32_t ulane = (uint32_t)((prow * p.ldu[e] + (((lane & 7) ^ prow ^ (4 * wpar)) * 8)) * 2);
   const char* ubase = reinterpret_cast<const char*>(p.U[e] + (long)(8 * wpar) * p.ldu[e]);
   const bool full = tok0 + B2_TOK <= p.M;                     // uniform
-  // (the blocks walk the column chunks in rotated orders: see lora_project_ring_kernel -- in lockstep every request in flight would
-  // address the same 128 bytes of a row, which a power-of-two row stride puts onto a few memory channels)
-  const int rot = (int)(((blockIdx.x + 3u * blockIdx.y) * 5u) % (unsigned)nch);
-  auto chunk_of = [&](int cs) { return cs + rot < nch ? cs + rot : cs + rot - nch; };
+  // (every block walks the column chunks in the same order: a token's tb must not depend on where its row sits in the batch -- the
+  // backward keeps the per-sample invariance the data-parallel equivalence tests rest on; rotated orders measured no gain here)
   auto issue = [&](int s) {
-    const int cs = s / B2_NT, t = s - cs * B2_NT;
-    const int c = chunk_of(cs);
+    const int c = s / B2_NT, t = s - c * B2_NT;
     char* st = smem + (s & (B2_NST - 1)) * B2_STAGE;
     if (full) {
 #pragma unroll
@@ -1173,7 +1170,7 @@ __global__ __launch_bounds__(256) void lora_bgrad_ring_kernel(BgradP p) {
         for (int i = 0; i < 4; ++i) db = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tT[t][k + i], f[i], db, 0, 0, 0);     // D[j = 4g+e][w = l15]
       }
     }
-    *reinterpret_cast<float4*>(slab + (long)(64 * chunk_of(c) + 16 * wave + l15) * 16 + 4 * g) = make_float4(db[0], db[1], db[2], db[3]);
+    *reinterpret_cast<float4*>(slab + (long)(64 * c + 16 * wave + l15) * 16 + 4 * g) = make_float4(db[0], db[1], db[2], db[3]);
   }
   // tb: lane holds rows j = 4 g .. + 3 of token l15
 #pragma unroll
