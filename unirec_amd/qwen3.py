@@ -383,25 +383,33 @@ class Qwen3LoRAModel(nn.Module):
     def prefetch_lora_bits(self, M, device, row0=0):
         """Generate the NEXT forward's LoRA dropout bit planes (all layers, all adapter groups) on a side stream.  The planes
         are pure functions of (seed, step, layer, group) -- nothing on the main stream feeds them -- so the caller starts
-        this before the item Q-Former's forward, whose small launches leave most of the chip idle, and the 8 ms of mask
-        arithmetic per step disappear under it.  The planes are allocated on the caller's stream (the caching allocator
-        keys blocks by stream) and written on the side stream after it has caught up with the caller's stream."""
+        this before the item Q-Former's forward, whose small launches leave most of the chip idle.  From the second step on the
+        planes are already there: the decoder's backward regenerates them for the following step the moment it has finished with
+        this step's (`_prefetch_next_step`), under the Q-Former's backward.  The planes are allocated on the caller's stream (the
+        caching allocator keys blocks by stream) and written on the side stream after it has caught up with the caller's stream."""
         p = self._drop_p()
-        self._bits_pre = None
         if p <= 0.0 or self.config.lora_r != 16 or not torch.is_grad_enabled():
+            self._bits_pre = None
             return
+        pre = self._bits_pre
+        if pre is not None and pre["step"] == self._lora_step and pre["M"] == M and pre["row0"] == int(row0) and pre["p"] == p:
+            return                                 # made under the previous step's backward
+        self._bits_pre = None
         main = torch.cuda.current_stream(device)
         if self._bits_stream is None:
             self._bits_stream = torch.cuda.Stream(device=device)
-        side, step = self._bits_stream, self._lora_step
         planes = {(i, g): torch.empty((nad, M, hip.lora_bits_ld(W)), dtype=torch.uint8, device=device)
                   for i in range(self.config.num_hidden_layers) for g, (W, nad) in enumerate(self._bits_groups())}
         # token-packed copies for the backward's token reductions (hip.lora_reduce's ring kernel), made on the side stream as well
         packed = {}
-        if M % 128 == 0:
+        if M % 128 == 0 and os.environ.get("UNIREC_BITS_T", "1") != "0":      # (lab switch: 0 = no token-packed copies, the register-staged reduction)
             packed = {(i, g): torch.empty((nad, M // 32, hip.lora_bits_t_ld(W)), dtype=torch.int32, device=device)
                       for i in range(self.config.num_hidden_layers) for g, (W, nad) in enumerate(self._bits_groups()) if W % 64 == 0}
-        side.wait_stream(main)
+        self._bits_stream.wait_stream(main)
+        self._generate_bits(planes, packed, self._lora_step, M, device, int(row0), p)
+
+    def _generate_bits(self, planes, packed, step, M, device, row0, p):
+        side = self._bits_stream
         with torch.cuda.stream(side):
             # one event per layer: the forward of layer i waits for ITS planes only, so the generator keeps running under the first
             # layers of the decoder when the Q-Former's forward is shorter than it; the token-packed copies (backward only) come last
@@ -413,7 +421,15 @@ class Qwen3LoRAModel(nn.Module):
             for (i, g), bt in packed.items():
                 hip.lora_bits_transpose(planes[(i, g)], self._bits_groups()[g][0], out=bt)
             ev_t = side.record_event()
-        self._bits_pre = {"step": step, "M": M, "planes": planes, "packed": packed, "events": events, "event_t": ev_t, "row0": int(row0)}
+        self._bits_pre = {"step": step, "M": M, "planes": planes, "packed": packed, "events": events, "event_t": ev_t, "row0": int(row0), "p": p}
+
+    def _prefetch_next_step(self, cur, device):
+        """Called by the decoder's backward when it has consumed this step's planes: the next step's are written into the SAME buffers
+        on the side stream (which first waits for the main stream to get here), under the Q-Former's backward and the optimizer."""
+        if os.environ.get("UNIREC_BITS_NEXT", "1") == "0" or not self.training:
+            return
+        self._bits_stream.wait_stream(torch.cuda.current_stream(device))
+        self._generate_bits(cur["planes"], cur["packed"], self._lora_step, cur["M"], device, cur["row0"], cur["p"])
 
     def _lora_bcomb(self, pack, device):
         """Second-K-range operands of the merged projection launches: y[q|k|v] = h W^T + [t_q|t_k|t_v] Bc^T with
@@ -515,6 +531,7 @@ class Qwen3LoRAModel(nn.Module):
         if pre is not None and pdrop > 0.0 and pre["step"] == step and pre["M"] == M and pre["row0"] == row0 and pack is not None:
             saved["bits_t"] = pre.get("packed", {})                      # (layer, group) -> token-packed copy for the backward
             saved["bits_t_event"] = pre["event_t"]
+            saved["bits_pre"] = pre                                      # (its buffers take the next step's planes after the backward)
             pre_events = pre["events"]                                   # planes prefetched on the side stream, one event per layer
             pre = pre["planes"]
         else:
@@ -679,7 +696,7 @@ class Qwen3LoRAModel(nn.Module):
             tb = hip.lora_bgrad(dy, t, [lt[b] for b in bnames], cols, gB, alpha=sc)     # dB and tb, dy read once
             gA = pack.fusedg(a_names) if len(a_names) > 1 else pack.g32(a_names[0])
             bits_t = packed_bits.get(group) if bits is not None else None
-            if bits is not None and bits_t is None and M % 128 == 0 and xin.shape[1] % 64 == 0:
+            if bits is not None and bits_t is None and M % 128 == 0 and xin.shape[1] % 64 == 0 and os.environ.get("UNIREC_BITS_T", "1") != "0":
                 bits_t = hip.lora_bits_transpose(bits, xin.shape[1])          # (no prefetch this step: made here)
             hip.lora_reduce(xin, tb, gA, nad=len(a_names), alpha=1.0 / (1.0 - pdrop), bits=bits, bits_t=bits_t)
             return tb
@@ -784,6 +801,8 @@ class Qwen3LoRAModel(nn.Module):
                 self.grad_ready_hook(i)
         if pack is not None:
             pack.publish_grads(touched)
+        if saved.get("bits_pre") is not None and self._bits_pre is None:
+            self._prefetch_next_step(saved.pop("bits_pre"), dev)
         if T > 0:
             return hip.inject_bwd(dx.view(B, S, D), saved["ids"], saved["first"], T)
         return None
