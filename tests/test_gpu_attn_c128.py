@@ -107,3 +107,25 @@ def test_bitwise_reproducible():
     b, _ = hip.attn_fwd(q, k, v, causal=True)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("S,B,mask", [(2048, 2, "none"), (1024, 4, "left"), (512, 8, "none")])
+def test_persistent_dkv_walk_equals_one_workgroup_per_key_block(S, B, mask, monkeypatch):
+    """The dK/dV kernel's persistent walk (8 x U workgroups, the key block rotating with the step) computes every (batch, kv head,
+    key block) exactly as the one-workgroup-per-block launch does: dk, dv bit for bit (UR_ATTN_DKV_PERSIST=0 switches it off).  Shapes
+    whose sweep divides evenly over 256 CUs: 16 (batch, kv head) groups x 16 / 8 / 4 key blocks."""
+    nq, nkv = 16, 8 if S != 512 else 8
+    q, k, v = _inputs(B, S, nq, nkv, 50 + S)
+    km = None
+    if mask == "left":
+        km = torch.ones((B, S), dtype=torch.uint8)
+        km[1, :200] = 0
+        km = km.to(DEV)
+    o, ctx = hip.attn_fwd(q, k, v, causal=True, key_mask=km)
+    dout = torch.randn(B, S, nq, 128, generator=torch.Generator().manual_seed(3)).to(DEV).to(torch.bfloat16)
+    dq1, dk1, dv1 = hip.attn_bwd(ctx, dout)
+    monkeypatch.setenv("UR_ATTN_DKV_PERSIST", "0")
+    dq0, dk0, dv0 = hip.attn_bwd(ctx, dout)
+    torch.cuda.synchronize()
+    assert torch.equal(dk1, dk0) and torch.equal(dv1, dv0) and torch.equal(dq1, dq0)
+    assert dk1.float().abs().max() > 0

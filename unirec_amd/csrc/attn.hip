@@ -2607,13 +2607,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // LDS: 4 ring slots x (1 KiB row constants | Q tile 16 KiB | dO tile 16 KiB).
 namespace c128 { constexpr int DKV_SLOT = 33792, DKV_LDS_BYTES = 4 * DKV_SLOT, DKV_HIGH = 2 * DKV_SLOT; }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv_c128_kernel(AttnP p) {
+// persist = 0: one workgroup per (batch, kv head, 128-key block), dealt by block_map.  persist = 1 (launch_dkv: 8 x U workgroups, the
+// key blocks per group nx a power of two dividing U, the groups a multiple of 8 U / nx): workgroup (lane = id & 7, u = id >> 3) walks
+// steps k = 0, 1, ...: at step k the U workgroups of an XCD lane work on U / nx consecutive (batch, kv head) groups (their Q / dO rows
+// shared in that XCD's L2), one key block each, and the key block ROTATES with the step (x = (u + k) mod nx), so every workgroup
+// sees every block size equally often: the sweep is balanced without a dynamic queue, and no workgroup launch (LDS allocation,
+// kernel-argument loads, wave start) sits between two key blocks -- measured as the larger part of the per-block fixed cost.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv_c128_kernel(AttnP p, int persist) {
   using namespace c128;
   using C = Cfg<128>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
-  const BlockMap bm = block_map<false>(p.Sk / 128, 1, p.nkv, p.B);
-  const int kvh = bm.head, b = bm.b, xk = bm.x;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nx = p.Sk / 128;
+  const int U = (int)gridDim.x >> 3, gps = persist ? U / nx : 1;                 // groups per step and XCD lane
+  const int nsteps = persist ? (p.nkv * p.B) / (8 * gps) : 1;
+  for (int step = 0; step < nsteps; ++step) {
+  int lane_i = tid & 63;
+  asm volatile("" : "+v"(lane_i));                  // (nothing lane-derived is carried from one key block to the next across the generated statement)
+  const int lane = lane_i, h = lane >> 5, l31 = lane & 31;
+  int kvh, b, xk;
+  if (persist) {
+    const int xl = (int)blockIdx.x & 7, u = (int)blockIdx.x >> 3;
+    const int grp = (step * gps + u / nx) * 8 + xl;
+    xk = (u + step) & (nx - 1);
+    kvh = grp % p.nkv; b = grp / p.nkv;
+    if (step > 0) __syncthreads();                  // every wave has left the previous key block's loop: the rings are free
+  } else {
+    const BlockMap bm = block_map<false>(nx, 1, p.nkv, p.B);
+    kvh = bm.head; b = bm.b; xk = bm.x;
+  }
   const int kb = 128 * xk + 32 * wave;
   const int key = kb + l31;
   const long ktok = (long)b * p.Sk + key;
@@ -2627,7 +2649,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (p.rk_src != nullptr) store_T<128>(p.rk_dst + ktok * p.rk_lddst + (long)kvh * 128, dk, 0.f, lane, true);
     else store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 0.f, lane, true);
     store_T<128>(p.dv + ktok * p.lddv + (long)kvh * 128, dv, 0.f, lane, true);
-    return;
+    continue;
   }
   // K~ = k * scale * log2(e) (rounded to bf16 once more) and V fragments of this lane's key
   const float c = p.scale * LOG2E;
@@ -2715,6 +2737,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 1.0f, lane, true);
   }
   store_T<128>(p.dv + ktok * p.lddv + (long)kvh * 128, dv, 1.0f, lane, true);
+  }
 }
 
 // ================================================================================================
@@ -2757,6 +2780,8 @@ inline bool c128_bwd_ok(const AttnP& p);
 inline int device_cu_count() { return ur_device_cu_count(); }
 // test / lab switch, read on every call: UR_ATTN_C128=0 sends the causal head_dim-128 forward back to attn_fwd_kernel
 inline bool fwd_c128_enabled() { const char* e = getenv("UR_ATTN_C128"); return !(e && e[0] == '0'); }
+// test / lab switch, read on every call: UR_ATTN_DKV_PERSIST=0 launches one workgroup per key block
+inline bool dkv_persist_enabled() { const char* e = getenv("UR_ATTN_DKV_PERSIST"); return !(e && e[0] == '0'); }
 inline bool fwd_gq2_enabled() { static const bool on = ur_lab_int("UR_FWD_GQ2", 0) == 1; return on; }
 template <int HD, bool CAUSAL, int NW>
 int launch_fwd(const AttnP& p, hipStream_t st) {
@@ -2834,7 +2859,11 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
     if (c128_bwd_ok(p)) {
       static std::atomic<uint64_t> once_c{0};   // per device
       if (ur_first_on_device(once_c)) { int rc = set_smem(&attn_bwd_dkv_c128_kernel, c128::DKV_LDS_BYTES, "ur_attn_bwd(dkv c128)"); if (rc) return rc; }
-      hipLaunchKernelGGL(attn_bwd_dkv_c128_kernel, grid, dim3(256), c128::DKV_LDS_BYTES, st, p);
+      // persistent walk where the sweep divides evenly (see the kernel): one workgroup per CU for the whole launch
+      const int ncu = device_cu_count(), nxk = p.Sk / 128, U = ncu / 8, ngroups = p.nkv * p.B;
+      const bool pers = dkv_persist_enabled() && (ncu % 8) == 0 && nxk <= U && (nxk & (nxk - 1)) == 0 && (U % nxk) == 0 && (ngroups % (8 * (U / nxk))) == 0;
+      if (pers) hipLaunchKernelGGL(attn_bwd_dkv_c128_kernel, dim3(ncu), dim3(256), c128::DKV_LDS_BYTES, st, p, 1);
+      else hipLaunchKernelGGL(attn_bwd_dkv_c128_kernel, grid, dim3(256), c128::DKV_LDS_BYTES, st, p, 0);
       UR_CHECK_LAUNCH("ur_attn_bwd(dkv c128)");
       return 0;
     }
