@@ -87,6 +87,7 @@ struct AttnP {
   const float* rp_rstd; long rp_rstd_ld; int rp_rstd_h0;      // non-null: rp_raw is the ROPED, normed q and 1 / rms comes from the forward (ur_attn_bwd_args.rope_rstd)
   // the k heads' q/k-norm + RoPE backward in the dK/dV kernel's store (with rp_rstd): roped k, its norm weight, first k column of rstd, raw-gradient output
   const bf16_t* rk_src; long rk_ld; const float* rk_w; int rk_rstd_h0; bf16_t* rk_dst; long rk_lddst;
+  int qslot;            // work-queue slot of the persistent dK/dV kernel (g_dkv_queue), zeroed by the dQ kernel of the same call
   // hand-scheduled causal head_dim-128 backward (both kernels or neither): plane 1 of `delta` holds -LSE * log2(e) instead of -LSE / scale
   int lse_log2;
 };
@@ -329,8 +330,7 @@ __device__ __forceinline__ int first_valid_tile(const unsigned long long* kw, in
 // blocks on ONE XCD, adjacent in time, and under the causal mask the heaviest block of the group first.
 struct BlockMap { int x, head, b; };
 template <bool HEAVY_LAST>     // HEAVY_LAST: work grows with x (forward, dQ); else it shrinks (dK/dV)
-__device__ __forceinline__ BlockMap block_map(int nx, int heads_per_group, int ngroups_per_batch, int B) {
-  const int id = blockIdx.x;
+__device__ __forceinline__ BlockMap block_map_id(int id, int nx, int heads_per_group, int ngroups_per_batch, int B) {
   const int gsz = nx * heads_per_group, ngroups = ngroups_per_batch * B;
   int grp, j;
   if ((ngroups & 7) == 0) { const int slot = id >> 3; grp = (slot / gsz) * 8 + (id & 7); j = slot % gsz; }
@@ -341,6 +341,11 @@ __device__ __forceinline__ BlockMap block_map(int nx, int heads_per_group, int n
   m.head = (grp % ngroups_per_batch) * heads_per_group + j % heads_per_group;
   m.b = grp / ngroups_per_batch;
   return m;
+}
+
+template <bool HEAVY_LAST>
+__device__ __forceinline__ BlockMap block_map(int nx, int heads_per_group, int ngroups_per_batch, int B) {
+  return block_map_id<HEAVY_LAST>((int)blockIdx.x, nx, heads_per_group, ngroups_per_batch, B);
 }
 
 // masked, scaled score (natural-log domain).  CAUSAL: SDPA semantics (-inf); else the Q-Former's
@@ -2292,6 +2297,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // the wave's 64 rows, forms the row constants delta = sum_d dO O and LSE2 = (m + ln l) log2e from the forward's statistics, and
 // publishes -delta and -LSE/scale for the dK/dV kernel exactly as attn_bwd_dq_kernel does.
 // LDS: K ring 4 x 16 KiB | V ring 4 x 16 KiB | key-state words.
+// Work queues of the persistent dK/dV kernel: [slot][XCD lane] = next key-block item of that lane.  A call takes the next slot of the
+// ring (host side, ur_attn_bwd); its dQ kernel zeroes the slot, its dK/dV kernel -- stream-ordered behind it -- draws from it.
+__device__ unsigned int g_dkv_queue[64][8];
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
@@ -2304,6 +2312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
   const int nx = (p.Sq + 255) / 256, ntiles = p.Sk / KT;
+  if (blockIdx.x == 0 && tid < 8) g_dkv_queue[p.qslot][tid] = 0u;      // (the dK/dV kernel of this call starts after this kernel has finished)
   const uint32_t lds0 = lds_off(smem);
   unsigned long long* words = reinterpret_cast<unsigned long long*>(smem + DQ_WORDS_LDS);
   i32x2 kava, dw, voff;
@@ -2605,37 +2614,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // tiles and the row constants (-delta, -LSE2 from attn_bwd_dq_c128_kernel) arrive by LDS-DMA three tiles ahead.  k is pre-scaled by
 // scale*log2e here, so P = exp2(S') is one instruction per score.  Padded keys are zeroed at the store (their lanes never mix).
 // LDS: 4 ring slots x (1 KiB row constants | Q tile 16 KiB | dO tile 16 KiB).
-namespace c128 { constexpr int DKV_SLOT = 33792, DKV_LDS_BYTES = 4 * DKV_SLOT, DKV_HIGH = 2 * DKV_SLOT; }
+namespace c128 { constexpr int DKV_SLOT = 33792, DKV_RING_BYTES = 4 * DKV_SLOT, DKV_LDS_BYTES = DKV_RING_BYTES + 16, DKV_HIGH = 2 * DKV_SLOT; }      // + the drawn queue item
 
-// persist = 0: one workgroup per (batch, kv head, 128-key block), dealt by block_map.  persist = 1 (launch_dkv: 8 x U workgroups, the
-// key blocks per group nx a power of two dividing U, the groups a multiple of 8 U / nx): workgroup (lane = id & 7, u = id >> 3) walks
-// steps k = 0, 1, ...: at step k the U workgroups of an XCD lane work on U / nx consecutive (batch, kv head) groups (their Q / dO rows
-// shared in that XCD's L2), one key block each, and the key block ROTATES with the step (x = (u + k) mod nx), so every workgroup
-// sees every block size equally often: the sweep is balanced without a dynamic queue, and no workgroup launch (LDS allocation,
-// kernel-argument loads, wave start) sits between two key blocks -- measured as the larger part of the per-block fixed cost.
+// persist = 0: one workgroup per (batch, kv head, 128-key block), dealt by block_map.  persist = 1 (launch_dkv: one workgroup per CU,
+// the groups a multiple of 8): the workgroup DRAWS its key blocks from the queue of its XCD lane (g_dkv_queue[slot][id & 7], zeroed
+// by the call's dQ kernel) in block_map's order -- heaviest blocks first, the blocks of a (batch, kv head) group on one XCD at about
+// the same time -- so the sweep balances under any padding like the hardware dispatcher's, but no workgroup launch (LDS allocation,
+// kernel-argument loads, wave start) sits between two key blocks: 5 % of the kernel on dense inputs.  (A static rotation of the
+// block sizes over the workgroups was as fast on dense inputs and 1.5 ms per step slower on the padded batch.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv_c128_kernel(AttnP p, int persist) {
   using namespace c128;
   using C = Cfg<128>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nx = p.Sk / 128;
-  const int U = (int)gridDim.x >> 3, gps = persist ? U / nx : 1;                 // groups per step and XCD lane
-  const int nsteps = persist ? (p.nkv * p.B) / (8 * gps) : 1;
-  for (int step = 0; step < nsteps; ++step) {
+  const int per_lane = persist ? (p.nkv * p.B / 8) * nx : 1;
+  unsigned int* qitem = reinterpret_cast<unsigned int*>(smem + DKV_RING_BYTES);
+  for (;;) {
   int lane_i = tid & 63;
   asm volatile("" : "+v"(lane_i));                  // (nothing lane-derived is carried from one key block to the next across the generated statement)
   const int lane = lane_i, h = lane >> 5, l31 = lane & 31;
-  int kvh, b, xk;
+  int id = (int)blockIdx.x;
   if (persist) {
-    const int xl = (int)blockIdx.x & 7, u = (int)blockIdx.x >> 3;
-    const int grp = (step * gps + u / nx) * 8 + xl;
-    xk = (u + step) & (nx - 1);
-    kvh = grp % p.nkv; b = grp / p.nkv;
-    if (step > 0) __syncthreads();                  // every wave has left the previous key block's loop: the rings are free
-  } else {
-    const BlockMap bm = block_map<false>(nx, 1, p.nkv, p.B);
-    kvh = bm.head; b = bm.b; xk = bm.x;
+    __syncthreads();                                // every wave has left the previous key block's loop (rings free) and read the previous item
+    if (tid == 0) *qitem = atomicAdd(&g_dkv_queue[p.qslot][blockIdx.x & 7], 1u);
+    __syncthreads();
+    const unsigned int t = *qitem;
+    if (t >= (unsigned int)per_lane) break;
+    id = (int)(t * 8u + (blockIdx.x & 7u));
   }
+  const BlockMap bm = block_map_id<false>(id, nx, 1, p.nkv, p.B);
+  const int kvh = bm.head, b = bm.b, xk = bm.x;
   const int kb = 128 * xk + 32 * wave;
   const int key = kb + l31;
   const long ktok = (long)b * p.Sk + key;
@@ -2649,7 +2658,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     if (p.rk_src != nullptr) store_T<128>(p.rk_dst + ktok * p.rk_lddst + (long)kvh * 128, dk, 0.f, lane, true);
     else store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 0.f, lane, true);
     store_T<128>(p.dv + ktok * p.lddv + (long)kvh * 128, dv, 0.f, lane, true);
-    continue;
+    if (persist) continue;
+    break;
   }
   // K~ = k * scale * log2(e) (rounded to bf16 once more) and V fragments of this lane's key
   const float c = p.scale * LOG2E;
@@ -2737,6 +2747,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 1.0f, lane, true);
   }
   store_T<128>(p.dv + ktok * p.lddv + (long)kvh * 128, dv, 1.0f, lane, true);
+  if (!persist) break;
   }
 }
 
@@ -2860,8 +2871,8 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
       static std::atomic<uint64_t> once_c{0};   // per device
       if (ur_first_on_device(once_c)) { int rc = set_smem(&attn_bwd_dkv_c128_kernel, c128::DKV_LDS_BYTES, "ur_attn_bwd(dkv c128)"); if (rc) return rc; }
       // persistent walk where the sweep divides evenly (see the kernel): one workgroup per CU for the whole launch
-      const int ncu = device_cu_count(), nxk = p.Sk / 128, U = ncu / 8, ngroups = p.nkv * p.B;
-      const bool pers = dkv_persist_enabled() && (ncu % 8) == 0 && nxk <= U && (nxk & (nxk - 1)) == 0 && (U % nxk) == 0 && (ngroups % (8 * (U / nxk))) == 0;
+      const int ncu = device_cu_count(), ngroups = p.nkv * p.B;
+      const bool pers = dkv_persist_enabled() && (ncu % 8) == 0 && (ngroups % 8) == 0 && (long)grid.x > ncu;
       if (pers) hipLaunchKernelGGL(attn_bwd_dkv_c128_kernel, dim3(ncu), dim3(256), c128::DKV_LDS_BYTES, st, p, 1);
       else hipLaunchKernelGGL(attn_bwd_dkv_c128_kernel, grid, dim3(256), c128::DKV_LDS_BYTES, st, p, 0);
       UR_CHECK_LAUNCH("ur_attn_bwd(dkv c128)");
@@ -2962,6 +2973,8 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
     p.rk_dst = (bf16_t*)g->rope_dk_raw; p.rk_lddst = g->rope_lddkraw;
   }
   hipStream_t st = (hipStream_t)stream;
+  static std::atomic<unsigned int> qring{0};
+  p.qslot = (int)(qring.fetch_add(1u, std::memory_order_relaxed) & 63u);
   p.lse_log2 = (a->head_dim == 128 && a->causal != 0 && c128_bwd_ok(p)) ? 1 : 0;
   if (tiny_shape(p, a->head_dim, a->causal != 0, true)) return launch_tiny(p, true, st);      // dQ, dK, dV in one kernel
   // the dQ kernel also computes the row constants (delta, -LSE/scale) and leaves them in `delta` for dK/dV
