@@ -339,22 +339,37 @@ def common_scalars():
     return out
 
 
-def prologue_code():
-    """state + the first three tiles' LDS-DMA + the first tile's row constants and fragments"""
+def dma_prologue_code():
+    """a statement of its own in the kernel (UR_ATTN_DKV_C128_DMA_ASM), issued as soon as the previous key block's loop has been left
+    by every wave -- before the C++ part stores that block's results and loads this block's K / V rows: the first tile's LDS-DMA
+    (Q, dO, row constants: 9 pieces)"""
+    out = [comment("---- prologue LDS-DMA (tile 0)")] + common_scalars()
+    out += [s_mov_b32(LT, Lit(0)), s_mov_b32(LHR, Lit(0)), s_mov_b32(LQ0, QSTART), s_nop(3)]
+    out += tile_ptrs()
+    for j in range(9):
+        out += dma_piece(j, 0)
+    return out
+
+
+def prologue_code(with_dma_prologue=True):
+    """state + the first three tiles' LDS-DMA + the first tile's row constants and fragments.  with_dma_prologue = False: tile 0 has
+    been requested by the statement above; this one re-derives the sweep state and requests tiles 1 and 2."""
     out = [comment("---- entry")]
     if STAMPS:
         out += [s_mov_b32(ACC(i), Lit(0)) for i in range(NACC)]
     out += common_scalars()
     out += [s_mov_b32(LT, Lit(0)), s_mov_b32(LHR, Lit(0)), s_mov_b32(LQ0, QSTART), s_nop(3)]
     for t in range(3):
-        out += tile_ptrs()
-        for j in range(9):
-            out += dma_piece(j, t)
+        if t > 0 or with_dma_prologue:
+            out += tile_ptrs()
+            for j in range(9):
+                out += dma_piece(j, t)
         out += _relabel(advance_load_tile(), "P%d" % t)
     for i in range(128):
         out.append(v_accvgpr_write(a(i), Lit(0)))
     out += [v_mov_b32(NEGINF, Lit(0xFF800000)), s_mov_b32(IT, Lit(0)), s_mov_b32(Q0S, QSTART), s_mov_b32(HRS, Lit(0))]
-    # tile 0 is needed before the first barrier of the loop guarantees it: wait for it here (its 9 pieces are the oldest)
+    # tile 0 is needed before the first barrier of the loop guarantees it: wait for it here (its 9 pieces are older than the 18 of
+    # tiles 1, 2 -- and so is whatever the C++ part loaded or stored between the two statements)
     out += [s_waitcnt(vmcnt=18), s_barrier()]
     out += const_reads(0, 0)
     for ks in range(3):
@@ -376,10 +391,19 @@ def _relabel(items, suffix):
     return out
 
 
-def build_program():
+def build_dma_program():
+    P = Program()
+    P.add(fix_hazards(dma_prologue_code())[0])
+    P.finalize()
+    return P
+
+
+def build_program(with_dma_prologue=True):
+    """with_dma_prologue = False: the kernel's main statement (tile 0 comes from build_dma_program's statement); the emulator runs the
+    single-statement form"""
     cnt = Counter()
     P = Program()
-    P.add(fix_hazards(prologue_code())[0])
+    P.add(fix_hazards(prologue_code(with_dma_prologue))[0])
     P.add(s_cmp("ge", IT, NTOT), s_cbranch_scc(1, "EXIT"))
     bodies = {}
     for p in range(4):

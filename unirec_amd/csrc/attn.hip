@@ -2630,125 +2630,178 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int nx = p.Sk / 128;
   const int per_lane = persist ? (p.nkv * p.B / 8) * nx : 1;
   unsigned int* qitem = reinterpret_cast<unsigned int*>(smem + DKV_RING_BYTES);
-  for (;;) {
-  int lane_i = tid & 63;
-  asm volatile("" : "+v"(lane_i));                  // (nothing lane-derived is carried from one key block to the next across the generated statement)
-  const int lane = lane_i, h = lane >> 5, l31 = lane & 31;
-  int id = (int)blockIdx.x;
-  if (persist) {
-    __syncthreads();                                // every wave has left the previous key block's loop (rings free) and read the previous item
-    if (tid == 0) *qitem = atomicAdd(&g_dkv_queue[p.qslot][blockIdx.x & 7], 1u);
-    __syncthreads();
-    const unsigned int t = *qitem;
-    if (t >= (unsigned int)per_lane) break;
-    id = (int)(t * 8u + (blockIdx.x & 7u));
-  }
-  const BlockMap bm = block_map_id<false>(id, nx, 1, p.nkv, p.B);
-  const int kvh = bm.head, b = bm.b, xk = bm.x;
-  const int kb = 128 * xk + 32 * wave;
-  const int key = kb + l31;
-  const long ktok = (long)b * p.Sk + key;
   const uint32_t lds0 = lds_off(smem);
-  const bool kvalid = p.kmask == nullptr || p.kmask[(long)b * p.Sk + key] != 0;
-  f32x16 dk[4], dv[4];
-  // causal (SDPA) semantics: a key block without a single valid key (left padding) has P = 0 everywhere: dK = dV = 0
-  if (p.kmask != nullptr && !__syncthreads_or(kvalid ? 1 : 0)) {
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dk[dt] = zero16(); dv[dt] = zero16(); }
-    if (p.rk_src != nullptr) store_T<128>(p.rk_dst + ktok * p.rk_lddst + (long)kvh * 128, dk, 0.f, lane, true);
-    else store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 0.f, lane, true);
-    store_T<128>(p.dv + ktok * p.lddv + (long)kvh * 128, dv, 0.f, lane, true);
-    if (persist) continue;
-    break;
-  }
-  // K~ = k * scale * log2(e) (rounded to bf16 once more) and V fragments of this lane's key
   const float c = p.scale * LOG2E;
-  i32x32 kv_, vv_;
-  {
-    const bf16_t* krow = p.k + ktok * p.ldk + (long)kvh * 128;
-    const bf16_t* vrow = p.v + ktok * p.ldv + (long)kvh * 128;
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const bf16x8 kf = g_frag(krow, ks, lane, true), vf = g_frag(vrow, ks, lane, true);
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        kv_[4 * ks + jj] = (int)pack_bf2(bf2f((bf16_t)kf[2 * jj]) * c, bf2f((bf16_t)kf[2 * jj + 1]) * c);
-        vv_[4 * ks + jj] = (int)((uint32_t)(uint16_t)vf[2 * jj] | ((uint32_t)(uint16_t)vf[2 * jj + 1] << 16));
-      }
-    }
-  }
-  i32x2 ra, ca, voff;
-  i32x8 ta, tb;
-  ra[0] = (int)(lds0 + C::off(l31, h)); ra[1] = ra[0] + DKV_HIGH;
-  ca[0] = (int)(lds0 + 16 * h); ca[1] = ca[0] + DKV_HIGH;
-  {
-    const int g16 = (lane >> 4) & 1, i = lane & 15;
-    const int row = 4 * h + (i >> 2), sub8 = 8 * (i & 1);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const int ch = 4 * dt + 2 * g16 + ((i & 3) >> 1);
-      ta[dt] = (int)(lds0 + C::off(row, ch) + sub8); ta[4 + dt] = ta[dt] + DKV_HIGH;
-      tb[dt] = (int)(lds0 + C::off(row + 8, ch) + sub8); tb[4 + dt] = tb[dt] + DKV_HIGH;
-    }
-  }
-  {
-    const int row = 4 * wave + (lane >> 4), pos = lane & 15;
-    const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
-    voff[0] = (int)((uint32_t)(row * p.ldq + (pos ^ sw) * 8) * 2u);
-    voff[1] = (int)((uint32_t)(row * p.lddo + (pos ^ sw) * 8) * 2u);
-  }
-  const int voffc = 4 * lane, xdiag = l31 - 4 * h;
-  const int hq0 = kvh * p.rep;
-  const bf16_t* qb = p.q + (long)b * p.Sq * p.ldq + (long)hq0 * 128;
-  const bf16_t* dob = p.dout + (long)b * p.Sq * p.lddo + (long)hq0 * 128;
-  const float* wsb = p.delta + ((long)b * p.nq + hq0) * p.Sq;
   const long nrows = (long)p.B * p.nq * p.Sq;
-  auto sgpr64 = [](const void* ptr) { return (unsigned long long)(uintptr_t)ptr; };
-  const unsigned long long qb_s = sgpr64(qb), dob_s = sgpr64(dob), wsb_s = sgpr64(wsb);
-  const uint32_t qb_lo = __builtin_amdgcn_readfirstlane((uint32_t)qb_s), qb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(qb_s >> 32));
-  const uint32_t do_lo = __builtin_amdgcn_readfirstlane((uint32_t)dob_s), do_hi = __builtin_amdgcn_readfirstlane((uint32_t)(dob_s >> 32));
-  const uint32_t ws_lo = __builtin_amdgcn_readfirstlane((uint32_t)wsb_s), ws_hi = __builtin_amdgcn_readfirstlane((uint32_t)(wsb_s >> 32));
   const int q16b = __builtin_amdgcn_readfirstlane((int)(p.ldq * 32)), d16b = __builtin_amdgcn_readfirstlane((int)(p.lddo * 32));
-  const int qstart = 128 * xk, ntot = __builtin_amdgcn_readfirstlane(((p.Sq - qstart) / KT) * p.rep);
-  const int kb_s = __builtin_amdgcn_readfirstlane(kb), sq = __builtin_amdgcn_readfirstlane(p.Sq);
+  const int sq = __builtin_amdgcn_readfirstlane(p.Sq);
   const uint32_t wsel = __builtin_amdgcn_readfirstlane((wave & 1) ? 0u : (uint32_t)(nrows * 4));
   const uint32_t cwave = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(wave & 1) * 256u), waveb = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)wave * 1024u);
-  c128::f32x32 k0, k1, v0, v1;
-  asm volatile(
-      "s_mov_b32 s36, %[qbl]\n\ts_mov_b32 s37, %[qbh]\n\ts_mov_b32 s38, %[dol]\n\ts_mov_b32 s39, %[doh]\n\ts_mov_b32 s40, %[wsl]\n\ts_mov_b32 s41, %[wsh]\n\t"
-      "s_mov_b32 s42, %[q16]\n\ts_mov_b32 s43, %[d16]\n\ts_mov_b32 s45, %[ntot]\n\ts_mov_b32 s47, %[kb]\n\ts_mov_b32 s58, %[qstart]\n\t"
-      "s_mov_b32 s35, %[sq]\n\ts_lshl_b32 s60, %[sq], 2\n\ts_mov_b32 s34, %[wsel]\n\ts_mov_b32 s56, %[cwave]\n\ts_mov_b32 s57, %[waveb]\n\t"
-      UR_ATTN_DKV_C128_ASM
-      : "=&{a[0:31]}"(k0), "=&{a[32:63]}"(k1), "=&{a[64:95]}"(v0), "=&{a[96:127]}"(v1)
-      : "{a[128:159]}"(kv_), "{a[160:191]}"(vv_), "{v[8:9]}"(voff), "{v10}"(voffc), "{v[144:145]}"(ra), "{v[146:153]}"(ta), "{v[154:161]}"(tb),
-        "{v[162:163]}"(ca), "{v164}"(xdiag),
-        [qbl] "s"(qb_lo), [qbh] "s"(qb_hi), [dol] "s"(do_lo), [doh] "s"(do_hi), [wsl] "s"(ws_lo), [wsh] "s"(ws_hi), [q16] "s"(q16b), [d16] "s"(d16b),
-        [ntot] "s"(ntot), [kb] "s"(kb_s), [qstart] "s"(qstart), [sq] "s"(sq), [wsel] "s"(wsel), [cwave] "s"(cwave), [waveb] "s"(waveb)
-      : UR_ATTN_DKV_C128_CLOBBERS);
+
+  // The key blocks of this workgroup are software-pipelined: as soon as every wave has left the loop of block n, block n + 1 is drawn,
+  // its first tile's LDS-DMA is requested, and block n's results are stored (with the k-norm + RoPE backward) under that latency; block
+  // n + 1's K / V rows are loaded and packed at the top of its own pass (requested before the stores they had to sit in registers
+  // across them: hipcc spilled each load the moment it was issued -- sixteen exposed round trips; packed but carried over the back
+  // edge they went through scratch as well).  Carried into the next pass: the scalars of block n + 1 only.
+  struct Blk { int kvh, b, kb, qstart, ntot; uint32_t qb_lo, qb_hi, do_lo, do_hi, ws_lo, ws_hi; bool more, run; };
+  i32x32 kv_, vv_;
+  // draw a key block, request its first tile and its K / V rows.  Caller: every wave has left the previous loop (persist: the barriers
+  // inside; the first draw: nothing has run yet).
+  // (macros, not lambdas: through a by-reference capture hipcc keeps kf / vf in scratch memory)
+#define UR_DKV_DRAW(d, first) do { \
+    int ln = tid & 63; \
+    asm volatile("" : "+v"(ln)); \
+    int id = (int)blockIdx.x; \
+    d.more = first; d.run = false; \
+    if (persist) { \
+      __syncthreads(); \
+      if (tid == 0) *qitem = atomicAdd(&g_dkv_queue[p.qslot][blockIdx.x & 7], 1u); \
+      __syncthreads(); \
+      const unsigned int t = *qitem; \
+      d.more = t < (unsigned int)per_lane; \
+      id = (int)(t * 8u + (blockIdx.x & 7u)); \
+    } \
+    if (!d.more) break; \
+    const BlockMap bm = block_map_id<false>(id, nx, 1, p.nkv, p.B); \
+    d.kvh = bm.head; d.b = bm.b; d.kb = 128 * bm.x + 32 * wave; \
+    const long ktok = (long)d.b * p.Sk + d.kb + (ln & 31); \
+    const bool kvalid = p.kmask == nullptr || p.kmask[ktok] != 0; \
+ \
+    d.run = p.kmask == nullptr || __syncthreads_or(kvalid ? 1 : 0) != 0; \
+    if (!d.run) break; \
+    i32x2 voff; \
+    { \
+      const int row = 4 * wave + (ln >> 4), pos = ln & 15; \
+      const int sw = ((row & 3) << 2) | ((row >> 2) & 3); \
+      voff[0] = (int)((uint32_t)(row * p.ldq + (pos ^ sw) * 8) * 2u); \
+      voff[1] = (int)((uint32_t)(row * p.lddo + (pos ^ sw) * 8) * 2u); \
+    } \
+    const int voffc = 4 * ln; \
+    const int hq0 = d.kvh * p.rep; \
+    auto sgpr64 = [](const void* ptr) { return (unsigned long long)(uintptr_t)ptr; }; \
+    const unsigned long long qb_s = sgpr64(p.q + (long)d.b * p.Sq * p.ldq + (long)hq0 * 128), dob_s = sgpr64(p.dout + (long)d.b * p.Sq * p.lddo + (long)hq0 * 128), \
+                             wsb_s = sgpr64(p.delta + ((long)d.b * p.nq + hq0) * p.Sq); \
+    d.qb_lo = __builtin_amdgcn_readfirstlane((uint32_t)qb_s); d.qb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(qb_s >> 32)); \
+    d.do_lo = __builtin_amdgcn_readfirstlane((uint32_t)dob_s); d.do_hi = __builtin_amdgcn_readfirstlane((uint32_t)(dob_s >> 32)); \
+    d.ws_lo = __builtin_amdgcn_readfirstlane((uint32_t)wsb_s); d.ws_hi = __builtin_amdgcn_readfirstlane((uint32_t)(wsb_s >> 32)); \
+    d.qstart = 128 * bm.x; \
+    d.ntot = __builtin_amdgcn_readfirstlane(((p.Sq - d.qstart) / KT) * p.rep); \
+    asm volatile( \
+        "s_mov_b32 s36, %[qbl]\n\ts_mov_b32 s37, %[qbh]\n\ts_mov_b32 s38, %[dol]\n\ts_mov_b32 s39, %[doh]\n\ts_mov_b32 s40, %[wsl]\n\ts_mov_b32 s41, %[wsh]\n\t" \
+        "s_mov_b32 s42, %[q16]\n\ts_mov_b32 s43, %[d16]\n\ts_mov_b32 s58, %[qstart]\n\t" \
+        "s_lshl_b32 s60, %[sq], 2\n\ts_mov_b32 s34, %[wsel]\n\ts_mov_b32 s56, %[cwave]\n\ts_mov_b32 s57, %[waveb]\n\t" \
+        UR_ATTN_DKV_C128_DMA_ASM \
+        : \
+        : "{v[8:9]}"(voff), "{v10}"(voffc), \
+          [qbl] "s"(__builtin_amdgcn_readfirstlane(d.qb_lo)), [qbh] "s"(__builtin_amdgcn_readfirstlane(d.qb_hi)), [dol] "s"(__builtin_amdgcn_readfirstlane(d.do_lo)), [doh] "s"(__builtin_amdgcn_readfirstlane(d.do_hi)), [wsl] "s"(__builtin_amdgcn_readfirstlane(d.ws_lo)), [wsh] "s"(__builtin_amdgcn_readfirstlane(d.ws_hi)), [q16] "s"(q16b), [d16] "s"(d16b), \
+          [qstart] "s"(__builtin_amdgcn_readfirstlane(d.qstart)), [sq] "s"(sq), [wsel] "s"(wsel), [cwave] "s"(cwave), [waveb] "s"(waveb) \
+        : UR_ATTN_DKV_C128_DMA_CLOBBERS); \
+  } while (0)
+  // K~ = k * scale * log2(e) (rounded to bf16 once more) and V fragments of this lane's key
+#define UR_DKV_PACK(d) do { \
+    int lp = tid & 63; \
+    asm volatile("" : "+v"(lp)); \
+    const long ktokp = (long)d.b * p.Sk + d.kb + (lp & 31); \
+    const bf16_t* krow = p.k + ktokp * p.ldk + (long)d.kvh * 128; \
+    const bf16_t* vrow = p.v + ktokp * p.ldv + (long)d.kvh * 128; \
+    bf16x8 kf[8], vf[8]; \
+_Pragma("unroll") \
+    for (int ks = 0; ks < 8; ++ks) { kf[ks] = g_frag(krow, ks, lp, true); vf[ks] = g_frag(vrow, ks, lp, true); } \
+_Pragma("unroll") \
+    for (int ks = 0; ks < 8; ++ks) \
+_Pragma("unroll") \
+      for (int jj = 0; jj < 4; ++jj) { \
+        kv_[4 * ks + jj] = (int)pack_bf2(bf2f((bf16_t)kf[ks][2 * jj]) * c, bf2f((bf16_t)kf[ks][2 * jj + 1]) * c); \
+        vv_[4 * ks + jj] = (int)((uint32_t)(uint16_t)vf[ks][2 * jj] | ((uint32_t)(uint16_t)vf[ks][2 * jj + 1] << 16)); \
+      } \
+  } while (0)
+  Blk cur, nxt;
+  UR_DKV_DRAW(cur, true);
+  while (cur.more) {
+    c128::f32x32 k0, k1, v0, v1;
+    if (cur.run) {
+      i32x32 kv_, vv_;
+      UR_DKV_PACK(cur);
+      int ln = tid & 63;
+      asm volatile("" : "+v"(ln));
+      const int h = ln >> 5, l31 = ln & 31;
+      i32x2 ra, ca, voff;
+      i32x8 ta, tb;
+      ra[0] = (int)(lds0 + C::off(l31, h)); ra[1] = ra[0] + DKV_HIGH;
+      ca[0] = (int)(lds0 + 16 * h); ca[1] = ca[0] + DKV_HIGH;
+      {
+        const int g16 = (ln >> 4) & 1, i = ln & 15;
+        const int row = 4 * h + (i >> 2), sub8 = 8 * (i & 1);
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < 4; ++dt) {
+          const int ch = 4 * dt + 2 * g16 + ((i & 3) >> 1);
+          ta[dt] = (int)(lds0 + C::off(row, ch) + sub8); ta[4 + dt] = ta[dt] + DKV_HIGH;
+          tb[dt] = (int)(lds0 + C::off(row + 8, ch) + sub8); tb[4 + dt] = tb[dt] + DKV_HIGH;
+        }
+      }
+      {
+        const int row = 4 * wave + (ln >> 4), pos = ln & 15;
+        const int sw = ((row & 3) << 2) | ((row >> 2) & 3);
+        voff[0] = (int)((uint32_t)(row * p.ldq + (pos ^ sw) * 8) * 2u);
+        voff[1] = (int)((uint32_t)(row * p.lddo + (pos ^ sw) * 8) * 2u);
+      }
+      const int voffc = 4 * ln, xdiag = l31 - 4 * h;
+      const int kb_s = __builtin_amdgcn_readfirstlane(cur.kb);
+      asm volatile(
+          "s_mov_b32 s36, %[qbl]\n\ts_mov_b32 s37, %[qbh]\n\ts_mov_b32 s38, %[dol]\n\ts_mov_b32 s39, %[doh]\n\ts_mov_b32 s40, %[wsl]\n\ts_mov_b32 s41, %[wsh]\n\t"
+          "s_mov_b32 s42, %[q16]\n\ts_mov_b32 s43, %[d16]\n\ts_mov_b32 s45, %[ntot]\n\ts_mov_b32 s47, %[kb]\n\ts_mov_b32 s58, %[qstart]\n\t"
+          "s_mov_b32 s35, %[sq]\n\ts_lshl_b32 s60, %[sq], 2\n\ts_mov_b32 s34, %[wsel]\n\ts_mov_b32 s56, %[cwave]\n\ts_mov_b32 s57, %[waveb]\n\t"
+          UR_ATTN_DKV_C128_ASM
+          : "=&{a[0:31]}"(k0), "=&{a[32:63]}"(k1), "=&{a[64:95]}"(v0), "=&{a[96:127]}"(v1)
+          : "{a[128:159]}"(kv_), "{a[160:191]}"(vv_), "{v[8:9]}"(voff), "{v10}"(voffc), "{v[144:145]}"(ra), "{v[146:153]}"(ta), "{v[154:161]}"(tb),
+            "{v[162:163]}"(ca), "{v164}"(xdiag),
+            [qbl] "s"(__builtin_amdgcn_readfirstlane(cur.qb_lo)), [qbh] "s"(__builtin_amdgcn_readfirstlane(cur.qb_hi)), [dol] "s"(__builtin_amdgcn_readfirstlane(cur.do_lo)), [doh] "s"(__builtin_amdgcn_readfirstlane(cur.do_hi)), [wsl] "s"(__builtin_amdgcn_readfirstlane(cur.ws_lo)), [wsh] "s"(__builtin_amdgcn_readfirstlane(cur.ws_hi)), [q16] "s"(q16b),
+            [d16] "s"(d16b), [ntot] "s"(__builtin_amdgcn_readfirstlane(cur.ntot)), [kb] "s"(kb_s), [qstart] "s"(__builtin_amdgcn_readfirstlane(cur.qstart)), [sq] "s"(sq), [wsel] "s"(wsel), [cwave] "s"(cwave), [waveb] "s"(waveb)
+          : UR_ATTN_DKV_C128_CLOBBERS);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int idx = 16 * (dt & 1) + r;
-      dk[dt][r] = kvalid ? (dt < 2 ? k0[idx] : k1[idx]) * p.scale : 0.f;       // padded key: whatever its lane computed is dropped
-      dv[dt][r] = kvalid ? (dt < 2 ? v0[idx] : v1[idx]) : 0.f;
+      for (int i = 0; i < 32; ++i) { k0[i] = 0.f; k1[i] = 0.f; v0[i] = 0.f; v1[i] = 0.f; }
     }
-  if (p.rk_src != nullptr) {
-    // k = rope(k_norm(k_raw)) ran in the q|k|v GEMM's epilogue: the lane owns its key's whole row, so dK leaves as the gradient of the
-    // RAW k projection (the arithmetic of qknorm_rope_bwd_roped_kernel; a padded key's zero gradient stays zero)
-    int lane_e = lane;
-    asm volatile("" : "+v"(lane_e));
-    const int key_e = kb + (lane_e & 31);
-    const long krow = (long)b * p.Sk + key_e;
-    rope_bwd_from_roped<128>(dk, p.rk_src + krow * p.rk_ld + (long)kvh * 128, p.rk_w, p.rp_cos + (long)key_e * 64, p.rp_sin + (long)key_e * 64,
-                             p.rp_rstd[krow * p.rp_rstd_ld + p.rk_rstd_h0 + kvh], lane_e >> 5);
-    store_T<128>(p.rk_dst + krow * p.rk_lddst + (long)kvh * 128, dk, 1.0f, lane_e, true);
-  } else {
-    store_T<128>(p.dk + ktok * p.lddk + (long)kvh * 128, dk, 1.0f, lane, true);
+    // the next block: drawn, requested
+    nxt.more = false; nxt.run = false;
+    if (persist) UR_DKV_DRAW(nxt, false);
+    // this block's results
+    {
+      int le = tid & 63;
+      asm volatile("" : "+v"(le));
+      const long ktok = (long)cur.b * p.Sk + cur.kb + (le & 31);
+      const bool kvalid = p.kmask == nullptr || p.kmask[ktok] != 0;       // padded key: whatever its lane computed is dropped
+      // (dV first, then dK with its RoPE backward: one 64-register accumulator at a time beside the next block's K / V rows in flight)
+      {
+        f32x16 dv[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const int idx = 16 * (dt & 1) + r; dv[dt][r] = kvalid ? (dt < 2 ? v0[idx] : v1[idx]) : 0.f; }
+        store_T<128>(p.dv + ktok * p.lddv + (long)cur.kvh * 128, dv, 1.0f, le, true);
+      }
+      asm volatile("" ::: "memory");
+      {
+        f32x16 dk[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const int idx = 16 * (dt & 1) + r; dk[dt][r] = kvalid ? (dt < 2 ? k0[idx] : k1[idx]) * p.scale : 0.f; }
+        if (p.rk_src != nullptr && cur.run) {
+          // k = rope(k_norm(k_raw)) ran in the q|k|v GEMM's epilogue: the lane owns its key's whole row, so dK leaves as the gradient of
+          // the RAW k projection (the arithmetic of qknorm_rope_bwd_roped_kernel; a padded key's zero gradient stays zero)
+          const int key_e = cur.kb + (le & 31);
+          rope_bwd_from_roped<128>(dk, p.rk_src + ktok * p.rk_ld + (long)cur.kvh * 128, p.rk_w, p.rp_cos + (long)key_e * 64, p.rp_sin + (long)key_e * 64,
+                                   p.rp_rstd[ktok * p.rp_rstd_ld + p.rk_rstd_h0 + cur.kvh], le >> 5);
+        }
+        if (p.rk_src != nullptr) store_T<128>(p.rk_dst + ktok * p.rk_lddst + (long)cur.kvh * 128, dk, 1.0f, le, true);
+        else store_T<128>(p.dk + ktok * p.lddk + (long)cur.kvh * 128, dk, 1.0f, le, true);
+      }
+    }
+    cur = nxt;
   }
-  store_T<128>(p.dv + ktok * p.lddv + (long)kvh * 128, dv, 1.0f, lane, true);
-  if (!persist) break;
-  }
+#undef UR_DKV_DRAW
+#undef UR_DKV_PACK
 }
 
 // ================================================================================================
