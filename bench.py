@@ -618,6 +618,12 @@ def main():
             f_[0] += e0.elapsed_time(e1); f_[1] += nbytes; f_[2] += 1
         streams = {k: {"launches": v[2], "ms_per_step": round(v[0] / args.steps, 3), "GB_per_s": round(v[1] / max(v[0], 1e-9) / 1e6, 1),
                        "hbm_fraction": round(v[1] / max(v[0], 1e-9) / 1e6 / peaks["hbm_GBps_spec"], 4)} for k, v in sorted(fam.items())}
+        if "lora_bits" in streams:
+            # the flag planes (and their token-packed copies) of step n + 1 are generated on a SIDE stream under step n's Q-Former backward:
+            # kernel time beside the step, not in it (profiles/r4_ab_step.txt)
+            streams["lora_bits"]["side_stream"] = True
+        streams["_sum_on_the_step_stream_ms"] = round(sum(v["ms_per_step"] for k, v in streams.items() if isinstance(v, dict) and not v.get("side_stream")
+                                                          and k not in ("adamw", "J6_candidate_scores")), 2)
         # HBM-side bytes of one launch from the separate rocprofv3 --pmc passes (profiles/r2_gemm_pmc.json: FETCH_SIZE x2 +
         # WRITE_SIZE, the MI355X_MICROARCH corrections); bench.py itself cannot collect PMC counters.  Reported for the
         # largest launch of the family, the merged gate|up forward (M=131072, N=6144, K=1024).
