@@ -23,7 +23,9 @@ import isa
 from attn_fwd import flatten, _tag, s_m0_add, ACC_ROW
 from attn_dq import s_mov_vcc, ds_read_b64, v_readfirstlane
 
-LEAD = 6
+LEAD = 6                     # transposed fragments: MFMA slots between a read and its use (their ring has 8 slots: < 8)
+LEAD_ROW = int(os.environ.get("UR_DKV_LEAD_ROW", "6"))     # row fragments (one register set per k-step: up to 14); NPRE of the next tile's come with this one
+NPRE = LEAD_ROW // 2
 SLOT = 33792                 # row constants 1 KiB (ns[64] f32 | nd[64] f32 | pad) | Q tile 16 KiB | dO tile 16 KiB  (every immediate of slot 1 < 64 KiB)
 CONST_OFF, QOFF, DOFF = 0, 1024, 17408
 LDS_BYTES = 4 * SLOT
@@ -280,12 +282,12 @@ def build_body(p, tag, cnt):
     mf[GYB:GYB + 16] = y_block(1)
     # row fragments of half b (half a's were requested by the previous iteration / the prologue): k-step ks first used by MFMA 2 ks of X_b
     for ks in range(8):
-        put(GXB + 2 * ks - LEAD, *row_read(QRF, ks, slot, 1, ks, False))
-        put(GXB + 2 * ks - LEAD, *row_read(DORF, ks, slot, 1, ks, True))
+        put(GXB + 2 * ks - LEAD_ROW, *row_read(QRF, ks, slot, 1, ks, False))
+        put(GXB + 2 * ks - LEAD_ROW, *row_read(DORF, ks, slot, 1, ks, True))
     # half a, k-steps 3..7 (0..2 came with the previous iteration)
-    for ks in range(3, 8):
-        put(GXA + 2 * ks - LEAD, *row_read(QRF, ks, slot, 0, ks, False))
-        put(GXA + 2 * ks - LEAD, *row_read(DORF, ks, slot, 0, ks, True))
+    for ks in range(NPRE, 8):
+        put(GXA + 2 * ks - LEAD_ROW, *row_read(QRF, ks, slot, 0, ks, False))
+        put(GXA + 2 * ks - LEAD_ROW, *row_read(DORF, ks, slot, 0, ks, True))
     # row constants of half b straight into its accumulators (free since the previous tile's Y_b consumed their fragments)
     put(GXA + 2, *const_reads(slot, 1))
     # transposed fragments: Y block MFMA 2 (4 s2 + dt) uses dO^T (ring slot 2 dt), MFMA + 1 uses Q^T (ring slot 2 dt + 1)
@@ -297,9 +299,9 @@ def build_body(p, tag, cnt):
                 put(first - LEAD + 1, *tr_reads(2 * dt + 1, slot, half, s2, dt, False))
     # next tile: row constants of half a into S'_a / dP'_a (their fragments were converted during X_b), row fragments 0..2
     put(GYB + 2, *const_reads(slot_n, 0))
-    for ks in range(3):
-        put(NG - LEAD + 2 * ks, *row_read(QRF, ks, slot_n, 0, ks, False))
-        put(NG - LEAD + 2 * ks, *row_read(DORF, ks, slot_n, 0, ks, True))
+    for ks in range(NPRE):
+        put(NG - LEAD_ROW + 2 * ks, *row_read(QRF, ks, slot_n, 0, ks, False))
+        put(NG - LEAD_ROW + 2 * ks, *row_read(DORF, ks, slot_n, 0, ks, True))
     # LDS-DMA of the tile three ahead
     for j, g in enumerate([1, 5, 9, 13, 49, 53, 57, 61, 63]):
         put(g, dma_piece(j, (p + 3) & 3))
@@ -327,7 +329,7 @@ def entry_pending():
     out = []
     for g in range(4):
         out += [tuple(range(S_(0, 4 * g), S_(0, 4 * g) + 4)), tuple(range(DP(0, 4 * g), DP(0, 4 * g) + 4))]
-    for ks in range(3):
+    for ks in range(NPRE):
         out += [tuple(range(QRF(ks), QRF(ks) + 4)), tuple(range(DORF(ks), DORF(ks) + 4))]
     return out
 
@@ -372,7 +374,7 @@ def prologue_code(with_dma_prologue=True):
     # tiles 1, 2 -- and so is whatever the C++ part loaded or stored between the two statements)
     out += [s_waitcnt(vmcnt=18), s_barrier()]
     out += const_reads(0, 0)
-    for ks in range(3):
+    for ks in range(NPRE):
         out += row_read(QRF, ks, 0, 0, ks, False) + row_read(DORF, ks, 0, 0, ks, True)
     return out
 

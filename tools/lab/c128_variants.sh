@@ -15,7 +15,8 @@ sys.path.insert(0, "tools/asmgen")
 import emit
 open("/tmp/c128var/$t/fwd.h", "w").write(emit.fwd_header())
 open("/tmp/c128var/$t/dq.h", "w").write(emit.dq_header())
+open("/tmp/c128var/$t/dkv.h", "w").write(emit.dkv_header())
 PY
-  tools/lab/lib_variant.sh attn c128_$t -DUR_ATTN_FWD_C128_HDR="\"/tmp/c128var/$t/fwd.h\"" -DUR_ATTN_DQ_C128_HDR="\"/tmp/c128var/$t/dq.h\"" $extra >/dev/null
+  tools/lab/lib_variant.sh attn c128_$t -DUR_ATTN_FWD_C128_HDR="\"/tmp/c128var/$t/fwd.h\"" -DUR_ATTN_DQ_C128_HDR="\"/tmp/c128var/$t/dq.h\"" -DUR_ATTN_DKV_C128_HDR="\"/tmp/c128var/$t/dkv.h\"" $extra >/dev/null
   echo built c128_$t
 done

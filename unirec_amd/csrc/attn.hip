@@ -2716,12 +2716,23 @@ _Pragma("unroll") \
       } \
   } while (0)
   Blk cur, nxt;
+#if UR_C128_STAMPS
+  unsigned long long acc_pack = 0, acc_asm = 0, acc_draw = 0, acc_dv = 0, acc_dk = 0, nblk = 0;
+#endif
   UR_DKV_DRAW(cur, true);
   while (cur.more) {
     c128::f32x32 k0, k1, v0, v1;
+#if UR_C128_STAMPS
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    unsigned long long t1 = t0, t2 = t0;
+#endif
     if (cur.run) {
       i32x32 kv_, vv_;
       UR_DKV_PACK(cur);
+#if UR_C128_STAMPS
+      asm volatile("" :: "v"(kv_), "v"(vv_));
+      t1 = __builtin_readcyclecounter();
+#endif
       int ln = tid & 63;
       asm volatile("" : "+v"(ln));
       const int h = ln >> 5, l31 = ln & 31;
@@ -2747,17 +2758,32 @@ _Pragma("unroll") \
       }
       const int voffc = 4 * ln, xdiag = l31 - 4 * h;
       const int kb_s = __builtin_amdgcn_readfirstlane(cur.kb);
+#if UR_C128_STAMPS
+      // (the generated loop's own accumulators land behind the C++ ones: words 8..13 of the wave's record; one block per workgroup
+      // -- UR_ATTN_DKV_PERSIST=0 -- gives one record per block)
+      unsigned int* dbg_asm = g_c128_stamps + ((size_t)(blockIdx.x & 8191) * 4 + wave) * 32 + 8;
+      const uint32_t db_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)dbg_asm), db_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uintptr_t)dbg_asm >> 32));
+#endif
       asm volatile(
           "s_mov_b32 s36, %[qbl]\n\ts_mov_b32 s37, %[qbh]\n\ts_mov_b32 s38, %[dol]\n\ts_mov_b32 s39, %[doh]\n\ts_mov_b32 s40, %[wsl]\n\ts_mov_b32 s41, %[wsh]\n\t"
           "s_mov_b32 s42, %[q16]\n\ts_mov_b32 s43, %[d16]\n\ts_mov_b32 s45, %[ntot]\n\ts_mov_b32 s47, %[kb]\n\ts_mov_b32 s58, %[qstart]\n\t"
           "s_mov_b32 s35, %[sq]\n\ts_lshl_b32 s60, %[sq], 2\n\ts_mov_b32 s34, %[wsel]\n\ts_mov_b32 s56, %[cwave]\n\ts_mov_b32 s57, %[waveb]\n\t"
+#if UR_C128_STAMPS
+          "s_mov_b32 s72, %[dbl]\n\ts_mov_b32 s73, %[dbh]\n\t"
+#endif
           UR_ATTN_DKV_C128_ASM
           : "=&{a[0:31]}"(k0), "=&{a[32:63]}"(k1), "=&{a[64:95]}"(v0), "=&{a[96:127]}"(v1)
           : "{a[128:159]}"(kv_), "{a[160:191]}"(vv_), "{v[8:9]}"(voff), "{v10}"(voffc), "{v[144:145]}"(ra), "{v[146:153]}"(ta), "{v[154:161]}"(tb),
             "{v[162:163]}"(ca), "{v164}"(xdiag),
             [qbl] "s"(__builtin_amdgcn_readfirstlane(cur.qb_lo)), [qbh] "s"(__builtin_amdgcn_readfirstlane(cur.qb_hi)), [dol] "s"(__builtin_amdgcn_readfirstlane(cur.do_lo)), [doh] "s"(__builtin_amdgcn_readfirstlane(cur.do_hi)), [wsl] "s"(__builtin_amdgcn_readfirstlane(cur.ws_lo)), [wsh] "s"(__builtin_amdgcn_readfirstlane(cur.ws_hi)), [q16] "s"(q16b),
             [d16] "s"(d16b), [ntot] "s"(__builtin_amdgcn_readfirstlane(cur.ntot)), [kb] "s"(kb_s), [qstart] "s"(__builtin_amdgcn_readfirstlane(cur.qstart)), [sq] "s"(sq), [wsel] "s"(wsel), [cwave] "s"(cwave), [waveb] "s"(waveb)
+#if UR_C128_STAMPS
+            , [dbl] "s"(db_lo), [dbh] "s"(db_hi)
+#endif
           : UR_ATTN_DKV_C128_CLOBBERS);
+#if UR_C128_STAMPS
+      t2 = __builtin_readcyclecounter();
+#endif
     } else {
 #pragma unroll
       for (int i = 0; i < 32; ++i) { k0[i] = 0.f; k1[i] = 0.f; v0[i] = 0.f; v1[i] = 0.f; }
@@ -2765,6 +2791,10 @@ _Pragma("unroll") \
     // the next block: drawn, requested
     nxt.more = false; nxt.run = false;
     if (persist) UR_DKV_DRAW(nxt, false);
+#if UR_C128_STAMPS
+    const unsigned long long t3 = __builtin_readcyclecounter();
+    unsigned long long t4 = t3;
+#endif
     // this block's results
     {
       int le = tid & 63;
@@ -2781,6 +2811,9 @@ _Pragma("unroll") \
         store_T<128>(p.dv + ktok * p.lddv + (long)cur.kvh * 128, dv, 1.0f, le, true);
       }
       asm volatile("" ::: "memory");
+#if UR_C128_STAMPS
+      t4 = __builtin_readcyclecounter();
+#endif
       {
         f32x16 dk[4];
 #pragma unroll
@@ -2798,8 +2831,19 @@ _Pragma("unroll") \
         else store_T<128>(p.dk + ktok * p.lddk + (long)cur.kvh * 128, dk, 1.0f, le, true);
       }
     }
+#if UR_C128_STAMPS
+    { const unsigned long long t5 = __builtin_readcyclecounter();
+      acc_pack += t1 - t0; acc_asm += t2 - t1; acc_draw += t3 - t2; acc_dv += t4 - t3; acc_dk += t5 - t4; nblk += 1; }
+#endif
     cur = nxt;
   }
+#if UR_C128_STAMPS
+  if ((tid & 63) == 0 && blockIdx.x < 8192) {
+    unsigned int* dbg = g_c128_stamps + ((size_t)blockIdx.x * 4 + wave) * 32;
+    dbg[0] = (unsigned int)acc_pack; dbg[1] = (unsigned int)acc_asm; dbg[2] = (unsigned int)acc_draw; dbg[3] = (unsigned int)acc_dv; dbg[4] = (unsigned int)acc_dk;
+    dbg[5] = (unsigned int)nblk; dbg[6] = 0xD0C5u;
+  }
+#endif
 #undef UR_DKV_DRAW
 #undef UR_DKV_PACK
 }
