@@ -2235,17 +2235,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     // the next block (decoded before the loop): once every wave has left the loop, its key state is built; its q rows and first tiles
     // are requested between the two halves of this block's epilogue (after the first half has freed its registers) and fly under the second half
-#if UR_C128_STAMPS
-    sa = __builtin_readcyclecounter();
-#endif
-    __syncthreads();
-#if UR_C128_STAMPS
-    sb = __builtin_readcyclecounter();
-#endif
-    if (nxt.valid) {
-      if (nxt.item != cur.item) { key_state(nxt); if (p.kmask) __syncthreads(); }
-      else { nxt.tfirst = cur.tfirst; nxt.mb_lo = cur.mb_lo; nxt.mb_hi = cur.mb_hi; }
-    }
+    // (the first half of the epilogue runs BEFORE the barrier: the waves with fewer diagonal tiles leave the loop up to ~4 k cycles
+    // early and spend that wait on their own stores)
     // epilogue (the row sums came off the matrix pipe: complete in every lane)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
@@ -2269,6 +2260,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       if (qb == 0) {
         asm volatile("" ::: "memory");
+#if UR_C128_STAMPS
+        sa = __builtin_readcyclecounter();
+#endif
+        __syncthreads();                     // every wave has left the loop: the key state of the next sample and the rings are free
+#if UR_C128_STAMPS
+        sb = __builtin_readcyclecounter();
+#endif
+        if (nxt.valid) {
+          if (nxt.item != cur.item) { key_state(nxt); if (p.kmask) __syncthreads(); }
+          else { nxt.tfirst = cur.tfirst; nxt.mb_lo = cur.mb_lo; nxt.mb_hi = cur.mb_hi; }
+        }
 #if UR_C128_STAMPS
         sc = __builtin_readcyclecounter();
 #endif
@@ -2564,21 +2566,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int i = 0; i < 32; ++i) { d0[i] = 0.f; d1[i] = 0.f; d2[i] = 0.f; d3[i] = 0.f; }
       }
       // the next block (decoded before the loop): once every wave has left the loop its key state is built and its first tiles are requested
-#if UR_C128_STAMPS
-      sa = __builtin_readcyclecounter();
-#endif
-      __syncthreads();
-#if UR_C128_STAMPS
-      sb = __builtin_readcyclecounter();
-#endif
-      if (nxt.valid) {
-        if (nxt.item != cur.item) { key_state(nxt); if (p.kmask) __syncthreads(); }
-        else { nxt.tfirst = cur.tfirst; nxt.mb_lo = cur.mb_lo; nxt.mb_hi = cur.mb_hi; }
-      }
-      request(nxt);
-#if UR_C128_STAMPS
-      sc = __builtin_readcyclecounter();
-#endif
+      // (the first 32 rows' dQ leave BEFORE that barrier: the waves with fewer diagonal tiles leave the loop up to ~4.7 k cycles early and
+      // spend that wait on their own stores; the request then flies under the second 32 rows' stores and the next block's row loads)
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const int row = q0 + 32 * qb + l31;
@@ -2592,6 +2581,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             acc[dt][r] = (qb == 0 ? (dt < 2 ? d0[idx] : d1[idx]) : (dt < 2 ? d2[idx] : d3[idx])) * p.scale;
           }
         dq_store_block<128>(p, acc, b, hq, row, ok, lane);
+        if (qb == 0) {
+          asm volatile("" ::: "memory");
+#if UR_C128_STAMPS
+          sa = __builtin_readcyclecounter();
+#endif
+          __syncthreads();                   // every wave has left the loop: the key-state words and the rings are free
+#if UR_C128_STAMPS
+          sb = __builtin_readcyclecounter();
+#endif
+          if (nxt.valid) {
+            if (nxt.item != cur.item) { key_state(nxt); if (p.kmask) __syncthreads(); }
+            else { nxt.tfirst = cur.tfirst; nxt.mb_lo = cur.mb_lo; nxt.mb_hi = cur.mb_hi; }
+          }
+          request(nxt);
+#if UR_C128_STAMPS
+          sc = __builtin_readcyclecounter();
+#endif
+        }
       }
 #if UR_C128_STAMPS
       if (lane == 0) {
