@@ -84,6 +84,41 @@ def test_persistent_bias_and_residual_identical():
     assert (b.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 3072, 768), (16384, 3072, 768), (8192, 4096, 320)])
+def test_persistent_gelu_epilogues_identical(M, N, K):
+    """The Q-Former FFN's two launches (reference models/qformer.py:386-395 forward: dense + GELU; backward: dX times gelu'(u)):
+    bias + GELU second output of the bf16-rounded pre-activation, and the product with gelu'(saved pre-activation)."""
+    R, S = _randn((M, K), 56), _randn((N, K), 57, 0.05)
+    bias = torch.randn(N, device=DEV)
+    aux = _randn((M, N), 58, 1.5)
+
+    def fwd():
+        g = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        u = hip.gemm(R, S, bias=bias, gelu_out=g)
+        return u, g
+    (ua, ga), (ub, gb) = _both(fwd)
+    assert torch.equal(ua, ub) and torch.equal(ga, gb)
+    assert torch.allclose(gb.float(), torch.nn.functional.gelu(ub.float()), rtol=1e-2, atol=1e-2)
+    for kw in (dict(), dict(bias=bias, alpha=0.5)):
+        a, b = _both(lambda: hip.gemm(R, S, gelu_grad_aux=aux, **kw))
+        assert torch.equal(a, b), str(list(kw))
+    x = aux.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    ref = (R.float() @ S.float().t()) * x.grad
+    assert (b.float() - (0.5 * ref + bias * x.grad)).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    # column views of wider buffers (row strides that differ from the widths)
+    wide_u, wide_g, wide_a = (torch.zeros(M, N + 256, device=DEV, dtype=torch.bfloat16) for _ in range(3))
+    wide_a[:, 128:128 + N] = aux
+
+    def fwd_views():
+        hip.gemm(R, S, bias=bias, out=wide_u[:, 64:64 + N], gelu_out=wide_g[:, 192:192 + N])
+        return wide_u.clone(), wide_g.clone()
+    (ua, ga), (ub, gb) = _both(fwd_views)
+    assert torch.equal(ua, ub) and torch.equal(ga, gb)
+    a, b = _both(lambda: hip.gemm(R, S, gelu_grad_aux=wide_a[:, 128:128 + N]))
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("nad", [1, 2, 3])
 def test_persistent_masked_lora_epilogue_identical(nad):
     """dX under LoRA dropout: dy W + sum_a keep_a / (1 - p) * (tb_a A_a)."""

@@ -2651,7 +2651,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   // across them: hipcc spilled each load the moment it was issued -- sixteen exposed round trips; packed but carried over the back
   // edge they went through scratch as well).  Carried into the next pass: the scalars of block n + 1 only.
   struct Blk { int kvh, b, kb, qstart, ntot; uint32_t qb_lo, qb_hi, do_lo, do_hi, ws_lo, ws_hi; bool more, run; };
-  i32x32 kv_, vv_;
   // draw a key block, request its first tile and its K / V rows.  Caller: every wave has left the previous loop (persist: the barriers
   // inside; the first draw: nothing has run yet).
   // (macros, not lambdas: through a by-reference capture hipcc keeps kf / vf in scratch memory)

@@ -553,13 +553,19 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             __builtin_nontemporal_store(v, (__attribute__((address_space(1))) u32x4_t*)(base + loff));
 #endif
           }
-      } else if constexpr (EPI == 2 || EPI == 5) {
-        constexpr bool RES = EPI == 2;                  // EPI 5: bias only (a RUNTIME residual switch made hipcc spill 16-25 registers)
+      } else if constexpr (EPI == 2 || EPI == 5 || EPI == 6 || EPI == 7) {
+        // EPI 5: bias only (a RUNTIME residual switch made hipcc spill 16-25 registers); EPI 6: bias, then GELU of the bf16-ROUNDED
+        // pre-activation into a second output (gemm.hip's rich epilogue: the backward's gelu'(u) sees the same u); EPI 7: the second
+        // operand is that saved pre-activation and gelu'(u) is multiplied in instead of a residual added
+        constexpr bool RES = EPI == 2 || EPI == 7, GRAD = EPI == 7, GOUT = EPI == 6;
         // bias / residual in the MFMA layout (lane: row m, 4 consecutive columns of each 16x16 sub-tile: 8-byte residual pieces),
         // then the plain path's pack + 16-lane swap + 16-byte store.  (Adding after an f32 swap -- 16-byte residual pieces --
         // costs 8 more live registers per row block; hipcc spilled 16-25 registers around it, some inside the K tiles.)
         const int nq4 = eg4 * 4;
-        const uint32_t loff_c = (uint32_t)((el15 * p.ldc + cs) * 2), loff_r = (uint32_t)((el15 * p.ldres + nq4) * 2);
+        const bf16_t* const rsrc = GRAD ? p.aux : p.res;
+        const long ldrs = GRAD ? p.ldaux : p.ldres;
+        const uint32_t loff_c = (uint32_t)((el15 * p.ldc + cs) * 2), loff_r = (uint32_t)((el15 * ldrs + nq4) * 2);
+        const uint32_t loff_g = GOUT ? (uint32_t)((el15 * p.ldg + cs) * 2) : 0u;
         // Software pipeline over the four quarter tiles q = 2 sh + rh (see the SwiGLU-backward branch below): the residual
         // pieces (and, per column half, the bias) of quarter q + 1 are issued BEFORE quarter q's stores -- a load issued after
         // stores cannot be waited for without their acknowledgements (vmcnt counts both, in order).
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
           if constexpr (RES) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-              const char* rbase = uniform_ptr(reinterpret_cast<const char*>(p.res + (long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldres + n0 + sh * 128 + wc * 32));
+              const char* rbase = uniform_ptr(reinterpret_cast<const char*>(rsrc + (long)(m0 + rh * 128 + wr * 64 + jj * 16) * ldrs + n0 + sh * 128 + wc * 32));
               ra[q & 1][jj] = ld_g<uint2>(rbase + loff_r);
               rb[q & 1][jj] = ld_g<uint2>(rbase + loff_r + 32);
             }
@@ -592,16 +598,27 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             float va[4], vb[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { va[e] = a[e] * alpha + bsa[sh][e]; vb[e] = b[e] * alpha + bsb[sh][e]; }
-            if constexpr (RES) {
+            if constexpr (RES && !GRAD) {
               const uint2 xa = ra[q & 1][jj], xb = rb[q & 1][jj];
               va[0] += bf_lo(xa.x); va[1] += bf_hi(xa.x); va[2] += bf_lo(xa.y); va[3] += bf_hi(xa.y);
               vb[0] += bf_lo(xb.x); vb[1] += bf_hi(xb.x); vb[2] += bf_lo(xb.y); vb[3] += bf_hi(xb.y);
+            }
+            if constexpr (GRAD) {
+              const uint2 xa = ra[q & 1][jj], xb = rb[q & 1][jj];
+              va[0] *= gelu_erf_grad_f(bf_lo(xa.x)); va[1] *= gelu_erf_grad_f(bf_hi(xa.x)); va[2] *= gelu_erf_grad_f(bf_lo(xa.y)); va[3] *= gelu_erf_grad_f(bf_hi(xa.y));
+              vb[0] *= gelu_erf_grad_f(bf_lo(xb.x)); vb[1] *= gelu_erf_grad_f(bf_hi(xb.x)); vb[2] *= gelu_erf_grad_f(bf_lo(xb.y)); vb[3] *= gelu_erf_grad_f(bf_hi(xb.y));
             }
             uint32_t a0 = pack_bf2(va[0], va[1]), a1 = pack_bf2(va[2], va[3]), b0 = pack_bf2(vb[0], vb[1]), b1 = pack_bf2(vb[2], vb[3]);
             swap16(a0, b0); swap16(a1, b1);
             char* cb = uniform_wptr(reinterpret_cast<char*>(p.C) + ((long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldc + n0 + sh * 128 + wc * 32) * 2);
             const u32x4_t o = {a0, a1, b0, b1};
             st_g<u32x4_t>(cb + loff_c, o);
+            if constexpr (GOUT) {
+              char* gb = uniform_wptr(reinterpret_cast<char*>(p.gelu_out) + ((long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldg + n0 + sh * 128 + wc * 32) * 2);
+              const u32x4_t og = {pack_bf2(gelu_erf_f(bf_lo(a0)), gelu_erf_f(bf_hi(a0))), pack_bf2(gelu_erf_f(bf_lo(a1)), gelu_erf_f(bf_hi(a1))),
+                                  pack_bf2(gelu_erf_f(bf_lo(b0)), gelu_erf_f(bf_hi(b0))), pack_bf2(gelu_erf_f(bf_lo(b1)), gelu_erf_f(bf_hi(b1)))};
+              st_g<u32x4_t>(gb + loff_g, og);
+            }
           }
         }
       } else {
@@ -716,7 +733,12 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
   static const int min_tiles = ur_lab_int("UR_PERS_MIN_TILES", 128);      // lab; default 128: half a round already gains from the register epilogue (C2 item stage 21.66 -> 21.05 ms; 256 and 512 equal within noise, user stage unchanged)
   if ((long)(p.M / BM) * (p.N / BN) < min_tiles) return false;
   if ((long)(p.M / BM) * (p.N / BN) >= (1L << 20) || p.N / BN >= (1 << 12) || p.M / BM >= (1 << 15)) return false;      // fdiv: n * d < 2^32
-  if (p.gelu_out || p.aux || p.sw_mode == 2) return false;
+  if (p.sw_mode == 2) return false;
+  if (p.gelu_out || p.aux) {                 // the GELU epilogues (EPI 6 / 7): alone on the first K range, never with a residual
+    if ((p.gelu_out && p.aux) || p.res || p.K2 > 0 || p.sw_mode || p.qk_q || p.sp_act) return false;
+    if (p.gelu_out && ((p.ldg & 7) || (reinterpret_cast<uintptr_t>(p.gelu_out) & 15))) return false;
+    if (p.aux && ((p.ldaux & 7) || (reinterpret_cast<uintptr_t>(p.aux) & 15))) return false;
+  }
   if (p.K2 > 0 && !p.drop_bits && p.K2 > BK) return false;
   if (p.drop_bits && p.K2 > 0) {
     if (p.drop_rank != 16 || (p.K2 & 15)) return false;                        // the masked epilogue here is rank 16 only
@@ -737,7 +759,7 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
   // (every epilogue operand is addressed as uniform base + a 32-bit lane offset of at most 16 rows)
   auto wide = [](long ld) { return ld * 32 >= (1L << 31); };
   if ((p.res && wide(p.ldres)) || (p.sw_mode == 1 && (wide(p.sw_ldgu) || wide(p.sw_lddgu))) || (p.qk_q && (wide(p.qk_ldq) || wide(p.qk_ldk) || wide(p.qk_ldv))) ||
-      (p.sp_act && wide(p.sp_ldact)) || (p.drop_bits && (wide(p.drop_bits_ld) || wide(p.lds2) || wide(p.ldr2))))
+      (p.sp_act && wide(p.sp_ldact)) || (p.gelu_out && wide(p.ldg)) || (p.aux && wide(p.ldaux)) || (p.drop_bits && (wide(p.drop_bits_ld) || wide(p.lds2) || wide(p.ldr2))))
     return false;
   return true;
 }
@@ -762,7 +784,7 @@ int gemm_pers_launch(GemmP p, hipStream_t st) {
     p.stagger = env_sx > 0 ? -env_sx : (env_st > 0 ? env_st : 0);
   }
   const int mode = drop ? 2 : (p.K2 > 0 ? 1 : 0);
-  const int epi = p.sp_act ? 4 : (p.qk_q ? 3 : (p.sw_mode == 1 ? 1 : (p.res ? 2 : (p.bias ? 5 : 0))));
+  const int epi = p.sp_act ? 4 : (p.qk_q ? 3 : (p.sw_mode == 1 ? 1 : (p.gelu_out ? 6 : (p.aux ? 7 : (p.res ? 2 : (p.bias ? 5 : 0))))));
 #define UR_PERS_CASE(E, MD) if (epi == E && mode == MD) return launch_pers<E, MD>(p, st)
   UR_PERS_CASE(0, 0); UR_PERS_CASE(0, 1); UR_PERS_CASE(0, 2);
   UR_PERS_CASE(1, 0); UR_PERS_CASE(1, 1); UR_PERS_CASE(1, 2);
@@ -770,6 +792,7 @@ int gemm_pers_launch(GemmP p, hipStream_t st) {
   UR_PERS_CASE(3, 0); UR_PERS_CASE(3, 1);
   UR_PERS_CASE(4, 0); UR_PERS_CASE(4, 1);
   UR_PERS_CASE(5, 0); UR_PERS_CASE(5, 1); UR_PERS_CASE(5, 2);
+  UR_PERS_CASE(6, 0); UR_PERS_CASE(7, 0);
 #undef UR_PERS_CASE
   UR_FAIL(-1, "ur_gemm(persistent): no kernel for epilogue %d, mode %d", epi, mode);
 }
