@@ -14,5 +14,5 @@ for (Mo, No, red) in [(768, 3072, 8192), (3072, 768, 8192), (2304, 768, 8192), (
         if red // sp < 128: continue
         t = timeit(lambda: hip.gemm(dy, x, r_kcontig=False, s_kcontig=False, out=out, split_k=sp), 10)
         t256 = ((Mo + 255) // 256) * ((No + 255) // 256) * sp
-        line += f"  s{sp}{'*' if t256 >= 256 else ''}: {t * 1e3:5.1f}"
+        line += f"  s{sp}{'*' if t256 >= 224 else ''}: {t * 1e3:5.1f}"
     print(line, flush=True)

@@ -361,8 +361,10 @@ __device__ __forceinline__ float mask_score(float raw, float scale, bool valid, 
 // tile serves both heads (half the LDS-DMA pieces per wave and tile, half the L2 -> LDS bytes per flop).  Measured: 1.82-1.84 ms
 // against 1.79-1.80 ms for the one-head workgroups (dense causal B 64 S 2048): the two waves of a SIMD now wait at the SAME
 // barrier, which costs more than the staging it saves.  Not the default.
+// (NW == 1: the few-query launches of the Q-Formers -- one wave per (sample, head), thousands of them, each a short latency-bound
+// chain: two waves per SIMD instead of the one that 276 registers allowed, and LDS for ONE K | V stage when Sk fits one tile)
 template <int HD, bool CAUSAL, int NW, bool GQ2 = false>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 2 : 1))) void attn_fwd_kernel(AttnP p) {
   constexpr int NWQ = GQ2 ? NW / 2 : NW;              // waves along the query axis
   using C = Cfg<HD>;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K tile | V tile]
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnP p) {
   const uint64_t drow = p.didx0 + ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
   const bool dropping = (!CAUSAL) && p.drop_thr != 0;
 
-  unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + 4 * C::TILE);
+  unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + (p.Sk <= KT ? 2 : 4) * C::TILE);      // (ur_attn_fwd's LDS size)
   fill_key_words(kwords, km, ntiles, p.Sk, tid, NW * 64);
   int t_first = 0;
   if (CAUSAL && km != nullptr) {
@@ -2925,7 +2927,9 @@ int launch_fwd(const AttnP& p, hipStream_t st) {
   static std::atomic<uint64_t> once{0};   // per device
   if (ur_first_on_device(once)) { int rc = set_smem(&attn_fwd_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_fwd"); if (rc) return rc; }
   dim3 grid(ur_cdiv(p.Sq, 32 * NW) * p.nq * p.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), fwd_smem<HD>(), st, p);
+  // one K | V stage and one pair of key words when every key fits one tile (the Q-Formers' 32-query launches: twice the waves per CU)
+  const int smem_bytes = p.Sk <= KT ? 2 * Cfg<HD>::TILE + 16 : fwd_smem<HD>();
+  hipLaunchKernelGGL((attn_fwd_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), smem_bytes, st, p);
   UR_CHECK_LAUNCH("ur_attn_fwd");
   return 0;
 }

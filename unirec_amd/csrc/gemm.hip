@@ -902,7 +902,10 @@ int launch(const GemmP& p, int splits, hipStream_t st) {
     }
   }
   static const bool force128 = ur_lab_int("UR_GEMM_FORCE128", 0) == 1;      // lab: 128x128 tiles (2 workgroups per CU) everywhere
-  if (p.M >= 256 && p.N >= 256 && big_wgs >= 256 && !force128) return launch_cfg<RK, SK, OUTF32, 256, 256, 2, 4>(p, splits, st);
+  // (token-reduction launches, both operands K-strided: one round of 224+ big tiles already beats the small tile -- the host picks
+  // such splits, qformer.py:_split_k_for)
+  const long big_min = (!RK && !SK) ? 224 : 256;
+  if (p.M >= 256 && p.N >= 256 && big_wgs >= big_min && !force128) return launch_cfg<RK, SK, OUTF32, 256, 256, 2, 4>(p, splits, st);
   return launch_cfg<RK, SK, OUTF32, 128, 128, 2, 2>(p, splits, st);
 }
 

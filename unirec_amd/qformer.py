@@ -129,12 +129,18 @@ def _split_k_for(out_rows, out_cols, red):
     tiles = ((out_rows + 127) // 128) * ((out_cols + 127) // 128)
     want = max(1, 512 // max(tiles, 1))
     sp = int(max(1, min(want, red // 256, 64)))
+    t256 = ((out_rows + 255) // 256) * ((out_cols + 255) // 256)
+    one_round = 256 // max(t256, 1)
+    if red < 16384 and out_rows >= 256 and out_cols >= 256 and t256 * one_round >= 224 and red // max(one_round, 1) >= 768:
+        # ONE round of 224-256 workgroups on the 256x256 tile (ur_gemm takes it from 224 for token reductions) beats 1.7 rounds of
+        # the small tile when each split keeps >= 12 K tiles: C2 (tools/lab/dw_split_c2.py) [768, 3072] over 8192 tokens split 3
+        # 85.6 us -> split 7 75.3 us, [2304, 768] split 4 66.6 -> split 9 63.8
+        return int(one_round)
     if red >= 16384:
         # long token reductions (the user Q-Former: 32 768 query tokens, 819 200 keys): enough splits for ur_gemm to take the
         # 256x256 tile (tiles * splits >= 256) in WHOLE rounds of 256 workgroups.  C3, out [2048, 1024] over 819 200 tokens: split 4
         # on 128x128 tiles 5.5 ms, split 8 4.0 ms; over 32 768 tokens (tools/lab/dw_split.py): [1024, 4096] split 2 454 us ->
         # split 4 335 us, [3072, 1024] split 2 416 -> split 16 298 (split 6 = 1.125 rounds: 392), [1024, 1024] split 8 118 -> 16 104
-        t256 = ((out_rows + 255) // 256) * ((out_cols + 255) // 256)
         whole = 256 // math.gcd(256, t256)
         if red // whole >= 1024:
             sp = max(1, min(64, whole))
