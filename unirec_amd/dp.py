@@ -291,16 +291,19 @@ class GradBuckets:
 def layer_boundaries(pack, layer_prefixes, group_size):
     """Bucket boundaries for a pack whose entries are ordered by layer: one bucket per `group_size`
     consecutive layers (plus whatever precedes the first / follows the last layer)."""
+    # (the Q-Formers keep the cross-attention K | V projections of ALL layers side by side ahead of layer 0 -- one GEMM serves them,
+    # qformer.py:_cross_kv_names -- and finish their gradients after the layer loop: they belong to the leading bucket)
+    hoisted = lambda n: ".crossattention.self.key." in n or ".crossattention.self.value." in n
     starts = []
     for pre in layer_prefixes:
-        offs = [pack.offsets[n] for n in pack.names if n.startswith(pre)]
+        offs = [pack.offsets[n] for n in pack.names if n.startswith(pre) and not hoisted(n)]
         starts.append(min(offs))
     bounds = [0]
     for k in range(0, len(starts), group_size):
         if starts[k] > bounds[-1]:
             bounds.append(starts[k])
     # everything after the last layer group (heads) gets its own trailing bucket
-    last_layer_end = max(pack.offsets[n] + ((pack.params[n].numel() + 7) // 8) * 8 for n in pack.names if n.startswith(layer_prefixes[-1]))
+    last_layer_end = max(pack.offsets[n] + ((pack.params[n].numel() + 7) // 8) * 8 for n in pack.names if n.startswith(layer_prefixes[-1]) and not hoisted(n))
     if last_layer_end < pack.numel:
         bounds.append(last_layer_end)
     bounds.append(pack.numel)

@@ -217,18 +217,29 @@ class BertModel(nn.Module):
     def live_named_parameters(self, prefix=""):
         named = dict(self.named_parameters())
         order = ["embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"]
+        # the cross-attention K | V projections of ALL layers read the same encoder states (models/qformer.py:186-188): their weights
+        # (and biases) sit side by side so that one GEMM serves every layer (_cross_kv_names; dp.layer_boundaries skips them)
+        order += self._cross_kv_names("")[0] + self._cross_kv_names("")[1]
         for i, lyr in enumerate(self.encoder.layer):
             lp = f"encoder.layer.{i}."
             blocks = ["attention."] + (["crossattention."] if lyr.has_cross_attention else [])
             for b in blocks:
-                order += [lp + b + f"self.{n}.weight" for n in ("query", "key", "value")]
-                order += [lp + b + f"self.{n}.bias" for n in ("query", "key", "value")]
+                qkv = ("query", "key", "value") if b == "attention." else ("query",)
+                order += [lp + b + f"self.{n}.weight" for n in qkv]
+                order += [lp + b + f"self.{n}.bias" for n in qkv]
                 order += [lp + b + "output.dense.weight", lp + b + "output.dense.bias",
                           lp + b + "output.LayerNorm.weight", lp + b + "output.LayerNorm.bias"]
             order += [lp + "intermediate_query.dense.weight", lp + "intermediate_query.dense.bias",
                       lp + "output_query.dense.weight", lp + "output_query.dense.bias",
                       lp + "output_query.LayerNorm.weight", lp + "output_query.LayerNorm.bias"]
         return [(prefix + n, named[n]) for n in order]
+
+    def _cross_kv_names(self, pre):
+        """([k0.weight, v0.weight, k1.weight, ...], [k0.bias, v0.bias, ...]) over the layers with cross attention, in layer order."""
+        cl = [i for i, lyr in enumerate(self.encoder.layer) if lyr.has_cross_attention]
+        ws = [f"{pre}encoder.layer.{i}.crossattention.self.{n}.weight" for i in cl for n in ("key", "value")]
+        bs = [f"{pre}encoder.layer.{i}.crossattention.self.{n}.bias" for i in cl for n in ("key", "value")]
+        return ws, bs
 
     def dead_parameters(self):
         return [p for n, p in self.named_parameters() if _dead(n)]
@@ -338,6 +349,12 @@ class BertModel(nn.Module):
         x, z0, mean0, rstd0 = hip.layernorm_fwd(qe16, w("embeddings.LayerNorm.weight"), w("embeddings.LayerNorm.bias"), eps,
                                                 M=M, p_post=p_h, seed_post=self._seed(1023, 0), drop_row0=row0)
         S["emb"] = (z0, mean0, rstd0, self._seed(1023, 0))
+        # ---- the cross-attention keys | values of EVERY layer: one projection of the encoder states (its input does not depend on the layer)
+        kvw, kvb = self._cross_kv_names(pre)
+        ncross = len(kvw) // 2
+        kv_all = hip.gemm(enc16, pack.fused16(kvw), bias=pack.fused32(kvb)) if ncross else None      # [B*T, ncross * 2H]
+        S["kv_all"] = kv_all
+        jc = 0
         for i, lyr in enumerate(self.encoder.layer):
             lp = pre + f"encoder.layer.{i}."
             L = {}
@@ -359,10 +376,7 @@ class BertModel(nn.Module):
             if lyr.has_cross_attention:
                 c = lp + "crossattention."
                 qc = hip.gemm(x1, pack.w16(c + "self.query.weight"), bias=pack.w32(c + "self.query.bias"))
-                Wkv = pack.fused16([c + "self.key.weight", c + "self.value.weight"])
-                bkv = pack.fused32([c + "self.key.bias", c + "self.value.bias"])
-                kv = hip.gemm(enc16, Wkv, bias=bkv)
-                kv5 = kv.view(B, T, 2, nh, dh)
+                kv5 = kv_all.view(B, T, ncross, 2, nh, dh)[:, :, jc]
                 s_att2 = self._seed(i, 3)
                 ctx2, actx2 = hip.attn_fwd(qc.view(B, Qn, nh, dh), kv5[:, :, 0], kv5[:, :, 1], causal=False, key_mask=mask_u8,
                                            dropout_p=p_a, seed=s_att2, drop_batch0=b0)
@@ -370,7 +384,8 @@ class BertModel(nn.Module):
                 s_h2 = self._seed(i, 4)
                 x2, z2, m2, r2 = hip.layernorm_fwd(y2, pack.w32(c + "output.LayerNorm.weight"),
                                                    pack.w32(c + "output.LayerNorm.bias"), eps, residual=x1, p_pre=p_h, seed_pre=s_h2, drop_row0=row0)
-                L["cross"] = (x1, qc, kv, actx2, ctx2, z2, m2, r2, s_h2)
+                L["cross"] = (x1, qc, jc, actx2, ctx2, z2, m2, r2, s_h2)
+                jc += 1
                 xc = x2
             # ---- query FFN (models/qformer.py:449-454, 481-484)
             f1, f2 = lp + "intermediate_query.dense.", lp + "output_query."
@@ -403,8 +418,8 @@ class BertModel(nn.Module):
                 if lyr.has_cross_attention:
                     c = lp + "crossattention."
                     groups += [((c + "self.query.weight",),), ((c + "output.dense.weight",),)]
-                    if with_enc:
-                        groups += [((c + "self.key.weight", c + "self.value.weight"),)]
+                if i == 0 and with_enc and self._cross_kv_names(pre)[0]:
+                    groups += [(tuple(self._cross_kv_names(pre)[0]),)]          # all layers' K | V: one dX for the encoder states
                 for (names,) in groups:
                     keys.append(names if len(names) > 1 else names[0])
                     srcs.append(pack.fused16(list(names)) if len(names) > 1 else pack.w16(names[0]))
@@ -442,6 +457,9 @@ class BertModel(nn.Module):
             out = pack.fusedg(names) if len(names) > 1 else pack.g32(names[0])
             hip.gemm(dy, xin, r_kcontig=False, s_kcontig=False, out=out, split_k=_split_k_for(out.shape[0], out.shape[1], dy.shape[0]))
 
+        kvw, kvb = self._cross_kv_names(pre)
+        ncross = len(kvw) // 2
+        dkv_all = torch.empty_like(S["kv_all"]) if ncross else None          # every layer's dK | dV, reduced by ONE launch after the loop
         for i in reversed(range(len(self.encoder.layer))):
             lyr = self.encoder.layer[i]
             L = S["layers"][i]
@@ -459,22 +477,17 @@ class BertModel(nn.Module):
             # ---- cross attention
             if lyr.has_cross_attention:
                 c = lp + "crossattention."
-                x1, qc, kv, actx2, ctx2, z2, m2, r2, s_h2 = L["cross"]
+                x1, qc, jc, actx2, ctx2, z2, m2, r2, s_h2 = L["cross"]
                 dz2, dy2 = hip.layernorm_bwd(dx, z2, m2, r2, pack.w32(c + "output.LayerNorm.weight"),
                                              pack.g32(c + "output.LayerNorm.weight"), pack.g32(c + "output.LayerNorm.bias"),
                                              dbias=pack.g32(c + "output.dense.bias"), p_pre=p_h, seed_pre=s_h2, drop_row0=row0)
                 dW(dy2, ctx2.view(M, H), [c + "output.dense.weight"])
                 dctx2 = dX(dy2, [c + "output.dense.weight"])
-                dkv = torch.empty_like(kv)
-                dkv5 = dkv.view(B, T, 2, nh, dh)
+                dkv5 = dkv_all.view(B, T, ncross, 2, nh, dh)[:, :, jc]
                 dqc = torch.empty_like(qc)
                 hip.attn_bwd(actx2, dctx2.view(B, Qn, nh, dh), dq=dqc.view(B, Qn, nh, dh), dk=dkv5[:, :, 0], dv=dkv5[:, :, 1])
                 dW(dqc, x1, [c + "self.query.weight"])
                 hip.colsum(dqc, out=pack.g32(c + "self.query.bias"))
-                dW(dkv, enc16, [c + "self.key.weight", c + "self.value.weight"])
-                hip.colsum(dkv, out=pack.fusedg([c + "self.key.bias", c + "self.value.bias"]))
-                if enc_needs_grad:
-                    d_enc = dX(dkv, [c + "self.key.weight", c + "self.value.weight"], residual=d_enc)
                 dx = dX(dqc, [c + "self.query.weight"], residual=dz2)
             # ---- self attention
             a = lp + "attention."
@@ -494,6 +507,12 @@ class BertModel(nn.Module):
             L.clear()
             if self.grad_ready_hook is not None:      # dp.GradBuckets: layer i's gradients are final
                 self.grad_ready_hook(i)
+        # ---- the cross-attention K | V projections of all layers: one token reduction, one bias sum (and one dX for the encoder states)
+        if ncross:
+            dW(dkv_all, enc16, kvw)
+            hip.colsum(dkv_all, out=pack.fusedg(kvb))
+            if enc_needs_grad:
+                d_enc = dX(dkv_all, kvw)
         # ---- embeddings LayerNorm; gradient of the batch-broadcast query table reduces over B
         z0, mean0, rstd0, s0 = S["emb"]
         dz0, _ = hip.layernorm_bwd(dx, z0, mean0, rstd0, pack.w32(pre + "embeddings.LayerNorm.weight"),
