@@ -52,6 +52,23 @@ def test_gemm_exact_integer(M, N, K, rk, sk):
         assert torch.equal(out16.double().cpu(), ref)
 
 
+# the 256x256 tile with K-strided operands (two 128-column LDS images per operand tile): the token reductions dW = dY^T X of the
+# Q-Formers (reference: autograd of nn.Linear, models/qformer.py:126-130) run the 8-phase loop on interior tiles from 224 workgroups
+# on; edge tiles, K tails and the mixed layouts keep the 2-slot loop on the same LDS image
+@pytest.mark.parametrize("M,N,K,split,rk,sk", [
+    (768, 3072, 8192, 7, False, False), (2304, 768, 8192, 9, False, False), (1024, 4096, 4096, 4, False, False),
+    (776, 3080, 1600, 5, False, False), (768, 3072, 8200, 7, False, False), (1024, 2048, 328, 8, False, False),
+    (4096, 4096, 512, 1, True, False), (4096, 4096, 520, 1, False, True), (4104, 4096, 512, 1, False, False)])
+def test_gemm_big_tile_k_strided_exact(M, N, K, split, rk, sk):
+    Rm, Sm = _ints((M, K), seed=11), _ints((N, K), seed=12)
+    R = _bf(Rm if rk else Rm.t())
+    S = _bf(Sm if sk else Sm.t())
+    ref = _ref_gemm(Rm, Sm)
+    out32 = hip.gemm(R, S, r_kcontig=rk, s_kcontig=sk, out_f32=True, split_k=split)
+    torch.cuda.synchronize()
+    assert torch.equal(out32.double().cpu(), ref), f"max err {(out32.double().cpu() - ref).abs().max()}"
+
+
 @pytest.mark.parametrize("rk,sk", LAYOUTS)
 def test_gemm_random_tolerance(rk, sk):
     M, N, K = 512, 768, 1024

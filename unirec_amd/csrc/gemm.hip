@@ -54,14 +54,18 @@ constexpr int KC_ROWB = BK * 2;            // K-contiguous tile row bytes: one f
 //                             -> conflict-free ds_read_b128 fragment reads (16 rows x 4 chunks per read), and one
 //                                LDS-DMA wave instruction moves 8 rows x 128 B = 8 FULL cache lines (a 32-deep
 //                                tile moves 16 half lines per instruction: 36 vs 49 B/clk/CU from L2, tools/lab)
-//   K-strided     [64 k][T] : 2T-byte rows, 32-B segment s of k-row r stored at segment s ^ f(r),
+//   K-strided     [64 k][T] : (T = 256: TWO images of 128 columns each, one after the other -- a half tile is then one contiguous
+//                             16 KiB region, as in the K-contiguous image, which is what the 8-phase loop refills and reads)
+//                             2T-byte rows, 32-B segment s of k-row r stored at segment s ^ f(r),
 //                             f(r) = (r & 3) | (((r >> 3) & 1) << 2)
 //                             -> the 8 (k-row, 32-B) pieces one half-wave ds_read_b64_tr_b16 touches
 //                                land on 8 different 32-B bank groups: conflict-free transposed reads
 template <int T> struct Tile {
   static constexpr int KC_BYTES = T * KC_ROWB;
-  static constexpr int KS_ROWB = T * 2;
-  static constexpr int KS_BYTES = BK * KS_ROWB;
+  static constexpr int KS_T = T == 256 ? 128 : T;      // columns of one K-strided image
+  static constexpr int KS_ROWB = KS_T * 2;
+  static constexpr int KS_IMG = BK * KS_ROWB;          // bytes of one image
+  static constexpr int KS_BYTES = BK * T * 2;
 };
 __device__ __forceinline__ int ks_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 __device__ __forceinline__ int kc_g(int r) { return (r >> 1) & 7; }
@@ -87,9 +91,11 @@ __device__ __forceinline__ void dma_tile(char* tile, const bf16_t* __restrict__ 
       const int g = min(row0 + row, rows_total - 1);
       src = base + (long)g * ld + k0 + ((pos ^ kc_g(row)) << 3);
     } else {
+      constexpr int TH = Tile<T>::KS_T;
       const int c = inst * 64 + lane;
-      const int kr = c / (T / 8), ch = c % (T / 8);
-      const int col = min(row0 + ((ch ^ (ks_f(kr) << 1)) << 3), rows_total - 8);
+      const int img = c / (TH * BK / 8), cc = c % (TH * BK / 8);
+      const int kr = cc / (TH / 8), ch = cc % (TH / 8);
+      const int col = min(row0 + img * TH + ((ch ^ (ks_f(kr) << 1)) << 3), rows_total - 8);
       src = base + (long)(k0 + kr) * ld + col;
     }
     __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + inst * 1024), 16, 0, 0);
@@ -112,9 +118,11 @@ __device__ __forceinline__ void dma_offsets(uint32_t (&voff)[(T * BK * 2 / 1024)
       const int g = min(row0 + row, rows_total - 1) - row0;
       e = (long)g * ld + ((pos ^ kc_g(row)) << 3);
     } else {
+      constexpr int TH = Tile<T>::KS_T;
       const int c = inst * 64 + lane;
-      const int kr = c / (T / 8), ch = c % (T / 8);
-      const int col = min(row0 + ((ch ^ (ks_f(kr) << 1)) << 3), rows_total - 8) - row0;
+      const int img = c / (TH * BK / 8), cc = c % (TH * BK / 8);
+      const int kr = cc / (TH / 8), ch = cc % (TH / 8);
+      const int col = min(row0 + img * TH + ((ch ^ (ks_f(kr) << 1)) << 3), rows_total - 8) - row0;
       e = (long)kr * ld + col;
     }
     voff[i] = (uint32_t)(e * 2);
@@ -141,7 +149,8 @@ __device__ __forceinline__ void reg_tile(char* tile, const bf16_t* __restrict__ 
       const int kr = c / (T / 8), ch = c % (T / 8);
       const int gk = k0 + kr, gcol = min(row0 + ch * 8, rows_total - 8);
       if (gk < kend) z = *reinterpret_cast<const uint4*>(base + (long)gk * ld + gcol);
-      off = kr * Tile<T>::KS_ROWB + ((ch ^ (ks_f(kr) << 1)) << 4);
+      constexpr int TH8 = Tile<T>::KS_T / 8;
+      off = (ch / TH8) * Tile<T>::KS_IMG + kr * Tile<T>::KS_ROWB + (((ch % TH8) ^ (ks_f(kr) << 1)) << 4);
     }
     *reinterpret_cast<uint4*>(tile + off) = z;
   }
@@ -159,6 +168,7 @@ __device__ __forceinline__ void lds_frags(bf16x8* f, const char* tile, int idx0,
     }
   } else {
     static_assert(N == 1 || (N % 2) == 0, "transposed fragment reads go in groups of 4 or 2");
+    if (T == 256 && idx0 >= 128) { tile += Tile<T>::KS_IMG; idx0 -= 128; }      // the second image (a group of fragments never straddles)
     const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
     const int ka = 32 * h + 8 * g + q;                  // k-rows ka (elements 0..3) and ka+4 (elements 4..7)
     const uint32_t ra = lds_off(tile) + ka * Tile<T>::KS_ROWB + pp * 8, rb = ra + 4 * Tile<T>::KS_ROWB;
@@ -393,28 +403,58 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   // BEFORE the read, and a barrier follows it in both wave groups before either group reads.  A half tile's buffer is
   // re-filled one phase after its last read; lgkmcnt(0) before the load segment's closing barrier makes those reads
   // complete before any wave can issue the refill.
-  constexpr bool PH8 = RK && SK && BM == 256 && BN == 256 && NWM == 2 && NWN == 4 && (UR_GEMM_ABLATE == 0) && !UR_GEMM_NO_PH8;
+  // The same loop serves the token reductions (dW = dY^T X: BOTH operands K-strided): a half tile is one 16 KiB image there too
+  // ([64 k][128 columns]), filled by two LDS-DMA pieces per wave (4 k-rows x 256 B each) and read with transposed LDS reads into
+  // the same fragment registers; phases, counted waits and hazards are unchanged.
+  constexpr bool PH8 = (RK == SK) && BM == 256 && BN == 256 && NWM == 2 && NWN == 4 && (UR_GEMM_ABLATE == 0) && !UR_GEMM_NO_PH8;
   if constexpr (PH8) {
     if (interior && nfull1 >= 3) {
+      constexpr bool KC = RK;
       const int l15 = lane & 15, g4 = lane >> 4;
       const uint32_t lo0 = l15 * 128 + (((g4) ^ ((l15 >> 1) & 7)) << 4), lo1 = l15 * 128 + (((4 + g4) ^ ((l15 >> 1) & 7)) << 4);
       bf16x8 R0[4][2], R1[4][2], S0[2][2], S1[2][2];
       auto rdR = [&](bf16x8 (&F)[4][2], const char* slot, int rh) {
-        const char* b = slot + S_BYTES + (rh * 128 + wr * 64) * 128;
+        if constexpr (KC) {
+          const char* b = slot + S_BYTES + (rh * 128 + wr * 64) * 128;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          F[jj][0] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + lo0);
-          F[jj][1] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + lo1);
+          for (int jj = 0; jj < 4; ++jj) {
+            F[jj][0] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + lo0);
+            F[jj][1] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + lo1);
+          }
+        } else {
+          bf16x8 t4[4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            lds_frags<false, 128, 4>(t4, slot + S_BYTES + rh * 16384, wr * 64, h, lane);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) F[jj][h] = t4[jj];
+          }
         }
       };
       auto rdS = [&](bf16x8 (&F)[2][2], const char* slot, int sh) {
-        const char* b = slot + (sh * 128 + wc * 32) * 128;
+        if constexpr (KC) {
+          const char* b = slot + (sh * 128 + wc * 32) * 128;
 #pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-          F[ii][0] = *reinterpret_cast<const bf16x8*>(b + ii * 2048 + lo0);
-          F[ii][1] = *reinterpret_cast<const bf16x8*>(b + ii * 2048 + lo1);
+          for (int ii = 0; ii < 2; ++ii) {
+            F[ii][0] = *reinterpret_cast<const bf16x8*>(b + ii * 2048 + lo0);
+            F[ii][1] = *reinterpret_cast<const bf16x8*>(b + ii * 2048 + lo1);
+          }
+        } else {
+          bf16x8 t2[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            lds_frags<false, 128, 2>(t2, slot + sh * 16384, wc * 32, h, lane);
+            F[0][h] = t2[0]; F[1][h] = t2[1];
+          }
         }
       };
+      // K-strided pieces: piece d of half hf = k-rows 32 d + 4 wave + (lane >> 4), 16-byte chunk lane & 15 of the half's 128 columns;
+      // the swizzle term f = ks_f(k-row) depends on the lane and on (wave >> 1) & 1 only: one lane offset per operand
+      const int tf = ((lane >> 4) & 3) | (((uwave >> 1) & 1) << 2);
+      const uint32_t tsv = (uint32_t)(((long)(lane >> 4) * p.lds + (((lane & 15) ^ (tf << 1)) << 3)) * 2);
+      const uint32_t trv = (uint32_t)(((long)(lane >> 4) * p.ldr + (((lane & 15) ^ (tf << 1)) << 3)) * 2);
+      const long tsw = (long)uwave * 4 * p.lds * 2, trw = (long)uwave * 4 * p.ldr * 2;          // the wave's first k-row
+      const long tsd = (long)32 * p.lds * 2, trd = (long)32 * p.ldr * 2;                        // piece 0 -> piece 1
       auto quad = [&](const bf16x8 (&S)[2][2], const bf16x8 (&R)[4][2], auto shc, auto rhc) {
         constexpr int sh = decltype(shc)::value, rh = decltype(rhc)::value;
         __builtin_amdgcn_s_setprio(1);
@@ -433,7 +473,9 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
           const int li = 2 * hf + d;
-          const char* src = ub + li * (IS_S ? spiece : rpiece) + (IS_S ? svoff0 : rvoff0);
+          const char* src;
+          if constexpr (KC) src = ub + li * (IS_S ? spiece : rpiece) + (IS_S ? svoff0 : rvoff0);
+          else src = ub + hf * 256 + (IS_S ? tsw + d * tsd : trw + d * trd) + (IS_S ? tsv : trv);
           char* dst = slot + (IS_S ? 0 : S_BYTES) + (li * (NT / 64) + uwave) * 1024;
           __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
         }
