@@ -410,6 +410,18 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
   if constexpr (PH8) {
     if (interior && nfull1 >= 3) {
       constexpr bool KC = RK;
+      // K-strided fragment (16 columns c, k-half h) = two transposed 4-row reads at k-rows 32 h + 8 g + q (+ 4): the swizzle term
+      // f = q | (g & 1) << 2 does not depend on h, so a lane needs ONE offset per fragment -- the k-half, the k-row + 4 and the half
+      // tile are immediates of the read (lds_frags spends ~30 vector instructions and a full wait per group on the same addresses)
+      uint32_t toffR[4], toffS[2];
+      {
+        const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3, tfz = tq | ((tg & 1) << 2);
+        const uint32_t l0 = (uint32_t)((8 * tg + tq) * 256 + tp * 8);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) toffR[jj] = l0 + (uint32_t)(((((wr * 4) ^ (tfz & 4)) | (jj ^ (tfz & 3)))) << 5);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) toffS[ii] = l0 + (uint32_t)(((((wc * 2) ^ (tfz & 6)) | (ii ^ (tfz & 1)))) << 5);
+      }
       const int l15 = lane & 15, g4 = lane >> 4;
       const uint32_t lo0 = l15 * 128 + (((g4) ^ ((l15 >> 1) & 7)) << 4), lo1 = l15 * 128 + (((4 + g4) ^ ((l15 >> 1) & 7)) << 4);
       bf16x8 R0[4][2], R1[4][2], S0[2][2], S1[2][2];
@@ -422,13 +434,26 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
             F[jj][1] = *reinterpret_cast<const bf16x8*>(b + jj * 2048 + lo1);
           }
         } else {
-          bf16x8 t4[4];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            lds_frags<false, 128, 4>(t4, slot + S_BYTES + rh * 16384, wr * 64, h, lane);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) F[jj][h] = t4[jj];
-          }
+          // (inline asm, one wait for the sixteen reads: as a builtin the read is a tracked LDS load, and hipcc drains the LDS-DMA
+          // queue -- s_waitcnt vmcnt(0) -- in front of every group because the pieces in flight may alias it)
+          const uint32_t b = lds_off(slot) + S_BYTES + rh * 16384;
+          const uint32_t a0 = b + toffR[0], a1 = b + toffR[1], a2 = b + toffR[2], a3 = b + toffR[3];
+          bf16x4 q00, q01, q02, q03, q10, q11, q12, q13, q20, q21, q22, q23, q30, q31, q32, q33;
+          asm volatile(
+              "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:1024\n\t"
+              "ds_read_b64_tr_b16 %2, %16 offset:8192\n\tds_read_b64_tr_b16 %3, %16 offset:9216\n\t"
+              "ds_read_b64_tr_b16 %4, %17\n\tds_read_b64_tr_b16 %5, %17 offset:1024\n\t"
+              "ds_read_b64_tr_b16 %6, %17 offset:8192\n\tds_read_b64_tr_b16 %7, %17 offset:9216\n\t"
+              "ds_read_b64_tr_b16 %8, %18\n\tds_read_b64_tr_b16 %9, %18 offset:1024\n\t"
+              "ds_read_b64_tr_b16 %10, %18 offset:8192\n\tds_read_b64_tr_b16 %11, %18 offset:9216\n\t"
+              "ds_read_b64_tr_b16 %12, %19\n\tds_read_b64_tr_b16 %13, %19 offset:1024\n\t"
+              "ds_read_b64_tr_b16 %14, %19 offset:8192\n\tds_read_b64_tr_b16 %15, %19 offset:9216\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(q00), "=&v"(q01), "=&v"(q02), "=&v"(q03), "=&v"(q10), "=&v"(q11), "=&v"(q12), "=&v"(q13),
+                "=&v"(q20), "=&v"(q21), "=&v"(q22), "=&v"(q23), "=&v"(q30), "=&v"(q31), "=&v"(q32), "=&v"(q33)
+              : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+          F[0][0] = cat4(q00, q01); F[0][1] = cat4(q02, q03); F[1][0] = cat4(q10, q11); F[1][1] = cat4(q12, q13);
+          F[2][0] = cat4(q20, q21); F[2][1] = cat4(q22, q23); F[3][0] = cat4(q30, q31); F[3][1] = cat4(q32, q33);
         }
       };
       auto rdS = [&](bf16x8 (&F)[2][2], const char* slot, int sh) {
@@ -440,12 +465,18 @@ __global__ __launch_bounds__(NWM * NWN * 64, 2) void gemm_kernel(GemmP p) {
             F[ii][1] = *reinterpret_cast<const bf16x8*>(b + ii * 2048 + lo1);
           }
         } else {
-          bf16x8 t2[2];
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            lds_frags<false, 128, 2>(t2, slot + sh * 16384, wc * 32, h, lane);
-            F[0][h] = t2[0]; F[1][h] = t2[1];
-          }
+          const uint32_t b = lds_off(slot) + sh * 16384;
+          const uint32_t a0 = b + toffS[0], a1 = b + toffS[1];
+          bf16x4 q00, q01, q02, q03, q10, q11, q12, q13;
+          asm volatile(
+              "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:1024\n\t"
+              "ds_read_b64_tr_b16 %2, %8 offset:8192\n\tds_read_b64_tr_b16 %3, %8 offset:9216\n\t"
+              "ds_read_b64_tr_b16 %4, %9\n\tds_read_b64_tr_b16 %5, %9 offset:1024\n\t"
+              "ds_read_b64_tr_b16 %6, %9 offset:8192\n\tds_read_b64_tr_b16 %7, %9 offset:9216\n\t"
+              "s_waitcnt lgkmcnt(0)"
+              : "=&v"(q00), "=&v"(q01), "=&v"(q02), "=&v"(q03), "=&v"(q10), "=&v"(q11), "=&v"(q12), "=&v"(q13)
+              : "v"(a0), "v"(a1));
+          F[0][0] = cat4(q00, q01); F[0][1] = cat4(q02, q03); F[1][0] = cat4(q10, q11); F[1][1] = cat4(q12, q13);
         }
       };
       // K-strided pieces: piece d of half hf = k-rows 32 d + 4 wave + (lane >> 4), 16-byte chunk lane & 15 of the half's 128 columns;
