@@ -15,7 +15,15 @@ BF16 = torch.bfloat16
 F32 = torch.float32
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as an integer handle.  (torch.cuda.current_stream() builds a Stream object per
+    call: 2.7 us, on every one of the ~870 launches of an item-stage step; the raw query is 0.3 us.)"""
+    if _raw_stream is not None and _get_device is not None:
+        return _raw_stream(_get_device())
     return torch.cuda.current_stream().cuda_stream
 
 

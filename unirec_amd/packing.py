@@ -40,6 +40,7 @@ class ParamPack:
             self.shapes[n] = tuple(p.shape)
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
+        self._views = {}
         self.device = norm_device(device)
         self.master = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.shadow = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
@@ -53,6 +54,14 @@ class ParamPack:
         self.live = set()          # names whose gradient entry a backward has written since the last clear_grads()
 
     def _view(self, flat, name, shape=None):
+        # (views are cached: a Q-Former step asks for ~330 of them, 4 us of slicing + reshaping each; the flat buffers never move)
+        key = (id(flat), name, shape)
+        v = self._views.get(key)
+        if v is None:
+            v = self._views[key] = self._make_view(flat, name, shape)
+        return v
+
+    def _make_view(self, flat, name, shape=None):
         o = self.offsets[name]
         shp = self.shapes[name] if shape is None else shape
         n = 1
@@ -77,6 +86,13 @@ class ParamPack:
 
     def fused(self, flat, names, rows_each=None):
         """One 2-D (or 1-D) view spanning several ADJACENT tensors with equal trailing shape."""
+        key = (id(flat), tuple(names))
+        v = self._views.get(key)
+        if v is None:
+            v = self._views[key] = self._make_fused(flat, names)
+        return v
+
+    def _make_fused(self, flat, names):
         first = names[0]
         o = self.offsets[first]
         total_rows = 0
