@@ -449,7 +449,7 @@ def measure_stage(args, rank, world, device):
                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": args.workload, "per_gpu_batch": B, "global_batch": B * world, "dropout": "off" if args.no_dropout else "on",
                           "parallelism": f"dp{world}"},
-               "step_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1), "loss": round(float(loss), 5),
+               "step_tflops_per_gpu": round(flops / (dt / args.steps) / 1e12, 1), "loss": round(float(loss.detach()), 5),
                "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "comm": _comm_info(world)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
@@ -713,7 +713,7 @@ def main():
             sa = argparse.Namespace(**{**vars(args), "workload": wl, "steps": args.stage_steps, "warmup": 3, "cpu_budget": args.stage_cpu_budget})
             so = measure_stage(sa, rank, world, device)
             if rank == 0:
-                stages[key] = {k: so[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "step_tflops_per_gpu", "max_mem_gb", "config", "roofline") if k in so}
+                stages[key] = {k: so[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "host_issue_ms_per_step", "step_tflops_per_gpu", "max_mem_gb", "config", "roofline") if k in so}
                 if "cpu_baseline" in so:
                     stages[key]["cpu_baseline"] = so["cpu_baseline"]
             gc.collect(); torch.cuda.empty_cache()
