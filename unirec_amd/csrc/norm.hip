@@ -61,9 +61,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[i][e] += r[e];
         }
-        if (zsave) {   // round z to bf16 first so forward and backward see the same z
+        {   // round z to bf16 first so forward and backward see the same z (also when no z is kept: a no-grad forward is bit-identical)
           uint4 pk = pack8(v[i]);
-          *reinterpret_cast<uint4*>(zsave + roff + e0) = pk;
+          if (zsave) *reinterpret_cast<uint4*>(zsave + roff + e0) = pk;
           unpack8(pk, v[i]);
         }
 #pragma unroll

@@ -347,7 +347,7 @@ class BertModel(nn.Module):
              "qe_rows": qe16.shape[0], "step_seed": self._step, "row0": row0}
         w = lambda n: pack.w32(pre + n)
         x, z0, mean0, rstd0 = hip.layernorm_fwd(qe16, w("embeddings.LayerNorm.weight"), w("embeddings.LayerNorm.bias"), eps,
-                                                M=M, p_post=p_h, seed_post=self._seed(1023, 0), drop_row0=row0)
+                                                M=M, p_post=p_h, seed_post=self._seed(1023, 0), drop_row0=row0, save_z=keep)
         S["emb"] = (z0, mean0, rstd0, self._seed(1023, 0))
         # ---- the cross-attention keys | values of EVERY layer: one projection of the encoder states (its input does not depend on the layer)
         kvw, kvb = self._cross_kv_names(pre)
@@ -369,7 +369,7 @@ class BertModel(nn.Module):
             y = hip.gemm(ctx_o.view(M, H), pack.w16(a + "output.dense.weight"), bias=pack.w32(a + "output.dense.bias"))
             s_h = self._seed(i, 2)
             x1, z1, m1, r1 = hip.layernorm_fwd(y, pack.w32(a + "output.LayerNorm.weight"), pack.w32(a + "output.LayerNorm.bias"),
-                                               eps, residual=x, p_pre=p_h, seed_pre=s_h, drop_row0=row0)
+                                               eps, residual=x, p_pre=p_h, seed_pre=s_h, drop_row0=row0, save_z=keep)
             L["self"] = (x, qkv, actx, ctx_o, z1, m1, r1, s_h)
             xc = x1
             # ---- cross attention (models/qformer.py:432-447)
@@ -383,7 +383,7 @@ class BertModel(nn.Module):
                 y2 = hip.gemm(ctx2.view(M, H), pack.w16(c + "output.dense.weight"), bias=pack.w32(c + "output.dense.bias"))
                 s_h2 = self._seed(i, 4)
                 x2, z2, m2, r2 = hip.layernorm_fwd(y2, pack.w32(c + "output.LayerNorm.weight"),
-                                                   pack.w32(c + "output.LayerNorm.bias"), eps, residual=x1, p_pre=p_h, seed_pre=s_h2, drop_row0=row0)
+                                                   pack.w32(c + "output.LayerNorm.bias"), eps, residual=x1, p_pre=p_h, seed_pre=s_h2, drop_row0=row0, save_z=keep)
                 L["cross"] = (x1, qc, jc, actx2, ctx2, z2, m2, r2, s_h2)
                 jc += 1
                 xc = x2
@@ -394,7 +394,7 @@ class BertModel(nn.Module):
             y3 = hip.gemm(hbuf, pack.w16(f2 + "dense.weight"), bias=pack.w32(f2 + "dense.bias"))
             s_h3 = self._seed(i, 5)
             x3, z3, m3, r3 = hip.layernorm_fwd(y3, pack.w32(f2 + "LayerNorm.weight"), pack.w32(f2 + "LayerNorm.bias"), eps,
-                                               residual=xc, p_pre=p_h, seed_pre=s_h3, drop_row0=row0)
+                                               residual=xc, p_pre=p_h, seed_pre=s_h3, drop_row0=row0, save_z=keep)
             L["ffn"] = (xc, u, hbuf, z3, m3, r3, s_h3)
             if keep:
                 S["layers"].append(L)
