@@ -136,3 +136,36 @@ def test_dropout_training_mode_is_reproducible_per_step():
     assert torch.equal(a, c) and not torch.equal(a, b)
     a.sum().backward()
     assert torch.isfinite(m.query_embeddings.grad).all()
+
+
+def test_gradient_checkpointing_is_bit_identical():
+    """/root/reference/models/qformer.py:525-548: `config.gradient_checkpointing` in training re-runs each layer's forward inside the
+    backward.  Here the re-run uses the same kernels and the dropout seeds of the recorded step: outputs and every parameter
+    gradient equal the plain run bit for bit (dropout on, cross-attention in every second layer, key mask), and the switch is
+    inert in eval mode / without grad."""
+    from unirec_amd.qformer_model import QFormerForItemRepresentation
+    torch.manual_seed(0)
+    m = QFormerForItemRepresentation(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256,
+                                     num_query_tokens=8, field_embedding_dim=64, num_fields=6, dropout=0.2).to(DEV).train()
+    x = torch.randn(16, 6, 64, device=DEV)
+    mask = (torch.rand(16, 6, device=DEV) < 0.7).long()
+    mask[:, 0] = 1
+    w = torch.randn(16, 8, 128, device=DEV)
+
+    def run(ckpt):
+        m.qformer.config.gradient_checkpointing = ckpt
+        m.qformer._step = 0
+        m.zero_grad(set_to_none=True)
+        out = m(x, mask)["query_outputs"]
+        (out.float() * w).sum().backward()
+        return out.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    o0, g0 = run(False)
+    o1, g1 = run(True)
+    assert torch.equal(o0, o1)
+    assert g0.keys() == g1.keys() and len(g0) > 40
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+    m.qformer._step = 0
+    with torch.no_grad():
+        assert torch.equal(m(x, mask)["query_outputs"], o0)
+    m.qformer.config.gradient_checkpointing = False

@@ -322,16 +322,15 @@ class BertModel(nn.Module):
         pa = float(self.config.attention_probs_dropout_prob) if self.training else 0.0
         return p, pa
 
-    def _seed(self, layer, site):
-        return (self.seed * 1000003 + self._step * 8191 + layer * 64 + site) & 0x7FFFFFFFFFFFFFFF
+    def _seed(self, layer, site, step=None):
+        return (self.seed * 1000003 + (self._step if step is None else step) * 8191 + layer * 64 + site) & 0x7FFFFFFFFFFFFFFF
 
     def _forward_impl(self, query_embeds, enc, mask_u8, B, keep=True):
         cfg = self.config
         pack = self._ensure_pack(query_embeds.device)
         pre = self._names()
         pack.refresh_shadow()
-        H, nh, I, eps = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size, cfg.layer_norm_eps
-        dh = H // nh
+        H, eps = cfg.hidden_size, cfg.layer_norm_eps
         Qn = query_embeds.shape[1]
         T = enc.shape[1]
         M, Me = B * Qn, B * T
@@ -343,8 +342,11 @@ class BertModel(nn.Module):
         enc16 = (hip.cast_f32_to_bf16(enc.detach().contiguous()) if enc.dtype == F32 else enc.detach().contiguous()).view(Me, -1)
         b0 = int(self.sample_offset) if self.sample_offset is not None else int(self.dp_rank) * B
         row0 = b0 * Qn                                   # rows of [B*Q, H] activations that precede this shard
+        # models/qformer.py:525-548: `config.gradient_checkpointing` in training keeps each layer's INPUT only; the backward re-runs the
+        # layer's forward (same kernels, same dropout seeds: bit-identical activations) before it walks the layer
+        ckpt = bool(keep and self.training and getattr(cfg, "gradient_checkpointing", False))
         S = {"B": B, "Q": Qn, "T": T, "p_h": p_h, "p_a": p_a, "layers": [], "enc16": enc16, "mask": mask_u8,
-             "qe_rows": qe16.shape[0], "step_seed": self._step, "row0": row0}
+             "qe_rows": qe16.shape[0], "step_seed": self._step, "row0": row0, "b0": b0, "ckpt": ckpt}
         w = lambda n: pack.w32(pre + n)
         x, z0, mean0, rstd0 = hip.layernorm_fwd(qe16, w("embeddings.LayerNorm.weight"), w("embeddings.LayerNorm.bias"), eps,
                                                 M=M, p_post=p_h, seed_post=self._seed(1023, 0), drop_row0=row0, save_z=keep)
@@ -354,52 +356,63 @@ class BertModel(nn.Module):
         ncross = len(kvw) // 2
         kv_all = hip.gemm(enc16, pack.fused16(kvw), bias=pack.fused32(kvb)) if ncross else None      # [B*T, ncross * 2H]
         S["kv_all"] = kv_all
-        jc = 0
-        for i, lyr in enumerate(self.encoder.layer):
-            lp = pre + f"encoder.layer.{i}."
-            L = {}
-            # ---- self attention
-            a = lp + "attention."
-            Wqkv = pack.fused16([a + "self.query.weight", a + "self.key.weight", a + "self.value.weight"])
-            bqkv = pack.fused32([a + "self.query.bias", a + "self.key.bias", a + "self.value.bias"])
-            qkv = hip.gemm(x, Wqkv, bias=bqkv)
-            q5 = qkv.view(B, Qn, 3, nh, dh)
-            s_att = self._seed(i, 1)
-            ctx_o, actx = hip.attn_fwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=False, dropout_p=p_a, seed=s_att, drop_batch0=b0)
-            y = hip.gemm(ctx_o.view(M, H), pack.w16(a + "output.dense.weight"), bias=pack.w32(a + "output.dense.bias"))
-            s_h = self._seed(i, 2)
-            x1, z1, m1, r1 = hip.layernorm_fwd(y, pack.w32(a + "output.LayerNorm.weight"), pack.w32(a + "output.LayerNorm.bias"),
-                                               eps, residual=x, p_pre=p_h, seed_pre=s_h, drop_row0=row0, save_z=keep)
-            L["self"] = (x, qkv, actx, ctx_o, z1, m1, r1, s_h)
-            xc = x1
-            # ---- cross attention (models/qformer.py:432-447)
-            if lyr.has_cross_attention:
-                c = lp + "crossattention."
-                qc = hip.gemm(x1, pack.w16(c + "self.query.weight"), bias=pack.w32(c + "self.query.bias"))
-                kv5 = kv_all.view(B, T, ncross, 2, nh, dh)[:, :, jc]
-                s_att2 = self._seed(i, 3)
-                ctx2, actx2 = hip.attn_fwd(qc.view(B, Qn, nh, dh), kv5[:, :, 0], kv5[:, :, 1], causal=False, key_mask=mask_u8,
-                                           dropout_p=p_a, seed=s_att2, drop_batch0=b0)
-                y2 = hip.gemm(ctx2.view(M, H), pack.w16(c + "output.dense.weight"), bias=pack.w32(c + "output.dense.bias"))
-                s_h2 = self._seed(i, 4)
-                x2, z2, m2, r2 = hip.layernorm_fwd(y2, pack.w32(c + "output.LayerNorm.weight"),
-                                                   pack.w32(c + "output.LayerNorm.bias"), eps, residual=x1, p_pre=p_h, seed_pre=s_h2, drop_row0=row0, save_z=keep)
-                L["cross"] = (x1, qc, jc, actx2, ctx2, z2, m2, r2, s_h2)
-                jc += 1
-                xc = x2
-            # ---- query FFN (models/qformer.py:449-454, 481-484)
-            f1, f2 = lp + "intermediate_query.dense.", lp + "output_query."
-            hbuf = torch.empty((M, I), dtype=BF16, device=x.device)
-            u = hip.gemm(xc, pack.w16(f1 + "weight"), bias=pack.w32(f1 + "bias"), gelu_out=hbuf)
-            y3 = hip.gemm(hbuf, pack.w16(f2 + "dense.weight"), bias=pack.w32(f2 + "dense.bias"))
-            s_h3 = self._seed(i, 5)
-            x3, z3, m3, r3 = hip.layernorm_fwd(y3, pack.w32(f2 + "LayerNorm.weight"), pack.w32(f2 + "LayerNorm.bias"), eps,
-                                               residual=xc, p_pre=p_h, seed_pre=s_h3, drop_row0=row0, save_z=keep)
-            L["ffn"] = (xc, u, hbuf, z3, m3, r3, s_h3)
+        for i in range(len(self.encoder.layer)):
+            x_in = x
+            x, L = self._layer_forward(i, x, S, pack, pre, save=keep and not ckpt)
             if keep:
-                S["layers"].append(L)
-            x = x3
+                S["layers"].append({"x_in": x_in} if ckpt else L)
         return x.view(B, Qn, H), (S if keep else None)
+
+    def _layer_forward(self, i, x, S, pack, pre, save):
+        """One encoder layer on x [B*Q, H] (models/qformer.py:409-511) -> (output, what its backward needs).  Dropout seeds come from the
+        step counter recorded in S, so a re-run under `gradient_checkpointing` reproduces the first run bit for bit."""
+        cfg = self.config
+        lyr = self.encoder.layer[i]
+        H, nh, I, eps = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size, cfg.layer_norm_eps
+        dh = H // nh
+        B, Qn, T, p_h, p_a, row0, b0, mask_u8, kv_all = S["B"], S["Q"], S["T"], S["p_h"], S["p_a"], S["row0"], S["b0"], S["mask"], S["kv_all"]
+        M = B * Qn
+        seed = lambda site: self._seed(i, site, step=S["step_seed"])
+        lp = pre + f"encoder.layer.{i}."
+        L = {}
+        # ---- self attention
+        a = lp + "attention."
+        Wqkv = pack.fused16([a + "self.query.weight", a + "self.key.weight", a + "self.value.weight"])
+        bqkv = pack.fused32([a + "self.query.bias", a + "self.key.bias", a + "self.value.bias"])
+        qkv = hip.gemm(x, Wqkv, bias=bqkv)
+        q5 = qkv.view(B, Qn, 3, nh, dh)
+        ctx_o, actx = hip.attn_fwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], causal=False, dropout_p=p_a, seed=seed(1), drop_batch0=b0)
+        y = hip.gemm(ctx_o.view(M, H), pack.w16(a + "output.dense.weight"), bias=pack.w32(a + "output.dense.bias"))
+        s_h = seed(2)
+        x1, z1, m1, r1 = hip.layernorm_fwd(y, pack.w32(a + "output.LayerNorm.weight"), pack.w32(a + "output.LayerNorm.bias"),
+                                           eps, residual=x, p_pre=p_h, seed_pre=s_h, drop_row0=row0, save_z=save)
+        L["self"] = (x, qkv, actx, ctx_o, z1, m1, r1, s_h)
+        xc = x1
+        # ---- cross attention (models/qformer.py:432-447)
+        if lyr.has_cross_attention:
+            c = lp + "crossattention."
+            ncross = kv_all.shape[1] // (2 * H)
+            jc = sum(1 for l2 in self.encoder.layer[:i] if l2.has_cross_attention)
+            qc = hip.gemm(x1, pack.w16(c + "self.query.weight"), bias=pack.w32(c + "self.query.bias"))
+            kv5 = kv_all.view(B, T, ncross, 2, nh, dh)[:, :, jc]
+            ctx2, actx2 = hip.attn_fwd(qc.view(B, Qn, nh, dh), kv5[:, :, 0], kv5[:, :, 1], causal=False, key_mask=mask_u8,
+                                       dropout_p=p_a, seed=seed(3), drop_batch0=b0)
+            y2 = hip.gemm(ctx2.view(M, H), pack.w16(c + "output.dense.weight"), bias=pack.w32(c + "output.dense.bias"))
+            s_h2 = seed(4)
+            x2, z2, m2, r2 = hip.layernorm_fwd(y2, pack.w32(c + "output.LayerNorm.weight"),
+                                               pack.w32(c + "output.LayerNorm.bias"), eps, residual=x1, p_pre=p_h, seed_pre=s_h2, drop_row0=row0, save_z=save)
+            L["cross"] = (x1, qc, jc, actx2, ctx2, z2, m2, r2, s_h2)
+            xc = x2
+        # ---- query FFN (models/qformer.py:449-454, 481-484)
+        f1, f2 = lp + "intermediate_query.dense.", lp + "output_query."
+        hbuf = torch.empty((M, I), dtype=BF16, device=x.device)
+        u = hip.gemm(xc, pack.w16(f1 + "weight"), bias=pack.w32(f1 + "bias"), gelu_out=hbuf)
+        y3 = hip.gemm(hbuf, pack.w16(f2 + "dense.weight"), bias=pack.w32(f2 + "dense.bias"))
+        s_h3 = seed(5)
+        x3, z3, m3, r3 = hip.layernorm_fwd(y3, pack.w32(f2 + "LayerNorm.weight"), pack.w32(f2 + "LayerNorm.bias"), eps,
+                                           residual=xc, p_pre=p_h, seed_pre=s_h3, drop_row0=row0, save_z=save)
+        L["ffn"] = (xc, u, hbuf, z3, m3, r3, s_h3)
+        return x3, L
 
     def _weight_transposes(self, pack, pre, with_enc):
         """W^T of every weight a dX product reads (dx = dy W), refreshed by ONE launch per backward: with [in, out] copies the
@@ -463,6 +476,8 @@ class BertModel(nn.Module):
         for i in reversed(range(len(self.encoder.layer))):
             lyr = self.encoder.layer[i]
             L = S["layers"][i]
+            if S["ckpt"]:          # gradient checkpointing: the layer's activations are rebuilt from its saved input
+                L = self._layer_forward(i, L["x_in"], S, pack, pre, save=True)[1]
             lp = pre + f"encoder.layer.{i}."
             # ---- FFN
             xc, u, hbuf, z3, m3, r3, s_h3 = L["ffn"]
@@ -505,6 +520,7 @@ class BertModel(nn.Module):
             hip.colsum(dqkv, out=pack.fusedg([a + "self.query.bias", a + "self.key.bias", a + "self.value.bias"]))
             dx = dX(dqkv, names, residual=dz1)
             L.clear()
+            S["layers"][i].clear()
             if self.grad_ready_hook is not None:      # dp.GradBuckets: layer i's gradients are final
                 self.grad_ready_hook(i)
         # ---- the cross-attention K | V projections of all layers: one token reduction, one bias sum (and one dX for the encoder states)
