@@ -576,17 +576,21 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    hip.PROFILE = []
-    hip.PROFILE_ATTN = []
-    hip.PROFILE_STREAM = []
+    # Inside the timed region: HIP events around the launches of the DOMINANT family only (the projection GEMMs: `roofline`).  The events
+    # of the attention launches and of the HBM-bound families (1000+ more per step; every timed record is a barrier packet, together
+    # 4-6 ms of a 425 ms step: same-box A/B with UNIREC_BENCH_EVENTS=0) run in a separate pass of the same step after the timed region.
+    ev_in_loop = os.environ.get("UNIREC_BENCH_EVENTS", "1") != "0"      # lab: 0 = no HIP events inside the timed region at all
+    if ev_in_loop:
+        hip.PROFILE = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     sync()
     dt = time.perf_counter() - t0
+    if not ev_in_loop:
+        print(json.dumps({"ms_per_step_without_events": round(dt / args.steps * 1e3, 2)}), flush=True)
+        return
     prof, hip.PROFILE = hip.PROFILE, None
-    aprof, hip.PROFILE_ATTN = hip.PROFILE_ATTN, None
-    sprof, hip.PROFILE_STREAM = hip.PROFILE_STREAM, None
     if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -597,6 +601,14 @@ def main():
     # what the timed steps left in the trainable parameters (f64 sums of the flat fp32 masters): equal runs give equal digits,
     # and under data parallelism every rank must print the same ones (tests/test_gpu_dp_rccl.py)
     checksum = {"lora": float(lpack.master.double().abs().sum().item()), "qformer": float(qpack.master.double().abs().sum().item())}
+    # the side pass: attention and HBM-bound family events (all ranks run it: the step holds collectives)
+    nside = max(1, min(args.steps, 3))
+    hip.PROFILE_ATTN, hip.PROFILE_STREAM = [], []
+    for _ in range(nside):
+        step()
+    sync()
+    aprof, hip.PROFILE_ATTN = hip.PROFILE_ATTN, None
+    sprof, hip.PROFILE_STREAM = hip.PROFILE_STREAM, None
 
     if rank == 0:
         # ---- roofline of the dominant kernel: forward projection GEMM gemm_kernel<RK=1,SK=1,bf16> -----
@@ -626,7 +638,7 @@ def main():
         for (e0, e1, family, nbytes) in sprof:
             f_ = fam.setdefault(family, [0.0, 0, 0])
             f_[0] += e0.elapsed_time(e1); f_[1] += nbytes; f_[2] += 1
-        streams = {k: {"launches": v[2], "ms_per_step": round(v[0] / args.steps, 3), "GB_per_s": round(v[1] / max(v[0], 1e-9) / 1e6, 1),
+        streams = {k: {"launches": v[2], "ms_per_step": round(v[0] / nside, 3), "GB_per_s": round(v[1] / max(v[0], 1e-9) / 1e6, 1),
                        "hbm_fraction": round(v[1] / max(v[0], 1e-9) / 1e6 / peaks["hbm_GBps_spec"], 4)} for k, v in sorted(fam.items())}
         if "lora_bits" in streams:
             # the flag planes (and their token-packed copies) of step n + 1 are generated on a SIDE stream under step n's Q-Former backward:
@@ -672,7 +684,7 @@ def main():
             if acausal and ahd == 128:
                 f = 4.0 * aB * anq * aSq * aSk * ahd / 2 * (1.0 if kind == "fwd" else 2.5)
                 att[kind][0] += e0.elapsed_time(e1); att[kind][1] += f; att[kind][2] += 1
-        attn = {k: {"launches": v[2], "avg_launch_ms": round(v[0] / max(v[2], 1), 4), "ms_per_step": round(v[0] / args.steps, 2),
+        attn = {k: {"launches": v[2], "avg_launch_ms": round(v[0] / max(v[2], 1), 4), "ms_per_step": round(v[0] / nside, 2),
                     "tflops": round(v[1] / max(v[0], 1e-9) / 1e9, 1), "frac_of_peak": round(v[1] / max(v[0], 1e-9) / 1e9 / 2500.0, 4)} for k, v in att.items()}
         # ... and on the EXECUTED FLOPs: what the kernels issue for this batch's masks (whole 64-key tiles incl. the masked half of
         # the diagonal ones, minus the leading all-padding key tiles they skip) -- the honest MFMA utilisation of the kernels
@@ -680,6 +692,7 @@ def main():
         for k in ("fwd", "bwd"):
             attn[k]["executed_over_algorithmic"] = round(ex[k], 4)
             attn[k]["frac_of_peak_executed"] = round(attn[k]["frac_of_peak"] * ex[k], 4)
+        attn["events"] = streams["_events"] = f"separate pass of {nside} steps right after the timed region (same process, same batch)"
         attn["kernels"] = ("attn_fwd_c128_kernel; attn_bwd_dq_c128_kernel + attn_bwd_dkv_c128_kernel (one ur_attn_bwd call): main loops "
                            "generated by tools/asmgen (one wave per SIMD, hand-scheduled); executed_over_algorithmic counts the MFMAs they issue: "
                            "forward incl. the row-sum products, backward 7 contractions for the 5 algorithmic ones (S and dP in both kernels)")
