@@ -69,6 +69,24 @@ def test_gemm_big_tile_k_strided_exact(M, N, K, split, rk, sk):
     assert torch.equal(out32.double().cpu(), ref), f"max err {(out32.double().cpu() - ref).abs().max()}"
 
 
+def test_gemm_big_tile_k_strided_stress_exact():
+    """The K-strided 8-phase loop keeps three half tiles of LDS-DMA in flight behind counted waits: exact integer results, repeated
+    under memory load from a second stream (a scheduling hazard shows up as rare wrong tiles), over 128 K tiles per workgroup."""
+    M, N, K, split = 1024, 4096, 32768, 4
+    Rm, Sm = _ints((M, K), seed=21), _ints((N, K), seed=22)
+    R, S = _bf(Rm.t()), _bf(Sm.t())
+    ref = (Rm.to(DEV).double() @ Sm.to(DEV).double().t()).float()
+    big = torch.randn(64 * 1024 * 1024, device=DEV)
+    s2 = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for it in range(6):
+        with torch.cuda.stream(s2):
+            big.mul_(1.0001)
+        out = hip.gemm(R, S, r_kcontig=False, s_kcontig=False, out_f32=True, split_k=split)
+        assert torch.equal(out, ref), f"iteration {it}: {(out - ref).abs().max().item()}"
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("rk,sk", LAYOUTS)
 def test_gemm_random_tolerance(rk, sk):
     M, N, K = 512, 768, 1024
