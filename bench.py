@@ -363,17 +363,22 @@ def measure_stage(args, rank, world, device):
         pack = m._ensure_pack(device)
         opt = FusedAdamW([pack], lr=1e-4)
         bk = dp.GradBuckets(pack.grad, [0, pack.numel])
+        merged = os.environ.get("UNIREC_ITEM_MERGED", "1") != "0"      # 0: anchor forward + one no-grad forward of positives | negatives
         def step():          # training/item_qformer_training.py:117-131: anchor with grad, pos/neg without
             opt.zero_grad()
-            out = m(xa, ma)
-            with torch.no_grad():         # samples are independent: positives and negatives share ONE no-grad forward of 2B items
-                dp.set_sample_offset(rank * 2 * B, m)      # its own counters: rank r's 2B rows of the ranks' concatenated pos|neg forwards
-                rep = m(xpn, mpn)["item_representation"]; pr, nr = rep[:B], rep[B:]
-                dp.set_sample_offset(None, m)
+            if merged:       # samples are independent: anchor | positives | negatives share ONE forward of 3B items, the backward walks the anchor rows
+                out, rep = m.forward_triplet(xa, ma, xpn, mpn); pr, nr = rep[:B], rep[B:]
+            else:
+                out = m(xa, ma)
+                with torch.no_grad():
+                    dp.set_sample_offset(rank * 2 * B, m)      # its own counters: rank r's 2B rows of the ranks' concatenated pos|neg forwards
+                    rep = m(xpn, mpn)["item_representation"]; pr, nr = rep[:B], rep[B:]
+                    dp.set_sample_offset(None, m)
             loss, _, _ = loss_fn(out, {"field_embeddings": xa}, pr, nr, ma)
             loss.backward(); bk.ready_all(); bk.wait(); opt.step(grad_scale=1.0 / world)
             return loss
-        unit, metric = "items/sec", "items/sec item Q-Former triplet step (C2: L12 Q32 H768 F14, anchor fwd+bwd, positives|negatives in one no-grad fwd, AdamW)"
+        unit, metric = "items/sec", ("items/sec item Q-Former triplet step (C2: L12 Q32 H768 F14, one forward of anchor|positives|negatives, backward over the anchor rows, AdamW)" if merged else
+                        "items/sec item Q-Former triplet step (C2: L12 Q32 H768 F14, anchor fwd+bwd, positives|negatives in one no-grad fwd, AdamW)")
         flops = 2 * 8.0e12 / 256 * B / 2          # 8.0 TFLOP per 256-item triplet step
     else:
         from unirec_amd.user_qformer import UserQFormer

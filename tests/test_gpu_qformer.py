@@ -169,3 +169,64 @@ def test_gradient_checkpointing_is_bit_identical():
     with torch.no_grad():
         assert torch.equal(m(x, mask)["query_outputs"], o0)
     m.qformer.config.gradient_checkpointing = False
+
+
+def test_forward_triplet_equals_the_separate_forwards():
+    """One forward over anchor | positives | negatives with the backward on the anchor rows (QFormerForItemRepresentation.forward_triplet)
+    against the reference's schedule (training/item_qformer_training.py:117-131: anchor with grad, the others without): without dropout
+    every kernel is row-independent, so outputs and ALL parameter gradients are equal bit for bit; with dropout the merged step is
+    reproducible and finite; gradient checkpointing composes with it."""
+    from unirec_amd.qformer_model import QFormerForItemRepresentation
+    from unirec_amd.losses import QFormerLoss
+    torch.manual_seed(0)
+    B = 24
+    m = QFormerForItemRepresentation(hidden_size=128, num_hidden_layers=4, num_attention_heads=2, intermediate_size=256,
+                                     num_query_tokens=8, field_embedding_dim=64, num_fields=6, dropout=0.0).to(DEV).train()
+
+    def fields(n):
+        x = torch.randn(n, 6, 64, device=DEV)
+        mk = (torch.rand(n, 6, device=DEV) < 0.7).long()
+        mk[:, 0] = 1
+        return x * mk[..., None], mk
+    (xa, ma), (xo, mo) = fields(B), fields(2 * B)
+    loss_fn = QFormerLoss()
+
+    def separate():
+        m.zero_grad(set_to_none=True)
+        out = m(xa, ma)
+        with torch.no_grad():
+            rep = m(xo, mo)["item_representation"]
+        loss, _, _ = loss_fn(out, {"field_embeddings": xa}, rep[:B], rep[B:], ma)
+        loss.backward()
+        return out, rep, loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    def merged():
+        m.zero_grad(set_to_none=True)
+        out, rep = m.forward_triplet(xa, ma, xo, mo)
+        loss, _, _ = loss_fn(out, {"field_embeddings": xa}, rep[:B], rep[B:], ma)
+        loss.backward()
+        return out, rep, loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    o0, r0, l0, g0 = separate()
+    o1, r1, l1, g1 = merged()
+    for k in ("query_outputs", "item_representation", "reconstructed_fields"):
+        assert torch.equal(o0[k], o1[k]), k
+    assert torch.equal(r0, r1) and torch.equal(l0, l1)
+    assert g0.keys() == g1.keys() and len(g0) > 40
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n
+    m.qformer.config.gradient_checkpointing = True
+    _, _, l2, g2 = merged()
+    m.qformer.config.gradient_checkpointing = False
+    assert torch.equal(l2, l0) and all(torch.equal(g0[n], g2[n]) for n in g0)
+    # dropout on: reproducible per step, finite
+    m2 = QFormerForItemRepresentation(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                                      num_query_tokens=8, field_embedding_dim=64, num_fields=6, dropout=0.2).to(DEV).train()
+    outs = []
+    for _ in range(2):
+        m2.qformer._step = 0
+        m2.zero_grad(set_to_none=True)
+        out, rep = m2.forward_triplet(xa, ma, xo, mo)
+        loss, _, _ = loss_fn(out, {"field_embeddings": xa}, rep[:B], rep[B:], ma)
+        loss.backward()
+        outs.append((loss.detach().clone(), m2.query_embeddings.grad.detach().clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.isfinite(outs[0][1]).all()

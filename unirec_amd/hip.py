@@ -515,6 +515,16 @@ class AttnCtx:
     __slots__ = ("args", "keep", "o", "stats")
 
 
+def attn_ctx_prefix(ctx, Bg):
+    """The forward context restricted to its first Bg samples (a backward over the leading rows of a larger forward): same pointers
+    and strides -- batch b of every operand sits at b * (tokens * stride) -- with B = Bg."""
+    a = AttnArgs.from_buffer_copy(ctx.args)
+    a.B = int(Bg)
+    c = AttnCtx()
+    c.args, c.keep, c.o, c.stats = a, ctx.keep, ctx.o, ctx.stats
+    return c
+
+
 def _tok_stride(t):
     # [B,S,heads,hd] view (possibly a slice of a fused projection buffer): elements between tokens
     if t.stride(3) != 1 or t.stride(2) != t.shape[3] or t.stride(0) != t.shape[1] * t.stride(1):

@@ -154,8 +154,8 @@ def _split_k_for(out_rows, out_cols, red):
 # -------------------------------------------------------------------------------------------------
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, query_embeds, enc, enc_mask_u8, B, qe_param_name):
-        out, saved = model._forward_impl(query_embeds, enc, enc_mask_u8, B)
+    def forward(ctx, model, query_embeds, enc, enc_mask_u8, B, qe_param_name, grad_items=None):
+        out, saved = model._forward_impl(query_embeds, enc, enc_mask_u8, B, grad_items=grad_items)
         ctx.model = model
         ctx.saved = saved
         ctx.enc_needs_grad = bool(enc.requires_grad)
@@ -167,7 +167,7 @@ class _EncoderFn(torch.autograd.Function):
         model = ctx.model
         d_qe, d_enc = model._backward_impl(ctx.saved, dout, ctx.enc_needs_grad, ctx.qe_param_name)
         ctx.saved = None
-        return None, d_qe, d_enc, None, None, None
+        return None, d_qe, d_enc, None, None, None, None
 
 
 class BertModel(nn.Module):
@@ -280,10 +280,12 @@ class BertModel(nn.Module):
                                attentions=None, cross_attentions=None)
 
     def encode(self, query_embeds, encoder_hidden_states, encoder_attention_mask=None, attention_mask=None,
-               qe_param_name=None):
+               qe_param_name=None, grad_items=None):
         """bf16 [B,Q,H] hidden states (internal fast path used by the wrappers).  qe_param_name: the
         pack entry that receives the query-table gradient directly (wrappers); None returns it through
-        autograd (free-standing BertModel use)."""
+        autograd (free-standing BertModel use).  grad_items = Bg < B: only the FIRST Bg samples carry gradient -- one forward
+        serves anchor | positives | negatives of a triplet step (training/item_qformer_training.py:117-131 runs three), and the
+        backward walks the leading Bg samples' rows only."""
         if not query_embeds.is_cuda:
             raise hip._lib.UniRecHipError("BertModel runs on the MI355X only: move the model and inputs to 'cuda' "
                                           "(there is no CPU fallback in the product path)")
@@ -314,7 +316,9 @@ class BertModel(nn.Module):
             # inference (token caches, evaluators, the no-grad positive / negative forward of the item step): no layer's
             # activations are kept, the peak is one layer instead of all of them
             return self._forward_impl(qe_src.detach(), enc.detach(), mask_u8, B, keep=False)[0]
-        return _EncoderFn.apply(self, qe_src, enc, mask_u8, B, qe_param_name)
+        if grad_items is not None and not (0 < int(grad_items) <= B):
+            raise ValueError(f"grad_items must be in 1..{B}")
+        return _EncoderFn.apply(self, qe_src, enc, mask_u8, B, qe_param_name, None if grad_items is None or int(grad_items) == B else int(grad_items))
 
     # ---- implementation (sequence of HIP calls) --------------------------------------------------
     def _drop(self):
@@ -325,7 +329,7 @@ class BertModel(nn.Module):
     def _seed(self, layer, site, step=None):
         return (self.seed * 1000003 + (self._step if step is None else step) * 8191 + layer * 64 + site) & 0x7FFFFFFFFFFFFFFF
 
-    def _forward_impl(self, query_embeds, enc, mask_u8, B, keep=True):
+    def _forward_impl(self, query_embeds, enc, mask_u8, B, keep=True, grad_items=None):
         cfg = self.config
         pack = self._ensure_pack(query_embeds.device)
         pre = self._names()
@@ -346,7 +350,7 @@ class BertModel(nn.Module):
         # layer's forward (same kernels, same dropout seeds: bit-identical activations) before it walks the layer
         ckpt = bool(keep and self.training and getattr(cfg, "gradient_checkpointing", False))
         S = {"B": B, "Q": Qn, "T": T, "p_h": p_h, "p_a": p_a, "layers": [], "enc16": enc16, "mask": mask_u8,
-             "qe_rows": qe16.shape[0], "step_seed": self._step, "row0": row0, "b0": b0, "ckpt": ckpt}
+             "qe_rows": qe16.shape[0], "step_seed": self._step, "row0": row0, "b0": b0, "ckpt": ckpt, "Bg": B if grad_items is None else int(grad_items)}
         w = lambda n: pack.w32(pre + n)
         x, z0, mean0, rstd0 = hip.layernorm_fwd(qe16, w("embeddings.LayerNorm.weight"), w("embeddings.LayerNorm.bias"), eps,
                                                 M=M, p_post=p_h, seed_post=self._seed(1023, 0), drop_row0=row0, save_z=keep)
@@ -440,7 +444,42 @@ class BertModel(nn.Module):
             self._wt = bt
         return dict(zip(bt[2], bt[3].run()))
 
+    @staticmethod
+    def _prefix(S, Bg):
+        """The saved state of a forward over B samples restricted to its first Bg (every saved tensor is row-major over samples: the
+        leading rows are a contiguous view); attention contexts get B = Bg (hip.attn_ctx_prefix)."""
+        Qn, T = S["Q"], S["T"]
+        Mg, Tg = Bg * Qn, Bg * T
+        P = dict(S)
+        P["B"] = Bg
+        P["enc16"] = S["enc16"][:Tg]
+        P["mask"] = None if S["mask"] is None else S["mask"][:Bg]
+        P["kv_all"] = None if S["kv_all"] is None else S["kv_all"][:Tg]
+        z0, mean0, rstd0, s0 = S["emb"]
+        P["emb"] = (None if z0 is None else z0[:Mg], mean0[:Mg], rstd0[:Mg], s0)
+        layers = []
+        for L in S["layers"]:
+            if "x_in" in L:                    # gradient checkpointing: the layer is re-run on the leading rows only
+                layers.append({"x_in": L["x_in"][:Mg]})
+                continue
+            x, qkv, actx, ctx_o, z1, m1, r1, s_h = L["self"]
+            N = {"self": (x[:Mg], qkv[:Mg], hip.attn_ctx_prefix(actx, Bg), ctx_o[:Bg], z1[:Mg], m1[:Mg], r1[:Mg], s_h)}
+            if "cross" in L:
+                x1, qc, jc, actx2, ctx2, z2, m2, r2, s_h2 = L["cross"]
+                N["cross"] = (x1[:Mg], qc[:Mg], jc, hip.attn_ctx_prefix(actx2, Bg), ctx2[:Bg], z2[:Mg], m2[:Mg], r2[:Mg], s_h2)
+            xc, u, hbuf, z3, m3, r3, s_h3 = L["ffn"]
+            N["ffn"] = (xc[:Mg], u[:Mg], hbuf[:Mg], z3[:Mg], m3[:Mg], r3[:Mg], s_h3)
+            layers.append(N)
+        P["layers"] = layers
+        return P
+
     def _backward_impl(self, S, dout, enc_needs_grad, qe_param_name=None):
+        if S.get("Bg", S["B"]) < S["B"]:
+            if enc_needs_grad or S["qe_rows"] == S["B"] * S["Q"]:
+                raise NotImplementedError("grad_items: the encoder states and per-sample query embeddings take no gradient on this path")
+            Bg = S["Bg"]
+            dout = dout[:Bg]
+            S = self._prefix(S, Bg)
         cfg = self.config
         pack = self._ensure_pack(dout.device)
         pre = self._names()

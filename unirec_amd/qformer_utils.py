@@ -109,6 +109,22 @@ class QFormerForItemRepresentation(nn.Module):
         query_embeds = self.query_embeddings.expand(B, -1, -1)
         return self.qformer.encode(query_embeds, field_embeddings, attention_mask, None, qe_param_name="query_embeddings")
 
+    def forward_triplet(self, anchor_fields, anchor_mask, other_fields, other_mask):
+        """The triplet step's forwards as ONE launch sequence (the reference runs anchor, positives and negatives through the model
+        one after the other, training/item_qformer_training.py:117-131, the last two without gradient): the encoder runs once over
+        anchor | others, only the anchor rows are walked by its backward.  Returns (the anchor's output dict, with autograd; the
+        others' item_representation [n_others, E], detached).  Dropout masks are keyed on the row index inside this merged batch."""
+        B = anchor_fields.shape[0]
+        x = torch.cat([anchor_fields, other_fields])
+        mask = None if anchor_mask is None else torch.cat([anchor_mask, other_mask])
+        q = self.query_embeddings.expand(x.shape[0], -1, -1)
+        h_all = self.qformer.encode(q, x, mask, None, qe_param_name="query_embeddings", grad_items=B)
+        h_a = h_all[:B]
+        item, rec = _ItemHeadsFn.apply(self, h_a)
+        with torch.no_grad():
+            other_item, _ = _ItemHeadsFn.apply(self, h_all[B:].detach())
+        return {"query_outputs": _CastFn.apply(h_a), "item_representation": item, "reconstructed_fields": rec}, other_item
+
     def forward(self, field_embeddings: torch.Tensor, attention_mask: torch.Tensor = None):
         h16 = self.encode_bf16(field_embeddings, attention_mask)
         if h16.shape[0] == 0:
