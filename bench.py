@@ -59,6 +59,8 @@ def parse():
                     help="drop gate|up and act after each layer's forward and rebuild them in the backward (memory for time: "
                          "the C5 shape --user-tokens --hist 100 --seq 4096 --batch 64 then runs as ONE launch)")
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--comm-bf16", action="store_true",
+                    help="multi-GPU, opt-in: the item Q-Former's gradient buckets cross xGMI as bf16 (dp.GradBuckets wire_dtype); default f32")
     ap.add_argument("--lora-dropout", type=float, default=0.1, help="LoRA adapter dropout (reference lora_dropout=0.1)")
     return ap.parse_args()
 
@@ -529,14 +531,14 @@ def main():
     opt = FusedAdamW(packs, lr=1e-4, weight_decay=0.01)
 
     # ---- gradient buckets in backward-completion order (LoRA 27..0, Q-Former 11..0, query table) ----
-    lgrp, qgrp = 7, 1          # LoRA: 4 buckets of 7 layers (10 MB each); Q-Former: one bucket per layer (60 MB f32): the exposed tail is the last layer's all-reduce
-    lb = dp.layer_boundaries(lpack, [f"layers.{i}." for i in range(cfg.num_hidden_layers)], lgrp)
-    qb = dp.layer_boundaries(qpack, [f"qformer.encoder.layer.{i}." for i in range(12)], qgrp)
-    lbk, qbk = dp.GradBuckets(lpack.grad, lb), dp.GradBuckets(qpack.grad, qb)
-    l_first = {min(i for i in range(cfg.num_hidden_layers) if i // lgrp == k): k for k in range((cfg.num_hidden_layers + lgrp - 1) // lgrp)}
-    qw.grad_ready_hook = lambda i: lbk.ready(l_first[i]) if i in l_first else None
-    q_first = {k * qgrp: 1 + k for k in range(12 // qgrp)}       # bucket 0 = query table + embedding LN, last = heads (unused here)
-    qf.qformer.grad_ready_hook = lambda i: qbk.ready(0) if i == -1 else (qbk.ready(q_first[i]) if i in q_first else None)
+    lgrp, qgrp = 7, 1          # LoRA: 4 buckets of 7 layers (10 MB each); Q-Former: one bucket per layer (60 MB f32): the exposed tail is the small query-table bucket
+    l_pre, q_pre = [f"layers.{i}." for i in range(cfg.num_hidden_layers)], [f"qformer.encoder.layer.{i}." for i in range(12)]
+    lb = dp.layer_boundaries(lpack, l_pre, lgrp)
+    qb = dp.layer_boundaries(qpack, q_pre, qgrp)           # [query table + embedding LN | hoisted cross-attention K|V of all layers | layer 0 | ... | layer 11 | heads]
+    # --comm-bf16 (opt-in): the item Q-Former's buckets travel as bf16 (its f32 gradients become final in the last milliseconds of the backward)
+    lbk, qbk = dp.GradBuckets(lpack.grad, lb), dp.GradBuckets(qpack.grad, qb, wire_dtype=torch.bfloat16 if args.comm_bf16 else None)
+    qw.grad_ready_hook = dp.bucket_hook(lpack, lbk, l_pre, lgrp)
+    qf.qformer.grad_ready_hook = dp.bucket_hook(qpack, qbk, q_pre, qgrp)      # -2: the hoisted K|V gradients leave from their own hook, -1: the query table
 
     nmb = max(1, args.micro_batches)
     if B % nmb:

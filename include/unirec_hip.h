@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 8
+#define UR_ABI_VERSION 9
 
 int ur_version(void);
 const char* ur_last_error(void);
@@ -241,9 +241,11 @@ typedef struct {
                             (((drop_batch0 + b) * nq + h) * Sq + q) * Sk + key, so a data-parallel rank draws the masks of ITS samples */
 } ur_attn_args;
 /* Backward: dout [B,Sq,nq,hd] -> dq [B,Sq,nq,hd], dk/dv [B,Sk,nkv,hd] (bf16, strides in elements).
- * delta: caller-provided f32 scratch [2,B,nq,Sq] (row constants of the backward: -rowsum(dO*O) and
- * -LSE/scale).  `a` must be the forward's arguments (o and stats filled by ur_attn_fwd).
- * No atomics: results are bitwise reproducible. */
+ * delta: caller-provided f32 scratch of ur_attn_bwd_workspace_floats(B, nq, Sq) = 2*B*nq*Sq + 16 words: the row constants of
+ * the backward (-rowsum(dO*O) and -LSE/scale) followed by the work-queue words of the persistent dK/dV kernel (zeroed by the
+ * call itself) -- the library keeps no mutable device state of its own, so calls on different streams never interfere as long
+ * as each brings its own workspace.  `a` must be the forward's arguments (o and stats filled by ur_attn_fwd).
+ * No floating-point atomics: results are bitwise reproducible. */
 typedef struct {
   const void* dout; void* dq; void* dk; void* dv;
   int64_t lddo, lddq, lddk, lddv;
@@ -271,6 +273,14 @@ typedef struct {
 } ur_attn_bwd_args;
 int ur_attn_fwd(const ur_attn_args* a, void* stream);
 int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, void* stream);
+/* f32 words the `delta` workspace of ur_attn_bwd must hold (row constants + the call's own work-queue words) */
+int64_t ur_attn_bwd_workspace_floats(int32_t B, int32_t nq, int32_t Sq);
+/* Keep flags of the counter-based dropout every kernel here regenerates instead of storing (nn.Dropout at models/qformer.py:107,
+ * 258, 287, 373): keep[i] = 1 iff element idx0 + i of the stream `seed` survives probability p.  Counters: hidden dropout of
+ * ur_layernorm_fwd/bwd: (drop_row0 + row) * H + column; attention probabilities of ur_attn_fwd/bwd:
+ * (((drop_batch0 + b) * nq + h) * Sq + query) * Sk + key.  Test / inspection entry: a parity test feeds these masks to the CPU
+ * oracle so that a TRAINING-mode step can be compared value for value. */
+int ur_dropout_keep(uint64_t seed, float p, uint64_t idx0, int64_t n, uint8_t* keep, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Qwen3 per-head q/k RMSNorm + rotary embedding -- modeling_qwen3.py:59-64 (norm over head_dim),

@@ -43,10 +43,11 @@ def run(outdir, Bg, dropout):
     xa, ma, xp, mp_, xn, mn = [t[lo:hi].to(dev) for t in (xa, ma, xp, mp_, xn, mn)]
     pack = m._ensure_pack(dev)
     opt = FusedAdamW([pack], lr=1e-3, weight_decay=0.01)
-    bounds = dp.layer_boundaries(pack, [f"qformer.encoder.layer.{i}." for i in range(2)], 1)
-    bk = dp.GradBuckets(pack.grad, bounds)
-    first = {i: 1 + i for i in range(2)}
-    m.qformer.grad_ready_hook = lambda i: bk.ready(0) if i == -1 else (bk.ready(first[i]) if i in first else None)
+    pre = [f"qformer.encoder.layer.{i}." for i in range(2)]
+    bounds = dp.layer_boundaries(pack, pre, 1)
+    bk = dp.GradBuckets(pack.grad, bounds, wire_dtype=torch.bfloat16 if os.environ.get("UNIREC_TEST_WIRE") == "bf16" else None)
+    m.qformer.grad_ready_hook = dp.bucket_hook(pack, bk, pre, 1)      # layers, the hoisted K|V bucket (-2), the query table (-1)
+    assert m.qformer.grad_ready_hook.hoisted_bucket == 1
     loss_fn = QFormerLoss(data_parallel=True)
     out = m(xa, ma)
     with torch.no_grad():

@@ -209,6 +209,26 @@ MID = {
 MID_STRIDE = 16
 
 
+# Training-mode cases (round 5): the reference's own classes in train() mode with dropout ON, every nn.Dropout applying the keep mask
+# the HIP kernels draw for that site (oracle/dropout_ref.py restates the counter-based generator; tests/golden/make_golden_r5.py).
+# p = 0.2 is the item Q-Former's default (models/qformer_utils.py:19).  item_c1_train: C1's architecture (the <= 4-query x <= 16-key
+# attention kernels); user_t96_train: 64 queries x 96 keys with ragged masks (the MFMA attention kernels); drop_seed / step: the
+# product's BertModel.seed and the step the forward runs as.
+TRAIN = {
+    "item_c1_train": dict(ALL["item_c1"], kind="item_train", p=0.2, drop_seed=0x5EED, step=1),
+    "user_t96_train": dict(ALL["user_t96"], kind="user_train", p=0.2, drop_seed=0xC0FFEE, step=3),
+}
+
+
+def train_masks(case):
+    """Every keep mask of the case's forward (numpy uint8), keyed as oracle/qformer_train_ref.py expects."""
+    from oracle import dropout_ref as DR
+    c = case["cfg"]
+    T = c["F"] if case["kind"] == "item_train" else case["T"]
+    cross_freq = 2 if case["kind"] == "item_train" else 1
+    return DR.qformer_masks(case["drop_seed"], case["step"], case["p"], case["B"], c["Q"], T, c["H"], c["nh"], c["L"], cross_freq)
+
+
 # LoRA pinned through the INSTALLED transformers Qwen3Model with MERGED weights W' = W + (alpha / r) B A (peft's
 # merge_and_unload identity; peft itself is not installed -- call site train_item_individual_token_joint.py:121-131):
 # 2 layers of the 0.6B shape, B 2 x S 256, left padding.  lora_B ~ N(0, 0.05) so the adapter term is ~40 % of |W|.

@@ -186,3 +186,63 @@ def test_micro_batch_accumulation_adds_the_stash_before_the_bucket_leaves():
     bk.ready(1); bk.ready(0); bk.wait()
     assert torch.equal(flat, torch.arange(24.0) + 1)
     assert float(bk.stash.abs().sum()) == 0.0    # ready for the next step
+
+
+def test_hoisted_cross_attention_kv_gets_its_own_bucket_and_hook():
+    """The Q-Formers keep the cross-attention K | V weights of all layers ahead of layer 0; their gradients are final BEFORE the
+    query-table reduction that closes the backward, so they leave from their own hook (signal -2) in their own bucket and the
+    exposed tail is the small leading bucket."""
+    shapes = [("query_embeddings", (1, 4, 16)), ("qformer.embeddings.LayerNorm.weight", (16,)), ("qformer.embeddings.LayerNorm.bias", (16,))]
+    shapes += [(f"qformer.encoder.layer.{i}.crossattention.self.{n}.weight", (16, 16)) for i in (0, 2) for n in ("key", "value")]
+    shapes += [(f"qformer.encoder.layer.{i}.crossattention.self.{n}.bias", (16,)) for i in (0, 2) for n in ("key", "value")]
+    for i in range(4):
+        shapes += [(f"qformer.encoder.layer.{i}.attention.self.query.weight", (16, 16)), (f"qformer.encoder.layer.{i}.attention.self.query.bias", (16,))]
+    shapes += [("head.weight", (8, 16))]
+    p = _FakePack(shapes)
+    pre = [f"qformer.encoder.layer.{i}." for i in range(4)]
+    b = dp.layer_boundaries(p, pre, 2)
+    kv0 = p.offsets["qformer.encoder.layer.0.crossattention.self.key.weight"]
+    assert b[:4] == [0, kv0, p.offsets["qformer.encoder.layer.0.attention.self.query.weight"], p.offsets["qformer.encoder.layer.2.attention.self.query.weight"]]
+
+    class Rec:
+        bounds = b
+        sent = []
+
+        def ready(self, i):
+            self.sent.append(i)
+    rec = Rec()
+    hook = dp.bucket_hook(p, rec, pre, 2)
+    assert hook.hoisted_bucket == 1
+    for sig in (3, 2, 1, 0, -2, -1):                 # the backward's order
+        hook(sig)
+    assert rec.sent == [3, 2, 1, 0]                  # layers 3-2, layers 1-0, K | V, query table: every bucket exactly once
+
+
+def _wire_worker(rank, world, port, tmp):
+    os.environ.update(GLOO_SOCKET_IFNAME="lo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dp.init_from_env(backend="gloo")
+    torch.set_num_threads(1)
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(4096, generator=g)
+    mine = flat.clone()
+    bk = dp.GradBuckets(flat, [0, 1000, 1000, 3000, 4096], wire_dtype=torch.bfloat16)
+    for i in reversed(range(bk.n)):
+        bk.ready(i)
+    bk.wait_bucket(3)
+    bk.wait()
+    assert not bk.unpack and flat.dtype == torch.float32
+    torch.save({"mine": mine, "sum": flat.clone()}, os.path.join(tmp, f"w{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bf16_wire_buckets_under_two_gloo_ranks(tmp_path):
+    """wire_dtype = bfloat16: every rank ends with the SAME f32 buffer = the bf16 sum of the ranks' bf16-rounded buckets."""
+    world, port = 2, _free_port()
+    mp.spawn(_wire_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = torch.load(tmp_path / "w0.pt"), torch.load(tmp_path / "w1.pt")
+    assert torch.equal(a["sum"], b["sum"])
+    want = (a["mine"].bfloat16() + b["mine"].bfloat16()).float()
+    assert torch.equal(a["sum"], want)
+    exact = a["mine"] + b["mine"]
+    assert float((a["sum"] - exact).norm() / exact.norm()) < 8e-3

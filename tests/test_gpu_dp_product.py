@@ -24,11 +24,11 @@ def _free_port():
     return p
 
 
-def _launch(outdir, world, Bg, dropout, mode=None):
+def _launch(outdir, world, Bg, dropout, mode=None, extra_env=None):
     port = _free_port()
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        env = dict(os.environ, **(extra_env or {}), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    UNIREC_DP_BACKEND="gloo", OMP_NUM_THREADS="2", GLOO_SOCKET_IFNAME="lo")      # loopback: the box's hostname may not resolve
         procs.append(subprocess.Popen([sys.executable, WORKER, str(outdir), str(Bg), str(dropout)] + ([mode] if mode else []), env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -100,3 +100,18 @@ def test_joint_step_under_two_ranks_equals_the_single_process_step_with_dropout_
         rel = float((g2 - g1).norm() / g1.norm())
         print(k, "2-rank vs 1-rank gradient rel err", rel)
         assert float(g1.norm()) > 0 and rel <= 3e-2, (k, rel)
+
+
+def test_bf16_wire_buckets_stay_within_bf16_rounding_of_the_f32_step(tmp_path):
+    """dp.GradBuckets(wire_dtype=bfloat16) -- the opt-in for the item Q-Former's pack: buckets are cast to bf16 as they become ready,
+    summed in bf16, cast back behind the wait.  Both ranks still end bit-identical, and the reduced gradient is the f32-wire one up to
+    one bf16 rounding per summand (relative Frobenius error ~2^-9)."""
+    Bg = 16
+    dw = tmp_path / "wire"; dw.mkdir()
+    r0, r1 = _launch(dw, 2, Bg, 0.0, extra_env={"UNIREC_TEST_WIRE": "bf16"})
+    assert torch.equal(r0["grad"], r1["grad"]) and torch.equal(r0["master"], r1["master"])
+    df = tmp_path / "f32"; df.mkdir()
+    f0, _ = _launch(df, 2, Bg, 0.0)
+    rel = float((r0["grad"] - f0["grad"]).norm() / f0["grad"].norm())
+    print("bf16-wire vs f32-wire reduced gradient rel err", rel)
+    assert 0 < rel <= 6e-3, rel

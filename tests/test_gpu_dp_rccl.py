@@ -70,10 +70,11 @@ def _joint_grads(nmb, B=4, S=256, hist=6, pool=20, layers=2, repeat=1):
     qw = model.base_model
     qpack, lpack = qf._ensure_pack(dev), qw._ensure_pack(dev)
     lb = dp.layer_boundaries(lpack, [f"layers.{i}." for i in range(layers)], 1)
-    qb = dp.layer_boundaries(qpack, [f"qformer.encoder.layer.{i}." for i in range(12)], 1)
+    q_pre = [f"qformer.encoder.layer.{i}." for i in range(12)]
+    qb = dp.layer_boundaries(qpack, q_pre, 1)
     lbk, qbk = dp.GradBuckets(lpack.grad, lb), dp.GradBuckets(qpack.grad, qb)
     qw.grad_ready_hook = lambda i: lbk.ready(i)
-    qf.qformer.grad_ready_hook = lambda i: qbk.ready(0) if i == -1 else qbk.ready(1 + i)
+    qf.qformer.grad_ready_hook = dp.bucket_hook(qpack, qbk, q_pre, 1)
     loss_fn = InfoNCELoss(0.07)
     outs = []
     for _ in range(repeat):

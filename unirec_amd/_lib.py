@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UNIREC_HIP_LIB selects another build of the SAME library (kernel A/B experiments); there is still no fallback.
 LIB_PATH = os.environ.get("UNIREC_HIP_LIB") or os.path.join(_HERE, "lib", "libunirec_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_void_p, c_int, c_i64, c_u64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
@@ -113,6 +113,8 @@ SIGNATURES = {
     "ur_rmsnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ur_attn_fwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
     "ur_attn_bwd": (c_int, [ctypes.POINTER(AttnArgs), ctypes.POINTER(AttnBwdArgs), c_void_p]),
+    "ur_attn_bwd_workspace_floats": (c_i64, [c_int, c_int, c_int]),
+    "ur_dropout_keep": (c_int, [c_u64, c_float, c_u64, c_i64, c_void_p, c_void_p]),
     "ur_rope_table": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ur_qknorm_rope_fwd": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p]),

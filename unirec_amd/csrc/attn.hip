@@ -87,7 +87,8 @@ struct AttnP {
   const float* rp_rstd; long rp_rstd_ld; int rp_rstd_h0;      // non-null: rp_raw is the ROPED, normed q and 1 / rms comes from the forward (ur_attn_bwd_args.rope_rstd)
   // the k heads' q/k-norm + RoPE backward in the dK/dV kernel's store (with rp_rstd): roped k, its norm weight, first k column of rstd, raw-gradient output
   const bf16_t* rk_src; long rk_ld; const float* rk_w; int rk_rstd_h0; bf16_t* rk_dst; long rk_lddst;
-  int qslot;            // work-queue slot of the persistent dK/dV kernel (g_dkv_queue), zeroed by the dQ kernel of the same call
+  unsigned int* queue;  // work queues of the persistent dK/dV kernel: 8 words (one per XCD lane) in the CALLER's workspace, behind the two row-constant
+                        // planes of `delta` (ur_attn_bwd_workspace_floats); zeroed by the dQ kernel of the same call
   // hand-scheduled causal head_dim-128 backward (both kernels or neither): plane 1 of `delta` holds -LSE * log2(e) instead of -LSE / scale
   int lse_log2;
 };
@@ -2301,9 +2302,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // the wave's 64 rows, forms the row constants delta = sum_d dO O and LSE2 = (m + ln l) log2e from the forward's statistics, and
 // publishes -delta and -LSE/scale for the dK/dV kernel exactly as attn_bwd_dq_kernel does.
 // LDS: K ring 4 x 16 KiB | V ring 4 x 16 KiB | key-state words.
-// Work queues of the persistent dK/dV kernel: [slot][XCD lane] = next key-block item of that lane.  A call takes the next slot of the
-// ring (host side, ur_attn_bwd); its dQ kernel zeroes the slot, its dK/dV kernel -- stream-ordered behind it -- draws from it.
-__device__ unsigned int g_dkv_queue[64][8];
+// Work queues of the persistent dK/dV kernel: p.queue[XCD lane] = next key-block item of that lane.  The eight words live in the
+// caller's workspace (the tail of `delta`): this call's dQ kernel zeroes them, its dK/dV kernel -- stream-ordered behind it -- draws
+// from them; two calls on two streams never share a word (the library owns no mutable device state).
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
@@ -2316,7 +2317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
   const int nx = (p.Sq + 255) / 256, ntiles = p.Sk / KT;
-  if (blockIdx.x == 0 && tid < 8) g_dkv_queue[p.qslot][tid] = 0u;      // (the dK/dV kernel of this call starts after this kernel has finished)
+  if (blockIdx.x == 0 && tid < 8) p.queue[tid] = 0u;      // (the dK/dV kernel of this call starts after this kernel has finished)
   const uint32_t lds0 = lds_off(smem);
   unsigned long long* words = reinterpret_cast<unsigned long long*>(smem + DQ_WORDS_LDS);
   i32x2 kava, dw, voff;
@@ -2663,7 +2664,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     d.more = first; d.run = false; \
     if (persist) { \
       __syncthreads(); \
-      if (tid == 0) *qitem = atomicAdd(&g_dkv_queue[p.qslot][blockIdx.x & 7], 1u); \
+      if (tid == 0) *qitem = atomicAdd(&p.queue[blockIdx.x & 7], 1u); \
       __syncthreads(); \
       const unsigned int t = *qitem; \
       d.more = t < (unsigned int)per_lane; \
@@ -2904,7 +2905,7 @@ int launch_fwd(const AttnP& p, hipStream_t st) {
   if constexpr (HD == 128 && CAUSAL && NW == 4) {
     if (p.rep == 2 && fwd_gq2_enabled()) {
       static std::atomic<uint64_t> once8{0};   // per device
-      if (ur_first_on_device(once8)) { int rc = set_smem(&attn_fwd_kernel<128, true, 8, true>, fwd_smem<128>(), "ur_attn_fwd(gq2)"); if (rc) return rc; }
+      UR_ONCE_PER_DEVICE(once8) { int rc = set_smem(&attn_fwd_kernel<128, true, 8, true>, fwd_smem<128>(), "ur_attn_fwd(gq2)"); if (rc) return rc; }
       dim3 grid(ur_cdiv(p.Sq, 128) * (p.nq / 2) * p.B);
       hipLaunchKernelGGL((attn_fwd_kernel<128, true, 8, true>), grid, dim3(512), fwd_smem<128>(), st, p);
       UR_CHECK_LAUNCH("ur_attn_fwd(gq2)");
@@ -2915,7 +2916,7 @@ int launch_fwd(const AttnP& p, hipStream_t st) {
     if (p.Sq == p.Sk && (p.Sk % KT) == 0 && p.Sk >= 128 && p.Sk <= c128::MAX_SK && fwd_c128_enabled() && (long)p.nq * p.B * 8 < (1L << 24) &&
         p.ldk * 2L * p.Sk < (1L << 31) && p.ldv * 2L * p.Sk < (1L << 31)) {
       static std::atomic<uint64_t> once_c{0};   // per device
-      if (ur_first_on_device(once_c)) { int rc = set_smem(&attn_fwd_c128_kernel, c128::LDS_BYTES, "ur_attn_fwd(c128)"); if (rc) return rc; }
+      UR_ONCE_PER_DEVICE(once_c) { int rc = set_smem(&attn_fwd_c128_kernel, c128::LDS_BYTES, "ur_attn_fwd(c128)"); if (rc) return rc; }
       const int nx = ur_cdiv(p.Sq, 256), nch = (nx + 1) / 2, nitems = p.nq * p.B * nch;
       auto magic = [](uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); };
       const C128Div dv{magic((uint32_t)(p.rep * nch)), magic((uint32_t)nch), magic((uint32_t)p.nkv)};
@@ -2925,7 +2926,7 @@ int launch_fwd(const AttnP& p, hipStream_t st) {
     }
   }
   static std::atomic<uint64_t> once{0};   // per device
-  if (ur_first_on_device(once)) { int rc = set_smem(&attn_fwd_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_fwd"); if (rc) return rc; }
+  UR_ONCE_PER_DEVICE(once) { int rc = set_smem(&attn_fwd_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_fwd"); if (rc) return rc; }
   dim3 grid(ur_cdiv(p.Sq, 32 * NW) * p.nq * p.B);
   // one K | V stage and one pair of key words when every key fits one tile (the Q-Formers' 32-query launches: twice the waves per CU)
   const int smem_bytes = p.Sk <= KT ? 2 * Cfg<HD>::TILE + 16 : fwd_smem<HD>();
@@ -2938,7 +2939,7 @@ int launch_dq(const AttnP& p, hipStream_t st) {
   if constexpr (HD == 128 && CAUSAL && NW == 4) {
     if (c128_bwd_ok(p)) {
       static std::atomic<uint64_t> once_c{0};   // per device
-      if (ur_first_on_device(once_c)) { int rc = set_smem(&attn_bwd_dq_c128_kernel, c128::DQ_LDS_BYTES, "ur_attn_bwd(dq c128)"); if (rc) return rc; }
+      UR_ONCE_PER_DEVICE(once_c) { int rc = set_smem(&attn_bwd_dq_c128_kernel, c128::DQ_LDS_BYTES, "ur_attn_bwd(dq c128)"); if (rc) return rc; }
       const int nx = ur_cdiv(p.Sq, 256), nch = (nx + 1) / 2, nitems = p.nq * p.B * nch;
       auto magic = [](uint32_t d) { return (uint32_t)(((1ull << 32) + d - 1) / d); };
       const C128Div dv{magic((uint32_t)(p.rep * nch)), magic((uint32_t)nch), magic((uint32_t)p.nkv)};
@@ -2948,7 +2949,7 @@ int launch_dq(const AttnP& p, hipStream_t st) {
     }
   }
   static std::atomic<uint64_t> once{0};   // per device
-  if (ur_first_on_device(once)) { int rc = set_smem(&attn_bwd_dq_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_bwd(dq)"); if (rc) return rc; }
+  UR_ONCE_PER_DEVICE(once) { int rc = set_smem(&attn_bwd_dq_kernel<HD, CAUSAL, NW>, fwd_smem<HD>(), "ur_attn_bwd(dq)"); if (rc) return rc; }
   dim3 grid(ur_cdiv(p.Sq, 32 * NW) * p.nq * p.B);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), fwd_smem<HD>(), st, p);
   UR_CHECK_LAUNCH("ur_attn_bwd(dq)");
@@ -2976,7 +2977,7 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
   if constexpr (HD == 128 && CAUSAL && NW == 4) {
     if (c128_bwd_ok(p)) {
       static std::atomic<uint64_t> once_c{0};   // per device
-      if (ur_first_on_device(once_c)) { int rc = set_smem(&attn_bwd_dkv_c128_kernel, c128::DKV_LDS_BYTES, "ur_attn_bwd(dkv c128)"); if (rc) return rc; }
+      UR_ONCE_PER_DEVICE(once_c) { int rc = set_smem(&attn_bwd_dkv_c128_kernel, c128::DKV_LDS_BYTES, "ur_attn_bwd(dkv c128)"); if (rc) return rc; }
       // persistent walk where the sweep divides evenly (see the kernel): one workgroup per CU for the whole launch
       const int ncu = device_cu_count(), ngroups = p.nkv * p.B;
       const bool pers = dkv_persist_enabled() && (ncu % 8) == 0 && (ngroups % 8) == 0 && (long)grid.x > ncu;
@@ -2989,13 +2990,13 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
   if (HD == 128 && NW == 4 && p.drop_thr == 0) {
     constexpr int SM2 = 2 * (2 * Cfg<128>::TILE + 4 * KT * (int)sizeof(float));      // = NB buffers of attn_bwd_dkv2_kernel
     static std::atomic<uint64_t> once2{0};   // per device
-    if (ur_first_on_device(once2)) { int rc = set_smem(&attn_bwd_dkv2_kernel<CAUSAL>, SM2, "ur_attn_bwd(dkv2)"); if (rc) return rc; }
+    UR_ONCE_PER_DEVICE(once2) { int rc = set_smem(&attn_bwd_dkv2_kernel<CAUSAL>, SM2, "ur_attn_bwd(dkv2)"); if (rc) return rc; }
     hipLaunchKernelGGL((attn_bwd_dkv2_kernel<CAUSAL>), grid, dim3(256), SM2, st, p);
     UR_CHECK_LAUNCH("ur_attn_bwd(dkv2)");
     return 0;
   }
   static std::atomic<uint64_t> once{0};   // per device
-  if (ur_first_on_device(once)) { int rc = set_smem(&attn_bwd_dkv_kernel<HD, CAUSAL, NW>, dkv_smem<HD>(), "ur_attn_bwd(dkv)"); if (rc) return rc; }
+  UR_ONCE_PER_DEVICE(once) { int rc = set_smem(&attn_bwd_dkv_kernel<HD, CAUSAL, NW>, dkv_smem<HD>(), "ur_attn_bwd(dkv)"); if (rc) return rc; }
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, CAUSAL, NW>), grid, dim3(NW * 64), dkv_smem<HD>(), st, p);
   UR_CHECK_LAUNCH("ur_attn_bwd(dkv)");
   return 0;
@@ -3046,6 +3047,10 @@ extern "C" int ur_attn_fwd(const ur_attn_args* a, void* stream) {
   return do_fwd(p, a->head_dim, a->causal != 0, (hipStream_t)stream);
 }
 
+extern "C" int64_t ur_attn_bwd_workspace_floats(int32_t B, int32_t nq, int32_t Sq) {
+  return 2 * (int64_t)B * nq * Sq + 16;      // two row-constant planes + the dK/dV kernel's eight queue words (padded to 64 bytes)
+}
+
 extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, void* stream) {
   AttnP p;
   int rc = fill(p, a);
@@ -3080,21 +3085,23 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
     p.rk_dst = (bf16_t*)g->rope_dk_raw; p.rk_lddst = g->rope_lddkraw;
   }
   hipStream_t st = (hipStream_t)stream;
-  static std::atomic<unsigned int> qring{0};
-  p.qslot = (int)(qring.fetch_add(1u, std::memory_order_relaxed) & 63u);
+  p.queue = reinterpret_cast<unsigned int*>(g->delta + 2 * (int64_t)a->B * a->nq * a->Sq);      // the workspace's tail (ur_attn_bwd_workspace_floats)
   p.lse_log2 = (a->head_dim == 128 && a->causal != 0 && c128_bwd_ok(p)) ? 1 : 0;
   if (tiny_shape(p, a->head_dim, a->causal != 0, true)) return launch_tiny(p, true, st);      // dQ, dK, dV in one kernel
   // the dQ kernel also computes the row constants (delta, -LSE/scale) and leaves them in `delta` for dK/dV
   // (only the generated dK/dV kernel carries the k heads' backward in its store; on every other path dk is written roped and the
   // stand-alone kernel turns it into the raw gradient here)
   const bool rope_k_fused = rope_k && p.lse_log2 != 0;
-  if (rope_k && !rope_k_fused) p.rk_src = nullptr;
+  if (rope_k && !rope_k_fused) {
+    // (checked BEFORE anything is launched: a refused call leaves every output untouched)
+    UR_REQUIRE(g->lddk == (int64_t)a->nkv * a->head_dim, "ur_attn_bwd: rope_k on this shape needs a dense dk [B*Sk, nkv*hd]");
+    p.rk_src = nullptr;
+  }
   rc = do_dq(p, a->head_dim, a->causal != 0, st);
   if (rc) return rc;
   rc = do_dkv(p, a->head_dim, a->causal != 0, st);
   if (rc) return rc;
   if (rope_k && !rope_k_fused) {
-    UR_REQUIRE(g->lddk == (int64_t)a->nkv * a->head_dim, "ur_attn_bwd: rope_k on this shape needs a dense dk [B*Sk, nkv*hd]");
     return ur_qknorm_rope_bwd_roped_k(g->dk, g->rope_k, g->rope_ldk, g->rope_rstd, g->rope_rstd_ld, g->rope_rstd_hk0, g->rope_k_weight, g->rope_cos,
                                       g->rope_sin, g->rope_dk_raw, g->rope_lddkraw, (int64_t)a->B * a->Sk, a->Sk, a->nkv, a->head_dim, stream);
   }

@@ -216,7 +216,7 @@ extern "C" int ur_catalog_scores(const float* user, const float* catalog, float*
   blocks_x = (N + rpb - 1) / rpb;
   const size_t smem = (size_t)CU_USERS * D * sizeof(float);
   static std::atomic<uint64_t> attr_set{0};   // per device
-  if (ur_first_on_device(attr_set)) {
+  UR_ONCE_PER_DEVICE(attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&catalog_scores_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, CU_USERS * 2048 * 4);
     if (e != hipSuccess) UR_FAIL((int)e, "ur_catalog_scores: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
   }

@@ -35,18 +35,25 @@ static inline int ur_lab_int(const char* name, int dflt) {
 
 // ---- per-device once flags -------------------------------------------------------------------------
 // hipFuncSetAttribute and the CU count are properties of (function, DEVICE): a process that drives several GPUs needs them per
-// device.  Bit d of the mask = done on device d (the guarded calls are idempotent: a race only repeats one).
+// device.  Bit d of the mask = done on device d (the guarded calls are idempotent: a race only repeats one; UR_ONCE_PER_DEVICE).
 static inline int ur_current_device() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
   return dev;
 }
-static inline bool ur_first_on_device(std::atomic<uint64_t>& mask) {
-  const uint64_t bit = 1ull << (ur_current_device() & 63);
-  if (mask.load(std::memory_order_relaxed) & bit) return false;
-  mask.fetch_or(bit, std::memory_order_relaxed);
-  return true;
-}
+// UR_ONCE_PER_DEVICE(mask) { body }: the body (a hipFuncSetAttribute) runs while bit d of the mask is clear, and the bit is set only
+// AFTER the body has completed: a second thread on the same device (PyTorch issues backward launches from its autograd thread) either
+// sees the bit -- then the attribute is applied -- or repeats the idempotent call; a body that leaves early (failure: `return rc`)
+// leaves the bit clear, so the next call tries again instead of launching without the attribute.
+struct ur_once_scope {
+  std::atomic<uint64_t>& mask;
+  uint64_t bit;
+  bool todo;
+  explicit ur_once_scope(std::atomic<uint64_t>& m) : mask(m), bit(1ull << (ur_current_device() & 63)), todo(!(m.load(std::memory_order_acquire) & bit)) {}
+  bool pending() const { return todo; }
+  void done() { mask.fetch_or(bit, std::memory_order_release); todo = false; }
+};
+#define UR_ONCE_PER_DEVICE(mask) for (ur_once_scope ur_once_(mask); ur_once_.pending(); ur_once_.done())
 static inline int ur_device_cu_count() {
   static std::atomic<int> cached[64];
   const int dev = ur_current_device() & 63;

@@ -259,3 +259,21 @@ extern "C" int ur_adamw_step(float* param, const float* grad, float* exp_avg, fl
   UR_CHECK_LAUNCH("ur_adamw_step");
   return 0;
 }
+
+// ---- keep flags of the counter-based dropout (test / inspection entry; include/unirec_hip.h) ----------------------------------
+namespace {
+__global__ void dropout_keep_kernel(uint64_t seed, uint32_t thr, uint64_t idx0, long n, uint8_t* __restrict__ keep) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    keep[i] = ur_dropout_scale(seed, idx0 + (uint64_t)i, thr, 1.0f) != 0.f ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int ur_dropout_keep(uint64_t seed, float p, uint64_t idx0, int64_t n, uint8_t* keep, void* stream) {
+  UR_REQUIRE(n >= 0 && (n == 0 || keep != nullptr), "ur_dropout_keep: null output");
+  UR_REQUIRE(p >= 0.f && p < 1.f, "ur_dropout_keep: p must be in [0, 1)");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(dropout_keep_kernel, dim3(ew_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, seed, p > 0.f ? ur_drop_threshold(p) : 0u, idx0, (long)n, keep);
+  UR_CHECK_LAUNCH("ur_dropout_keep");
+  return 0;
+}

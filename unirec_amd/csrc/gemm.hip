@@ -924,7 +924,7 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
   constexpr int RING = NSTAGE * (S_BYTES + R_BYTES), CTILE = BM * (BN * 2 + 16);      // bf16 tile == f32 half tile rows
   constexpr int SMEM = OUTF32 ? RING : (RING > CTILE ? RING : CTILE);
   static std::atomic<uint64_t> attr_set{0};   // per device
-  if (ur_first_on_device(attr_set)) {
+  UR_ONCE_PER_DEVICE(attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<RK, SK, OUTF32, BM, BN, NWM, NWN, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) UR_FAIL((int)e, "ur_gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));

@@ -697,7 +697,7 @@ template <int EPI, int MODE>
 int launch_pers(const GemmP& p, hipStream_t st) {
   static std::atomic<uint64_t> attr_set{0};   // per device
   constexpr int SMEM = 2 * STAGE + (EPI == 3 ? 2 * 256 * 4 * (int)sizeof(float) : 0);
-  if (ur_first_on_device(attr_set)) {
+  UR_ONCE_PER_DEVICE(attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pers_kernel<EPI, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) UR_FAIL((int)e, "ur_gemm(persistent): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
   }

@@ -1310,7 +1310,7 @@ extern "C" int ur_lora_project(const ur_lora_args* a, void* stream) {
   if (ring) {
     static std::atomic<uint64_t> attr_set[2];      // per device, per kernel
     const void* fn = masked ? reinterpret_cast<const void*>(&lora_project_ring_kernel<true>) : reinterpret_cast<const void*>(&lora_project_ring_kernel<false>);
-    if (ur_first_on_device(attr_set[masked ? 1 : 0])) {
+    UR_ONCE_PER_DEVICE(attr_set[masked ? 1 : 0]) {
       hipError_t er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P2_SMEM);
       if (er != hipSuccess) UR_FAIL((int)er, "ur_lora_project: hipFuncSetAttribute failed: %s", hipGetErrorString(er));
     }
@@ -1400,7 +1400,7 @@ template <int NAD, bool MASKED>
 static int launch_reduce_ring(const RedP& p, dim3 grid, hipStream_t st) {
   constexpr int SMEM = r2_nst(NAD) * r2_stage<NAD, MASKED>();
   static std::atomic<uint64_t> attr_set{0};      // per device
-  if (ur_first_on_device(attr_set)) {
+  UR_ONCE_PER_DEVICE(attr_set) {
     hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void*>(&lora_reduce_ring_kernel<NAD, MASKED>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (er != hipSuccess) UR_FAIL((int)er, "ur_lora_reduce: hipFuncSetAttribute failed: %s", hipGetErrorString(er));
   }
@@ -1563,7 +1563,7 @@ extern "C" int ur_lora_bgrad(const ur_lora_args* a, void* workspace, int64_t wor
                  : kind == 1 ? reinterpret_cast<const void*>(&lora_bgrad_ring_kernel<2>) : reinterpret_cast<const void*>(&lora_bgrad_ring_kernel<4>);
   const int smem = kind == 0 ? BG_SMEM : b2_smem(kind == 1 ? 2 : 4);
   static std::atomic<uint64_t> attr_set[3];      // per device, per kernel
-  if (ur_first_on_device(attr_set[kind])) {
+  UR_ONCE_PER_DEVICE(attr_set[kind]) {
     hipError_t er = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (er != hipSuccess) UR_FAIL((int)er, "ur_lora_bgrad: hipFuncSetAttribute failed: %s", hipGetErrorString(er));
   }

@@ -220,10 +220,21 @@ def use_native_comm(group=None):
 class GradBuckets:
     """Contiguous buckets over one flat gradient buffer, reduced as they become ready."""
 
-    def __init__(self, flat_grad, boundaries, group=None, comm=None):
+    def __init__(self, flat_grad, boundaries, group=None, comm=None, wire_dtype=None):
         """boundaries: ascending element offsets [0, ..., numel]; bucket i = [b[i], b[i+1]).  comm: a NativeComm to reduce
-        through (default: torch.distributed's group, or the process's native communicator under UNIREC_DP_COMM=native)."""
+        through (default: torch.distributed's group, or the process's native communicator under UNIREC_DP_COMM=native).
+        wire_dtype = torch.bfloat16 (opt-in; default: the buffer's own f32): a bucket travels as bf16 -- cast into a staging buffer
+        when it becomes ready, summed in bf16 by the collective (UR_COMM_BF16), cast back into the f32 gradient buffer behind its
+        wait.  Half the bytes on the links for the one pack whose all-reduce cannot hide under the backward (the item Q-Former of the
+        joint step is UPSTREAM of the decoder: its 714 MB of f32 gradients become final in the backward's last milliseconds, SURVEY
+        5.8); the price is one bf16 rounding of every summand and partial sum (relative error <= world * 2^-9 of the largest term).
+        The optimizer state and the master weights stay f32."""
         self.flat = flat_grad
+        if wire_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("GradBuckets: wire_dtype must be None / torch.float32 / torch.bfloat16")
+        self.wire = None               # bf16 staging buffer of the whole pack (allocated on first use)
+        self.wire_on = wire_dtype == torch.bfloat16
+        self.unpack = []               # buckets whose reduced bf16 image still has to be cast back: (lo, hi, ticket or None)
         self.bounds = list(boundaries)
         self.group = group
         self.pending = []
@@ -256,11 +267,21 @@ class GradBuckets:
         if self.stash is not None:
             self.flat[lo:hi].add_(self.stash[lo:hi])
             self.stash[lo:hi].zero_()
-        if self.enabled and self.comm is not None:
-            self.comm.all_reduce_(self.flat[lo:hi])
+        if not self.enabled:
+            return
+        buf = self.flat[lo:hi]
+        if self.wire_on:
+            if self.wire is None:
+                self.wire = torch.empty(self.flat.numel(), dtype=torch.bfloat16, device=self.flat.device)
+            buf = self.wire[lo:hi]
+            _cast(self.flat[lo:hi], buf)
+        if self.comm is not None:
+            self.comm.all_reduce_(buf)
             self.tickets[i] = self.comm.ticket()
-        elif self.enabled:
-            self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.pending.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.wire_on:
+            self.unpack.append((i, lo, hi))
 
     def begin_micro_batch(self, last):
         """Gradient accumulation over micro-batches inside ONE optimizer step (every backward OVERWRITES the flat gradient
@@ -276,8 +297,24 @@ class GradBuckets:
         """the current stream waits for bucket i's all-reduce only (native communicator; otherwise for everything queued)"""
         if self.comm is not None and self.enabled and i in self.tickets:
             self.comm.wait(stream, ticket=self.tickets[i])
+            if self.unpack:
+                if stream is not None and self.flat.is_cuda:
+                    with torch.cuda.stream(stream):
+                        self._unpack(only=i)
+                else:
+                    self._unpack(only=i)
         else:
             self.wait()
+
+    def _unpack(self, only=None):
+        """reduced bf16 images -> the f32 gradient buffer (the caller has fenced the current stream behind their all-reduces)"""
+        rest = []
+        for (i, lo, hi) in self.unpack:
+            if only is None or i == only:
+                _cast(self.wire[lo:hi], self.flat[lo:hi])
+            else:
+                rest.append((i, lo, hi))
+        self.unpack = rest
 
     def wait(self):
         if self.comm is not None and self.enabled:
@@ -286,19 +323,39 @@ class GradBuckets:
         for w in self.pending:
             w.wait()
         self.pending = []
+        if self.unpack:
+            self._unpack()
+
+
+def _cast(src, dst):
+    """dst <- src across f32 / bf16 (a device cast kernel for device buffers, torch's copy on the host: the gloo rehearsals)"""
+    if src.is_cuda:
+        from . import hip
+        (hip.cast_f32_to_bf16 if src.dtype == torch.float32 else hip.cast_bf16_to_f32)(src, dst)
+    else:
+        dst.copy_(src)
+
+
+def _hoisted(n):
+    return ".crossattention.self.key." in n or ".crossattention.self.value." in n
 
 
 def layer_boundaries(pack, layer_prefixes, group_size):
     """Bucket boundaries for a pack whose entries are ordered by layer: one bucket per `group_size`
     consecutive layers (plus whatever precedes the first / follows the last layer)."""
     # (the Q-Formers keep the cross-attention K | V projections of ALL layers side by side ahead of layer 0 -- one GEMM serves them,
-    # qformer.py:_cross_kv_names -- and finish their gradients after the layer loop: they belong to the leading bucket)
-    hoisted = lambda n: ".crossattention.self.key." in n or ".crossattention.self.value." in n
+    # qformer.py:_cross_kv_names.  Their gradients are final right after the layer loop, BEFORE the embedding LayerNorm / query-table
+    # reduction that closes the backward: they get a bucket of their own, sent from its own hook (BertModel.grad_ready_hook(-2)),
+    # so the exposed tail of the step is the small query-table bucket, not 50 MB of K | V gradients)
+    hoisted = _hoisted
     starts = []
     for pre in layer_prefixes:
         offs = [pack.offsets[n] for n in pack.names if n.startswith(pre) and not hoisted(n)]
         starts.append(min(offs))
     bounds = [0]
+    h_offs = [pack.offsets[n] for n in pack.names if hoisted(n)]
+    if h_offs and 0 < min(h_offs) < min(starts):
+        bounds.append(min(h_offs))
     for k in range(0, len(starts), group_size):
         if starts[k] > bounds[-1]:
             bounds.append(starts[k])
@@ -308,3 +365,36 @@ def layer_boundaries(pack, layer_prefixes, group_size):
         bounds.append(last_layer_end)
     bounds.append(pack.numel)
     return sorted(set(bounds))
+
+
+def bucket_hook(pack, buckets, layer_prefixes, group_size):
+    """`grad_ready_hook` of a model whose backward walks its layers last to first (BertModel, Qwen3LoRAModel) for the buckets of
+    `layer_boundaries(pack, layer_prefixes, group_size)`: signal i >= 0 = layer i's gradients are final (the bucket of a layer group
+    goes out when its LOWEST layer is done), -2 = the hoisted cross-attention K | V gradients, -1 = whatever precedes them (query
+    table, embedding LayerNorm).  Buckets are found by OFFSET, so the mapping follows the boundaries whatever they contain."""
+    import bisect
+    bounds = buckets.bounds
+
+    def at(off):
+        return bisect.bisect_right(bounds, off) - 1
+    first_of = {}
+    for i, pre in enumerate(layer_prefixes):
+        offs = [pack.offsets[n] for n in pack.names if n.startswith(pre) and not _hoisted(n)]
+        if (i % group_size) == 0 and offs:
+            first_of[i] = at(min(offs))
+    h_offs = [pack.offsets[n] for n in pack.names if _hoisted(n)]
+    h_bucket = at(min(h_offs)) if h_offs else None
+    lead = 0
+    if h_bucket == lead:
+        h_bucket = None            # no boundary between them (nothing precedes the K | V block): one signal, the last one, sends it
+
+    def hook(i):
+        if i == -1:
+            buckets.ready(lead)
+        elif i == -2:
+            if h_bucket is not None:
+                buckets.ready(h_bucket)
+        elif i in first_of and first_of[i] not in (lead, h_bucket):
+            buckets.ready(first_of[i])
+    hook.first_of, hook.hoisted_bucket = first_of, h_bucket
+    return hook

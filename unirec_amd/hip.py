@@ -582,7 +582,8 @@ def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None, rope_rstd=None, 
     if dv is None:
         dv = torch.empty(v.shape, dtype=BF16, device=q.device)
     a = ctx.args
-    delta = torch.empty((2, a.B, a.nq, a.Sq), dtype=F32, device=q.device)   # row constants: -rowsum(dO*O), -LSE/scale
+    # workspace: the row constants (-rowsum(dO*O), -LSE/scale) + the call's own work-queue words (the library owns no device state)
+    delta = torch.empty((int(lib.ur_attn_bwd_workspace_floats(a.B, a.nq, a.Sq)),), dtype=F32, device=q.device)
     g = AttnBwdArgs()
     g.dout, g.dq, g.dk, g.dv = dout.data_ptr(), (0 if dq is None else dq.data_ptr()), dk.data_ptr(), dv.data_ptr()
     g.lddo, g.lddq, g.lddk, g.lddv = _tok_stride(dout), (0 if dq is None else _tok_stride(dq)), _tok_stride(dk), _tok_stride(dv)
@@ -609,6 +610,15 @@ def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None, rope_rstd=None, 
     else:
         check(lib.ur_attn_bwd(ctypes.byref(a), ctypes.byref(g), _stream()), "ur_attn_bwd")
     return dq, dk, dv
+
+
+def dropout_keep(seed, p, idx0, n, device):
+    """uint8 [n]: keep flags of elements idx0 .. idx0 + n - 1 of the dropout stream `seed` (ur_dropout_keep) -- test / inspection
+    helper: hidden dropout counters are (drop_row0 + row) * H + col, attention ones (((b0 + b) * nq + h) * Sq + q) * Sk + key."""
+    lib = _lib.load()
+    out = torch.empty((int(n),), dtype=torch.uint8, device=device)
+    check(lib.ur_dropout_keep(int(seed), float(p), int(idx0), int(n), out.data_ptr(), _stream()), "ur_dropout_keep")
+    return out
 
 
 def cast_f32_to_bf16(src, dst=None):

@@ -55,10 +55,21 @@ class FusedAdamW:
         if len(sd["packs"]) != len(self.packs):
             raise ValueError(f"optimizer state holds {len(sd['packs'])} packs, this optimizer {len(self.packs)}")
         for p, (m, v), s, rec in zip(self.packs, self.state, self.steps, sd["packs"]):
-            if list(rec["names"]) != list(p.names) or dict(rec["offsets"]) != dict(p.offsets):
-                raise ValueError("optimizer state does not match the parameter pack layout")
-            m.copy_(rec["exp_avg"].to(m.device))
-            v.copy_(rec["exp_avg_sq"].to(v.device))
+            if list(rec["names"]) == list(p.names) and dict(rec["offsets"]) == dict(p.offsets):
+                m.copy_(rec["exp_avg"].to(m.device))
+                v.copy_(rec["exp_avg_sq"].to(v.device))
+            elif set(rec["names"]) == set(p.names):
+                # same tensors, another order (a pack layout change between versions, e.g. the hoisted cross-attention K|V weights):
+                # the moments move tensor by tensor, recorded offsets -> current offsets
+                rm, rv, roff = rec["exp_avg"].to(m.device), rec["exp_avg_sq"].to(v.device), dict(rec["offsets"])
+                for n in p.names:
+                    lo, num = p.offsets[n], p.params[n].numel()
+                    if roff[n] + num > rm.numel():
+                        raise ValueError(f"optimizer state: recorded range of {n} lies outside the recorded moments")
+                    m[lo:lo + num].copy_(rm[roff[n]:roff[n] + num])
+                    v[lo:lo + num].copy_(rv[roff[n]:roff[n] + num])
+            else:
+                raise ValueError("optimizer state does not match the parameter pack (different tensor names)")
             s.update(rec["steps"])
         self.step_count = int(sd["step_count"])
         self.lr, self.betas, self.eps, self.weight_decay = sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]

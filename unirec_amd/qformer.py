@@ -568,6 +568,8 @@ class BertModel(nn.Module):
             hip.colsum(dkv_all, out=pack.fusedg(kvb))
             if enc_needs_grad:
                 d_enc = dX(dkv_all, kvw)
+            if self.grad_ready_hook is not None:
+                self.grad_ready_hook(-2)              # the hoisted K | V gradients of every layer are final (their own bucket: dp.bucket_hook)
         # ---- embeddings LayerNorm; gradient of the batch-broadcast query table reduces over B
         z0, mean0, rstd0, s0 = S["emb"]
         dz0, _ = hip.layernorm_bwd(dx, z0, mean0, rstd0, pack.w32(pre + "embeddings.LayerNorm.weight"),

@@ -116,7 +116,14 @@ class QFormerForItemRepresentation(nn.Module):
         others' item_representation [n_others, E], detached).  Dropout masks are keyed on the row index inside this merged batch."""
         B = anchor_fields.shape[0]
         x = torch.cat([anchor_fields, other_fields])
-        mask = None if anchor_mask is None else torch.cat([anchor_mask, other_mask])
+        # each side's padding mask on its own terms, as the separate forwards apply them: a missing one is all ones
+        if anchor_mask is None and other_mask is None:
+            mask = None
+        else:
+            ones = lambda f, like: torch.ones(f.shape[:2], dtype=like.dtype, device=f.device)
+            am = anchor_mask if anchor_mask is not None else ones(anchor_fields, other_mask)
+            om = other_mask if other_mask is not None else ones(other_fields, anchor_mask)
+            mask = torch.cat([am, om.to(am.dtype)])
         q = self.query_embeddings.expand(x.shape[0], -1, -1)
         h_all = self.qformer.encode(q, x, mask, None, qe_param_name="query_embeddings", grad_items=B)
         h_a = h_all[:B]

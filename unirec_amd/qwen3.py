@@ -389,12 +389,12 @@ class Qwen3LoRAModel(nn.Module):
         caching allocator keys blocks by stream) and written on the side stream after it has caught up with the caller's stream."""
         p = self._drop_p()
         if p <= 0.0 or self.config.lora_r != 16 or not torch.is_grad_enabled():
-            self._bits_pre = None
+            self._release_prefetched(device)
             return
         pre = self._bits_pre
         if pre is not None and pre["step"] == self._lora_step and pre["M"] == M and pre["row0"] == int(row0) and pre["p"] == p:
             return                                 # made under the previous step's backward
-        self._bits_pre = None
+        self._release_prefetched(device)
         main = torch.cuda.current_stream(device)
         if self._bits_stream is None:
             self._bits_stream = torch.cuda.Stream(device=device)
@@ -407,6 +407,15 @@ class Qwen3LoRAModel(nn.Module):
                       for i in range(self.config.num_hidden_layers) for g, (W, nad) in enumerate(self._bits_groups()) if W % 64 == 0}
         self._bits_stream.wait_stream(main)
         self._generate_bits(planes, packed, self._lora_step, M, device, int(row0), p)
+
+    def _release_prefetched(self, device=None):
+        """Drop a prefetched plane set that no forward will consume (last partial batch of an epoch, train -> eval, a different
+        micro-batch).  The planes were allocated on the caller's stream but are WRITTEN on the side stream: the caller's stream
+        first waits for the generator's last event, so the caching allocator cannot hand the blocks to main-stream tensors while
+        the side stream is still writing masks into them."""
+        pre, self._bits_pre = self._bits_pre, None
+        if pre is not None and pre.get("event_t") is not None:
+            torch.cuda.current_stream(device).wait_event(pre["event_t"])
 
     def _generate_bits(self, planes, packed, step, M, device, row0, p):
         side = self._bits_stream
@@ -427,6 +436,10 @@ class Qwen3LoRAModel(nn.Module):
         """Called by the decoder's backward when it has consumed this step's planes: the next step's are written into the SAME buffers
         on the side stream (which first waits for the main stream to get here), under the Q-Former's backward and the optimizer."""
         if os.environ.get("UNIREC_BITS_NEXT", "1") == "0" or not self.training:
+            return
+        if self.sample_offset is not None:
+            # micro-batching / explicit shards: the next forward's first row is not this one's, so planes written here would only be
+            # thrown away (and every backward would generate a full set for nothing)
             return
         self._bits_stream.wait_stream(torch.cuda.current_stream(device))
         self._generate_bits(cur["planes"], cur["packed"], self._lora_step, cur["M"], device, cur["row0"], cur["p"])
@@ -528,7 +541,11 @@ class Qwen3LoRAModel(nn.Module):
                  "pdrop": pdrop, "step": step}
         row0 = self.first_sample(B) * S                # token rows that precede this shard in the global minibatch
         pre, self._bits_pre = self._bits_pre, None
-        if pre is not None and pdrop > 0.0 and pre["step"] == step and pre["M"] == M and pre["row0"] == row0 and pack is not None:
+        if pre is not None and not (pdrop > 0.0 and pre["step"] == step and pre["M"] == M and pre["row0"] == row0 and pack is not None):
+            self._bits_pre = pre
+            self._release_prefetched(dev)           # not this forward's planes: order their last writes before the blocks are reused
+            pre = None
+        if pre is not None:
             saved["bits_t"] = pre.get("packed", {})                      # (layer, group) -> token-packed copy for the backward
             saved["bits_t_event"] = pre["event_t"]
             saved["bits_pre"] = pre                                      # (its buffers take the next step's planes after the backward)
