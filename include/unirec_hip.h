@@ -237,12 +237,13 @@ typedef struct {
   int32_t causal;
   float scale;
   float dropout_p; uint64_t seed;
-  int64_t drop_batch0;   /* batch rows that precede b = 0 of this call in the GLOBAL minibatch: the dropout counter of an element is
-                            (((drop_batch0 + b) * nq + h) * Sq + q) * Sk + key, so a data-parallel rank draws the masks of ITS samples */
+  int64_t drop_batch0;   /* batch rows that precede b = 0 of this call in the GLOBAL minibatch: the dropout ROW of (b, h, q) is
+                            ((drop_batch0 + b) * nq + h) * Sq + q (ur_attn_dropout_keep), so a data-parallel rank draws the masks of ITS samples */
 } ur_attn_args;
 /* Backward: dout [B,Sq,nq,hd] -> dq [B,Sq,nq,hd], dk/dv [B,Sk,nkv,hd] (bf16, strides in elements).
- * delta: caller-provided f32 scratch of ur_attn_bwd_workspace_floats(B, nq, Sq) = 2*B*nq*Sq + 16 words: the row constants of
- * the backward (-rowsum(dO*O) and -LSE/scale) followed by the work-queue words of the persistent dK/dV kernel (zeroed by the
+ * delta: caller-provided f32 scratch of ur_attn_bwd_workspace_floats(B, nq, Sq) = 4*B*nq*Sq + 16 words: the row constants of
+ * the backward (-rowsum(dO*O) and -LSE/scale), two planes of per-row dropout keys (written by the dQ kernel, read by the dK/dV
+ * kernel; untouched without dropout) and the work-queue words of the persistent dK/dV kernel (zeroed by the
  * call itself) -- the library keeps no mutable device state of its own, so calls on different streams never interfere as long
  * as each brings its own workspace.  `a` must be the forward's arguments (o and stats filled by ur_attn_fwd).
  * No floating-point atomics: results are bitwise reproducible. */
@@ -276,11 +277,15 @@ int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, void* stream);
 /* f32 words the `delta` workspace of ur_attn_bwd must hold (row constants + the call's own work-queue words) */
 int64_t ur_attn_bwd_workspace_floats(int32_t B, int32_t nq, int32_t Sq);
 /* Keep flags of the counter-based dropout every kernel here regenerates instead of storing (nn.Dropout at models/qformer.py:107,
- * 258, 287, 373): keep[i] = 1 iff element idx0 + i of the stream `seed` survives probability p.  Counters: hidden dropout of
- * ur_layernorm_fwd/bwd: (drop_row0 + row) * H + column; attention probabilities of ur_attn_fwd/bwd:
- * (((drop_batch0 + b) * nq + h) * Sq + query) * Sk + key.  Test / inspection entry: a parity test feeds these masks to the CPU
- * oracle so that a TRAINING-mode step can be compared value for value. */
+ * 258, 287, 373).  Test / inspection entries: a parity test feeds these masks to the reference's own nn.Dropout modules and to the
+ * CPU oracle, so that a TRAINING-mode step can be compared value for value.
+ *   ur_dropout_keep: hidden dropout of ur_layernorm_fwd/bwd: keep[i] = 1 iff element idx0 + i of the stream `seed` survives
+ *     probability p; the counter of (row, column) is (drop_row0 + row) * H + column.
+ *   ur_attn_dropout_keep: attention probabilities of ur_attn_fwd/bwd: keep[r * Sk + key] for the rows row0 .. row0 + nrows - 1, a
+ *     row being R = ((drop_batch0 + b) * nq + h) * Sq + query.  One 32-bit word decides a PAIR of keys (2 kp, 2 kp + 1) of a row
+ *     (two 16-bit fields against p * 65536: unirec_amd/csrc/common.hip.h ur_attn_pair_word; oracle/dropout_ref.py restates it). */
 int ur_dropout_keep(uint64_t seed, float p, uint64_t idx0, int64_t n, uint8_t* keep, void* stream);
+int ur_attn_dropout_keep(uint64_t seed, float p, uint64_t row0, int64_t nrows, int32_t Sk, uint8_t* keep, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Qwen3 per-head q/k RMSNorm + rotary embedding -- modeling_qwen3.py:59-64 (norm over head_dim),

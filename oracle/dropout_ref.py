@@ -2,14 +2,15 @@
 
 The HIP kernels never store a dropout mask: every site regenerates ``keep = hash(seed, element counter) >= p * 2^32`` in the
 forward and in the backward (unirec_amd/csrc/common.hip.h: ur_hash2 / ur_dropout_scale / ur_drop_threshold).  This module restates
-that generator and the two counter layouts so that
+that generator (and the pair-word form the attention kernels use: attn_keep_rows) and the counter layouts so that
 
   * the golden generator (tests/golden/make_golden_r5.py) can make the REFERENCE's nn.Dropout modules
     (/root/reference/models/qformer.py:66,107 embeddings; :135,258 attention probabilities; :283,287 BertSelfOutput; :369,373
     BertOutput) apply exactly the masks the kernels draw, and
   * the parity tests can feed the same masks to the training-mode oracle (oracle/qformer_train_ref.py).
 
-`ur_dropout_keep` (include/unirec_hip.h) exports the device-side flags; a GPU test checks them against this file bit for bit.
+`ur_dropout_keep` / `ur_attn_dropout_keep` (include/unirec_hip.h) export the device-side flags; a GPU test checks them against this
+file bit for bit.
 """
 import numpy as np
 
@@ -55,11 +56,48 @@ def hidden_keep(seed, p, rows, H, row0=0):
     return keep_range(seed, p, int(row0) * int(H), int(rows) * int(H)).reshape(int(rows), int(H))
 
 
+def threshold16(p):
+    """p * 65536 rounded, at least 1 for p > 0 -- common.hip.h: ur_drop_threshold16 as attn.hip uses it."""
+    if p <= 0:
+        return np.uint64(0)
+    t = float(np.float32(p)) * 65536.0 + 0.5
+    return np.uint64(max(1, int(min(max(t, 0.0), 65535.0))))
+
+
+def attn_row_keys(seed, rows):
+    """the two 32-bit keys of dropout rows `rows` (uint64 array) -- common.hip.h: ur_attn_row_key"""
+    rows = np.asarray(rows, dtype=np.uint64)
+    return hash2(seed, rows * np.uint64(2)), hash2(seed, rows * np.uint64(2) + np.uint64(1))
+
+
+def attn_pair_word(k1, k2, kp):
+    """decision word of key pair kp of a row with keys (k1, k2) -- common.hip.h: ur_attn_pair_word (a two-multiply finaliser over
+    kp ^ k1 with k2 added between the rounds)"""
+    x = _u32(np.asarray(kp, dtype=np.uint64) ^ k1)
+    x ^= x >> np.uint64(16)
+    x = _u32(x * np.uint64(0x7FEB352D))
+    x = _u32(x + k2)
+    x ^= x >> np.uint64(15)
+    x = _u32(x * np.uint64(0x846CA68B))
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def attn_keep_rows(seed, p, row0, nrows, Sk):
+    """uint8 [nrows, Sk]: keep flags of dropout rows row0 .. row0 + nrows - 1 (one 32-bit word per PAIR of keys: its low / high
+    16 bits decide keys 2 kp / 2 kp + 1 against p * 65536) -- what ur_attn_dropout_keep exports."""
+    rows = np.uint64(int(row0)) + np.arange(int(nrows), dtype=np.uint64)
+    k1, k2 = attn_row_keys(seed, rows)
+    kp = np.arange((int(Sk) + 1) // 2, dtype=np.uint64)
+    w = attn_pair_word(k1[:, None], k2[:, None], kp[None, :])
+    fields = np.stack([w & np.uint64(0xFFFF), w >> np.uint64(16)], -1).reshape(int(nrows), -1)[:, :int(Sk)]
+    return (fields >= threshold16(p)).astype(np.uint8)
+
+
 def attn_keep(seed, p, B, nh, Sq, Sk, b0=0):
-    """[B, nh, Sq, Sk] keep mask of an attention-probability site: counter = (((b0 + b) * nh + h) * Sq + q) * Sk + key
-    (attn.hip: AttnP.didx0)."""
-    n = int(B) * int(nh) * int(Sq) * int(Sk)
-    return keep_range(seed, p, int(b0) * int(nh) * int(Sq) * int(Sk), n).reshape(int(B), int(nh), int(Sq), int(Sk))
+    """[B, nh, Sq, Sk] keep mask of an attention-probability site: dropout row of (b, h, q) = ((b0 + b) * nh + h) * Sq + q
+    (attn.hip: AttnP.drow0)."""
+    return attn_keep_rows(seed, p, int(b0) * int(nh) * int(Sq), int(B) * int(nh) * int(Sq), Sk).reshape(int(B), int(nh), int(Sq), int(Sk))
 
 
 # dropout sites of one Q-Former layer, in the product's numbering (unirec_amd/qformer.py:_layer_forward); the embeddings site is

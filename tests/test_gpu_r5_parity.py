@@ -101,6 +101,13 @@ def test_dropout_keep_export_matches_the_numpy_generator(seed, p, idx0, n):
     assert np.array_equal(got, DR.keep_range(seed, p, idx0, n))
 
 
+@pytest.mark.parametrize("seed,p,row0,nrows,Sk", [(0x5EED, 0.2, 0, 513, 96), (0x7FFFFFFFFFFFFFF1, 0.1, (1 << 33) - 3, 40, 1600), (3, 0.5, 77, 64, 13),
+                                                  (0xC0FFEE, 0.0, 0, 5, 8)])
+def test_attention_dropout_keep_export_matches_the_numpy_generator(seed, p, row0, nrows, Sk):
+    got = hip.attn_dropout_keep(seed, p, row0, nrows, Sk, DEV).cpu().numpy()
+    assert np.array_equal(got, DR.attn_keep_rows(seed, p, row0, nrows, Sk))
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # (ii) training mode against the reference (masks fed) and the training-mode oracle
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -314,3 +321,57 @@ def test_forward_triplet_with_only_one_mask():
             want_a = m(xa, am)["item_representation"]
         assert torch.equal(rep, want_rep)
         assert torch.equal(out["item_representation"].detach(), want_a)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# (vii) right-padded keys (ragged histories): the masked tail is not swept
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Sq,Sk,p_drop", [(64, 1600, 0.0), (64, 1600, 0.1), (32, 200, 0.2), (64, 320, 0.0)])
+def test_right_padded_key_tail_is_skipped_without_changing_a_bit(Sq, Sk, p_drop, monkeypatch):
+    """Additive-mask semantics (models/qformer.py:241-244): a masked key has probability exactly 0 once its row has one allowed key, so
+    the forward / dQ sweeps end at the last key tile holding a valid key and the few-query dK/dV kernel writes zeros for key blocks
+    without one.  Against the fp32 reference (no dropout), against the SAME call with the padded keys' mask bytes set but their K / V
+    rows replaced by garbage (nothing of a trimmed tile may be read into the result), and -- a sample WITHOUT any valid key is the
+    uniform softmax over all keys -- against the reference for that sample too."""
+    from tests.test_gpu_attention import _ref, _randn
+    B, nh, hd = 4, 2, 64
+    q, k, v = _randn((B, Sq, nh, hd), 1, 0.5), _randn((B, Sk, nh, hd), 2, 0.5), _randn((B, Sk, nh, hd), 3)
+    lens = [Sk, Sk // 2 + 3, max(1, Sk // 5), 0]                  # full, two ragged, one sample without a valid key
+    km = torch.zeros(B, Sk, dtype=torch.uint8)
+    for b, n in enumerate(lens):
+        km[b, :n] = 1
+    km = km.to(DEV)
+    dout = _randn((B, Sq, nh, hd), 4)
+
+    def run(kk, vv):
+        o, ctx = hip.attn_fwd(q, kk, vv, causal=False, key_mask=km, dropout_p=p_drop, seed=21, drop_batch0=2)
+        dq, dk, dv = hip.attn_bwd(ctx, dout)
+        torch.cuda.synchronize()
+        return o, dq, dk, dv
+    o, dq, dk, dv = run(k, v)
+    if p_drop == 0.0:
+        qf, kf, vf = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
+        ref = _ref(qf, kf, vf, km, False)
+        ref.backward(dout.float())
+        assert torch.allclose(o.float(), ref.detach(), rtol=2e-2, atol=2e-2)
+        for name, got, want in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+            err, scale = (got.float() - want).abs().max().item(), want.abs().max().item()
+            assert err <= 2e-2 * scale + 2e-2, f"{name}: max err {err} (scale {scale})"
+    # padded keys of samples that have a valid key: gradients exactly zero
+    for b, n in enumerate(lens):
+        if 0 < n < Sk:
+            assert float(dk[b, n:].float().abs().max()) == 0.0 and float(dv[b, n:].float().abs().max()) == 0.0
+    # garbage in the padded rows of those samples must not reach any output (whole trimmed tiles are never read; partial ones are masked)
+    k2, v2 = k.clone(), v.clone()
+    for b, n in enumerate(lens):
+        if 0 < n < Sk:
+            k2[b, n:] = 37.0
+            v2[b, n:] = -53.0
+    o2, dq2, dk2, dv2 = run(k2, v2)
+    sel = [b for b, n in enumerate(lens) if n > 0]
+    assert torch.equal(o[sel], o2[sel]) and torch.equal(dq[sel], dq2[sel]) and torch.equal(dk[sel], dk2[sel]) and torch.equal(dv[sel], dv2[sel])
+    # the few-query kernel against the generic one, bit for bit (same arithmetic, the generic kernel sweeps everything)
+    if Sq <= 64 and Sk >= 256:
+        monkeypatch.setenv("UR_ATTN_FEWQ", "0")
+        o3, dq3, dk3, dv3 = run(k, v)
+        assert torch.equal(dk, dk3) and torch.equal(dv, dv3) and torch.equal(dq, dq3)

@@ -84,3 +84,28 @@ def test_mask_generator_statistics(p):
     assert not np.array_equal(DR.keep_range(7, p, 0, 4096), DR.keep_range(7, p, 1 << 32, 4096))
     assert np.array_equal(DR.keep_range(7, p, 100, 64), DR.keep_range(7, p, 0, 164)[100:])
     assert DR.site_seed(0x5EED, 1, 0, 1) != DR.site_seed(0x5EED, 1, 0, 2) != DR.site_seed(0x5EED, 2, 0, 1)
+
+
+@pytest.mark.parametrize("p", [0.1, 0.2, 0.5])
+def test_attention_pair_word_statistics(p):
+    """The attention sites draw one 32-bit word per PAIR of keys of a row: the two 16-bit fields of a word, neighbouring words,
+    neighbouring rows, diagonal neighbours and two seeds must be uncorrelated, every column / row mean within its binomial range."""
+    nrows, Sk = 4096, 1600
+    K = DR.attn_keep_rows(0x5EED, p, 0, nrows, Sk).astype(np.float64)
+    n = K.size
+    assert abs(K.mean() - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5
+    c = K - K.mean()
+    lim = 5 * p * (1 - p) / n ** 0.5
+    cov = lambda a, b: float((a * b).mean())
+    assert abs(cov(c[:, 0::2], c[:, 1::2])) < lim            # the two fields of one word
+    assert abs(cov(c[:, 1:-1:2], c[:, 2::2])) < lim          # neighbouring words
+    assert abs(cov(c[:-1], c[1:])) < lim and abs(cov(c[:-2], c[2:])) < lim      # rows
+    assert abs(cov(c[:-1, :-1], c[1:, 1:])) < lim
+    K2 = DR.attn_keep_rows(0x5EEE, p, 0, nrows, Sk).astype(np.float64)
+    assert abs(cov(c, K2 - K2.mean())) < lim
+    assert np.abs(K.mean(0) - (1 - p)).max() < 6 * (p * (1 - p) / nrows) ** 0.5
+    assert np.abs(K.mean(1) - (1 - p)).max() < 6 * (p * (1 - p) / Sk) ** 0.5
+    # rows beyond 2^31 and an odd key count
+    a = DR.attn_keep_rows(7, p, (1 << 33) + 5, 8, 13)
+    assert a.shape == (8, 13) and np.array_equal(a[3], DR.attn_keep_rows(7, p, (1 << 33) + 8, 1, 13)[0])
+    assert np.array_equal(DR.attn_keep(9, p, 2, 3, 4, 6, b0=5).reshape(-1, 6), DR.attn_keep_rows(9, p, 5 * 3 * 4, 2 * 3 * 4, 6))

@@ -115,6 +115,7 @@ SIGNATURES = {
     "ur_attn_bwd": (c_int, [ctypes.POINTER(AttnArgs), ctypes.POINTER(AttnBwdArgs), c_void_p]),
     "ur_attn_bwd_workspace_floats": (c_i64, [c_int, c_int, c_int]),
     "ur_dropout_keep": (c_int, [c_u64, c_float, c_u64, c_i64, c_void_p, c_void_p]),
+    "ur_attn_dropout_keep": (c_int, [c_u64, c_float, c_u64, c_i64, c_int, c_void_p, c_void_p]),
     "ur_rope_table": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "ur_qknorm_rope_fwd": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int,
                                    c_int, c_int, c_int, c_float, c_void_p]),

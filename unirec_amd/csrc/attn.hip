@@ -75,8 +75,10 @@ struct AttnP {
   long ldq, ldk, ldv, ldo;
   const uint8_t* kmask;
   int B, Sq, Sk, nq, nkv, rep;
-  float scale; uint32_t drop_thr; float drop_inv; uint64_t seed;
-  uint64_t didx0;       // dropout counter of (batch row 0, head 0, query 0, key 0) in the GLOBAL minibatch: drop_batch0 * nq * Sq * Sk
+  float scale; uint32_t drop_thr; float drop_inv; uint64_t seed;      // drop_thr: p * 65536 (16-bit decision fields, common.hip.h: ur_attn_pair_word); 0 = no dropout
+  uint64_t drow0;       // dropout ROW index of (batch row 0, head 0, query 0) in the GLOBAL minibatch: drop_batch0 * nq * Sq
+  uint32_t* rowkeys;    // backward: the two 32-bit dropout keys of every query row, planes [2][B*nq*Sq] behind the row constants of `delta`
+                        // (written by the dQ kernel, whose lanes own query rows; read by the dK/dV kernels, whose lanes own keys)
   // backward
   const bf16_t* dout; bf16_t* dq; bf16_t* dk; bf16_t* dv; const float* delta;
   long lddo, lddq, lddk, lddv;
@@ -325,6 +327,17 @@ __device__ __forceinline__ int first_valid_tile(const unsigned long long* kw, in
   return t;
 }
 
+// Additive-mask (Q-Former) semantics: a masked key's score is finfo.min, so its probability is exp(finfo.min - m) = 0 EXACTLY as
+// soon as the row has one allowed key (m is then a real score); only a row without any allowed key is the uniform softmax over all
+// keys.  Every query of a sample sees the same key mask, so when the sample has a valid key the trailing run of key tiles without
+// one -- the right padding of a ragged history, 25 % of the keys of the C3 batch -- contributes nothing to O, l, dQ (and gets
+// dK = dV = 0): the sweep ends at the last tile that holds a valid key, K / V loads included.  Bit-identical to the full sweep.
+__device__ __forceinline__ int trim_masked_tail(const unsigned long long* kw, int ntiles) {
+  int t = ntiles;
+  while (t > 0 && kw[2 * (t - 1)] == 0ull) --t;
+  return t == 0 ? ntiles : t;          // no valid key at all: the uniform row needs every key
+}
+
 // Workgroup -> (x block, head, batch).  The grid is 1-D.  Consecutive workgroup ids are dealt round-robin to
 // the 8 XCDs, each with its own L2, so the ids are re-read as (xcd = id % 8, slot = id / 8): every (batch,
 // kv head) group -- whose blocks stream the same K/V (forward, dQ) or the same Q/dO (dK/dV) -- gets all its
@@ -397,19 +410,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
 
   int kend = p.Sk;
   if (CAUSAL) kend = min(p.Sk, (bm.x + 1) * (32 * NWQ));
-  const int ntiles = (kend + KT - 1) / KT;
+  int ntiles = (kend + KT - 1) / KT;
   const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * HD;
   const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * HD;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
-  const uint64_t drow = p.didx0 + ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
   const bool dropping = (!CAUSAL) && p.drop_thr != 0;
+  ur_rowkey rk = {0u, 0u};            // this lane's query row: two keys for the whole sweep
+  if (dropping) rk = ur_attn_row_key(p.seed, p.drow0 + ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q));
 
   unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + (p.Sk <= KT ? 2 : 4) * C::TILE);      // (ur_attn_fwd's LDS size)
   fill_key_words(kwords, km, ntiles, p.Sk, tid, NW * 64);
   int t_first = 0;
-  if (CAUSAL && km != nullptr) {
+  if (km != nullptr) {
     __syncthreads();
-    t_first = first_valid_tile(kwords, ntiles);
+    if (CAUSAL) t_first = first_valid_tile(kwords, ntiles);
+    else ntiles = trim_masked_tail(kwords, ntiles);
   }
   Loader<HD, NW * 64> ks, vs;
   ks.init(p.ldk, tid); vs.init(p.ldv, tid);
@@ -461,7 +476,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
         // interior sub-tile (every key valid and below the diagonal), or -- `diag` -- every key valid ON the causal diagonal:
         // the same mask-free softmax after one position compare per element (the general path below costs ~7 vector
         // instructions per element for the key-state bits; every 32-query block crosses the diagonal once)
-        const bool allv = (v32 == 0xffffffffu) && !dropping;
+        const bool allv = (v32 == 0xffffffffu);          // (with dropout too: the keep factors are applied to the finished probabilities below)
         const bool diag = CAUSAL && allv && kbase + 31 > qblk;
         const bool fast = allv;
         float mx = NEG_INF;
@@ -531,11 +546,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 1
 #endif
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float pr = fast_exp2((s[r] - muse) * LOG2E);
-            rs += pr;
-            if (dropping) pr *= ur_dropout_scale(p.seed, drow + (uint64_t)(kbase + acc_row(r, h)), p.drop_thr, p.drop_inv);
-            s[r] = pr;
+          for (int r = 0; r < 16; ++r) { s[r] = fast_exp2((s[r] - muse) * LOG2E); rs += s[r]; }
+        }
+        if (dropping) {
+          // registers 4 g .. 4 g + 3 hold keys kbase + 8 g + 4 h + 0 .. 3: two pair words per group (models/qformer.py:258: the row sum
+          // above is taken BEFORE dropout, as softmax-then-dropout requires)
+          const uint32_t kp0 = (uint32_t)(kbase + 4 * h) >> 1;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const uint32_t w0 = ur_attn_pair_word(rk.k1, rk.k2, kp0 + 4 * g), w1 = ur_attn_pair_word(rk.k1, rk.k2, kp0 + 4 * g + 1);
+            s[4 * g] *= ur_attn_keep_scale(w0, 0u, p.drop_thr, p.drop_inv);
+            s[4 * g + 1] *= ur_attn_keep_scale(w0, 1u, p.drop_thr, p.drop_inv);
+            s[4 * g + 2] *= ur_attn_keep_scale(w1, 0u, p.drop_thr, p.drop_inv);
+            s[4 * g + 3] *= ur_attn_keep_scale(w1, 1u, p.drop_thr, p.drop_inv);
           }
         }
         rs += __shfl_xor(rs, 32, 64);
@@ -762,19 +785,29 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
 
   int kend = p.Sk;
   if (CAUSAL) kend = min(p.Sk, (bm.x + 1) * (32 * NW));
-  const int ntiles = (kend + KT - 1) / KT;
+  int ntiles = (kend + KT - 1) / KT;
   const bf16_t* kb = p.k + (long)b * p.Sk * p.ldk + (long)kvh * HD;
   const bf16_t* vb = p.v + (long)b * p.Sk * p.ldv + (long)kvh * HD;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
-  const uint64_t drow = p.didx0 + ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q) * (uint64_t)p.Sk;
   const bool dropping = (!CAUSAL) && p.drop_thr != 0;
+  ur_rowkey rk = {0u, 0u};
+  if (dropping) {
+    // this lane's query row: its two dropout keys, also published for the dK/dV kernel (whose lanes own keys, not rows)
+    rk = ur_attn_row_key(p.seed, p.drow0 + ((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)q));
+    if (qok && h == 0) {
+      const long nrows = (long)p.B * p.nq * p.Sq;
+      p.rowkeys[srow] = rk.k1;
+      p.rowkeys[nrows + srow] = rk.k2;
+    }
+  }
 
   unsigned long long* kwords = reinterpret_cast<unsigned long long*>(smem + 4 * C::TILE);
   fill_key_words(kwords, km, ntiles, p.Sk, tid, NW * 64);
   int t_first = 0;
-  if (CAUSAL && km != nullptr) {
+  if (km != nullptr) {
     __syncthreads();
-    t_first = first_valid_tile(kwords, ntiles);
+    if (CAUSAL) t_first = first_valid_tile(kwords, ntiles);
+    else ntiles = trim_masked_tail(kwords, ntiles);          // trailing key tiles without a valid key: dS = 0 exactly (see trim_masked_tail)
   }
   Loader<HD, NW * 64> ks, vs;
   ks.init(p.ldk, tid); vs.init(p.ldv, tid);
@@ -810,7 +843,19 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(vtile, 32 * sub, st, lane), dof[st], dp, 0, 0, 0);
         }
         const uint32_t v32 = (uint32_t)(kbits.valid >> (32 * sub)), i32 = (uint32_t)(kbits.inr >> (32 * sub));
-        const bool fast = (v32 == 0xffffffffu) && !dropping;          // incl. the causal diagonal (one compare per element)
+        const bool fast = (v32 == 0xffffffffu);          // incl. the causal diagonal (one compare per element) and dropout (keep factors on dP)
+        if (dropping) {
+          // dS = P (keep / (1 - p) * dP - delta): the keep factors of this lane's 16 keys (two pair words per group of four)
+          const uint32_t kp0 = (uint32_t)(kbase + 4 * h) >> 1;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const uint32_t w0 = ur_attn_pair_word(rk.k1, rk.k2, kp0 + 4 * g), w1 = ur_attn_pair_word(rk.k1, rk.k2, kp0 + 4 * g + 1);
+            dp[4 * g] *= ur_attn_keep_scale(w0, 0u, p.drop_thr, p.drop_inv);
+            dp[4 * g + 1] *= ur_attn_keep_scale(w0, 1u, p.drop_thr, p.drop_inv);
+            dp[4 * g + 2] *= ur_attn_keep_scale(w1, 0u, p.drop_thr, p.drop_inv);
+            dp[4 * g + 3] *= ur_attn_keep_scale(w1, 1u, p.drop_thr, p.drop_inv);
+          }
+        }
         if (fast) {
           if (CAUSAL && kbase + 31 > qblk) {
             const int dqk = opaque(q - kbase - 4 * h);
@@ -828,9 +873,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
             const int kr = kb0 + bit;
             const float sc = mask_score<CAUSAL>(s[r], p.scale, (vh >> bit) & 1u, (ih >> bit) & 1u, kr, qq);
             const float pr = (sc == NEG_INF) ? 0.f : fast_exp2((sc - m) * LOG2E) * invs;
-            float g = dp[r];
-            if (dropping) g *= ur_dropout_scale(p.seed, drow + (uint64_t)kr, p.drop_thr, p.drop_inv);
-            s[r] = pr * (g - dlt);
+            s[r] = pr * (dp[r] - dlt);
           }
         }
 #pragma unroll
@@ -856,11 +899,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnP p) {
 // dK/dV: one 32-key block per wave (lane = key column).  Per 32-query sub-tile:
 //   S[q][key] = Q K^T, dP[q][key] = dO V^T (A = Q / dO rows from LDS, B = K / V fragments in registers)
 //   dV^T[d][key] += dO^T[d][q] * (P.drop)[q][key];   dK^T[d][key] += Q^T[d][q] * dS[q][key]
-// LDS per buffer: Q tile | dO tile | row stats ((m, 1/l) pairs [64][2], delta [64]).
+// LDS per buffer: Q tile | dO tile | row stats ((m, 1/l) pairs [64][2], delta [64], the rows' dropout keys k1 [64], k2 [64]).
 template <int HD, bool CAUSAL, int NW>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void attn_bwd_dkv_kernel(AttnP p) {
   using C = Cfg<HD>;
-  constexpr int STG = 2 * C::TILE + 3 * KT * (int)sizeof(float);
+  constexpr int STG = 2 * C::TILE + 5 * KT * (int)sizeof(float);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5;
   const BlockMap bm = block_map<false>((p.Sk + 32 * NW - 1) / (32 * NW), 1, p.nkv, p.B);
@@ -924,6 +967,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
       __builtin_amdgcn_global_load_lds((gbl_void*)(p.stats + (sbase + r0) * 2 + (lane & 1)), (lds_void*)fb, 4, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_void*)(p.stats + (sbase + r1) * 2 + (lane & 1)), (lds_void*)(fb + 256), 4, 0, 0);
       __builtin_amdgcn_global_load_lds((gbl_void*)(p.delta + sbase + rd), (lds_void*)(fb + 512), 4, 0, 0);
+      if (dropping) {      // (uniform) the rows' dropout keys, published by the dQ kernel of this call
+        const long nrows = (long)p.B * p.nq * p.Sq;
+        __builtin_amdgcn_global_load_lds((gbl_void*)(p.rowkeys + sbase + rd), (lds_void*)(fb + 768), 4, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(p.rowkeys + nrows + sbase + rd), (lds_void*)(fb + 1024), 4, 0, 0);
+      }
     }
   };
   auto store_tile = [&](char* buf) {
@@ -941,7 +989,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
     if (it + 1 < ntot) load_tile(it + 1, smem + ((it + 1) & 1) * STG);
     const bf16_t* qb_; const bf16_t* dob_; long sbase_; int q0;
     tile_ptrs(it, qb_, dob_, sbase_, q0);
-    const int hq = kvh * p.rep + it / ntq;
+    [[maybe_unused]] const int hq = kvh * p.rep + it / ntq;
     // Interior tile (all keys valid, both 32-query sub-tiles in range and past the causal diagonal, no
     // dropout): software-pipelined -- sub-tile 1's S/dP MFMAs are independent of sub-tile 0's softmax
     // VALU and sub-tile 0's dV/dK MFMAs of sub-tile 1's softmax, so one wave keeps both pipes busy.
@@ -1054,6 +1102,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
             const float4 bq = *reinterpret_cast<const float4*>(fst + 2 * qr + 4);
             const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
             const float ma[4] = {a.x, a.z, bq.x, bq.z}, iv[4] = {a.y, a.w, bq.y, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
+            uint4 k1q = make_uint4(0, 0, 0, 0), k2q = make_uint4(0, 0, 0, 0);          // dropout keys of rows qr .. qr + 3
+            if (dropping) {
+              k1q = *reinterpret_cast<const uint4*>(fst + 3 * KT + qr);
+              k2q = *reinterpret_cast<const uint4*>(fst + 4 * KT + qr);
+            }
+            const uint32_t k1[4] = {k1q.x, k1q.y, k1q.z, k1q.w}, k2[4] = {k2q.x, k2q.y, k2q.z, k2q.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int r = 4 * rq + e;
@@ -1062,8 +1116,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
               const float ps = (sc == NEG_INF || qpos >= p.Sq) ? 0.f : fast_exp2((sc - ma[e]) * LOG2E) * iv[e];
               float g = dp[r], pd = ps;
               if (dropping) {
-                const float dsc = ur_dropout_scale(p.seed, p.didx0 + (((uint64_t)((long)b * p.nq + hq) * p.Sq + (uint64_t)qpos) * (uint64_t)p.Sk) + (uint64_t)keyo,
-                                                   p.drop_thr, p.drop_inv);
+                const float dsc = ur_attn_keep_scale(ur_attn_pair_word(k1[e], k2[e], (uint32_t)keyo >> 1), (uint32_t)keyo, p.drop_thr, p.drop_inv);
                 g *= dsc; pd *= dsc;
               }
               s[r] = pd;
@@ -1119,25 +1172,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
   const int hq = pair % p.nq, b = pair / p.nq;
   char* qtile = smem;
   char* dotile = smem + C::TILE;
-  float* fst = reinterpret_cast<float*>(smem + 2 * C::TILE);      // [128] (m, 1/l) pairs, [64] -delta
+  float* fst = reinterpret_cast<float*>(smem + 2 * C::TILE);      // [128] (m, 1/l) pairs, [64] -delta, [64] + [64] the rows' dropout keys
+  int* flag = reinterpret_cast<int*>(fst + 5 * KT);               // [0]: the sample has a valid key
   const long sbase = ((long)b * p.nq + hq) * p.Sq;
+  const bool dropping = p.drop_thr != 0;
+  const uint8_t* kmrow = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
   {
     Loader<HD, 256> qs, dos;
     qs.issue(qtile, p.q + (long)b * p.Sq * p.ldq + (long)hq * HD, p.ldq, 0, p.Sq, tid);
     dos.issue(dotile, p.dout + (long)b * p.Sq * p.lddo + (long)hq * HD, p.lddo, 0, p.Sq, tid);
+    if (tid == 0) flag[0] = 0;
     if (tid < 2 * KT) fst[tid] = p.stats[(sbase + min(tid >> 1, p.Sq - 1)) * 2 + (tid & 1)];      // rows past Sq: clamped copies,
     else if (tid < 3 * KT) fst[tid] = p.delta[sbase + min(tid - 2 * KT, p.Sq - 1)];             // masked by position below
+    if (dropping && tid < 2 * KT) {
+      const long nrows = (long)p.B * p.nq * p.Sq;
+      reinterpret_cast<uint32_t*>(fst)[3 * KT + tid] = p.rowkeys[(tid >> 6) * nrows + sbase + min(tid & 63, p.Sq - 1)];
+    }
     qs.commit(qtile, tid);
     dos.commit(dotile, tid);
   }
   __syncthreads();
+  // does the sample have a valid key at all?  (then key blocks without one have dK = dV = 0 exactly: trim_masked_tail's argument)
+  if (kmrow != nullptr) {
+    int any = 0;
+    for (int i = tid * 16; i < p.Sk; i += 256 * 16) {
+      if (i + 16 <= p.Sk && ((reinterpret_cast<uintptr_t>(kmrow + i) & 15) == 0)) {
+        const uint4 w = *reinterpret_cast<const uint4*>(kmrow + i);
+        any |= (w.x | w.y | w.z | w.w) != 0u;
+      } else {
+        for (int j = i; j < min(i + 16, p.Sk); ++j) any |= kmrow[j] != 0;
+      }
+    }
+    if (any) flag[0] = 1;
+    __syncthreads();
+  }
+  const bool sample_has_key = kmrow != nullptr && flag[0] != 0;
 
   const int nblk = (p.Sk + 31) >> 5;
   const int blk_hi = min(nblk, (chunk + 1) * bpc);
   const float c2 = p.scale * LOG2E;
-  const bool dropping = p.drop_thr != 0;
-  const uint64_t drop_row0 = p.didx0 + (uint64_t)sbase * (uint64_t)p.Sk;       // dropout counter of (b, hq, query 0, key 0)
-  const uint8_t* kmrow = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
   const bf16_t* kbase = p.k + (long)b * p.Sk * p.ldk + (long)hq * HD;
   const bf16_t* vbase = p.v + (long)b * p.Sk * p.ldv + (long)hq * HD;
 
@@ -1154,6 +1227,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
     if (kok && kmrow) m = kmrow[key];
     state = (kok ? 1u : 0u) | ((kok && m != 0) ? 2u : 0u);          // bit 0: inside Sk, bit 1: allowed by the key mask
   };
+  auto key_state = [&](int blk) {
+    const int key = blk * 32 + (lane & 31);
+    const bool kok = blk < blk_hi && key < p.Sk;
+    uint32_t m = 1;
+    if (kok && kmrow) m = kmrow[key];
+    return (kok ? 1u : 0u) | ((kok && m != 0) ? 2u : 0u);
+  };
 
   bf16x8 kf[C::NS], vf[C::NS];
   uint32_t state;
@@ -1167,6 +1247,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
     uint32_t state_n;
     load_kv(blk + 4, kn, vn, state_n);                                // lands under this block's arithmetic
 #else
+    if (sample_has_key) {
+      // a key block without one valid key while the sample has some: every probability is exactly 0 -> dK = dV = 0, nothing is read
+      const uint32_t st0 = key_state(blk);
+      if (!__any((st0 & 2u) != 0)) {
+        const int key0 = blk * 32 + (lane & 31);
+        const bool kok0 = (st0 & 1u) != 0;
+        const long ktok0 = (long)b * p.Sk + (kok0 ? key0 : 0);
+        f32x16 z[C::NDT];
+#pragma unroll
+        for (int dt = 0; dt < C::NDT; ++dt) z[dt] = zero16();
+        store_T<HD>(p.dk + ktok0 * p.lddk + (long)hq * HD, z, 0.f, lane, kok0);
+        store_T<HD>(p.dv + ktok0 * p.lddv + (long)hq * HD, z, 0.f, lane, kok0);
+        continue;
+      }
+    }
     load_kv(blk, kf, vf, state);
 #endif
     const int kblk = blk * 32, key = kblk + (lane & 31);
@@ -1211,6 +1306,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
           const float4 bq = *reinterpret_cast<const float4*>(fst + 2 * qr + 4);
           const float4 cq = *reinterpret_cast<const float4*>(fst + 2 * KT + qr);
           const float ma[4] = {a.x, a.z, bq.x, bq.z}, iv[4] = {a.y, a.w, bq.y, bq.w}, dl[4] = {cq.x, cq.y, cq.z, cq.w};
+          uint4 k1q = make_uint4(0, 0, 0, 0), k2q = make_uint4(0, 0, 0, 0);          // dropout keys of rows qr .. qr + 3
+          if (dropping) {
+            k1q = *reinterpret_cast<const uint4*>(fst + 3 * KT + qr);
+            k2q = *reinterpret_cast<const uint4*>(fst + 4 * KT + qr);
+          }
+          const uint32_t k1[4] = {k1q.x, k1q.y, k1q.z, k1q.w}, k2[4] = {k2q.x, k2q.y, k2q.z, k2q.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int r = 4 * rq + e;
@@ -1219,7 +1320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
             const float ps = (sc == NEG_INF || qpos >= p.Sq) ? 0.f : fast_exp2((sc - ma[e]) * LOG2E) * iv[e];
             float g = dp[r], pd = ps;
             if (dropping) {
-              const float dsc = ur_dropout_scale(p.seed, drop_row0 + (uint64_t)qpos * (uint64_t)p.Sk + (uint64_t)keyo, p.drop_thr, p.drop_inv);
+              const float dsc = ur_attn_keep_scale(ur_attn_pair_word(k1[e], k2[e], (uint32_t)keyo >> 1), (uint32_t)keyo, p.drop_thr, p.drop_inv);
               g *= dsc; pd *= dsc;
             }
             s[r] = pd;
@@ -1906,8 +2007,9 @@ __device__ __forceinline__ void tiny_probs(const AttnP& p, const TinyPair& t, co
     }
     mrow[qi] = mx; inv[qi] = 1.0f / l;             // l >= 1: the maximum itself contributes exp(0)
     if (p.drop_thr != 0) {
-      const uint64_t idx = p.didx0 + (((uint64_t)((long)t.b * p.nq + t.hq) * p.Sq + (uint64_t)qi) * (uint64_t)p.Sk) + (uint64_t)t.sl;
-      const bool kp = ur_dropout_scale(p.seed, idx, p.drop_thr, 1.0f) != 0.f;
+      // lane = key t.sl of query row qi: the row's two keys, then the pair word of this key (the same words the MFMA kernels draw)
+      const ur_rowkey rk = ur_attn_row_key(p.seed, p.drow0 + ((uint64_t)((long)t.b * p.nq + t.hq) * p.Sq + (uint64_t)qi));
+      const bool kp = ur_attn_keep_scale(ur_attn_pair_word(rk.k1, rk.k2, (uint32_t)t.sl >> 1), (uint32_t)t.sl, p.drop_thr, 1.0f) != 0.f;
       keep[qi] = (uint32_t)(__ballot(kp) >> (16 * t.g)) & 0xffffu;
     }
   }
@@ -2859,7 +2961,7 @@ _Pragma("unroll") \
 
 // ================================================================================================
 template <int HD> constexpr int fwd_smem() { return 4 * Cfg<HD>::TILE + MAX_KTILES * 16; }
-template <int HD> constexpr int dkv_smem() { return 2 * (2 * Cfg<HD>::TILE + 3 * KT * (int)sizeof(float)); }
+template <int HD> constexpr int dkv_smem() { return 2 * (2 * Cfg<HD>::TILE + 5 * KT * (int)sizeof(float)); }
 
 template <typename K>
 int set_smem(K kern, int bytes, const char* name) {
@@ -2885,8 +2987,8 @@ int fill(AttnP& p, const ur_attn_args* a) {
   p.ldq = a->ldq; p.ldk = a->ldk; p.ldv = a->ldv; p.ldo = a->ldo; p.kmask = a->key_mask;
   p.B = a->B; p.Sq = a->Sq; p.Sk = a->Sk; p.nq = a->nq; p.nkv = a->nkv; p.rep = a->nq / a->nkv;
   p.scale = a->scale; p.seed = a->seed;
-  p.didx0 = (uint64_t)a->drop_batch0 * (uint64_t)a->nq * (uint64_t)a->Sq * (uint64_t)a->Sk;
-  p.drop_thr = a->dropout_p > 0.f ? ur_drop_threshold(a->dropout_p) : 0u;
+  p.drow0 = (uint64_t)a->drop_batch0 * (uint64_t)a->nq * (uint64_t)a->Sq;
+  p.drop_thr = a->dropout_p > 0.f ? std::max(1u, ur_drop_threshold16(a->dropout_p)) : 0u;
   p.drop_inv = a->dropout_p > 0.f ? 1.0f / (1.0f - a->dropout_p) : 1.0f;
   return 0;
 }
@@ -2964,7 +3066,7 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
   if (HD == 64 && !CAUSAL && NW == 4 && p.rep == 1 && p.Sq <= KT && p.Sk >= 256 && fewq_enabled()) {
     // few queries, many keys: one workgroup per (batch, head) pair -- or per chunk of its key blocks while the pairs
     // alone do not fill the chip (>= 8 key blocks, i.e. two per wave, per workgroup)
-    constexpr int SMF = 2 * Cfg<64>::TILE + 3 * KT * (int)sizeof(float);
+    constexpr int SMF = 2 * Cfg<64>::TILE + 5 * KT * (int)sizeof(float) + 16;
     const int nblk = ur_cdiv(p.Sk, 32), pairs = p.nq * p.B;
     int nchunk = std::max(1, std::min(ur_cdiv(4096, pairs), nblk / 8));
     const int bpc = ur_cdiv(ur_cdiv(nblk, nchunk), 4) * 4;
@@ -3048,7 +3150,7 @@ extern "C" int ur_attn_fwd(const ur_attn_args* a, void* stream) {
 }
 
 extern "C" int64_t ur_attn_bwd_workspace_floats(int32_t B, int32_t nq, int32_t Sq) {
-  return 2 * (int64_t)B * nq * Sq + 16;      // two row-constant planes + the dK/dV kernel's eight queue words (padded to 64 bytes)
+  return 4 * (int64_t)B * nq * Sq + 16;      // two row-constant planes + two planes of dropout row keys + the dK/dV kernel's eight queue words (padded to 64 bytes)
 }
 
 extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, void* stream) {
@@ -3085,7 +3187,9 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
     p.rk_dst = (bf16_t*)g->rope_dk_raw; p.rk_lddst = g->rope_lddkraw;
   }
   hipStream_t st = (hipStream_t)stream;
-  p.queue = reinterpret_cast<unsigned int*>(g->delta + 2 * (int64_t)a->B * a->nq * a->Sq);      // the workspace's tail (ur_attn_bwd_workspace_floats)
+  // the workspace behind the two row-constant planes: two planes of dropout row keys, then the queue words (ur_attn_bwd_workspace_floats)
+  p.rowkeys = reinterpret_cast<uint32_t*>(g->delta + 2 * (int64_t)a->B * a->nq * a->Sq);
+  p.queue = reinterpret_cast<unsigned int*>(g->delta + 4 * (int64_t)a->B * a->nq * a->Sq);
   p.lse_log2 = (a->head_dim == 128 && a->causal != 0 && c128_bwd_ok(p)) ? 1 : 0;
   if (tiny_shape(p, a->head_dim, a->causal != 0, true)) return launch_tiny(p, true, st);      // dQ, dK, dV in one kernel
   // the dQ kernel also computes the row constants (delta, -LSE/scale) and leaves them in `delta` for dK/dV

@@ -199,6 +199,35 @@ static inline uint32_t ur_drop_threshold16(float p) {
 __device__ __forceinline__ float ur_dropout_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
   return (ur_hash2(seed, idx) >= thr) ? inv_keep : 0.0f;
 }
+// ---- attention-probability dropout: one 32-bit word per PAIR of keys ----------------------------------------------------------
+// The attention kernels draw one decision per (query row, key).  With ur_hash2 per element that was three quarter-rate 32-bit
+// multiplies + ~12 vector instructions per probability -- more than the softmax itself (the C3 cross-attention forward / dQ launches
+// ran 611 / 644 us with dropout against 417 / 450 us without).  Here a ROW (global index R = ((batch0 + b) * heads + h) * Sq + q) owns
+// two 32-bit keys (two ur_hash2 draws, once per row: per lane and kernel where the lane is the query, by the dQ kernel into the
+// backward's workspace where the lane is the key), and the word of key pair kp = key >> 1 is a two-multiply finaliser over kp ^ k1
+// with k2 added between the rounds (the row enters twice: two rows whose first keys differ only in low bits do not share a shifted
+// stream).  Its halves are the 16-bit decision fields of keys 2 kp and 2 kp + 1: keep iff field >= p * 65536.
+// oracle/dropout_ref.py restates it; ur_attn_dropout_keep exports the flags.
+struct ur_rowkey { uint32_t k1, k2; };
+__device__ __forceinline__ ur_rowkey ur_attn_row_key(uint64_t seed, uint64_t row) {
+  ur_rowkey r;
+  r.k1 = ur_hash2(seed, 2ull * row);
+  r.k2 = ur_hash2(seed, 2ull * row + 1ull);
+  return r;
+}
+__device__ __forceinline__ uint32_t ur_attn_pair_word(uint32_t k1, uint32_t k2, uint32_t kp) {
+  uint32_t x = kp ^ k1;
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x += k2;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+// scale (1 / (1 - p)) of key `key` if kept, 0 if dropped; `word` = ur_attn_pair_word(k1, k2, key >> 1)
+__device__ __forceinline__ float ur_attn_keep_scale(uint32_t word, uint32_t key, uint32_t thr16, float inv_keep) {
+  const uint32_t f = (key & 1u) ? (word >> 16) : (word & 0xffffu);
+  return f >= thr16 ? inv_keep : 0.0f;
+}
 static inline uint32_t ur_drop_threshold(float p) {
   double t = (double)p * 4294967296.0;
   if (t < 0) t = 0;

@@ -269,6 +269,28 @@ __global__ void dropout_keep_kernel(uint64_t seed, uint32_t thr, uint64_t idx0, 
 }
 }  // namespace
 
+namespace {
+__global__ void attn_dropout_keep_kernel(uint64_t seed, uint32_t thr16, uint64_t row0, long nrows, int Sk, uint8_t* __restrict__ keep) {
+  const long n = nrows * Sk, stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const long row = i / Sk;
+    const uint32_t key = (uint32_t)(i - row * Sk);
+    const ur_rowkey rk = ur_attn_row_key(seed, row0 + (uint64_t)row);
+    keep[i] = ur_attn_keep_scale(ur_attn_pair_word(rk.k1, rk.k2, key >> 1), key, thr16, 1.0f) != 0.f ? 1 : 0;
+  }
+}
+}  // namespace
+
+extern "C" int ur_attn_dropout_keep(uint64_t seed, float p, uint64_t row0, int64_t nrows, int32_t Sk, uint8_t* keep, void* stream) {
+  UR_REQUIRE(nrows >= 0 && Sk > 0 && (nrows == 0 || keep != nullptr), "ur_attn_dropout_keep: bad arguments");
+  UR_REQUIRE(p >= 0.f && p < 1.f, "ur_attn_dropout_keep: p must be in [0, 1)");
+  if (nrows == 0) return 0;
+  const uint32_t thr16 = p > 0.f ? (ur_drop_threshold16(p) > 1u ? ur_drop_threshold16(p) : 1u) : 0u;
+  hipLaunchKernelGGL(attn_dropout_keep_kernel, dim3(ew_grid(nrows * Sk, 256)), dim3(256), 0, (hipStream_t)stream, seed, thr16, row0, (long)nrows, (int)Sk, keep);
+  UR_CHECK_LAUNCH("ur_attn_dropout_keep");
+  return 0;
+}
+
 extern "C" int ur_dropout_keep(uint64_t seed, float p, uint64_t idx0, int64_t n, uint8_t* keep, void* stream) {
   UR_REQUIRE(n >= 0 && (n == 0 || keep != nullptr), "ur_dropout_keep: null output");
   UR_REQUIRE(p >= 0.f && p < 1.f, "ur_dropout_keep: p must be in [0, 1)");

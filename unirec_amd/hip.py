@@ -614,10 +614,19 @@ def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None, rope_rstd=None, 
 
 def dropout_keep(seed, p, idx0, n, device):
     """uint8 [n]: keep flags of elements idx0 .. idx0 + n - 1 of the dropout stream `seed` (ur_dropout_keep) -- test / inspection
-    helper: hidden dropout counters are (drop_row0 + row) * H + col, attention ones (((b0 + b) * nq + h) * Sq + q) * Sk + key."""
+    helper: hidden dropout counters are (drop_row0 + row) * H + col (attention probabilities: attn_dropout_keep)."""
     lib = _lib.load()
     out = torch.empty((int(n),), dtype=torch.uint8, device=device)
     check(lib.ur_dropout_keep(int(seed), float(p), int(idx0), int(n), out.data_ptr(), _stream()), "ur_dropout_keep")
+    return out
+
+
+def attn_dropout_keep(seed, p, row0, nrows, Sk, device):
+    """uint8 [nrows, Sk]: keep flags of the attention-probability dropout for the rows row0 .. (ur_attn_dropout_keep); a row is
+    ((drop_batch0 + b) * heads + h) * Sq + query -- test / inspection helper."""
+    lib = _lib.load()
+    out = torch.empty((int(nrows), int(Sk)), dtype=torch.uint8, device=device)
+    check(lib.ur_attn_dropout_keep(int(seed), float(p), int(row0), int(nrows), int(Sk), out.data_ptr(), _stream()), "ur_attn_dropout_keep")
     return out
 
 
