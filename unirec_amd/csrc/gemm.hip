@@ -963,10 +963,11 @@ int launch_cfg(GemmP p, int splits, hipStream_t st) {
 template <bool RK, bool SK, bool OUTF32>
 int launch(const GemmP& p, int splits, hipStream_t st) {
   const long big_wgs = (long)ur_cdiv(p.M, 256) * ur_cdiv(p.N, 256) * splits;
+  static const bool force128 = ur_lab_int("UR_GEMM_FORCE128", 0) == 1;      // lab: 128x128 tiles (2 workgroups per CU) everywhere
   if constexpr (RK && SK && !OUTF32) {
     if (urgemm::gemm_pers_eligible(p, splits, RK, SK, OUTF32)) return urgemm::gemm_pers_launch(p, st);    // gemm_pers.hip
     if (p.sw_gu && p.sw_mode == 1) {       // SwiGLU backward epilogue: K-contiguous bf16 launches only (ur_gemm checks)
-      if (p.M >= 256 && p.N >= 256 && big_wgs >= 256) return launch_cfg<true, true, false, 256, 256, 2, 4, 1>(p, splits, st);
+      if (p.M >= 256 && p.N >= 256 && big_wgs >= 256 && !force128) return launch_cfg<true, true, false, 256, 256, 2, 4, 1>(p, splits, st);
       return launch_cfg<true, true, false, 128, 128, 2, 2, 1>(p, splits, st);
     }
     if (p.sw_gu && p.sw_mode == 2) {       // SwiGLU forward epilogue
@@ -974,7 +975,6 @@ int launch(const GemmP& p, int splits, hipStream_t st) {
       return launch_cfg<true, true, false, 128, 128, 2, 2, 2>(p, splits, st);
     }
   }
-  static const bool force128 = ur_lab_int("UR_GEMM_FORCE128", 0) == 1;      // lab: 128x128 tiles (2 workgroups per CU) everywhere
   // (token-reduction launches, both operands K-strided: one round of 224+ big tiles already beats the small tile -- the host picks
   // such splits, qformer.py:_split_k_for)
   const long big_min = (!RK && !SK) ? 224 : 256;
