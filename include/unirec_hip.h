@@ -271,11 +271,19 @@ typedef struct {
    * in its store (dk is then not written); other shapes write dk (dense [B*Sk, nkv*hd] required) and run ur_qknorm_rope_bwd_roped_k. */
   const void* rope_k; int64_t rope_ldk; const float* rope_k_weight; int32_t rope_rstd_hk0;
   void* rope_dk_raw; int64_t rope_lddkraw;
+  /* kv_colsum != NULL: the call also writes the column sums over ALL keys of all batch rows of dK and dV, f32 [2][nq * head_dim]
+   * ([dK sums | dV sums], feature h * head_dim + d) -- the bias gradients of the K | V projections that feed this attention
+   * (models/qformer.py:186-188: key / value are nn.Linear WITH bias), which otherwise cost the caller a second pass over dK | dV (13 GB
+   * per step for the user Q-Former at C3).  Produced by the few-query dK/dV kernel only (<= 64 queries, >= 256 keys, head_dim 64, one
+   * kv head per query head, non-causal): ur_attn_bwd_kv_colsum_floats(a) is the size in f32 words of the scratch kv_colsum_ws the
+   * caller must then provide, or 0 when the shape does not take that kernel (pass kv_colsum = NULL and sum dK | dV yourself). */
+  float* kv_colsum; float* kv_colsum_ws;
 } ur_attn_bwd_args;
 int ur_attn_fwd(const ur_attn_args* a, void* stream);
 int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, void* stream);
 /* f32 words the `delta` workspace of ur_attn_bwd must hold (row constants + the call's own work-queue words) */
 int64_t ur_attn_bwd_workspace_floats(int32_t B, int32_t nq, int32_t Sq);
+int64_t ur_attn_bwd_kv_colsum_floats(const ur_attn_args* a);
 /* Keep flags of the counter-based dropout every kernel here regenerates instead of storing (nn.Dropout at models/qformer.py:107,
  * 258, 287, 373).  Test / inspection entries: a parity test feeds these masks to the reference's own nn.Dropout modules and to the
  * CPU oracle, so that a TRAINING-mode step can be compared value for value.

@@ -375,3 +375,39 @@ def test_right_padded_key_tail_is_skipped_without_changing_a_bit(Sq, Sk, p_drop,
         monkeypatch.setenv("UR_ATTN_FEWQ", "0")
         o3, dq3, dk3, dv3 = run(k, v)
         assert torch.equal(dk, dk3) and torch.equal(dv, dv3) and torch.equal(dq, dq3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# (viii) the K | V bias gradients out of the few-query dK/dV kernel
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,nh,Sq,Sk,p_drop", [(3, 2, 64, 1600, 0.1), (5, 4, 40, 333, 0.0), (70, 16, 64, 256, 0.2)])
+def test_few_query_kernel_emits_the_column_sums_of_dk_dv(B, nh, Sq, Sk, p_drop):
+    """ur_attn_bwd_args.kv_colsum: [sum over batch and keys of dK | of dV] per (head, feature) -- the bias gradients of the K | V
+    projections (models/qformer.py:186-188) -- from the kernel's f32 accumulators, against the column sums of the bf16 dK / dV it
+    stores (ragged masks incl. a sample without a valid key, dropout, key counts that are not multiples of 32); dq / dk / dv themselves
+    do not change by a bit, and shapes the few-query kernel does not take report so."""
+    from tests.test_gpu_attention import _randn
+    q, k, v = _randn((B, Sq, nh, 64), 1, 0.5), _randn((B, Sk, nh, 64), 2, 0.5), _randn((B, Sk, nh, 64), 3)
+    g = torch.Generator().manual_seed(Sk)
+    lens = torch.randint(Sk // 2, Sk + 1, (B,), generator=g)
+    km = (torch.arange(Sk)[None, :] < lens[:, None]).to(torch.uint8)
+    km[1] = 0
+    km = km.to(DEV)
+    dout = _randn((B, Sq, nh, 64), 4)
+    o, ctx = hip.attn_fwd(q, k, v, causal=False, key_mask=km, dropout_p=p_drop, seed=5)
+    assert hip.attn_bwd_kv_colsum_supported(ctx)
+    dq0, dk0, dv0 = hip.attn_bwd(ctx, dout)
+    cs = torch.full((2 * nh * 64,), float("nan"), dtype=torch.float32, device=DEV)
+    dq1, dk1, dv1 = hip.attn_bwd(ctx, dout, kv_colsum=cs)
+    torch.cuda.synchronize()
+    assert torch.equal(dq0, dq1) and torch.equal(dk0, dk1) and torch.equal(dv0, dv1)
+    want = torch.cat([dk1.float().sum(dim=(0, 1)).reshape(-1), dv1.float().sum(dim=(0, 1)).reshape(-1)])
+    scale = want.abs().max().item()
+    err = (cs - want).abs().max().item()
+    # the stored gradients are bf16-rounded per element (2^-9 relative each, random sign): the sums agree to a few 1e-3 of the largest
+    assert torch.isfinite(cs).all() and err <= 4e-3 * scale + 1e-4, (err, scale)
+    # a shape that takes another dK/dV kernel says so
+    o2, ctx2 = hip.attn_fwd(q, k[:, :64].contiguous(), v[:, :64].contiguous(), causal=False)
+    assert not hip.attn_bwd_kv_colsum_supported(ctx2)
+    with pytest.raises(ValueError):
+        hip.attn_bwd(ctx2, dout, kv_colsum=cs)

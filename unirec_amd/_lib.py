@@ -70,7 +70,8 @@ class AttnBwdArgs(ctypes.Structure):
                 ("rope_sin", c_void_p), ("rope_eps", c_float), ("rope_dq_raw", c_void_p), ("rope_lddraw", c_i64),
                 ("rope_rstd", c_void_p), ("rope_rstd_ld", c_i64), ("rope_rstd_h0", c_int),
                 ("rope_k", c_void_p), ("rope_ldk", c_i64), ("rope_k_weight", c_void_p), ("rope_rstd_hk0", c_int),
-                ("rope_dk_raw", c_void_p), ("rope_lddkraw", c_i64)]
+                ("rope_dk_raw", c_void_p), ("rope_lddkraw", c_i64),
+                ("kv_colsum", c_void_p), ("kv_colsum_ws", c_void_p)]
 
 
 # name -> (restype, argtypes).  Every symbol include/unirec_hip.h declares must appear here
@@ -114,6 +115,7 @@ SIGNATURES = {
     "ur_attn_fwd": (c_int, [ctypes.POINTER(AttnArgs), c_void_p]),
     "ur_attn_bwd": (c_int, [ctypes.POINTER(AttnArgs), ctypes.POINTER(AttnBwdArgs), c_void_p]),
     "ur_attn_bwd_workspace_floats": (c_i64, [c_int, c_int, c_int]),
+    "ur_attn_bwd_kv_colsum_floats": (c_i64, [ctypes.POINTER(AttnArgs)]),
     "ur_dropout_keep": (c_int, [c_u64, c_float, c_u64, c_i64, c_void_p, c_void_p]),
     "ur_attn_dropout_keep": (c_int, [c_u64, c_float, c_u64, c_i64, c_int, c_void_p, c_void_p]),
     "ur_rope_table": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),

@@ -89,6 +89,7 @@ struct AttnP {
   const float* rp_rstd; long rp_rstd_ld; int rp_rstd_h0;      // non-null: rp_raw is the ROPED, normed q and 1 / rms comes from the forward (ur_attn_bwd_args.rope_rstd)
   // the k heads' q/k-norm + RoPE backward in the dK/dV kernel's store (with rp_rstd): roped k, its norm weight, first k column of rstd, raw-gradient output
   const bf16_t* rk_src; long rk_ld; const float* rk_w; int rk_rstd_h0; bf16_t* rk_dst; long rk_lddst;
+  float* colsum_part;   // few-query dK/dV kernel: per (batch) partial column sums of dK | dV over the keys, [B][2][nq][hd] f32 (ur_attn_bwd_args.kv_colsum); NULL = off
   unsigned int* queue;  // work queues of the persistent dK/dV kernel: 8 words (one per XCD lane) in the CALLER's workspace, behind the two row-constant
                         // planes of `delta` (ur_attn_bwd_workspace_floats); zeroed by the dQ kernel of the same call
   // hand-scheduled causal head_dim-128 backward (both kernels or neither): plane 1 of `delta` holds -LSE * log2(e) instead of -LSE / scale
@@ -1156,6 +1157,32 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 // per SIMD covering each other's K / V load latency (an explicit register prefetch of the next block measured 3 % slower:
 // 256 VGPRs + spills).  No barrier after the prologue.  Same arithmetic in the same order as
 // attn_bwd_dkv_kernel -> bit-identical results (tests/test_gpu_attention.py).  Non-causal, rep == 1, Sq <= 64.
+// Sum over the 32 lanes of a lane half of each of 32 registers, transposed: lane j (of its half) returns the sum of register j.
+// Five halving steps; at a step the lane keeps the register half its bit selects and adds the partner's copy of it: lanes 16 apart
+// by v_permlane16_swap, then row_mirror (j ^ 15), row_half_mirror (j ^ 7), quad reversal (j ^ 3), quad swap (j ^ 1) -- each partner has
+// the selecting bit flipped, and together the masks generate every lane of the row.  31 exchanges + adds instead of 32 x 5 shuffles.
+template <int CTRL>
+__device__ __forceinline__ float dppx_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lanes_transpose_sum32(const float (&v)[32], int lane) {
+  float a[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[r]), __float_as_uint(v[r + 16]), false, false);
+    a[r] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);      // rows 0 / 2: register r over lanes j, j + 16; rows 1 / 3: register r + 16
+  }
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+  float b[8], c[4], d[2];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) b[r] = (b3 ? a[r + 8] : a[r]) + dppx_f32<0x140>(b3 ? a[r] : a[r + 8]);        // row_mirror
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = (b2 ? b[r + 4] : b[r]) + dppx_f32<0x141>(b2 ? b[r] : b[r + 4]);        // row_half_mirror
+#pragma unroll
+  for (int r = 0; r < 2; ++r) d[r] = (b1 ? c[r + 2] : c[r]) + dppx_f32<0x1B>(b1 ? c[r] : c[r + 2]);         // quad_perm [3, 2, 1, 0]
+  return (b0 ? d[1] : d[0]) + dppx_f32<0xB1>(b0 ? d[0] : d[1]);                                              // quad_perm [1, 0, 3, 2]
+}
+
 #ifndef UR_FEWQ_PREFETCH
 #define UR_FEWQ_PREFETCH 0      // 1 = register prefetch of the next key block: 256 VGPRs + 5 spills, measured 3 % slower than relying on the second wave of the SIMD
 #endif
@@ -1237,6 +1264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
 
   bf16x8 kf[C::NS], vf[C::NS];
   uint32_t state;
+  float csk = 0.f, csv = 0.f;          // this lane's feature of the dK / dV column sums over the wave's key blocks
   int blk = chunk * bpc + wave;
 #if UR_FEWQ_PREFETCH
   load_kv(blk, kf, vf, state);
@@ -1341,6 +1369,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
         }
       }
     }
+    if (p.colsum_part != nullptr) {
+      // column sums of dK | dV over this block's 32 keys (the K | V projections' bias gradients, models/qformer.py:186-188: the caller no
+      // longer re-reads the 13 GB of dK | dV of a C3 step for them): register 16 dt + i of the lane half = feature 32 dt + acc_row(i, h)
+      float t[32];
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[16 * dt + i] = dk[dt][i];
+      csk += lanes_transpose_sum32(t, lane);
+#pragma unroll
+      for (int dt = 0; dt < C::NDT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t[16 * dt + i] = dv[dt][i];
+      csv += lanes_transpose_sum32(t, lane);
+    }
     const long ktok = (long)b * p.Sk + (kok ? key : 0);
     store_T<HD>(p.dk + ktok * p.lddk + (long)hq * HD, dk, p.scale, lane, kok);     // dS was kept unscaled
     store_T<HD>(p.dv + ktok * p.lddv + (long)hq * HD, dv, 1.0f, lane, kok);
@@ -1350,6 +1393,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
     state = state_n;
 #endif
   }
+  if (p.colsum_part != nullptr) {
+    // the four waves' sums -> one partial per (batch, head): [b][dK | dV][head][feature] (the launcher gives such calls ONE workgroup per pair)
+    float* red = reinterpret_cast<float*>(flag + 4);          // [4 waves][2][64]
+    red[(wave * 2 + 0) * 64 + lane] = csk;
+    red[(wave * 2 + 1) * 64 + lane] = csv;
+    __syncthreads();
+    if (tid < 128) {
+      const int t = tid >> 6, l = tid & 63, j = l & 31, hh = l >> 5;
+      const float sum = red[(0 * 2 + t) * 64 + l] + red[(1 * 2 + t) * 64 + l] + red[(2 * 2 + t) * 64 + l] + red[(3 * 2 + t) * 64 + l];
+      const int d = 32 * (j >> 4) + acc_row(j & 15, hh);
+      p.colsum_part[(((long)b * 2 + t) * p.nq + hq) * HD + d] = (t == 0) ? sum * p.scale : sum;       // (dS was kept unscaled)
+    }
+  }
+}
+
+// out[i] = sum_b part[b][i]: the per-batch partial column sums of the few-query dK/dV kernel -> [dK sums | dV sums] (fixed order: reproducible)
+__global__ void kv_colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int B, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int bq = 0;
+  for (; bq + 4 <= B; bq += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] += part[(long)(bq + u) * n + i];
+  }
+  for (; bq < B; ++bq) acc[0] += part[(long)bq * n + i];
+  out[i] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 // ================================================================================================
@@ -3066,9 +3136,10 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
   if (HD == 64 && !CAUSAL && NW == 4 && p.rep == 1 && p.Sq <= KT && p.Sk >= 256 && fewq_enabled()) {
     // few queries, many keys: one workgroup per (batch, head) pair -- or per chunk of its key blocks while the pairs
     // alone do not fill the chip (>= 8 key blocks, i.e. two per wave, per workgroup)
-    constexpr int SMF = 2 * Cfg<64>::TILE + 5 * KT * (int)sizeof(float) + 16;
+    constexpr int SMF = 2 * Cfg<64>::TILE + 5 * KT * (int)sizeof(float) + 16 + 4 * 2 * 64 * (int)sizeof(float);      // + flag + the waves' column sums
     const int nblk = ur_cdiv(p.Sk, 32), pairs = p.nq * p.B;
     int nchunk = std::max(1, std::min(ur_cdiv(4096, pairs), nblk / 8));
+    if (p.colsum_part != nullptr) nchunk = 1;          // the column sums leave as ONE partial per (batch, head): one workgroup per pair
     const int bpc = ur_cdiv(ur_cdiv(nblk, nchunk), 4) * 4;
     nchunk = ur_cdiv(nblk, bpc);
     hipLaunchKernelGGL((attn_bwd_dkv_fewq_kernel<64>), dim3(pairs * nchunk), dim3(256), SMF, st, p, nchunk, bpc);
@@ -3104,12 +3175,16 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
   return 0;
 }
 
+inline int pick_nw(int S) { return S <= 32 ? 1 : (S <= 64 ? 2 : 4); }
+// the shapes whose dK/dV run on attn_bwd_dkv_fewq_kernel (the only kernel that can also emit the column sums of dK | dV)
+inline bool fewq_shape(const AttnP& p, int hd, bool causal) {
+  return hd == 64 && !causal && pick_nw(p.Sk) == 4 && p.rep == 1 && p.Sq <= KT && p.Sk >= 256 && fewq_enabled();
+}
 inline bool c128_bwd_ok(const AttnP& p) {
   return p.Sq == p.Sk && (p.Sk % 128) == 0 && p.Sk >= 128 && p.Sk <= c128::MAX_SK && fwd_c128_enabled() && (long)p.nq * p.B * 8 < (1L << 24) &&
          p.ldk * 2L * p.Sk < (1L << 31) && p.ldv * 2L * p.Sk < (1L << 31) && p.ldq * 2L * p.Sq < (1L << 31) && p.lddo * 2L * p.Sq < (1L << 31) &&
          p.drop_thr == 0 && (long)p.B * p.nq * p.Sq * 4 < (1L << 31);
 }
-inline int pick_nw(int S) { return S <= 32 ? 1 : (S <= 64 ? 2 : 4); }
 
 #define UR_ATTN_DISPATCH(HD_, CAUSAL_, NW_, FN, ...)                                      \
   do {                                                                                    \
@@ -3147,6 +3222,13 @@ extern "C" int ur_attn_fwd(const ur_attn_args* a, void* stream) {
   UR_REQUIRE(a->o && UR_ALIGNED16(a->o) && (a->ldo % 4) == 0 && a->ldo >= (int64_t)a->nq * a->head_dim, "ur_attn_fwd: bad output");
   if (tiny_shape(p, a->head_dim, a->causal != 0, false)) return launch_tiny(p, false, (hipStream_t)stream);
   return do_fwd(p, a->head_dim, a->causal != 0, (hipStream_t)stream);
+}
+
+extern "C" int64_t ur_attn_bwd_kv_colsum_floats(const ur_attn_args* a) {
+  AttnP p;
+  if (!a || fill(p, a) != 0 || a->B <= 0) return 0;
+  if (tiny_shape(p, a->head_dim, a->causal != 0, true) || !fewq_shape(p, a->head_dim, a->causal != 0)) return 0;
+  return 2 * (int64_t)a->B * a->nq * a->head_dim;
 }
 
 extern "C" int64_t ur_attn_bwd_workspace_floats(int32_t B, int32_t nq, int32_t Sq) {
@@ -3187,6 +3269,12 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
     p.rk_dst = (bf16_t*)g->rope_dk_raw; p.rk_lddst = g->rope_lddkraw;
   }
   hipStream_t st = (hipStream_t)stream;
+  p.colsum_part = nullptr;
+  if (g->kv_colsum != nullptr) {
+    UR_REQUIRE(g->kv_colsum_ws != nullptr && ur_attn_bwd_kv_colsum_floats(a) > 0,
+               "ur_attn_bwd: kv_colsum is produced by the few-query dK/dV kernel only (ur_attn_bwd_kv_colsum_floats(a) == 0 for this shape) and needs kv_colsum_ws");
+    p.colsum_part = g->kv_colsum_ws;
+  }
   // the workspace behind the two row-constant planes: two planes of dropout row keys, then the queue words (ur_attn_bwd_workspace_floats)
   p.rowkeys = reinterpret_cast<uint32_t*>(g->delta + 2 * (int64_t)a->B * a->nq * a->Sq);
   p.queue = reinterpret_cast<unsigned int*>(g->delta + 4 * (int64_t)a->B * a->nq * a->Sq);
@@ -3205,6 +3293,11 @@ extern "C" int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, voi
   if (rc) return rc;
   rc = do_dkv(p, a->head_dim, a->causal != 0, st);
   if (rc) return rc;
+  if (p.colsum_part != nullptr) {
+    const int n = 2 * a->nq * a->head_dim;
+    hipLaunchKernelGGL(kv_colsum_reduce_kernel, dim3(ur_cdiv(n, 64)), dim3(64), 0, st, (const float*)p.colsum_part, g->kv_colsum, (int)a->B, n);
+    UR_CHECK_LAUNCH("ur_attn_bwd(kv colsum)");
+  }
   if (rope_k && !rope_k_fused) {
     return ur_qknorm_rope_bwd_roped_k(g->dk, g->rope_k, g->rope_ldk, g->rope_rstd, g->rope_rstd_ld, g->rope_rstd_hk0, g->rope_k_weight, g->rope_cos,
                                       g->rope_sin, g->rope_dk_raw, g->rope_lddkraw, (int64_t)a->B * a->Sk, a->Sk, a->nkv, a->head_dim, stream);

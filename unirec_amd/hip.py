@@ -564,7 +564,12 @@ def attn_fwd(q, k, v, *, causal, key_mask=None, scale=None, dropout_p=0.0, seed=
     return out, ctx
 
 
-def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None, rope_rstd=None, rope_k=None):
+def attn_bwd_kv_colsum_supported(ctx):
+    """True when attn_bwd(ctx, ..., kv_colsum=) can also produce the column sums of dK | dV (the few-query dK/dV kernel's shapes)."""
+    return int(_lib.load().ur_attn_bwd_kv_colsum_floats(ctypes.byref(ctx.args))) > 0
+
+
+def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None, rope_rstd=None, rope_k=None, kv_colsum=None):
     """dout [B,Sq,nq,hd] -> (dq, dk, dv); outputs may be strided views into a fused gradient buffer.
     rope_q = (q_raw [M, >= nq*hd] view, q_norm_weight f32 [hd], cos, sin, eps, dq_raw [M, >= nq*hd] view): the dQ kernel carries
     the q-norm + RoPE backward and writes the gradient of the RAW q projection into dq_raw; no dq is produced (returns None).
@@ -572,7 +577,9 @@ def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None, rope_rstd=None, 
     is then the ROPED q (the attention's own q) and 1 / rms comes from rstd (ur_attn_bwd_args.rope_rstd).
     rope_k = (k_r [M, >= nkv*hd] view, k_norm_weight, first k head's column of rstd, dk_raw [M, >= nkv*hd] view) with rope_rstd: the
     k heads' backward too (in the dK/dV kernel's store where the generated kernel runs, else by the stand-alone kernel inside the call;
-    dk is scratch then)."""
+    dk is scratch then).
+    kv_colsum = f32 [2 * nq * hd] (contiguous): also receives [column sums of dK | of dV] over all keys and batch rows -- the K | V
+    projections' bias gradients -- when attn_bwd_kv_colsum_supported(ctx)."""
     lib = _lib.load()
     q, k, v, _ = ctx.keep
     if dq is None and rope_q is None:
@@ -601,6 +608,15 @@ def attn_bwd(ctx, dout, dq=None, dk=None, dv=None, rope_q=None, rope_rstd=None, 
                 g.rope_k, g.rope_ldk, g.rope_k_weight, g.rope_rstd_hk0 = k_r.data_ptr(), k_r.stride(0), kw.data_ptr(), int(hk0)
                 g.rope_dk_raw, g.rope_lddkraw = dk_raw.data_ptr(), dk_raw.stride(0)
     g.delta = delta.data_ptr()
+    if kv_colsum is not None:
+        nws = int(lib.ur_attn_bwd_kv_colsum_floats(ctypes.byref(a)))
+        if nws <= 0:
+            raise ValueError("attn_bwd: kv_colsum is not available for this shape (attn_bwd_kv_colsum_supported)")
+        _need(kv_colsum, F32, "kv_colsum")
+        if kv_colsum.numel() != 2 * a.nq * a.head_dim or not kv_colsum.is_contiguous():
+            raise ValueError("attn_bwd: kv_colsum must be a contiguous f32 tensor of 2 * nq * head_dim elements")
+        cws = torch.empty((nws,), dtype=F32, device=q.device)
+        g.kv_colsum, g.kv_colsum_ws = kv_colsum.data_ptr(), cws.data_ptr()
     if PROFILE_ATTN is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

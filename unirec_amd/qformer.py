@@ -113,6 +113,7 @@ class _EncoderParams(nn.Module):
         self.layer = nn.ModuleList([_LayerParams(config, i) for i in range(config.num_hidden_layers)])
 
 
+_KV_COLSUM = os.environ.get("UNIREC_KV_COLSUM", "1") != "0"     # test / lab: 0 = the K | V bias gradients by a column-sum pass over dK | dV again
 _USE_WT = os.environ.get("UNIREC_QF_WT", "1") != "0"     # lab: 0 = dX products read the [out, in] weights as K-strided operands again
 _DEAD_RE = re.compile(r"(^|\.)layer\.\d+\.(intermediate\.dense|output\.dense|output\.LayerNorm)\.")
 
@@ -512,6 +513,7 @@ class BertModel(nn.Module):
         kvw, kvb = self._cross_kv_names(pre)
         ncross = len(kvw) // 2
         dkv_all = torch.empty_like(S["kv_all"]) if ncross else None          # every layer's dK | dV, reduced by ONE launch after the loop
+        kv_colsum_fused = None             # True: the attention backward wrote the K | V bias gradients itself (every cross layer)
         for i in reversed(range(len(self.encoder.layer))):
             lyr = self.encoder.layer[i]
             L = S["layers"][i]
@@ -539,7 +541,16 @@ class BertModel(nn.Module):
                 dctx2 = dX(dy2, [c + "output.dense.weight"])
                 dkv5 = dkv_all.view(B, T, ncross, 2, nh, dh)[:, :, jc]
                 dqc = torch.empty_like(qc)
-                hip.attn_bwd(actx2, dctx2.view(B, Qn, nh, dh), dq=dqc.view(B, Qn, nh, dh), dk=dkv5[:, :, 0], dv=dkv5[:, :, 1])
+                # the K | V bias gradients of this layer = column sums of its dK | dV: the few-query dK/dV kernel emits them with the
+                # gradients (user Q-Former: 64 queries x 1600 keys) and the second pass over every layer's dK | dV below disappears
+                cs = None
+                if kv_colsum_fused is not False and _KV_COLSUM and hip.attn_bwd_kv_colsum_supported(actx2):
+                    cs = pack.fusedg(kvb)[jc * 2 * H:(jc + 1) * 2 * H]
+                    kv_colsum_fused = True
+                else:
+                    assert kv_colsum_fused is not True, "cross-attention layers of one model take the same kernel"
+                    kv_colsum_fused = False
+                hip.attn_bwd(actx2, dctx2.view(B, Qn, nh, dh), dq=dqc.view(B, Qn, nh, dh), dk=dkv5[:, :, 0], dv=dkv5[:, :, 1], kv_colsum=cs)
                 dW(dqc, x1, [c + "self.query.weight"])
                 hip.colsum(dqc, out=pack.g32(c + "self.query.bias"))
                 dx = dX(dqc, [c + "self.query.weight"], residual=dz2)
@@ -565,7 +576,8 @@ class BertModel(nn.Module):
         # ---- the cross-attention K | V projections of all layers: one token reduction, one bias sum (and one dX for the encoder states)
         if ncross:
             dW(dkv_all, enc16, kvw)
-            hip.colsum(dkv_all, out=pack.fusedg(kvb))
+            if kv_colsum_fused is not True:
+                hip.colsum(dkv_all, out=pack.fusedg(kvb))
             if enc_needs_grad:
                 d_enc = dX(dkv_all, kvw)
             if self.grad_ready_hook is not None:
