@@ -427,6 +427,13 @@ def measure_stage(args, rank, world, device):
         step()
     sync()
     prof, hip.PROFILE = hip.PROFILE, None
+    # ... and one more pass with events around every attention launch, aggregated per SHAPE (so the few-query cross-attention launches
+    # -- the north-star's small-Q / large-KV kernel -- read separately from the self-attention ones)
+    hip.PROFILE_ATTN = []
+    for _ in range(min(nprof, 3)):
+        step()
+    sync()
+    aprof, hip.PROFILE_ATTN = hip.PROFILE_ATTN, None
     if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -450,6 +457,19 @@ def measure_stage(args, rank, world, device):
                 "avg_launch_ms": round(g_ms / max(len(prof), 1), 4), "gemm_ms_per_step": round(g_ms / nprof, 2),
                 "events": f"separate pass of {nprof} steps right after the timed region (same process, same inputs)",
                 "step_frac_of_peak": round(flops / (dt / args.steps) / 2.5e15, 4)}
+        # attention launches by shape: K | V (and dK | dV) bytes once per pass against the HBM peak (forward / dQ read K | V; the backward
+        # launch = dQ + dK/dV reads K | V twice and writes dK | dV once)
+        ashape = {}
+        for (e0, e1, kind, aB, aSq, aSk, anq, ahd, acausal) in aprof:
+            v = ashape.setdefault((kind, aSq, aSk), [0.0, 0, aB, anq, ahd])
+            v[0] += e0.elapsed_time(e1); v[1] += 1
+        attn_shapes = {}
+        for (kind, aSq, aSk), (ms, n, aB, anq, ahd) in sorted(ashape.items()):
+            kvb = 2.0 * aB * aSk * anq * ahd * 2           # K | V bytes of one pass (bf16; one kv head per query head in the Q-Formers)
+            nbytes = kvb if kind == "fwd" else 3.0 * kvb   # bwd: K | V twice + dK | dV once (the masked key tail is not read: an upper bound)
+            attn_shapes[f"{kind}_q{aSq}_k{aSk}"] = {"launches_per_step": n // max(1, min(nprof, 3)), "avg_launch_us": round(ms / n * 1e3, 1),
+                                                    "GB_per_s_upper": round(nbytes / (ms / n) / 1e6, 1)}
+        roof["attention_by_shape"] = attn_shapes
         out = {"metric": metric, "value": round(world * B * args.steps / dt, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "host_issue_ms_per_step": round(t_host / args.steps * 1e3, 2),
                "higher_is_better": True, "scaling": "weak",
