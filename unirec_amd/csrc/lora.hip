@@ -378,7 +378,10 @@ __global__ __launch_bounds__(256, 2) void rms_lora_kernel(RmsLoraP p) {
   constexpr int SUB = NAD * 16 * 128;
   constexpr int STAGE = 2 * SUB;
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) float wlds[D];          // the norm weight, staged once: the chunk loop reads it from LDS (two global loads per
+                                                                  // 32-column step sat in front of every normalisation: 64 L2 round trips per wave)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l15 = lane & 15;
+  *reinterpret_cast<float4*>(wlds + 4 * tid) = *reinterpret_cast<const float4*>(p.W + 4 * tid);          // 256 threads x 4 = D (made visible by the first chunk's barrier)
   const int tok = blockIdx.x * 64 + wave * 16 + l15;
   const int m = min(tok, p.M - 1);
   const bool mok = tok < p.M;
@@ -450,7 +453,7 @@ _Pragma("unroll") \
  \
       float wv[8]; \
       { \
-        const float4 w0 = *reinterpret_cast<const float4*>(p.W + 32 * c + 8 * g), w1 = *reinterpret_cast<const float4*>(p.W + 32 * c + 8 * g + 4); \
+        const float4 w0 = *reinterpret_cast<const float4*>(wlds + 32 * c + 8 * g), w1 = *reinterpret_cast<const float4*>(wlds + 32 * c + 8 * g + 4); \
         wv[0] = w0.x; wv[1] = w0.y; wv[2] = w0.z; wv[3] = w0.w; wv[4] = w1.x; wv[5] = w1.y; wv[6] = w1.z; wv[7] = w1.w; \
       } \
       const uint32_t wd[4] = {xf[c].x, xf[c].y, xf[c].z, xf[c].w}; \
