@@ -1186,6 +1186,9 @@ __device__ __forceinline__ float lanes_transpose_sum32(const float (&v)[32], int
 #ifndef UR_FEWQ_PREFETCH
 #define UR_FEWQ_PREFETCH 0      // 1 = register prefetch of the next key block: 256 VGPRs + 5 spills, measured 3 % slower than relying on the second wave of the SIMD
 #endif
+#ifndef UR_FEWQ_ABLATE
+#define UR_FEWQ_ABLATE 0        // lab builds only (WRONG results): 1 = no dK / dV stores, 2 = no K / V loads (zero fragments)
+#endif
 #ifndef UR_FEWQ_WAVES
 #define UR_FEWQ_WAVES 2         // lab: waves per SIMD the kernel is compiled for
 #endif
@@ -1247,8 +1250,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
     const long krow = kok ? key : 0;
 #pragma unroll
     for (int st = 0; st < C::NS; ++st) {
+#if UR_FEWQ_ABLATE == 2
+      kf[st] = g_frag(kbase + krow * p.ldk, st, lane, false);
+      vf[st] = g_frag(vbase + krow * p.ldv, st, lane, false);
+#else
       kf[st] = g_frag(kbase + krow * p.ldk, st, lane, kok);
       vf[st] = g_frag(vbase + krow * p.ldv, st, lane, kok);
+#endif
     }
     uint32_t m = 1;
     if (kok && kmrow) m = kmrow[key];
@@ -1385,8 +1393,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
       csv += lanes_transpose_sum32(t, lane);
     }
     const long ktok = (long)b * p.Sk + (kok ? key : 0);
+#if UR_FEWQ_ABLATE == 1          // lab (timing only, results wrong): no dK / dV stores
+    asm volatile("" :: "v"(dk[0][0]), "v"(dv[0][0]), "v"(dk[1][15]), "v"(dv[1][15]));
+#else
     store_T<HD>(p.dk + ktok * p.lddk + (long)hq * HD, dk, p.scale, lane, kok);     // dS was kept unscaled
     store_T<HD>(p.dv + ktok * p.lddv + (long)hq * HD, dv, 1.0f, lane, kok);
+#endif
 #if UR_FEWQ_PREFETCH
 #pragma unroll
     for (int st = 0; st < C::NS; ++st) { kf[st] = kn[st]; vf[st] = vn[st]; }
