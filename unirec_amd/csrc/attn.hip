@@ -1184,7 +1184,9 @@ __device__ __forceinline__ float lanes_transpose_sum32(const float (&v)[32], int
 }
 
 #ifndef UR_FEWQ_PREFETCH
-#define UR_FEWQ_PREFETCH 0      // 1 = register prefetch of the next key block: 256 VGPRs + 5 spills, measured 3 % slower than relying on the second wave of the SIMD
+#define UR_FEWQ_PREFETCH 0      // lab: 2 = the next live key block's K / V fragments are requested in the MIDDLE of the current block, into the registers the
+                                // last S / dP product has just released -- hipcc keeps both sets live instead (256 VGPRs + 96 B of scratch): 2.28 -> 2.83 ms
+                                // for dQ + dK/dV of a C3 layer; round 3's whole-block register prefetch likewise (256 VGPRs + 5 spills, 3 % slower).  0 = at the top
 #endif
 #ifndef UR_FEWQ_ABLATE
 #define UR_FEWQ_ABLATE 0        // lab builds only (WRONG results): 1 = no dK / dV stores, 2 = no K / V loads (zero fragments)
@@ -1222,16 +1224,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
     dos.commit(dotile, tid);
   }
   __syncthreads();
-  // does the sample have a valid key at all?  (then key blocks without one have dK = dV = 0 exactly: trim_masked_tail's argument)
+  // which 32-key blocks hold a valid key, and does the sample have one at all?  (then blocks without one have dK = dV = 0 exactly:
+  // trim_masked_tail's argument.)  One byte per block in LDS: the loop decides without a mask load in its way.
+  unsigned char* live = reinterpret_cast<unsigned char*>(flag + 4 + 4 * 2 * 64);          // [<= 256 blocks], behind the waves' column sums
   if (kmrow != nullptr) {
     int any = 0;
-    for (int i = tid * 16; i < p.Sk; i += 256 * 16) {
-      if (i + 16 <= p.Sk && ((reinterpret_cast<uintptr_t>(kmrow + i) & 15) == 0)) {
-        const uint4 w = *reinterpret_cast<const uint4*>(kmrow + i);
-        any |= (w.x | w.y | w.z | w.w) != 0u;
+    for (int j = tid; j < ((p.Sk + 31) >> 5); j += 256) {
+      int lv = 0;
+      const int i0 = 32 * j;
+      if (i0 + 32 <= p.Sk && ((reinterpret_cast<uintptr_t>(kmrow + i0) & 15) == 0)) {
+        const uint4 w0 = *reinterpret_cast<const uint4*>(kmrow + i0), w1 = *reinterpret_cast<const uint4*>(kmrow + i0 + 16);
+        lv = (w0.x | w0.y | w0.z | w0.w | w1.x | w1.y | w1.z | w1.w) != 0u;
       } else {
-        for (int j = i; j < min(i + 16, p.Sk); ++j) any |= kmrow[j] != 0;
+        for (int i = i0; i < min(i0 + 32, p.Sk); ++i) lv |= kmrow[i] != 0;
       }
+      live[j] = (unsigned char)lv;
+      any |= lv;
     }
     if (any) flag[0] = 1;
     __syncthreads();
@@ -1262,44 +1270,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
     if (kok && kmrow) m = kmrow[key];
     state = (kok ? 1u : 0u) | ((kok && m != 0) ? 2u : 0u);          // bit 0: inside Sk, bit 1: allowed by the key mask
   };
-  auto key_state = [&](int blk) {
-    const int key = blk * 32 + (lane & 31);
-    const bool kok = blk < blk_hi && key < p.Sk;
-    uint32_t m = 1;
-    if (kok && kmrow) m = kmrow[key];
-    return (kok ? 1u : 0u) | ((kok && m != 0) ? 2u : 0u);
-  };
 
   bf16x8 kf[C::NS], vf[C::NS];
-  uint32_t state;
+  uint32_t state = 0;
   float csk = 0.f, csv = 0.f;          // this lane's feature of the dK / dV column sums over the wave's key blocks
   int blk = chunk * bpc + wave;
-#if UR_FEWQ_PREFETCH
-  load_kv(blk, kf, vf, state);
+  bool have = false;                   // kf / vf / state already hold block `blk` (requested in the middle of the previous block)
+#if UR_FEWQ_PREFETCH == 2
+  const int last_sub = p.Sq > 32 ? 1 : 0;
 #endif
   for (; blk < blk_hi; blk += 4) {
-#if UR_FEWQ_PREFETCH
-    bf16x8 kn[C::NS], vn[C::NS];
-    uint32_t state_n;
-    load_kv(blk + 4, kn, vn, state_n);                                // lands under this block's arithmetic
-#else
-    if (sample_has_key) {
+    if (sample_has_key && live[blk] == 0) {
       // a key block without one valid key while the sample has some: every probability is exactly 0 -> dK = dV = 0, nothing is read
-      const uint32_t st0 = key_state(blk);
-      if (!__any((st0 & 2u) != 0)) {
-        const int key0 = blk * 32 + (lane & 31);
-        const bool kok0 = (st0 & 1u) != 0;
-        const long ktok0 = (long)b * p.Sk + (kok0 ? key0 : 0);
-        f32x16 z[C::NDT];
+      const int key0 = blk * 32 + (lane & 31);
+      const bool kok0 = key0 < p.Sk;
+      const long ktok0 = (long)b * p.Sk + (kok0 ? key0 : 0);
+      f32x16 z[C::NDT];
 #pragma unroll
-        for (int dt = 0; dt < C::NDT; ++dt) z[dt] = zero16();
-        store_T<HD>(p.dk + ktok0 * p.lddk + (long)hq * HD, z, 0.f, lane, kok0);
-        store_T<HD>(p.dv + ktok0 * p.lddv + (long)hq * HD, z, 0.f, lane, kok0);
-        continue;
-      }
+      for (int dt = 0; dt < C::NDT; ++dt) z[dt] = zero16();
+      store_T<HD>(p.dk + ktok0 * p.lddk + (long)hq * HD, z, 0.f, lane, kok0);
+      store_T<HD>(p.dv + ktok0 * p.lddv + (long)hq * HD, z, 0.f, lane, kok0);
+      continue;
     }
-    load_kv(blk, kf, vf, state);
-#endif
+    if (!have) load_kv(blk, kf, vf, state);
     const int kblk = blk * 32, key = kblk + (lane & 31);
     const bool kok = (state & 1u) != 0, kvalid = (state & 2u) != 0;
     const bool all_valid = __all(kvalid);
@@ -1316,6 +1309,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(qtile, 32 * sub, st, lane), kf[st], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag<HD>(dotile, 32 * sub, st, lane), vf[st], dp, 0, 0, 0);
       }
+#if UR_FEWQ_PREFETCH == 2
+      if (sub == last_sub) {
+        // the K / V fragments have had their last use: the wave's NEXT live block is requested into the same registers here and lands
+        // under this block's softmax, dV / dK products and stores (the kernel is bound by this per-block chain, not by bytes)
+        const int nb = blk + 4;
+        have = nb < blk_hi && !(sample_has_key && live[nb] == 0);
+        if (have) load_kv(nb, kf, vf, state);
+      }
+#endif
       const bool fast = all_valid && !dropping && (qbase + 32 <= p.Sq);
       if (fast) {
 #pragma unroll
@@ -1398,11 +1400,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UR_FEWQ_WAV
 #else
     store_T<HD>(p.dk + ktok * p.lddk + (long)hq * HD, dk, p.scale, lane, kok);     // dS was kept unscaled
     store_T<HD>(p.dv + ktok * p.lddv + (long)hq * HD, dv, 1.0f, lane, kok);
-#endif
-#if UR_FEWQ_PREFETCH
-#pragma unroll
-    for (int st = 0; st < C::NS; ++st) { kf[st] = kn[st]; vf[st] = vn[st]; }
-    state = state_n;
 #endif
   }
   if (p.colsum_part != nullptr) {
@@ -3148,7 +3145,7 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
   if (HD == 64 && !CAUSAL && NW == 4 && p.rep == 1 && p.Sq <= KT && p.Sk >= 256 && fewq_enabled()) {
     // few queries, many keys: one workgroup per (batch, head) pair -- or per chunk of its key blocks while the pairs
     // alone do not fill the chip (>= 8 key blocks, i.e. two per wave, per workgroup)
-    constexpr int SMF = 2 * Cfg<64>::TILE + 5 * KT * (int)sizeof(float) + 16 + 4 * 2 * 64 * (int)sizeof(float);      // + flag + the waves' column sums
+    constexpr int SMF = 2 * Cfg<64>::TILE + 5 * KT * (int)sizeof(float) + 16 + 4 * 2 * 64 * (int)sizeof(float) + 256;      // + flag + the waves' column sums + one liveness byte per key block
     const int nblk = ur_cdiv(p.Sk, 32), pairs = p.nq * p.B;
     int nchunk = std::max(1, std::min(ur_cdiv(4096, pairs), nblk / 8));
     if (p.colsum_part != nullptr) nchunk = 1;          // the column sums leave as ONE partial per (batch, head): one workgroup per pair
