@@ -114,7 +114,9 @@ int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, voi
 /* Launches with K-contiguous operands, bf16 output, M, N multiples of 256, K a multiple of 64 (>= 256), >= 128 output tiles and
  * a plain / bias / residual / masked-LoRA / SwiGLU-backward epilogue run on the persistent kernel (csrc/gemm_pers.hip: one
  * workgroup per CU walks its tiles, the LDS-DMA ring never drains, epilogue from registers) -- bit-identical to the generic
- * kernel.  ur_gemm_persistent_mode(0) keeps every launch on the generic kernel, (1) enables the persistent one, (-1) returns
+ * kernel.  ur_gemm_persistent_mode(0) keeps every launch on the generic kernel, (1) enables the persistent one, (2) additionally
+ * sends LoRA-free plain / SwiGLU-backward launches with K % 512 == 0 to the wave-specialised lab kernel (csrc/gemm_ws.hip: plain
+ * results bit-identical; SwiGLU backward from the bf16-rounded product, i.e. identical to ur_gemm + ur_swiglu_bwd), (-1) returns
  * to the default (environment UR_GEMM_PERSISTENT, default 1); returns the previous setting.  Process-wide; for A/B timing
  * and the bit-identity tests. */
 int ur_gemm_persistent_mode(int mode);

@@ -23,8 +23,7 @@
 #include "unirec_hip.h"
 
 namespace {
-using urgemm::GemmP;
-using urgemm::uniform_ptr;
+using namespace urgemm;
 
 #ifndef UR_PERS_ABLATE
 #define UR_PERS_ABLATE 0          // lab builds only (WRONG results): 1 = epilogue without its stores, 2 = no epilogue, 3 = vmcnt(12) in every K tile, 4 = plain (not non-temporal) stores
@@ -46,58 +45,6 @@ __device__ long long g_pers_stamps[256 * 2 * 8];
 #endif
 constexpr int BK = 64, BM = 256, BN = 256;
 constexpr int S_BYTES = BN * 128, R_BYTES = BM * 128, STAGE = S_BYTES + R_BYTES;      // one ring slot = 64 KiB
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ char* uniform_wptr(char* p) { return const_cast<char*>(uniform_ptr(p)); }
-// Epilogue accesses name the GLOBAL address space: a pointer rebuilt from scalar halves (uniform_ptr) or read out of the
-// by-value argument struct is a generic pointer to hipcc, which then emits FLAT loads / stores -- and the wait-count pass answers
-// any pending FLAT access with s_waitcnt vmcnt(0) lgkmcnt(0) instead of the exact in-order count (no load could stay in flight
-// across a batch of stores).  global_load / global_store get exact counts.
-template <int W> struct raw_words { typedef uint32_t type __attribute__((ext_vector_type(W))); };
-template <> struct raw_words<1> { typedef uint32_t type; };
-template <class T> __device__ __forceinline__ T ld_g(const void* p) {
-  typedef typename raw_words<sizeof(T) / 4>::type raw_t;                   // (HIP's uint4 / float4 classes do not copy out of an address space)
-  const raw_t r = *(const __attribute__((address_space(1))) raw_t*)(p);
-  return __builtin_bit_cast(T, r);
-}
-template <class T> __device__ __forceinline__ void st_g(void* p, const T& v) {
-  typedef typename raw_words<sizeof(T) / 4>::type raw_t;
-  *(__attribute__((address_space(1))) raw_t*)(p) = __builtin_bit_cast(raw_t, v);
-}
-
-// XCD-aware tile order of gemm.hip, as a function of the (virtual) block id: ids equal mod 8 share an XCD
-// n / d for n * d < 2^32 by one scalar multiply-high: magic = ceil(2^32 / d) (host, TileOrder)
-struct TileOrder { int nwg, gn, gcw, rows_x, per; uint32_t m_gn, m_per, m_gcw; };
-__device__ __forceinline__ int fdiv(int n, uint32_t magic) { return (int)__umulhi((uint32_t)n, magic); }
-__device__ __forceinline__ void tile_coords(const TileOrder& o, int vid, int& bm, int& bn) {
-  const int q = o.nwg >> 3, r = o.nwg & 7, x = vid & 7;
-  const int id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (vid >> 3);
-  if (o.gcw > 0) {
-    const int j = id - x * q;                        // gm % 8 == 0: every XCD owns rows_x whole tile rows (r == 0)
-    const int ch = fdiv(j, o.m_per), rem = j - ch * o.per;
-    const int rr = fdiv(rem, o.m_gcw);
-    bm = x * o.rows_x + rr;
-    bn = ch * o.gcw + (rem - rr * o.gcw);
-  } else {
-    bm = fdiv(id, o.m_gn); bn = id - bm * o.gn;
-  }
-}
-
-// two lanes 16 apart exchange halves: afterwards (a, b) of a lane in 16-lane row rho hold 2 x 4 CONSECUTIVE columns
-//   a' = [a.row0, b.row0, a.row2, b.row2], b' = [a.row1, b.row1, a.row3, b.row3]
-__device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
-  const u32x2_t r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-  a = r[0]; b = r[1];
-}
-__device__ __forceinline__ void swap16f(float& a, float& b) {
-  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-  swap16(ua, ub);
-  a = __uint_as_float(ua); b = __uint_as_float(ub);
-}
 
 // EPI: 0 = plain (alpha only), 2 = residual (+ bias), 5 = bias only, 1 = SwiGLU backward (result is d(act); dgate | dup leave instead of C),
 //      3 = q/k-norm + RoPE of the q|k|v projection (ur_gemm_args.qkr_*; q_r, k_r, v and the row constants leave instead of C),
@@ -765,6 +712,11 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
 }
 
 int gemm_pers_launch(GemmP p, hipStream_t st) {
+  {
+    static const int env_mode = [] { const char* e = getenv("UR_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
+    const int set = g_pers_mode.load(std::memory_order_relaxed);
+    if ((set >= 0 ? set : env_mode) == 2 && gemm_ws_eligible(p)) return gemm_ws_launch(p, st);      // gemm_ws.hip
+  }
   p.gm = p.M / BM; p.gn = p.N / BN;
   p.gcw = 0;
   {
@@ -806,6 +758,6 @@ extern "C" int ur_lab_pers_stamps(long long* host, int n) {
 #endif
 
 extern "C" int ur_gemm_persistent_mode(int mode) {
-  const int prev = urgemm::g_pers_mode.exchange(mode < 0 ? -1 : (mode ? 1 : 0));
+  const int prev = urgemm::g_pers_mode.exchange(mode < 0 ? -1 : (mode > 2 ? 1 : mode));
   return prev;
 }
