@@ -34,6 +34,9 @@ using namespace urgemm;
 #ifndef UR_PERS_EPI_WAIT
 #define UR_PERS_EPI_WAIT 0        // lab: 1 = the epilogue starts with s_waitcnt vmcnt(0): the next tile's two prefetched K tiles have landed before the first C store
 #endif
+#ifndef UR_PERS_REMAP
+#define UR_PERS_REMAP 1           // 0 = the 128-apart column groups and 16 rows x 64 B stores everywhere (A/B builds)
+#endif
 #ifndef UR_PERS_STAMPS
 #define UR_PERS_STAMPS 0          // lab builds only: n > 0 = waves 0 and 4 of every workgroup log s_memtime around their n-th output tile (ur_lab_pers_stamps)
 #endif
@@ -54,6 +57,11 @@ constexpr int S_BYTES = BN * 128, R_BYTES = BM * 128, STAGE = S_BYTES + R_BYTES;
 template <int EPI, int MODE>
 __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder ord, int ntiles) {
   constexpr bool DROP = MODE == 2, K2S = MODE == 1;
+  // REMAP: a wave's two 32-column groups are ADJACENT output columns (n0 + wc*64 + sh*32 ..) instead of 128 apart, so that one store
+  // instruction can cover 8 rows x 128 contiguous bytes -- whole lines -- where the old shape wrote 16 rows x 64 bytes (store-only
+  // kernels: 5.8-6.0 TB/s against 3.3-4.0, tools/lab/store_lab.hip).  The LDS image does not change: LDS row sh*128 + wc*32 + x of the
+  // S tile is FILLED from weight row n0 + wc*64 + sh*32 + x (a different scalar offset per LDS-DMA piece, nothing else).
+  constexpr bool REMAP = UR_PERS_REMAP && EPI != 3 && EPI != 4;      // (EPI 3 / 4: the tile's 128-column halves are two heads / gate | up)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int uwave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
   int vid = blockIdx.x, m0, n0;                            // current output tile
   { int bm, bn; tile_coords(ord, vid, bm, bn); m0 = bm * BM; n0 = bn * BN; }
   int tiles_left = (ntiles - (int)blockIdx.x + gstride - 1) / gstride;      // >= 1: the grid never exceeds ntiles
-  auto s_base = [&](int n) { return reinterpret_cast<const char*>(p.S + (long)(n + uwave * 8) * p.lds); };
+  auto s_base = [&](int n) { return reinterpret_cast<const char*>(p.S + (long)(n + (REMAP ? (uwave & 3) * 8 + (uwave >> 2) * 64 : uwave * 8)) * p.lds); };
   auto r_base = [&](int m) { return reinterpret_cast<const char*>(p.R + (long)(m + uwave * 8) * p.ldr); };
   const char* ubs = uniform_ptr(s_base(n0));               // K tile being fetched: uniform bases of this wave's first piece
   const char* ubr = uniform_ptr(r_base(m0));
@@ -100,7 +108,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
       const int li = 2 * hf + d;
       char* dst = slot + (IS_S ? 0 : S_BYTES) + (li * 8 + uwave) * 1024;
       if constexpr (!Z) {
-        const char* src = (IS_S ? ubs + li * sp_main : ubr + li * rp_main) + (IS_S ? vo_s : vo_r);
+        // (REMAP: piece li = 2 hf + d of the wave holds LDS rows 64 li + 8 wave ..: 32-row group (li >> 1) * 4 + (li & 1) * 2 + (wave >> 2)
+        // = (sh, wc') -> weight rows (wc' * 2 + sh) * 32 ..)
+        const long s_off = REMAP ? (long)(d * 128 + hf * 32) * p.lds * 2 : li * sp_main;
+        const char* src = (IS_S ? ubs + s_off : ubr + li * rp_main) + (IS_S ? vo_s : vo_r);
         __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)dst, 16, 0, 0);
       } else {
         // the K2 tile: rows of lds2 / ldr2 elements; k chunks at or beyond K2 must read as zero.  A raw buffer descriptor over the
@@ -117,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
         asm volatile("" : "+v"(zl));
         const int zk = (zl & 7) ^ (((zl >> 4) + 4 * (uwave & 1)) & 7);
         const uint32_t vo = (zk * 8 < p.K2) ? (uint32_t)((zl >> 3) * ld2 * 2 + zk * 16) : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, vo, (int)(li * 64 * ld2 * 2), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 16, vo, (int)((IS_S && REMAP ? d * 128 + hf * 32 : li * 64) * ld2 * 2), 0, 0);
       }
     }
   };
@@ -273,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
       {
         char* slot = smem + (q & 1) * STAGE;
         const char* nslot = smem + ((q + 1) & 1) * STAGE;
-        ubs = uniform_ptr(reinterpret_cast<const char*>(p.S2 + (long)(n0 + uwave * 8) * p.lds2));
+        ubs = uniform_ptr(reinterpret_cast<const char*>(p.S2 + (long)(n0 + (REMAP ? (uwave & 3) * 8 + (uwave >> 2) * 64 : uwave * 8)) * p.lds2));
         ubr = uniform_ptr(reinterpret_cast<const char*>(p.R2 + (long)(m0 + uwave * 8) * p.ldr2));
         ktile(slot, nslot, std::false_type{}, std::integral_constant<int, 12>{}, std::true_type{});
         ++q;
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
         uint2 fl[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const char* ub = uniform_ptr(reinterpret_cast<const char*>(p.S2 + (long)(n0 + (i >> 1) * 128 + wc * 32 + (i & 1) * 16) * p.lds2 + a * 16));
+          const char* ub = uniform_ptr(reinterpret_cast<const char*>(p.S2 + (long)(n0 + (REMAP ? wc * 64 + (i >> 1) * 32 : (i >> 1) * 128 + wc * 32) + (i & 1) * 16) * p.lds2 + a * 16));
           s2[i] = ld_g<bf16x4>(ub + lo_s2);
         }
 #pragma unroll
@@ -333,8 +344,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
           const long mb = m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16;
           const char* ub = uniform_ptr(reinterpret_cast<const char*>(p.R2 + mb * p.ldr2 + a * 16));
           r2[j] = ld_g<bf16x4>(ub + lo_r2);
-          const char* fb = uniform_ptr(reinterpret_cast<const char*>(p.drop_bits + (long)a * p.drop_bits_stride + mb * p.drop_bits_ld + ((n0 + wc * 32) >> 3)));
-          fl[j] = make_uint2(ld_g<uint32_t>(fb + lo_fl), ld_g<uint32_t>(fb + lo_fl + 16));
+          const char* fb = uniform_ptr(reinterpret_cast<const char*>(p.drop_bits + (long)a * p.drop_bits_stride + mb * p.drop_bits_ld + ((n0 + (REMAP ? wc * 64 : wc * 32)) >> 3)));
+          fl[j] = make_uint2(ld_g<uint32_t>(fb + lo_fl), ld_g<uint32_t>(fb + lo_fl + (REMAP ? 4 : 16)));      // the flag words of the wave's two 32-column groups
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -479,6 +490,46 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
       // after the 16-lane swap a lane holds 8 consecutive columns of row m: cs = (eg4 & 1) * 16 + (eg4 >> 1) * 8 within the wave's 32
       const int cs = (eg4 & 1) * 16 + (eg4 >> 1) * 8;
       const float alpha = p.alpha;
+      // lanes l15 < 8 keep their own group-0 piece in store 1 and take the group-1 piece of the lane 8 rows further into store 2; lanes >= 8 the other way round
+      [[maybe_unused]] const int r7 = el15 & 7;
+      [[maybe_unused]] const bool lo8 = el15 < 8;
+      [[maybe_unused]] auto line_offs = [&](long ld, uint32_t& o1, uint32_t& o2) {
+        o1 = (uint32_t)((r7 * ld + (lo8 ? 0 : 32) + cs) * 2); o2 = (uint32_t)(((8 + r7) * ld + (lo8 ? 32 : 0) + cs) * 2);
+      };
+      [[maybe_unused]] auto merge_lines = [&](const uint32_t (&xa)[4], const uint32_t (&xb)[4], u32x4_t& z1, u32x4_t& z2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          z1[e] = (uint32_t)__builtin_amdgcn_update_dpp((int)xa[e], (int)xb[e], 0x128, 0xf, 0xc, false);     // row_ror:8 into lanes 8..15 of each 16-lane row
+          z2[e] = (uint32_t)__builtin_amdgcn_update_dpp((int)xa[e], (int)xb[e], 0x128, 0xf, 0x3, false);     // ... into lanes 0..7
+        }
+      };
+      if constexpr (EPI == 0 && REMAP) {
+        // whole-line stores: XA = the lane's 8 columns of group sh 0, XB = of group sh 1 (32 columns further); one DPP row rotation by 8
+        // lanes hands XB to the lane 8 rows away, merged under a bank mask: store 1 = rows 0..7 x 128 bytes, store 2 = rows 8..15
+        uint32_t loff1, loff2;
+        line_offs(p.ldc, loff1, loff2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          uint32_t xa[4], xb[4];
+          {
+            const f32x4 a = acc[0][j], b = acc[1][j];
+            xa[0] = pack_bf2(a[0] * alpha, a[1] * alpha); xa[1] = pack_bf2(a[2] * alpha, a[3] * alpha);
+            xa[2] = pack_bf2(b[0] * alpha, b[1] * alpha); xa[3] = pack_bf2(b[2] * alpha, b[3] * alpha);
+            swap16(xa[0], xa[2]); swap16(xa[1], xa[3]);
+          }
+          {
+            const f32x4 a = acc[2][j], b = acc[3][j];
+            xb[0] = pack_bf2(a[0] * alpha, a[1] * alpha); xb[1] = pack_bf2(a[2] * alpha, a[3] * alpha);
+            xb[2] = pack_bf2(b[0] * alpha, b[1] * alpha); xb[3] = pack_bf2(b[2] * alpha, b[3] * alpha);
+            swap16(xb[0], xb[2]); swap16(xb[1], xb[3]);
+          }
+          u32x4_t z1, z2;
+          merge_lines(xa, xb, z1, z2);
+          char* base = uniform_wptr(reinterpret_cast<char*>(p.C) + ((long)(m0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16) * p.ldc + n0 + wc * 64) * 2);
+          __builtin_nontemporal_store(z1, (__attribute__((address_space(1))) u32x4_t*)(base + loff1));
+          __builtin_nontemporal_store(z2, (__attribute__((address_space(1))) u32x4_t*)(base + loff2));
+        }
+      } else
       if constexpr (EPI == 0) {
         const uint32_t loff = (uint32_t)((el15 * p.ldc + cs) * 2);
 #pragma unroll
@@ -500,6 +551,86 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             __builtin_nontemporal_store(v, (__attribute__((address_space(1))) u32x4_t*)(base + loff));
 #endif
           }
+      } else if constexpr ((EPI == 2 || EPI == 5 || EPI == 6 || EPI == 7) && REMAP) {
+        // bias / residual / GELU with whole-line stores.  Bias and residual are added in the MFMA layout (8-byte residual pieces, as below);
+        // quarter q = (row half q >> 1, row blocks 2 (q & 1) .. + 1) x BOTH column groups, so that every row block has its two pieces
+        // at hand for the line merge; the residual pieces of quarter q + 1 are issued before quarter q's stores.
+        constexpr bool RES = EPI == 2 || EPI == 7, GRAD = EPI == 7, GOUT = EPI == 6;
+        const int nq4 = eg4 * 4;
+        const bf16_t* const rsrc = GRAD ? p.aux : p.res;
+        const long ldrs = GRAD ? p.ldaux : p.ldres;
+        uint32_t loc1, loc2, log1 = 0, log2 = 0;
+        line_offs(p.ldc, loc1, loc2);
+        if constexpr (GOUT) line_offs(p.ldg, log1, log2);
+        const uint32_t loff_r = (uint32_t)((el15 * ldrs + nq4) * 2);
+        uint2 ra[2][2][2], rb[2][2][2];          // [buffer][row block of the quarter][column group]
+        float bsa[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, bsb[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (p.bias) {
+#pragma unroll
+          for (int sh = 0; sh < 2; ++sh) {
+            const float4 b0 = ld_g<float4>(p.bias + n0 + wc * 64 + sh * 32 + nq4), b1 = ld_g<float4>(p.bias + n0 + wc * 64 + sh * 32 + 16 + nq4);
+            bsa[sh][0] = b0.x; bsa[sh][1] = b0.y; bsa[sh][2] = b0.z; bsa[sh][3] = b0.w; bsb[sh][0] = b1.x; bsb[sh][1] = b1.y; bsb[sh][2] = b1.z; bsb[sh][3] = b1.w;
+          }
+        }
+        auto load_quarter = [&](int q) {
+          if constexpr (RES) {
+            const int rh = q >> 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int sh = 0; sh < 2; ++sh) {
+                const char* rbase = uniform_ptr(reinterpret_cast<const char*>(rsrc + (long)(m0 + rh * 128 + wr * 64 + (2 * (q & 1) + t) * 16) * ldrs + n0 + wc * 64 + sh * 32));
+                ra[q & 1][t][sh] = ld_g<uint2>(rbase + loff_r);
+                rb[q & 1][t][sh] = ld_g<uint2>(rbase + loff_r + 32);
+              }
+          }
+        };
+        load_quarter(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (q + 1 < 4) load_quarter(q + 1);
+          const int rh = q >> 1;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int jj = 2 * (q & 1) + t, j = 4 * rh + jj;
+            uint32_t x[2][4];
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+              const f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
+              float va[4], vb[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { va[e] = a[e] * alpha + bsa[sh][e]; vb[e] = b[e] * alpha + bsb[sh][e]; }
+              if constexpr (RES && !GRAD) {
+                const uint2 xa = ra[q & 1][t][sh], xb = rb[q & 1][t][sh];
+                va[0] += bf_lo(xa.x); va[1] += bf_hi(xa.x); va[2] += bf_lo(xa.y); va[3] += bf_hi(xa.y);
+                vb[0] += bf_lo(xb.x); vb[1] += bf_hi(xb.x); vb[2] += bf_lo(xb.y); vb[3] += bf_hi(xb.y);
+              }
+              if constexpr (GRAD) {
+                const uint2 xa = ra[q & 1][t][sh], xb = rb[q & 1][t][sh];
+                va[0] *= gelu_erf_grad_f(bf_lo(xa.x)); va[1] *= gelu_erf_grad_f(bf_hi(xa.x)); va[2] *= gelu_erf_grad_f(bf_lo(xa.y)); va[3] *= gelu_erf_grad_f(bf_hi(xa.y));
+                vb[0] *= gelu_erf_grad_f(bf_lo(xb.x)); vb[1] *= gelu_erf_grad_f(bf_hi(xb.x)); vb[2] *= gelu_erf_grad_f(bf_lo(xb.y)); vb[3] *= gelu_erf_grad_f(bf_hi(xb.y));
+              }
+              x[sh][0] = pack_bf2(va[0], va[1]); x[sh][1] = pack_bf2(va[2], va[3]); x[sh][2] = pack_bf2(vb[0], vb[1]); x[sh][3] = pack_bf2(vb[2], vb[3]);
+              swap16(x[sh][0], x[sh][2]); swap16(x[sh][1], x[sh][3]);
+            }
+            u32x4_t z1, z2;
+            merge_lines(x[0], x[1], z1, z2);
+            char* cb = uniform_wptr(reinterpret_cast<char*>(p.C) + ((long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldc + n0 + wc * 64) * 2);
+            st_g<u32x4_t>(cb + loc1, z1);
+            st_g<u32x4_t>(cb + loc2, z2);
+            if constexpr (GOUT) {
+              char* gb = uniform_wptr(reinterpret_cast<char*>(p.gelu_out) + ((long)(m0 + rh * 128 + wr * 64 + jj * 16) * p.ldg + n0 + wc * 64) * 2);
+              u32x4_t g1, g2;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                g1[e] = pack_bf2(gelu_erf_f(bf_lo(z1[e])), gelu_erf_f(bf_hi(z1[e])));
+                g2[e] = pack_bf2(gelu_erf_f(bf_lo(z2[e])), gelu_erf_f(bf_hi(z2[e])));
+              }
+              st_g<u32x4_t>(gb + log1, g1);
+              st_g<u32x4_t>(gb + log2, g2);
+            }
+          }
+        }
       } else if constexpr (EPI == 2 || EPI == 5 || EPI == 6 || EPI == 7) {
         // EPI 5: bias only (a RUNTIME residual switch made hipcc spill 16-25 registers); EPI 6: bias, then GELU of the bf16-ROUNDED
         // pre-activation into a second output (gemm.hip's rich epilogue: the backward's gelu'(u) sees the same u); EPI 7: the second
@@ -568,6 +699,69 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
             }
           }
         }
+      } else if constexpr (EPI == 1 && REMAP) {
+        // ---- SwiGLU backward with whole-line loads and stores: the f32 products change lanes first (the line merge on 8 registers per
+        // column group), then gate / up arrive and dgate / dup leave in the merged layout: 8 rows x 128 contiguous bytes per
+        // instruction.  Same software pipeline as below: quarter q = (row half, two row blocks) x both column groups.
+        __builtin_amdgcn_sched_barrier(0);
+        int em0 = __builtin_amdgcn_readfirstlane(m0), en0 = __builtin_amdgcn_readfirstlane(n0);
+        asm volatile("" : "+s"(em0), "+s"(en0));
+        // three buffers of one row block each (its gate / up pieces at the two store positions: 16 registers), two row blocks ahead:
+        // the same 8 loads per wave in flight as two quarter-tile buffers, in 48 registers instead of 64 (the merged f32 products need 16)
+        uint4 gw[3][2], uw[3][2];
+        uint32_t lg1, lg2, ld1, ld2;
+        line_offs(p.sw_ldgu, lg1, lg2);
+        line_offs(p.sw_lddgu, ld1, ld2);
+        const long up_g = (long)p.sw_I * 2;
+        auto load_block = [&](int j, uint4 (&g)[2], uint4 (&u)[2]) {
+          const char* gb = uniform_ptr(reinterpret_cast<const char*>(p.sw_gu + (long)(em0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16) * p.sw_ldgu + en0 + wc * 64));
+          g[0] = ld_g<uint4>(gb + lg1); g[1] = ld_g<uint4>(gb + lg2);
+          u[0] = ld_g<uint4>(gb + up_g + lg1); u[1] = ld_g<uint4>(gb + up_g + lg2);
+        };
+        load_block(0, gw[0], uw[0]);
+        load_block(1, gw[1], uw[1]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (j + 2 < 8) load_block(j + 2, gw[(j + 2) % 3], uw[(j + 2) % 3]);
+          char* db = uniform_wptr(reinterpret_cast<char*>(p.sw_dgu + (long)(em0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16) * p.sw_lddgu + en0 + wc * 64));
+          float x[2][8];
+#pragma unroll
+          for (int sh = 0; sh < 2; ++sh) {
+            f32x4 a = acc[2 * sh][j], b = acc[2 * sh + 1][j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { float xx = a[e], yy = b[e]; swap16f(xx, yy); a[e] = xx; b[e] = yy; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[sh][e] = a[e] * alpha; x[sh][4 + e] = b[e] * alpha; }
+          }
+#pragma unroll
+          for (int pos = 0; pos < 2; ++pos) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+              v[e] = pos ? __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x[0][e]), __float_as_int(x[1][e]), 0x128, 0xf, 0x3, false))
+                         : __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x[0][e]), __float_as_int(x[1][e]), 0x128, 0xf, 0xc, false));
+            // d(act) = v (f32, unrounded): dgate = v u silu'(g), dup = v silu(g)   (elementwise.hip: swiglu_bwd_kernel)
+            const uint4 gq4 = gw[j % 3][pos], uq4 = uw[j % 3][pos];
+            const uint32_t gq[4] = {gq4.x, gq4.y, gq4.z, gq4.w}, uq[4] = {uq4.x, uq4.y, uq4.z, uq4.w};
+            uint32_t og[4], ou[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float dgv[2], duv[2];
+#pragma unroll
+              for (int hh = 0; hh < 2; ++hh) {
+                const float gg = hh ? bf_hi(gq[e]) : bf_lo(gq[e]), uu = hh ? bf_hi(uq[e]) : bf_lo(uq[e]);
+                const float d = v[2 * e + hh];
+                const float sg = sigmoid_f(gg);
+                duv[hh] = d * (gg * sg);
+                dgv[hh] = d * uu * (sg * (1.0f + gg * (1.0f - sg)));
+              }
+              og[e] = pack_bf2(dgv[0], dgv[1]); ou[e] = pack_bf2(duv[0], duv[1]);
+            }
+            const u32x4_t vg = {og[0], og[1], og[2], og[3]}, vu = {ou[0], ou[1], ou[2], ou[3]};
+            st_g<u32x4_t>(db + (pos ? ld2 : ld1), vg);
+            st_g<u32x4_t>(db + up_g + (pos ? ld2 : ld1), vu);
+          }
+        }
       } else {
         // ---- SwiGLU backward (EPI 1; no bias / residual: gemm_pers_eligible).  vmcnt counts loads and stores in issue order, so a
         // load issued AFTER a batch of stores cannot be waited for without those stores' acknowledgements: four quarter-tile
@@ -575,7 +769,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
         // beside a 23 us K loop at K = 1024).  Software pipeline instead: quarter q + 1's gate / up pieces are issued BEFORE
         // quarter q's stores, into the second of two 32-register buffers; the wait for quarter q's pieces then leaves the 8
         // stores of q - 1 and the 8 loads of q + 1 in flight (hipcc counts them: vmcnt(16)).
-        static_assert(EPI == 1, "the remaining epilogue is the SwiGLU backward");
+        static_assert(EPI == 1 && !REMAP, "the remaining epilogue is the SwiGLU backward in the 128-apart layout");
         __builtin_amdgcn_sched_barrier(0);       // (behind the masked LoRA epilogue: its uniform bases are dead before these are made)
         int em0 = __builtin_amdgcn_readfirstlane(m0), en0 = __builtin_amdgcn_readfirstlane(n0);
         asm volatile("" : "+s"(em0), "+s"(en0));
