@@ -696,7 +696,7 @@ def main():
                                            "frac": round(e1_fl / max(e1_ms, 1e-9) / 1e9 / 2500.0, 4),
                                            "note": "gemm_pers_kernel<1, 2>: the down-projection dX launch that carries the SwiGLU backward in its epilogue (inside `frac` since round 5)"},
                 "frac_without_swiglu_backward": round((tot_fl - x1_fl) / max(tot_ms - x1_ms, 1e-9) / 1e9 / 2500.0, 4),
-                "hbm_bound_families": streams, "kernel": "gemm_pers_kernel<EPI 0|1|2|3|4|5, MODE> + gemm_kernel<true,true,false,256,256,2,4,0> (K-contiguous 256x256 projection GEMM: forward + "
+                "hbm_bound_families": streams, "kernel": "gemm_pers_kernel<EPI 0|1|2|3|4|5, MODE> (every launch of the C4 step since the gate|up dX launch moved to it; other shapes: gemm_kernel<true,true,false,256,256,2,4,0>) (K-contiguous 256x256 projection GEMM: forward + "
                           "frozen-weight dX incl. the launch that carries the SwiGLU backward; the persistent kernel takes the launches csrc/gemm_pers.hip:gemm_pers_eligible "
                           "accepts; launches with a q/k-norm + RoPE, SwiGLU-forward or SwiGLU-backward epilogue are counted with their GEMM FLOPs only)",
                 "plain_epilogue_launches": {"launches": pl_n, "avg_launch_ms": round(pl_ms / max(pl_n, 1), 4),

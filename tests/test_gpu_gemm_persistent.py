@@ -119,10 +119,10 @@ def test_persistent_gelu_epilogues_identical(M, N, K):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("nad", [1, 2, 3])
-def test_persistent_masked_lora_epilogue_identical(nad):
+@pytest.mark.parametrize("nad,K", [(1, 512), (2, 512), (3, 512), (2, 6144)])      # (K = 6144: the gate|up dX launch of the C4 step, on the persistent kernel since round 5)
+def test_persistent_masked_lora_epilogue_identical(nad, K):
     """dX under LoRA dropout: dy W + sum_a keep_a / (1 - p) * (tb_a A_a)."""
-    M, N, K, r, p = 8192, 4096, 512, 16, 0.1
+    M, N, r, p = 8192, 4096, 16, 0.1
     dy, Wt = _randn((M, K), 61), _randn((N, K), 62, 0.05)
     tb, At = _randn((M, nad * r), 63), _randn((N, nad * r), 64, 0.1)
     bits = hip.lora_dropout_bits(7, p, M, N, nad, DEV)

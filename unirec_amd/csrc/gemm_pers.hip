@@ -883,10 +883,11 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
   if (p.K2 > 0 && !p.drop_bits && p.K2 > BK) return false;
   if (p.drop_bits && p.K2 > 0) {
     if (p.drop_rank != 16 || (p.K2 & 15)) return false;                        // the masked epilogue here is rank 16 only
-    // measured (tools/lab/gemm_pers_ab.py, C4 shapes; profiles/r3_gemm_pers_ab.txt): with the masked LoRA epilogue the persistent
-    // kernel wins at K = 1024 (+5 %, +17 % with the SwiGLU backward epilogue), is even at K = 4096 (+1 %) and loses 1.5 % at
-    // K = 6144 (8 long tiles per CU: nothing to hide, and the joined epilogue costs two barrier intervals)
-    static const int kmax = ur_lab_int("UR_PERS_DROP_KMAX", 4096);
+    // measured (tools/lab/gemm_pers_ab.py, C4 shapes): with the masked LoRA epilogue the persistent kernel wins at K = 1024 (+5 %, +17 %
+    // with the SwiGLU backward epilogue) and was even at K = 4096 / lost 1.5 % at K = 6144 in round 3 (profiles/r3_gemm_pers_ab.txt: 8 long
+    // tiles per CU, nothing to hide, and the joined epilogue costs two barrier intervals); with the whole-line epilogue stores of round 5
+    // it wins there too (K = 4096 +8 %, K = 6144 +2-3 %, same box), so the limit only keeps untested lengths off it
+    static const int kmax = ur_lab_int("UR_PERS_DROP_KMAX", 8192);
     if (p.K > kmax) return false;
   }
   if (p.sw_mode == 1 && (p.bias || p.res)) return false;
