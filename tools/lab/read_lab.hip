@@ -50,13 +50,14 @@ float run(const char* X, int M, int W, unsigned* out, int grid) {
 }
 
 int main() {
-  const int M = 131072;
   unsigned* out; (void)hipMalloc(&out, 64);
-  for (int W : {1024, 2048, 6144}) {
+  // (row strides: 2 KiB, 2 KiB + 128 B, 4 KiB, 4 KiB + 128 B, 6 KiB, 8 KiB, 12 KiB; M scaled so that every matrix is ~1.6 GB, far beyond the 256 MiB Infinity Cache)
+  for (int W : {1024, 1088, 2048, 2112, 3072, 4096, 6144}) {
+    const int M = (int)(((size_t)131072 * 6144 / W) / 256 * 256);
     char* X; (void)hipMalloc(&X, (size_t)M * W * 2); (void)hipMemset(X, 1, (size_t)M * W * 2);
     const double gb = (double)M * W * 2 / 1e9;
-    for (int grid : {512, 1024}) {
-      float a = run<128>(X, M, W, out, grid), b = run<256>(X, M, W, out, grid), c = run<512>(X, M, W, out, grid), d = run<1024>(X, M, W, out, grid), e = run<2048>(X, M, W, out, grid);
+    for (int grid : {1024}) {
+      float a = run<128>(X, M, W, out, grid), b = run<256>(X, M, W, out, grid), c = run<512>(X, M, W, out, grid), d = run<1024>(X, M, W, out, grid), e = W % 1024 == 0 ? run<2048>(X, M, W, out, grid) : 1e9f;
       printf("W=%5d (%.2f GB) grid %4d: chunk 128 B %.0f GB/s | 256 B %.0f | 512 B %.0f | 1024 B %.0f | 2048 B %.0f\n", W, gb, grid, gb / a * 1e3, gb / b * 1e3, gb / c * 1e3, gb / d * 1e3, gb / e * 1e3);
     }
     (void)hipFree(X);
