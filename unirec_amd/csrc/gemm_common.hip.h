@@ -52,6 +52,11 @@ template <class T> __device__ __forceinline__ T ld_g(const void* p) {
   const raw_t r = *(const __attribute__((address_space(1))) raw_t*)(p);
   return __builtin_bit_cast(T, r);
 }
+template <class T> __device__ __forceinline__ T ld_g_nt(const void* p) {      // read-once streams (the SwiGLU backward's gate | up, a residual)
+  typedef typename raw_words<sizeof(T) / 4>::type raw_t;
+  const raw_t r = __builtin_nontemporal_load((const __attribute__((address_space(1))) raw_t*)(p));
+  return __builtin_bit_cast(T, r);
+}
 template <class T> __device__ __forceinline__ void st_g(void* p, const T& v) {
   typedef typename raw_words<sizeof(T) / 4>::type raw_t;
   *(__attribute__((address_space(1))) raw_t*)(p) = __builtin_bit_cast(raw_t, v);

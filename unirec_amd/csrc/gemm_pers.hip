@@ -34,6 +34,14 @@ using namespace urgemm;
 #ifndef UR_PERS_EPI_WAIT
 #define UR_PERS_EPI_WAIT 0        // lab: 1 = the epilogue starts with s_waitcnt vmcnt(0): the next tile's two prefetched K tiles have landed before the first C store
 #endif
+#ifndef UR_PERS_NT
+#define UR_PERS_NT 0              // lab: 1 = the epilogues' read-once operands (gate | up of the SwiGLU backward, residual / GELU aux) are loaded non-temporally
+#endif
+#if UR_PERS_NT
+#define UR_LD_STREAM ld_g_nt
+#else
+#define UR_LD_STREAM ld_g
+#endif
 #ifndef UR_PERS_REMAP
 #define UR_PERS_REMAP 1           // 0 = the 128-apart column groups and 16 rows x 64 B stores everywhere (A/B builds)
 #endif
@@ -580,8 +588,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
 #pragma unroll
               for (int sh = 0; sh < 2; ++sh) {
                 const char* rbase = uniform_ptr(reinterpret_cast<const char*>(rsrc + (long)(m0 + rh * 128 + wr * 64 + (2 * (q & 1) + t) * 16) * ldrs + n0 + wc * 64 + sh * 32));
-                ra[q & 1][t][sh] = ld_g<uint2>(rbase + loff_r);
-                rb[q & 1][t][sh] = ld_g<uint2>(rbase + loff_r + 32);
+                ra[q & 1][t][sh] = UR_LD_STREAM<uint2>(rbase + loff_r);
+                rb[q & 1][t][sh] = UR_LD_STREAM<uint2>(rbase + loff_r + 32);
               }
           }
         };
@@ -715,8 +723,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pers_kernel(GemmP p, TileOrder or
         const long up_g = (long)p.sw_I * 2;
         auto load_block = [&](int j, uint4 (&g)[2], uint4 (&u)[2]) {
           const char* gb = uniform_ptr(reinterpret_cast<const char*>(p.sw_gu + (long)(em0 + (j >> 2) * 128 + wr * 64 + (j & 3) * 16) * p.sw_ldgu + en0 + wc * 64));
-          g[0] = ld_g<uint4>(gb + lg1); g[1] = ld_g<uint4>(gb + lg2);
-          u[0] = ld_g<uint4>(gb + up_g + lg1); u[1] = ld_g<uint4>(gb + up_g + lg2);
+          g[0] = UR_LD_STREAM<uint4>(gb + lg1); g[1] = UR_LD_STREAM<uint4>(gb + lg2);
+          u[0] = UR_LD_STREAM<uint4>(gb + up_g + lg1); u[1] = UR_LD_STREAM<uint4>(gb + up_g + lg2);
         };
         load_block(0, gw[0], uw[0]);
         load_block(1, gw[1], uw[1]);

@@ -23,6 +23,12 @@
 #include "common.hip.h"
 #include "unirec_hip.h"
 
+// Cache policy of the ring kernels' activation pieces (the aux operand of global_load_lds): 2 = nt.  They are read once per kernel, like the
+// register-staged kernels' ld_stream loads; with the default policy the rings ran 4.4 TB/s where nt reaches 5.05 (lora_bgrad on a
+// [131072, 4096] input: 244 -> 212 us; the ring DEPTH does not matter: 2 stages 252 us).  0 = default policy (A/B builds).
+#ifndef UR_RING_AUX
+#define UR_RING_AUX 2
+#endif
 namespace {
 
 typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
@@ -277,10 +283,10 @@ __global__ __launch_bounds__(256) void lora_project_ring_kernel(ProjP p) {
       const int piece = 4 * i + wave;
       if (full) {
         const char* ub = bg_uniform_ptr(reinterpret_cast<const char*>(p.X + (long)(tok0 + 8 * piece) * p.ldx + col0 + 64 * c));
-        __builtin_amdgcn_global_load_lds((gbl_void*)(ub + xlane), (lds_void*)(st + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(ub + xlane), (lds_void*)(st + piece * 1024), 16, 0, UR_RING_AUX);
       } else {
         const int m = min(tok0 + 8 * piece + prow, p.M - 1);
-        __builtin_amdgcn_global_load_lds((gbl_void*)(p.X + (long)m * p.ldx + col0 + 64 * c + schunk * 8), (lds_void*)(st + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(p.X + (long)m * p.ldx + col0 + 64 * c + schunk * 8), (lds_void*)(st + piece * 1024), 16, 0, UR_RING_AUX);
       }
     }
     {
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(256) void lora_reduce_ring_kernel(RedP p) {
     for (int i = 0; i < 4; ++i) {
       const int piece = 4 * i + wave;
       const char* ub = bg_uniform_ptr(reinterpret_cast<const char*>(p.X + (t0 + 8 * piece) * p.ldx + col0 + cb));
-      __builtin_amdgcn_global_load_lds((gbl_void*)(ub + xlane), (lds_void*)(st + piece * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void*)(ub + xlane), (lds_void*)(st + piece * 1024), 16, 0, UR_RING_AUX);
     }
 #pragma unroll
     for (int a = 0; a < NAD; ++a) {
@@ -1078,7 +1084,10 @@ __global__ __launch_bounds__(256, 2) void lora_bgrad_kernel(BgradP p) {
 // TWO ways: tokens for tb (wave w: tokens 64 w .. + 63 of the tile as MFMA column operands, all 64 columns), columns for dB
 // (wave w: columns 16 w .. + 15 as hardware-transposed operands, all 256 tokens) -- the dB partial of a column is complete
 // inside one wave, so it leaves straight from the accumulators after the block's last token tile: no cross-wave sum.
-constexpr int B2_TILE = 256, B2_NST = 4;
+#ifndef UR_B2_NST
+#define UR_B2_NST 4          // lab: ring depth of lora_bgrad_ring_kernel (a power of two; 2 = one stage in flight)
+#endif
+constexpr int B2_TILE = 256, B2_NST = UR_B2_NST;
 constexpr int B2_XS = B2_TILE * 128, B2_STAGE = B2_XS + 2048;                   // dy tile + B^T chunk
 constexpr int b2_smem(int nt) { return B2_NST * B2_STAGE + (nt > 2 ? 0 : nt * B2_TILE * 32); }   // + t [tokens][16] (prologue staging; NT 4: inside the ring)
 template <int B2_NT>
@@ -1114,7 +1123,7 @@ __global__ __launch_bounds__(256) void lora_bgrad_ring_kernel(BgradP p) {
       for (int i = 0; i < 8; ++i) {
         const int piece = 4 * i + wave;                       // rows 8 piece .. + 7
         const char* ub = bg_uniform_ptr(reinterpret_cast<const char*>(p.X + (long)(tok0 + t * B2_TILE + 8 * piece) * p.ldx + col0 + 64 * c));
-        __builtin_amdgcn_global_load_lds((gbl_void*)(ub + xlane), (lds_void*)(st + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)(ub + xlane), (lds_void*)(st + piece * 1024), 16, 0, UR_RING_AUX);
       }
     } else {
 #pragma unroll
@@ -1122,7 +1131,7 @@ __global__ __launch_bounds__(256) void lora_bgrad_ring_kernel(BgradP p) {
         const int piece = 4 * i + wave;
         const int m = min(tok0 + t * B2_TILE + 8 * piece + prow, p.M - 1);
         const char* src = reinterpret_cast<const char*>(p.X + (long)m * p.ldx + col0 + 64 * c + (((lane & 7) ^ prow ^ (4 * wpar)) * 8));
-        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(st + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(st + piece * 1024), 16, 0, UR_RING_AUX);
       }
     }
     const char* uu = bg_uniform_ptr(ubase + 128 * c);

@@ -298,6 +298,15 @@ __global__ __launch_bounds__(256) void rms_fwd_kernel(const bf16_t* __restrict__
   }
 }
 
+#ifndef UR_RMS_NT
+#define UR_RMS_NT 7             // bits: 1 = x, 2 = dout, 4 = add read non-temporally (each is read once; 10.55 -> 9.85 ms per C4 step), 8 = dx stored non-temporally (no gain)
+#endif
+typedef unsigned int rms_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ uint4 rms_ld16(const bf16_t* p) {
+  if (!NT) return *reinterpret_cast<const uint4*>(p);
+  const rms_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const rms_u32x4*>(p));
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
 template <int NCH>
 __global__ __launch_bounds__(256) void rms_bwd_kernel(const bf16_t* __restrict__ dout, const bf16_t* __restrict__ x,
                                                       const float* __restrict__ w, const float* __restrict__ rstd,
@@ -314,8 +323,8 @@ __global__ __launch_bounds__(256) void rms_bwd_kernel(const bf16_t* __restrict__
       const int e0 = (lane + i * 64) * 8;
       if (e0 < D) {
         float ww[8];
-        unpack8(*reinterpret_cast<const uint4*>(dout + roff + e0), g[i]);
-        unpack8(*reinterpret_cast<const uint4*>(x + roff + e0), xh[i]);
+        unpack8(rms_ld16<(UR_RMS_NT & 2) != 0>(dout + roff + e0), g[i]);
+        unpack8(rms_ld16<(UR_RMS_NT & 1) != 0>(x + roff + e0), xh[i]);
         load8f(w + e0, ww);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { g[i][e] *= ww[e]; xh[i][e] *= rs; s += g[i][e] * xh[i][e]; }
@@ -331,11 +340,17 @@ __global__ __launch_bounds__(256) void rms_bwd_kernel(const bf16_t* __restrict__
         for (int e = 0; e < 8; ++e) o[e] = rs * (g[i][e] - xh[i][e] * m);
         if (add) {
           float a[8];
-          unpack8(*reinterpret_cast<const uint4*>(add + roff + e0), a);
+          unpack8(rms_ld16<(UR_RMS_NT & 4) != 0>(add + roff + e0), a);
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] += a[e];
         }
-        *reinterpret_cast<uint4*>(dx + roff + e0) = pack8(o);
+        if (UR_RMS_NT & 8) {
+          const uint4 pv = pack8(o);
+          const rms_u32x4 tv = {pv.x, pv.y, pv.z, pv.w};
+          __builtin_nontemporal_store(tv, reinterpret_cast<rms_u32x4*>(dx + roff + e0));
+        } else {
+          *reinterpret_cast<uint4*>(dx + roff + e0) = pack8(o);
+        }
       }
     }
   }
