@@ -267,3 +267,67 @@ def test_wave_specialised_swiglu_backward_equals_the_unfused_pair():
     finally:
         hip.gemm_persistent_mode(prev)
     assert torch.equal(dgu, ref)
+
+
+# ---- seeded sweep over shapes, row strides and epilogue combinations: persistent == generic, bit for bit ----
+# (round 5 re-mapped which output columns a wave owns and how its epilogue addresses every operand; the cases above pin each epilogue at
+# one or two shapes, this one walks odd tile counts, K tile counts of both parities, strided views of every operand and the combinations)
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_persistent_equals_generic_on_random_configurations(seed):
+    import random
+    rng = random.Random(1000 + seed)
+    N = rng.choice([2048, 2304, 3072, 4096])
+    M = 256 * rng.randint(max(4, (128 * 65536) // (256 * N) + 1), 40)
+    K = 64 * rng.randint(4, 20)
+    kind = ["plain", "bias", "residual", "bias_residual", "lora", "lora_residual", "drop", "gelu_out", "gelu_grad", "swiglu_bwd", "swiglu_bwd_drop", "drop3"][seed]
+    pad = lambda cols: rng.choice([0, 8, 64])
+
+    def strided(shape, sd, std=1.0):            # a column view of a wider buffer: row stride != width, 16-byte aligned start
+        extra = pad(shape[1])
+        off = rng.choice([0, 8, 16]) if extra else 0
+        buf = _randn((shape[0], shape[1] + extra + (16 if extra else 0)), sd, std)
+        return buf[:, off:off + shape[1]]
+    R, S = strided((M, K), 11 * seed + 1), strided((N, K), 11 * seed + 2, 0.05)
+    kw = {}
+    r, p = 16, 0.1
+    if kind in ("bias", "bias_residual", "gelu_out"):
+        kw["bias"] = torch.randn(N, device=DEV)
+    if kind in ("residual", "bias_residual", "lora_residual"):
+        kw["residual"] = strided((M, N), 11 * seed + 3)
+    if kind in ("lora", "lora_residual"):
+        k2 = rng.choice([16, 32, 48])
+        kw["R2"], kw["S2"] = strided((M, k2), 11 * seed + 4), strided((N, k2), 11 * seed + 5, 0.1)
+    if kind in ("drop", "drop3", "swiglu_bwd_drop"):
+        nad = 3 if kind == "drop3" else (1 if kind == "swiglu_bwd_drop" else rng.choice([1, 2]))
+        kw["R2"], kw["S2"] = _randn((M, nad * r), 11 * seed + 4), _randn((N, nad * r), 11 * seed + 5, 0.1)
+        kw["drop"] = (hip.lora_dropout_bits(seed + 3, p, M, N, nad, DEV), p, r)
+    if kind == "gelu_grad":
+        kw["gelu_grad_aux"] = strided((M, N), 11 * seed + 6, 1.5)
+    if rng.random() < 0.5 and kind not in ("swiglu_bwd", "swiglu_bwd_drop"):
+        kw["alpha"] = 0.5
+
+    def run():
+        if kind == "gelu_out":
+            g = torch.zeros(M, N + 64, device=DEV, dtype=torch.bfloat16)[:, 32:32 + N]
+            u = hip.gemm(R, S, gelu_out=g, **kw)
+            return torch.cat([u, g], 1)
+        if kind in ("swiglu_bwd", "swiglu_bwd_drop"):
+            gu = _randn((M, 2 * N), 11 * seed + 7)
+            dgu = torch.zeros_like(gu)
+            hip.gemm(R, S, swiglu_bwd=(gu, dgu), **kw)
+            return dgu
+        out = torch.zeros(M, N + 64, device=DEV, dtype=torch.bfloat16)[:, 16:16 + N] if rng.random() < 0.5 else None
+        return hip.gemm(R, S, out=out, **kw).clone()
+    state = rng.getstate()
+    prev = hip.gemm_persistent_mode(0)
+    try:
+        a = run()
+        torch.cuda.synchronize()
+        rng.setstate(state)
+        hip.gemm_persistent_mode(1)
+        b = run()
+        torch.cuda.synchronize()
+    finally:
+        hip.gemm_persistent_mode(prev)
+    assert a.shape == b.shape and torch.equal(a, b), f"{kind} M={M} N={N} K={K}: {(a.float() - b.float()).abs().max().item()}"
+    assert torch.isfinite(b.float()).all() and b.float().abs().max().item() > 0
