@@ -443,6 +443,7 @@ bool gemm_ws_eligible(const GemmP& p) {
   if ((p.M % BM) || (p.N % BN) || (p.K % (BK * NGROUP / 4)) || p.K < BK * NGROUP / 2) return false;      // an epilogue step every >= 2 phases
   if (p.K2 > 0 || p.bias || p.res || p.gelu_out || p.aux || p.qk_q || p.sp_act || p.sw_mode == 2) return false;
   if ((long)(p.M / BM) * (p.N / BN) >= (1L << 20) || p.M / BM >= (1 << 15)) return false;
+  if ((long)p.N * p.lds * 2 >= (1L << 31) || p.ldr * 64 >= (1L << 31)) return false;      // 32-bit scalar / lane offsets of the loader waves' buffer descriptors
   return true;
 }
 
