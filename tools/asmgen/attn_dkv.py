@@ -23,9 +23,14 @@ import isa
 from attn_fwd import flatten, _tag, s_m0_add, ACC_ROW
 from attn_dq import s_mov_vcc, ds_read_b64, v_readfirstlane
 
-LEAD = 6                     # transposed fragments: MFMA slots between a read and its use (their ring has 8 slots: < 8)
+LEAD = int(os.environ.get("UR_DKV_LEAD", "6"))      # transposed fragments: MFMA slots between a read and its use (their ring has 8 slots: < 8)
 LEAD_ROW = int(os.environ.get("UR_DKV_LEAD_ROW", "6"))     # row fragments (one register set per k-step: up to 14); NPRE of the next tile's come with this one
 NPRE = LEAD_ROW // 2
+# first gap of a half's vector stream behind the start of the MFMA block it rides in: 3 = the X block's last MFMA has retired before the first
+# exp reads its accumulator.  (Lab sweep, whole backward at B 64 / S 2048: 0 and 1 run 1.5 % faster -- and are WRONG, the emulator suite fails on NaN:
+# the stream reads S' under the MFMA's latency; 2: -0.5 %, 5 / 6: nothing.  UR_DKV_SOFT0 overrides for lab builds.)
+SOFT0 = int(os.environ.get("UR_DKV_SOFT0", "3"))
+DMA_GAPS = [int(x) for x in os.environ.get("UR_DKV_DMA_GAPS", "1,5,9,13,49,53,57,61,63").split(",")]      # lab: the MFMA gaps that carry the tile's 9 LDS-DMA pieces
 SLOT = 33792                 # row constants 1 KiB (ns[64] f32 | nd[64] f32 | pad) | Q tile 16 KiB | dO tile 16 KiB  (every immediate of slot 1 < 64 KiB)
 CONST_OFF, QOFF, DOFF = 0, 1024, 17408
 LDS_BYTES = 4 * SLOT
@@ -303,10 +308,10 @@ def build_body(p, tag, cnt):
         put(NG - LEAD_ROW + 2 * ks, *row_read(QRF, ks, slot_n, 0, ks, False))
         put(NG - LEAD_ROW + 2 * ks, *row_read(DORF, ks, slot_n, 0, ks, True))
     # LDS-DMA of the tile three ahead
-    for j, g in enumerate([1, 5, 9, 13, 49, 53, 57, 61, 63]):
+    for j, g in enumerate(DMA_GAPS):
         put(g, dma_piece(j, (p + 3) & 3))
     # vector streams
-    ev = [(pos, o, i) for pos, o, i in soft_events(0, GXB + 3)] + [(pos, o, i) for pos, o, i in soft_events(1, GYA + 3)]
+    ev = [(pos, o, i) for pos, o, i in soft_events(0, GXB + SOFT0)] + [(pos, o, i) for pos, o, i in soft_events(1, GYA + SOFT0)]
     for pos, o, i in sorted(ev, key=lambda t: (t[0], t[1])):
         put(pos, _tag([i], "soft")[0])
     put(GXB + 1, _tag(diag_block(0, tag, cnt), "max"))
