@@ -246,3 +246,90 @@ def test_bf16_wire_buckets_under_two_gloo_ranks(tmp_path):
     assert torch.equal(a["sum"], want)
     exact = a["mine"] + b["mine"]
     assert float((a["sum"] - exact).norm() / exact.norm()) < 8e-3
+
+
+def test_lora_shaped_pack_sends_every_bucket_exactly_once():
+    """The LoRA pack has NOTHING ahead of `layers.0.` (offset 0) and Qwen3LoRAModel.backward fires layer signals only (no -1): the
+    lead bucket must leave with layer 0 (a 28-layer pack in groups of 7 used to send 3 of its 4 buckets)."""
+    shapes = []
+    for i in range(28):
+        shapes += [(f"layers.{i}.q.lora_A", (16, 64)), (f"layers.{i}.q.lora_B", (64, 16))]
+    p = _FakePack(shapes)
+    pre = [f"layers.{i}." for i in range(28)]
+    for grp in (7, 1, 28, 5):
+        b = dp.layer_boundaries(p, pre, grp)
+
+        class Rec:
+            bounds = b
+
+            def __init__(self):
+                self.sent = []
+
+            def ready(self, i):
+                self.sent.append(i)
+        rec = Rec()
+        hook = dp.bucket_hook(p, rec, pre, grp)
+        assert hook.lead_by_layer
+        for sig in reversed(range(28)):              # Qwen3LoRAModel.backward: layers 27 .. 0, nothing else
+            hook(sig)
+        n = len(b) - 1
+        assert rec.sent == list(reversed(range(n))), (grp, rec.sent)
+        hook(-1)                                      # a stray closing signal must not send the lead bucket twice
+        assert rec.sent == list(reversed(range(n)))
+
+
+def _world4_worker(rank, world, port, tmp):
+    os.environ.update(GLOO_SOCKET_IFNAME="lo", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    dp.init_from_env(backend="gloo")
+    torch.set_num_threads(1)
+    # a Q-Former-shaped pack (query table | hoisted K|V | 4 layers | head) and a LoRA-shaped one, both driven through bucket_hook in the
+    # backward's signal order; f32 wire for the LoRA pack, bf16 wire for the Q-Former pack (bench.py --comm-bf16)
+    qshapes = [("query_embeddings", (1, 4, 16)), ("qformer.embeddings.LayerNorm.weight", (16,))]
+    qshapes += [(f"qformer.encoder.layer.{i}.crossattention.self.{n}.weight", (16, 16)) for i in (0, 2) for n in ("key", "value")]
+    for i in range(4):
+        qshapes += [(f"qformer.encoder.layer.{i}.attention.self.query.weight", (16, 16))]
+    qshapes += [("head.weight", (8, 16))]
+    lshapes = [(f"layers.{i}.q.lora_A", (16, 32)) for i in range(8)]
+    out = {}
+    for tag, shapes, pre, grp, wire, sigs in (
+            ("q", qshapes, [f"qformer.encoder.layer.{i}." for i in range(4)], 1, torch.bfloat16, [3, 2, 1, 0, -2, -1]),
+            ("l", lshapes, [f"layers.{i}." for i in range(8)], 2, None, list(reversed(range(8))))):
+        p = _FakePack(shapes)
+        g = torch.Generator().manual_seed(7 * rank + len(shapes))
+        p.grad.copy_(torch.randn(p.numel, generator=g))
+        mine = p.grad.clone()
+        bk = dp.GradBuckets(p.grad, dp.layer_boundaries(p, pre, grp), wire_dtype=wire)
+        sent = []
+        ready = bk.ready
+        bk.ready = lambda i, _r=ready, _s=sent: (_s.append(i), _r(i))[1]
+        hook = dp.bucket_hook(p, bk, pre, grp)
+        for s in sigs:
+            hook(s)
+        bk.wait()
+        out[tag] = {"mine": mine, "sum": p.grad.clone(), "sent": sent, "n": bk.n, "head_lo": bk.bounds[-2]}
+    torch.save(out, os.path.join(tmp, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world4_gloo_bucket_order_and_bf16_wire(tmp_path):
+    """world 4: every layer / K|V / lead bucket leaves exactly once in the backward's order on all four
+    ranks, ranks end bitwise identical, the f32 wire equals the sum and the bf16 wire stays inside world * 2^-9."""
+    world, port = 4, _free_port()
+    mp.spawn(_world4_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    R4 = [torch.load(tmp_path / f"r{r}.pt") for r in range(world)]
+    for tag in ("q", "l"):
+        n, head_lo = R4[0][tag]["n"], R4[0][tag]["head_lo"]
+        for r in range(world):
+            sent = R4[r][tag]["sent"]
+            # the trailing head bucket of the Q-Former pack is never signalled (untouched heads carry no gradient)
+            want = list(reversed(range(n - 1))) if tag == "q" else list(reversed(range(n)))
+            assert sent == want, (tag, r, sent)
+            assert torch.equal(R4[r][tag]["sum"][:head_lo] if tag == "q" else R4[r][tag]["sum"], R4[0][tag]["sum"][:head_lo] if tag == "q" else R4[0][tag]["sum"])
+        exact = sum(R4[r][tag]["mine"] for r in range(world))
+        got = R4[0][tag]["sum"]
+        if tag == "l":
+            assert torch.allclose(got, exact, rtol=1e-5, atol=1e-6)
+        else:
+            e = float((got[:head_lo] - exact[:head_lo]).norm() / exact[:head_lo].norm())
+            assert e < world * 2.0 ** -9, e

@@ -73,7 +73,8 @@ def _joint_grads(nmb, B=4, S=256, hist=6, pool=20, layers=2, repeat=1):
     q_pre = [f"qformer.encoder.layer.{i}." for i in range(12)]
     qb = dp.layer_boundaries(qpack, q_pre, 1)
     lbk, qbk = dp.GradBuckets(lpack.grad, lb), dp.GradBuckets(qpack.grad, qb)
-    qw.grad_ready_hook = lambda i: lbk.ready(i)
+    qw.grad_ready_hook = dp.bucket_hook(lpack, lbk, [f"layers.{i}." for i in range(layers)], 1)     # bench.py's wiring (the lead bucket leaves with layer 0)
+    assert qw.grad_ready_hook.lead_by_layer
     qf.qformer.grad_ready_hook = dp.bucket_hook(qpack, qbk, q_pre, 1)
     loss_fn = InfoNCELoss(0.07)
     outs = []

@@ -48,6 +48,19 @@ def test_optimizer_state_survives_a_pack_layout_change():
         FusedAdamW([other]).load_state_dict({**sd, "packs": sd["packs"]})
 
 
+def test_optimizer_state_refuses_the_same_names_at_another_shape():
+    """the reorder branch must not load moments recorded for another shape of the same tensor names (a different LoRA
+    rank): recorded extents are derived from the recorded offsets and compared with the current sizes."""
+    def pk(order, rank):
+        g = torch.Generator().manual_seed(3)
+        ps = {"l.lora_A": (rank, 32), "l.lora_B": (32, rank), "m.lora_A": (rank, 32)}
+        return ParamPack([(n, nn.Parameter(torch.randn(ps[n], generator=g))) for n in order], "cpu")
+    sd = FusedAdamW([pk(["l.lora_A", "l.lora_B", "m.lora_A"], 16)]).state_dict()
+    with pytest.raises(ValueError, match="recorded with"):
+        FusedAdamW([pk(["m.lora_A", "l.lora_A", "l.lora_B"], 8)]).load_state_dict(sd)
+    FusedAdamW([pk(["m.lora_A", "l.lora_A", "l.lora_B"], 16)]).load_state_dict(sd)     # same shapes, another order: accepted
+
+
 def test_attention_backward_workspace_holds_the_queue_words():
     """ur_attn_bwd's workspace = two row-constant planes + the call's own eight work-queue words (no library-owned device state)."""
     lib = _lib.load()

@@ -387,14 +387,20 @@ def bucket_hook(pack, buckets, layer_prefixes, group_size):
     lead = 0
     if h_bucket == lead:
         h_bucket = None            # no boundary between them (nothing precedes the K | V block): one signal, the last one, sends it
+    # a pack with NOTHING ahead of layer 0 (the LoRA pack: `layers.0.` sits at offset 0) has no -1 signal to wait for -- its model
+    # (Qwen3LoRAModel.backward) fires layer signals only -- so the lead bucket goes out with layer 0, the lowest layer of its group
+    lead_by_layer = first_of.get(0) == lead and h_bucket is None and not h_offs
 
     def hook(i):
         if i == -1:
-            buckets.ready(lead)
+            if not lead_by_layer:
+                buckets.ready(lead)
         elif i == -2:
             if h_bucket is not None:
                 buckets.ready(h_bucket)
+        elif i == 0 and lead_by_layer:
+            buckets.ready(lead)
         elif i in first_of and first_of[i] not in (lead, h_bucket):
             buckets.ready(first_of[i])
-    hook.first_of, hook.hoisted_bucket = first_of, h_bucket
+    hook.first_of, hook.hoisted_bucket, hook.lead_by_layer = first_of, h_bucket, lead_by_layer
     return hook

@@ -62,10 +62,17 @@ class FusedAdamW:
                 # same tensors, another order (a pack layout change between versions, e.g. the hoisted cross-attention K|V weights):
                 # the moments move tensor by tensor, recorded offsets -> current offsets
                 rm, rv, roff = rec["exp_avg"].to(m.device), rec["exp_avg_sq"].to(v.device), dict(rec["offsets"])
+                # every recorded tensor's extent = the gap to the next recorded offset (or the buffer's end) must be the 8-padded size
+                # of the CURRENT tensor: the same names at another shape (a different LoRA rank, hidden size) would otherwise load
+                # moments that overlap the neighbours
+                order = sorted(roff.values()) + [rm.numel()]
+                extent = {o: order[k + 1] - o for k, o in enumerate(order[:-1])}
+                for n in p.names:
+                    num = p.params[n].numel()
+                    if extent[roff[n]] != (num + 7) // 8 * 8:
+                        raise ValueError(f"optimizer state: {n} was recorded with {extent[roff[n]]} (padded) elements, the pack holds {num}")
                 for n in p.names:
                     lo, num = p.offsets[n], p.params[n].numel()
-                    if roff[n] + num > rm.numel():
-                        raise ValueError(f"optimizer state: recorded range of {n} lies outside the recorded moments")
                     m[lo:lo + num].copy_(rm[roff[n]:roff[n] + num])
                     v[lo:lo + num].copy_(rv[roff[n]:roff[n] + num])
             else:
