@@ -244,6 +244,29 @@ LORA_PROJ = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_a
 LORA_FULL = ("layers.0.self_attn.q_proj", "layers.0.self_attn.v_proj", "layers.1.self_attn.o_proj", "layers.1.mlp.gate_proj", "layers.0.mlp.down_proj")
 
 
+# BASELINE configs[3] (C4, the headline) at its EXACT architecture and lengths, two sequences (round 6): the reference's 12-layer H 1024
+# Q 2 F 14 item Q-Former on 50 history items per sequence -> 100 injected tokens -> the installed Qwen3Model at the 0.6B shape (28 layers,
+# D 1024, 16 / 8 heads of 128, I 3072) with merged LoRA r 16 at S 2048, left padding -> all-S mean pool -> InfoNCE over a pool of 1000 (the
+# positive + 999 negatives) -> MRR rank; gradients back into the Q-Former and into the adapters (tests/golden/make_golden_r6.py).  Only the
+# embedding TABLE is smaller than the model card's (4096 + 100 rows instead of 151 669 + 100: a row lookup, no arithmetic).
+C4 = {
+    "joint_c4": dict(kind="joint_c4", seed=66, B=2, S=2048, hist=50, N=999, D=1024, first_special_id=4096, pad_side="left",
+                     lora_r=16, lora_alpha=32.0, lora_b_std=0.05,
+                     cfg=dict(H=1024, L=12, nh=16, I=4096, Q=2, F=14, E=1024),
+                     qwen=dict(D=1024, L=28, nq=16, nkv=8, hd=128, I=3072, vocab=4096 + 100)),
+}
+# gradients kept (a [1024, 1024] weight is 4 MB: every C4_ROW_STRIDE-th row + the Frobenius norm of the whole tensor)
+C4_ROW_STRIDE = 32
+C4_QF_KEYS = ("qformer.encoder.layer.10.crossattention.self.key.weight", "qformer.encoder.layer.0.crossattention.self.query.weight",
+              "qformer.encoder.layer.11.intermediate_query.dense.weight", "qformer.encoder.layer.5.attention.self.value.weight")
+C4_LORA_FULL = ("layers.0.self_attn.q_proj", "layers.27.mlp.down_proj")
+
+
+def c4_rows(g):
+    g = np.asarray(g)
+    return np.ascontiguousarray(g[::C4_ROW_STRIDE]) if g.ndim == 2 and g.shape[0] >= 256 else g
+
+
 def lora_weight_rules(case):
     """oracle.weights rule: lora_B with the case's std (the default 0.02 makes the adapter term a few % of the base)."""
     def rule(k, shp):

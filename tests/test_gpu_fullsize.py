@@ -1,5 +1,6 @@
 """GPU: the joint step at BASELINE.json's full C4 size (B=64 x S=2048, hist 50, pool 1000, 28 Qwen3 layers, item
-Q-Former L12 H1024) through SIZE-INDEPENDENT properties -- the oracle cannot run this size in seconds:
+Q-Former L12 H1024) through SIZE-INDEPENDENT properties (the same architecture and lengths meet a reference-produced vector at
+B 2 in tests/test_gpu_r6_parity.py; the oracle needs ~1 min per sequence here, so the full batch is checked by what does not need it):
   * shard invariance: a user's embedding does not depend on which other users share the launch (the property data
     parallelism rests on: rank r's shard of the global batch gives the rows the global batch would), bit for bit;
   * gradient additivity: the gradients of a batch are the sum of the gradients of its two halves (what the RCCL
