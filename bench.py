@@ -40,8 +40,8 @@ def parse():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--pool", type=int, default=1000)
     ap.add_argument("--layers", type=int, default=28, help="Qwen3 layers (28 = the named model; fewer is a debug run)")
-    ap.add_argument("--workload", choices=["joint", "item", "user"], default="joint",
-                    help="joint = C4 headline (default); item = C2 item Q-Former step; user = C3 user Q-Former step")
+    ap.add_argument("--workload", choices=["joint", "item", "user", "item_c1"], default="joint",
+                    help="joint = C4 headline (default); item = C2 item Q-Former step; user = C3 user Q-Former step; item_c1 = C1 tiny item Q-Former eval forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run the CPU oracle leg and print its JSON")
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--no-stages", dest="stages", action="store_false",
                     help="joint workload: skip the item (C2) / user (C3) stage measurements that follow the headline in the same process")
     ap.add_argument("--stage-steps", type=int, default=10)
+    ap.add_argument("--no-c5-stage", dest="c5_stage", action="store_false",
+                    help="joint workload: skip the C5 line (hist 100, S 4096, pool 10000, user tokens, B 64; 1 warm-up + 2 steps) that follows the stages")
+    ap.add_argument("--c5-cpu-budget", type=float, default=45.0, help="seconds of oracle work the C5 cpu_baseline leg may start")
+    ap.add_argument("--cpu-runs", type=int, default=3, help="(internal) timed repeats of the cpu_baseline leg after its warm-up (0: the cold run is the sample)")
     ap.add_argument("--stage-cpu-budget", type=float, default=25.0, help="seconds of oracle work per stage cpu_baseline leg")
     ap.add_argument("--recompute-mlp", action="store_true",
                     help="drop gate|up and act after each layer's forward and rebuild them in the backward (memory for time: "
@@ -216,6 +220,8 @@ def _best_of(step, budget_s, runs=3):
     """warm-up 1 + best of 3, inside a time budget (a run that would overshoot the budget is not started)."""
     t_start = time.time()
     t0 = time.time(); step(); warm = time.time() - t0
+    if runs <= 0:
+        return warm, f"1 run (cold, {warm:.1f} s; bounded sample: no repeats asked for)"
     times = []
     for _ in range(runs):
         if times and time.time() - t_start + min(times) > budget_s:
@@ -246,19 +252,28 @@ def cpu_baseline(args, cfg, dims):
             t = torch.ones(s)
         PW[k] = t.requires_grad_(".lora_" in k)
     first = 4096
-    b = make_batch(1, args.hist, args.seq, args.pool, F, E, D, Qi, first, first, 7, "cpu")
+    n_user = 64 if args.user_tokens else 0
+    ucfg, PU = None, {}
+    if n_user:           # C5 / U4: the User Q-Former (reference default: L4 Q64 H1024 I4096) over hist x 32 cached item tokens, its 64 query tokens injected
+        ucfg = R.QFormerCfg(D, 4, 16, 4096, n_user, D, 1)
+        PU = {k: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for k, s in R.user_qformer_shapes(ucfg, 32).items()}
+        PW["embed_tokens.weight"] = torch.randn(first + args.hist * Qi + n_user, D, generator=g) * 0.02
+    b = make_batch(1, args.hist, args.seq, args.pool, F, E, D, Qi, first, first, 7, "cpu", n_user=n_user)
 
     def step():
-        for t in list(PQ.values()) + list(PW.values()):
+        for t in list(PQ.values()) + list(PW.values()) + list(PU.values()):
             t.grad = None
         out = R.item_qformer_forward(PQ, qcfg, b["history_field_embeddings"].view(args.hist, F, E), b["history_attention_mask"].view(args.hist, F))
         toks = out["query_outputs"].view(1, args.hist, Qi, D)
+        if n_user:
+            _, uqo = R.user_qformer_forward(PU, ucfg, b["user_sequence_tokens"].float(), b["user_attention_mask"], 32)
+            toks = torch.cat([toks.view(1, args.hist * Qi, D), uqo], dim=1).view(1, 1, args.hist * Qi + n_user, D)
         u = Q.joint_forward(PW, wc, b["input_ids"], b["attention_mask"], toks, first)
         loss = Q.infonce_loss(u, b["positive_item_embeddings"], b["negative_item_embeddings"])
         loss.backward()
-    dt, how = _best_of(step, args.cpu_budget)
+    dt, how = _best_of(step, args.cpu_budget, runs=args.cpu_runs)
     return {"value": round(1.0 / dt, 5), "unit": "user-sequences/sec", "cores": threads, "kind": "port",
-            "sample": f"1 user-sequence (hist={args.hist}, S={args.seq}, pool={args.pool}, {cfg.num_hidden_layers} layers), "
+            "sample": f"1 user-sequence (hist={args.hist}, S={args.seq}, pool={args.pool}, {cfg.num_hidden_layers} layers" + (", User Q-Former over hist x 32 tokens + 64 user tokens" if n_user else "") + "), "
                       f"oracle fp32 fwd+bwd, {how}"}
 
 
@@ -268,6 +283,24 @@ def cpu_baseline_stage(args):
     from oracle import qformer_ref as R
     threads = _cpu_threads(args)
     g = torch.Generator().manual_seed(0)
+    if args.workload == "item_c1":
+        # BASELINE configs[0] exactly: the evaluate_item_qformer.py path (evaluation/evaluate_item_qformer.py:66-104), eval forward + masked MSE + cosine
+        B, F, E = 16, 8, 256
+        cfg = R.QFormerCfg(256, 2, 4, 1024, 4, E, 2)
+        P = {k: torch.randn(s, generator=g) * 0.02 for k, s in R.item_qformer_shapes(cfg, F).items()}
+        x = torch.randn(B, F, E, generator=g); x = x / x.norm(dim=-1, keepdim=True)
+        mk = (torch.rand(B, F, generator=g) < 0.8).long(); mk[:, 0] = 1
+        x = x * mk[..., None]
+        reps = 200
+
+        def step():
+            with torch.no_grad():
+                for _ in range(reps):
+                    out = R.item_qformer_forward(P, cfg, x, mk)
+                    R.eval_reconstruction(out["reconstructed_fields"], x, mk)
+        dt, how = _best_of(step, args.cpu_budget)
+        return {"value": round(B * reps / dt, 1), "unit": "items/sec", "latency_us": round(dt / reps * 1e6, 1), "cores": threads, "kind": "port",
+                "sample": f"{reps} eval forwards of {B} items (C1: L2 Q4 H256 nh4 I1024 F8 E256) + masked MSE / cosine, oracle fp32, {how}"}
     if args.workload == "item":
         B, F = 64, 14
         cfg = R.QFormerCfg(768, 12, 12, 3072, 32, 1024, 2)
@@ -312,8 +345,8 @@ def cpu_baseline_subprocess(args):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--workload", args.workload, "--hist", str(args.hist),
            "--seq", str(args.seq), "--pool", str(args.pool), "--layers", str(args.layers), "--cpu-threads", str(args.cpu_threads),
-           "--cpu-budget", str(args.cpu_budget)]
-    unit = {"item": "items/sec"}.get(args.workload, "user-sequences/sec")
+           "--cpu-budget", str(args.cpu_budget), "--cpu-runs", str(getattr(args, "cpu_runs", 3))] + (["--user-tokens"] if getattr(args, "user_tokens", False) else [])
+    unit = {"item": "items/sec", "item_c1": "items/sec"}.get(args.workload, "user-sequences/sec")
     try:
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_budget + 150, env={**os.environ, "HIP_VISIBLE_DEVICES": ""})
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -348,6 +381,8 @@ def measure_stage(args, rank, world, device):
     torch.manual_seed(1234)
     g = torch.Generator().manual_seed(1234 + rank)
     p = 0.0 if args.no_dropout else None
+    if args.workload == "item_c1":
+        return measure_item_c1(args, rank, world, device, g)
     if args.workload == "item":
         from unirec_amd.qformer_utils import QFormerForItemRepresentation
         B = args.batch if args.batch != 64 else 256
@@ -486,6 +521,76 @@ def measure_stage(args, rank, world, device):
     return None
 
 
+def measure_item_c1(args, rank, world, device, g):
+    """BASELINE configs[0] (C1) on the GPU: the evaluate_item_qformer.py path -- eval-mode forward of the tiny item Q-Former (L2 Q4 H256 nh4
+    I1024 F8 E256) over a batch of 16 cached field embeddings + the masked MSE / cosine sums (ur_recon_stats) INSIDE the timed call
+    (evaluation/evaluate_item_qformer.py:66-104).  A forward is ~40 launches of a few microseconds: the line reports the latency of one call
+    as issued launch by launch and, when the capture succeeds, as ONE hipGraph replay (the launch-bound inner loop the graph is for)."""
+    from unirec_amd import hip
+    from unirec_amd.qformer_utils import QFormerForItemRepresentation
+    B, F, E = 16, 8, 256
+    m = QFormerForItemRepresentation(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=1024, num_query_tokens=4,
+                                     field_embedding_dim=E, num_fields=F, dropout=0.2).to(device).eval()
+    x = torch.randn(B, F, E, generator=g); x = x / x.norm(dim=-1, keepdim=True)
+    mk = (torch.rand(B, F, generator=g) < 0.8).long(); mk[:, 0] = 1
+    x = (x * mk[..., None]).to(device)
+    mk = mk.to(device)
+    mkf = mk.float()
+
+    def call():
+        with torch.no_grad():
+            out = m(x, mk)
+            return hip.recon_stats(out["reconstructed_fields"].contiguous(), x, mkf)
+
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n, r
+    reps = 200
+    for _ in range(10):
+        call()
+    dt, sums = timed(call, reps)
+    graph = {"captured": False}
+    try:                         # one hipGraph replay per call (stream capture on a side stream; allocations come from the graph's private pool)
+        gr = torch.cuda.CUDAGraph()
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                call()
+        torch.cuda.current_stream().wait_stream(st)
+        with torch.cuda.graph(gr, stream=st):
+            gsums = call()
+        for _ in range(10):
+            gr.replay()
+        dtg, _ = timed(gr.replay, reps)
+        same = bool(torch.equal(gsums, sums))
+        graph = {"captured": True, "latency_us": round(dtg * 1e6, 1), "items_per_s": round(B / dtg, 1), "bit_identical_to_the_launch_by_launch_call": same}
+    except Exception as e:       # noqa: BLE001 -- the launch-by-launch number stands on its own
+        graph = {"captured": False, "error": f"{type(e).__name__}: {str(e)[:160]}"}
+    if rank != 0:
+        return None
+    sums = sums.float().cpu().tolist()
+    # bytes one call has to move: the live bf16 weights once + the field embeddings + the reconstruction read back by the metric kernel
+    live = sum(p_.numel() for n_, p_ in m.named_parameters() if n_ in m._ensure_pack(device).params)
+    nbytes = 2.0 * live + 4.0 * B * F * E * 3
+    best = min(dt, graph.get("latency_us", 1e30) * 1e-6)
+    roof = {"bound": "hbm", "achieved": round(nbytes / best / 1e9, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / best / 1e9 / 8000.0, 6), "traffic": None,
+            "note": f"latency-bound: {nbytes / 1e6:.2f} MB of weights + inputs per call; the call is a chain of ~40 dependent launches over 64 query rows, not a stream"}
+    out = {"metric": "items/sec item Q-Former eval forward + reconstruction metrics (C1: L2 Q4 H256 nh4 I1024 F8 E256, batch 16; evaluate_item_qformer.py path)",
+           "value": round(B / best, 1), "unit": "items/sec", "n_gpus": 1, "steps": reps, "warmup": 10, "ms_per_step": round(best * 1e3, 4),
+           "latency_us": {"launch_by_launch": round(dt * 1e6, 1), "hip_graph": graph.get("latency_us")}, "hip_graph": graph,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "item_c1", "per_gpu_batch": B, "mode": "eval (dropout off)", "eval_mse": round(sums[0] / max(sums[1], 1.0), 6), "eval_cos_mean": round(sums[2] / max(sums[1], 1.0), 6)},
+           "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "roofline": roof}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_subprocess(args)
+    return out
+
+
 def _check_world(args, world):
     """--gpus N must be the number of ranks that actually run (a silent 1-rank run would report a 1-GPU number as N)."""
     if world != args.gpus and os.environ.get("UNIREC_DP_FORCE") != "1":
@@ -524,13 +629,55 @@ def main():
         raise SystemExit(dp.launch_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     if args.workload != "joint":
         return run_stage(args)
-    from unirec_amd import dp, hip
-    from unirec_amd.joint import InfoNCELoss
-    from unirec_amd.optim import FusedAdamW
+    from unirec_amd import dp
     rank, world, local = dp.init_from_env()
     _check_world(args, world)
     device = torch.device("cuda", local % max(1, torch.cuda.device_count()))      # (modulo: gloo rehearsal of N ranks on one GPU)
     torch.cuda.set_device(device)
+    out = measure_joint(args, rank, world, device)
+    if out is False:
+        return
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    import gc
+    # ---- per-stage lines (BASELINE configs[0], [1], [2], [4]), measured in this same process after the headline; every rank
+    # takes part (the stages all-reduce their gradient packs like the joint step)
+    stages = {}
+    if args.stages and args.batch == 64 and args.hist == 50 and args.seq == 2048 and not args.user_tokens and args.layers == 28:
+        gc.collect(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+        for wl, key in (("item_c1", "item_c1"), ("item", "item_c2"), ("user", "user_c3")):
+            sa = argparse.Namespace(**{**vars(args), "workload": wl, "steps": args.stage_steps, "warmup": 3, "cpu_budget": args.stage_cpu_budget})
+            so = measure_stage(sa, rank, world, device)
+            if rank == 0:
+                stages[key] = {k: so[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "latency_us", "host_issue_ms_per_step", "step_tflops_per_gpu", "max_mem_gb", "config", "roofline", "hip_graph") if k in so}
+                if "cpu_baseline" in so:
+                    stages[key]["cpu_baseline"] = so["cpu_baseline"]
+            gc.collect(); torch.cuda.empty_cache()
+        if args.c5_stage:
+            # BASELINE configs[4] (C5): the C4 step with hist 100, S 4096, pool 10000 and the User Q-Former's 64 tokens (U4), B 64 as ONE launch
+            # (recompute_mlp keeps it inside 288 GB); 1 warm-up + 2 timed steps, its own roofline / attention / cpu_baseline on a bounded sample
+            torch.cuda.reset_peak_memory_stats()
+            ca = argparse.Namespace(**{**vars(args), "hist": 100, "seq": 4096, "pool": 10000, "user_tokens": True, "recompute_mlp": True, "steps": 2, "warmup": 1,
+                                       "micro_batches": 1, "cpu_budget": args.c5_cpu_budget, "cpu_runs": 1})
+            so = measure_joint(ca, rank, world, device, side_steps=1)
+            if rank == 0 and so:
+                stages["joint_c5"] = {k: so[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "step_tflops_per_gpu", "loss", "max_mem_gb", "config", "roofline", "attention", "comm",
+                                                         "cpu_baseline") if k in so}
+            gc.collect(); torch.cuda.empty_cache()
+    if rank == 0:
+        if stages:
+            out["stages"] = stages
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dp.close_native_comms()
+        torch.distributed.destroy_process_group()
+
+
+def measure_joint(args, rank, world, device, side_steps=3):
+    """One joint workload (C4 by default; C5 with --user-tokens --hist 100 --seq 4096 --pool 10000) on an initialised device / process group
+    -> the line's JSON object (rank 0), None on the other ranks, False when a lab switch already printed its own line."""
+    from unirec_amd import dp, hip
+    from unirec_amd.joint import InfoNCELoss
+    from unirec_amd.optim import FusedAdamW
     model, qf, cfg, dims = build(args, device)
     Qi, F, E, D = dims
     B = args.batch
@@ -560,6 +707,7 @@ def main():
     qw.grad_ready_hook = dp.bucket_hook(lpack, lbk, l_pre, lgrp)
     qf.qformer.grad_ready_hook = dp.bucket_hook(qpack, qbk, q_pre, qgrp)      # -2: the hoisted K|V gradients leave from their own hook, -1: the query table
 
+    comm_on, waits = bool(lbk.enabled or qbk.enabled), []
     nmb = max(1, args.micro_batches)
     if B % nmb:
         raise SystemExit(f"--batch {B} is not a multiple of --micro-batches {nmb}")
@@ -587,9 +735,17 @@ def main():
             if ubk is not None:
                 ubk.ready_all()
             total = loss.detach() if total is None else total + loss.detach()
+        # the step stream now WAITS for the bucket all-reduces still in flight on the communicator's side stream: HIP events around the waits
+        # time what the backward did not cover (`comm.exposed_wait_ms_per_step`; two records per step, only when a process group is up)
+        if comm_on:
+            w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            w0.record()
         if ubk is not None:
             ubk.wait()
         lbk.wait(); qbk.wait()
+        if comm_on:
+            w1.record()
+            waits.append((w0, w1))
         opt.step(grad_scale=1.0 / world)
         return total
 
@@ -609,14 +765,24 @@ def main():
     ev_in_loop = os.environ.get("UNIREC_BENCH_EVENTS", "1") != "0"      # lab: 0 = no HIP events inside the timed region at all
     if ev_in_loop:
         hip.PROFILE = []
+    del waits[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     sync()
     dt = time.perf_counter() - t0
+    comm_extra = {}
+    if comm_on:
+        nb = [bk for bk in (lbk, qbk, ubk) if bk is not None]
+        comm_extra = {"exposed_wait_ms_per_step": round(sum(a.elapsed_time(b) for a, b in waits) / max(len(waits), 1), 3),
+                      "buckets": {"lora": lbk.n, "item_qformer": qbk.n, **({"user_qformer": ubk.n} if ubk is not None else {})},
+                      "bytes_per_step": int(sum((2 if bk.wire_on else 4) * sum(max(0, bk.bounds[i + 1] - bk.bounds[i]) for i in range(bk.n)) for bk in nb)),
+                      "wire": {"lora": "f32", "item_qformer": "bf16" if qbk.wire_on else "f32"},
+                      "exposed_wait_note": "HIP events on the step stream around GradBuckets.wait() of every pack: the time the stream stalls on bucket tickets the backward did not cover (0 when the all-reduces hide)"}
+    del waits[:]
     if not ev_in_loop:
         print(json.dumps({"ms_per_step_without_events": round(dt / args.steps * 1e3, 2)}), flush=True)
-        return
+        return False
     prof, hip.PROFILE = hip.PROFILE, None
     if dist_on:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -629,7 +795,7 @@ def main():
     # and under data parallelism every rank must print the same ones (tests/test_gpu_dp_rccl.py)
     checksum = {"lora": float(lpack.master.double().abs().sum().item()), "qformer": float(qpack.master.double().abs().sum().item())}
     # the side pass: attention and HBM-bound family events (all ranks run it: the step holds collectives)
-    nside = max(1, min(args.steps, 3))
+    nside = max(1, min(args.steps, side_steps))
     hip.PROFILE_ATTN, hip.PROFILE_STREAM = [], []
     for _ in range(nside):
         step()
@@ -740,35 +906,14 @@ def main():
                           "hist": args.hist, "pool": args.pool, "dropout": 0.0 if args.no_dropout else 0.2, "lora_dropout": 0.0 if args.no_dropout else args.lora_dropout,
                           "micro_batches": nmb, "recompute_mlp": bool(qw.recompute_mlp), "parallelism": f"dp{world}", "random_init": True},
                "step_tflops_per_gpu": round(fl / (dt / args.steps) / 1e12, 1), "loss": round(lossv, 4),
-               "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "attention": attn, "comm": _comm_info(world), "param_checksum": checksum}
+               "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "attention": attn, "comm": {**_comm_info(world), **comm_extra}, "param_checksum": checksum}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args)
         elif world > 1:
             out["cpu_baseline_note"] = "the CPU oracle leg runs on rank 0 of the N=1 line only"
-    # ---- per-stage lines (items/s of the item Q-Former step C2, sequences/s of the user Q-Former step C3), measured in
-    # this same process after the headline; every rank takes part (the stages all-reduce their gradient packs like the joint step)
-    stages = {}
-    if args.stages and args.batch == 64 and args.hist == 50 and not args.user_tokens:
-        del model, qf, batch, opt, lbk, qbk, loss_fn, qpack, lpack, packs, step
-        qw.grad_ready_hook = None
-        del qw
-        import gc
-        gc.collect(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
-        for wl, key in (("item", "item_c2"), ("user", "user_c3")):
-            sa = argparse.Namespace(**{**vars(args), "workload": wl, "steps": args.stage_steps, "warmup": 3, "cpu_budget": args.stage_cpu_budget})
-            so = measure_stage(sa, rank, world, device)
-            if rank == 0:
-                stages[key] = {k: so[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "host_issue_ms_per_step", "step_tflops_per_gpu", "max_mem_gb", "config", "roofline") if k in so}
-                if "cpu_baseline" in so:
-                    stages[key]["cpu_baseline"] = so["cpu_baseline"]
-            gc.collect(); torch.cuda.empty_cache()
-    if rank == 0:
-        if stages:
-            out["stages"] = stages
-        print(json.dumps(out), flush=True)
-    if dist_on:
-        dp.close_native_comms()
-        torch.distributed.destroy_process_group()
+    qw.grad_ready_hook = None                 # (the hooks hold the buckets: drop the cycle so the packs can be freed before the next workload)
+    qf.qformer.grad_ready_hook = None
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":
