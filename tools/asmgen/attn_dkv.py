@@ -22,6 +22,9 @@ from isa import *      # noqa: F401,F403
 import isa
 from attn_fwd import flatten, _tag, s_m0_add, ACC_ROW
 from attn_dq import s_mov_vcc, ds_read_b64, v_readfirstlane
+import balance
+
+BALANCE = os.environ.get("UR_ASMGEN_BALANCE", "1") == "1"      # round 6: dependency-aware re-placement of the side instructions (balance.py)
 
 LEAD = int(os.environ.get("UR_DKV_LEAD", "6"))      # transposed fragments: MFMA slots between a read and its use (their ring has 8 slots: < 8)
 LEAD_ROW = int(os.environ.get("UR_DKV_LEAD_ROW", "6"))     # row fragments (one register set per k-step: up to 14); NPRE of the next tile's come with this one
@@ -132,11 +135,26 @@ def slot_off(slot):
     return (slot >> 1, (slot & 1) * SLOT)
 
 
+# round 6: the swizzled row-fragment addresses of k-steps 1..7 (RA ^ 32 ks) live in registers of their own (v174..v187: the statement
+# clobbers v8..v255 and used 166 of them) instead of one v_xor_b32 per read: 32 vector instructions (128 issue cycles) less per tile
+PRE_ADDR = os.environ.get("UR_DKV_PRE_ADDR", "1") == "1"
+
+
+def RAK(hi, ks):
+    return RA(hi) if ks == 0 else v(174 + 7 * hi + ks - 1)
+
+
+def row_addr_setup():
+    if not PRE_ADDR:
+        return []
+    return [valu2("v_xor_b32", RAK(hi, ks), Lit(32 * ks), RA(hi), lambda p, q: p ^ q) for hi in range(2) for ks in range(1, 8)]
+
+
 def row_read(ring, rslot, slot, half, ks, is_do):
     hi, imm = slot_off(slot)
     imm += 8192 * half + (DOFF if is_do else QOFF)
-    if ks == 0:
-        return _tag([ds_read_b128(ring(rslot), RA(hi), imm)], "frag")
+    if ks == 0 or PRE_ADDR:
+        return _tag([ds_read_b128(ring(rslot), RAK(hi, ks), imm)], "frag")
     return _tag([valu2("v_xor_b32", TMPA, Lit(32 * ks), RA(hi), lambda p, q: p ^ q), ds_read_b128(ring(rslot), TMPA, imm)], "frag")
 
 
@@ -364,7 +382,7 @@ def prologue_code(with_dma_prologue=True):
     out = [comment("---- entry")]
     if STAMPS:
         out += [s_mov_b32(ACC(i), Lit(0)) for i in range(NACC)]
-    out += common_scalars()
+    out += common_scalars() + row_addr_setup()
     out += [s_mov_b32(LT, Lit(0)), s_mov_b32(LHR, Lit(0)), s_mov_b32(LQ0, QSTART), s_nop(3)]
     for t in range(3):
         if t > 0 or with_dma_prologue:
@@ -420,6 +438,8 @@ def build_program(with_dma_prologue=True):
         seq += [s_add_i32(Q0S, Q0S, Lit(64)), s_cmp("lt", Q0S, SQ4_ROWS), s_cbranch_scc(1, "SAMEHEAD_%d" % p), s_mov_b32(Q0S, QSTART),
                 s_add_i32(HRS, HRS, Lit(1)), label("SAMEHEAD_%d" % p)]
         seq += stamp_acc(2)
+        if BALANCE:
+            seq = balance.balance(flatten(seq), entry_lgkm=entry_pending())
         fixed, _ = fix_hazards(seq, entry_lgkm=entry_pending())
         bodies[name] = fixed
         P.add(label(name), fixed, s_add_i32(IT, IT, Lit(1)), s_cmp("ge", IT, NTOT), s_cbranch_scc(1, "EXIT"))

@@ -24,6 +24,7 @@ import isa
 from attn_fwd import (flatten, _tag, s_m0_add, s_andn2_b64, KSLOT, VSLOT, VBASE_LDS, ACC_ROW)
 
 LEADK, LEADV, LEADT = 6, 6, 8
+BALANCE = os.environ.get("UR_ASMGEN_BALANCE", "1") == "1"      # round 6: dependency-aware re-placement of the side instructions (balance.py)
 WORDS_LDS = 131072
 LDS_BYTES = WORDS_LDS + 64 * 8
 ASM_VGPR_FIRST = 8
@@ -406,6 +407,9 @@ def build_program(with_dma_prologue=True):
     def emit_body(name, p, kind, last):
         seq = top() + dma_setup() + build_body(p, kind, last, name, cnt)
         seq += stamp_acc({"PRO": 2, "PROL": 2}.get(name, 6 if last else 4))
+        if BALANCE:
+            import balance
+            seq = balance.balance(flatten(seq), entry_lgkm=entry_pending() if kind == "steady" else (), temps={TMPA})
         fixed, _ = fix_hazards(seq, entry_lgkm=entry_pending() if kind == "steady" else ())
         bodies[name] = fixed
         return fixed

@@ -418,6 +418,7 @@ def build_body(p, kind, last, sites, tag, with_dma=True):
 
 
 ABLATE = set(x for x in os.environ.get("UR_ASMGEN_ABLATE", "").split(",") if x)   # lab: timing-only builds (results WRONG)
+BALANCE = os.environ.get("UR_ASMGEN_BALANCE_FWD", os.environ.get("UR_ASMGEN_BALANCE", "1")) == "1"      # round 6: dependency-aware re-placement of the side instructions (balance.py)
 
 
 def _ablated(i):
@@ -570,6 +571,9 @@ def build_program(with_dma_prologue=True):
         seq += dma_setup()
         seq += build_body(p, kind, last, sites, name)
         seq += stamp_acc({"PRO": 2, "PROL": 2}.get(name, 6 if last else 4))
+        if BALANCE:
+            import balance
+            seq = balance.balance(flatten(seq), entry_lgkm=entry_pending() if kind == "steady" else (), temps={TMPA})
         fixed, _ = fix_hazards(seq, entry_lgkm=entry_pending() if kind == "steady" else ())
         bodies[name] = fixed
         return fixed
