@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 9
+#define UR_ABI_VERSION 10
 
 int ur_version(void);
 const char* ur_last_error(void);
@@ -114,11 +114,10 @@ int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, voi
 /* Launches with K-contiguous operands, bf16 output, M, N multiples of 256, K a multiple of 64 (>= 256), >= 128 output tiles and
  * a plain / bias / residual / masked-LoRA / SwiGLU-backward epilogue run on the persistent kernel (csrc/gemm_pers.hip: one
  * workgroup per CU walks its tiles, the LDS-DMA ring never drains, epilogue from registers) -- bit-identical to the generic
- * kernel.  ur_gemm_persistent_mode(0) keeps every launch on the generic kernel, (1) enables the persistent one, (2) additionally
- * sends LoRA-free plain / SwiGLU-backward launches with K % 512 == 0 to the wave-specialised lab kernel (csrc/gemm_ws.hip: plain
- * results bit-identical; SwiGLU backward from the bf16-rounded product, i.e. identical to ur_gemm + ur_swiglu_bwd), (-1) returns
- * to the default (environment UR_GEMM_PERSISTENT, default 1); returns the previous setting.  Process-wide; for A/B timing
- * and the bit-identity tests. */
+ * kernel.  ur_gemm_persistent_mode(0) keeps every launch on the generic kernel, (1) enables the persistent one (2 behaves as 1 in
+ * the product library; round 5's wave-specialised lab kernel left the product build in round 6: tools/lab/gemm_ws.hip), (-1) returns
+ * to the default (1); returns the previous setting.  Process-wide; for A/B timing and the bit-identity tests.  The library reads
+ * no environment variable. */
 int ur_gemm_persistent_mode(int mode);
 
 /* ------------------------------------------------------------------------------------------------
@@ -283,6 +282,17 @@ typedef struct {
 } ur_attn_bwd_args;
 int ur_attn_fwd(const ur_attn_args* a, void* stream);
 int ur_attn_bwd(const ur_attn_args* a, const ur_attn_bwd_args* g, void* stream);
+/* Kernel selection of ur_attn_fwd / ur_attn_bwd (round 6: replaces the UR_ATTN_* environment variables the library used to read -- a
+ * product library's launch sequence must not depend on its caller's environment).  Process-wide words, defaults = the product path;
+ * every alternative is a complete path kept for the bit-identity / oracle tests (tests/test_gpu_switches.py) and for A/B timing:
+ *   UR_ATTN_MODE_TINY        3 (default): <= 4-query x <= 16-key shapes on the VALU kernels, forward (bit 0) and backward (bit 1); 0: MFMA kernels
+ *   UR_ATTN_MODE_C128        1: causal head_dim-128 launches on the generated loops (tools/asmgen); 0: the compiler-scheduled kernels
+ *   UR_ATTN_MODE_DKV_PERSIST 1: one dK/dV workgroup per CU drawing key blocks from the call's work queue; 0: one workgroup per key block
+ *   UR_ATTN_MODE_FEWQ        1: few-query x many-key shapes on attn_bwd_dkv_fewq_kernel; 0: attn_bwd_dkv_kernel
+ * ur_attn_mode(key, value) sets the word and returns the previous value (value -1: back to the default; -2: query only); -1 for an
+ * unknown key.  Replaces nothing of the reference (SDPA picks its kernels itself, modeling_qwen3.py:185-208). */
+enum { UR_ATTN_MODE_TINY = 0, UR_ATTN_MODE_C128 = 1, UR_ATTN_MODE_DKV_PERSIST = 2, UR_ATTN_MODE_FEWQ = 3, UR_ATTN_MODE_COUNT = 4 };
+int ur_attn_mode(int key, int value);
 /* f32 words the `delta` workspace of ur_attn_bwd must hold (row constants + the call's own work-queue words) */
 int64_t ur_attn_bwd_workspace_floats(int32_t B, int32_t nq, int32_t Sq);
 int64_t ur_attn_bwd_kv_colsum_floats(const ur_attn_args* a);

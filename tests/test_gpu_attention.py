@@ -125,7 +125,7 @@ def test_attention_dropout_is_deterministic_and_unbiased():
 def test_tiny_attention_kernels(B, nh, Sq, Sk, p_drop, monkeypatch):
     """<= 4 queries x <= 16 keys (the item Q-Former of the joint step: 2 x 2 and 2 x 14) runs on the DPP-row kernels
     (4 pairs per wave, one backward kernel): against the fp32 reference without dropout, and against the MFMA kernels
-    (UR_ATTN_TINY=0; same dropout counters, so the same masks) with it.  Pair counts that do not fill a wave, ragged
+    (ur_attn_mode(UR_ATTN_MODE_TINY, 0); same dropout counters, so the same masks) with it.  Pair counts that do not fill a wave, ragged
     masks and a fully masked sample (uniform softmax) included."""
     q, k, v = _randn((B, Sq, nh, 64), 1, 0.7), _randn((B, Sk, nh, 64), 2, 0.7), _randn((B, Sk, nh, 64), 3)
     g = torch.Generator(device="cpu").manual_seed(Sk * 10 + Sq)
@@ -134,16 +134,14 @@ def test_tiny_attention_kernels(B, nh, Sq, Sk, p_drop, monkeypatch):
     km[1] = 0
     km = km.to(DEV)
     dout = _randn((B, Sq, nh, 64), 4)
-    monkeypatch.setenv("UR_ATTN_TINY", "1")
     o1, c1 = hip.attn_fwd(q, k, v, causal=False, key_mask=km, dropout_p=p_drop, seed=9)
     dq1, dk1, dv1 = hip.attn_bwd(c1, dout)
-    monkeypatch.setenv("UR_ATTN_TINY", "0")
-    o0, c0 = hip.attn_fwd(q, k, v, causal=False, key_mask=km, dropout_p=p_drop, seed=9)
-    dq0, dk0, dv0 = hip.attn_bwd(c0, dout)
-    # mixed: MFMA backward from the tiny forward's context (its row statistics must be the same quantities)
-    dqm, dkm, dvm = hip.attn_bwd(c1, dout)
-    torch.cuda.synchronize()
-    monkeypatch.delenv("UR_ATTN_TINY")
+    with hip.attn_mode_set(hip.ATTN_MODE_TINY, 0):
+        o0, c0 = hip.attn_fwd(q, k, v, causal=False, key_mask=km, dropout_p=p_drop, seed=9)
+        dq0, dk0, dv0 = hip.attn_bwd(c0, dout)
+        # mixed: MFMA backward from the tiny forward's context (its row statistics must be the same quantities)
+        dqm, dkm, dvm = hip.attn_bwd(c1, dout)
+        torch.cuda.synchronize()
     if p_drop == 0.0:
         qf, kf, vf = (t.float().detach().clone().requires_grad_(True) for t in (q, k, v))
         ref = _ref(qf, kf, vf, km, False)
@@ -176,9 +174,8 @@ def test_few_query_dkv_kernel_matches_generic_kernel_bitwise(B, nh, Sq, Sk, p_dr
     km = km.to(DEV)
     dout = _randn((B, Sq, nh, 64), 4)
     o, ctx = hip.attn_fwd(q, k, v, causal=False, key_mask=km, dropout_p=p_drop, seed=5)
-    monkeypatch.setenv("UR_ATTN_FEWQ", "0")
-    dq0, dk0, dv0 = hip.attn_bwd(ctx, dout)
-    monkeypatch.setenv("UR_ATTN_FEWQ", "1")
+    with hip.attn_mode_set(hip.ATTN_MODE_FEWQ, 0):
+        dq0, dk0, dv0 = hip.attn_bwd(ctx, dout)
     dq1, dk1, dv1 = hip.attn_bwd(ctx, dout)
     torch.cuda.synchronize()
     assert torch.equal(dq0, dq1)

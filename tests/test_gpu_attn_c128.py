@@ -1,6 +1,6 @@
 """GPU: the hand-scheduled causal head_dim-128 forward (attn_fwd_c128_kernel: generated main loop, tools/asmgen) against
 (a) a plain PyTorch fp32 reference of the same op (SDPA semantics, transformers modeling_qwen3.py:185-208) and
-(b) the compiler-scheduled attn_fwd_kernel it replaces (UR_ATTN_C128=0), including the (m, 1/l) row statistics the backward reads."""
+(b) the compiler-scheduled attn_fwd_kernel it replaces (ur_attn_mode(UR_ATTN_MODE_C128, 0)), including the (m, 1/l) row statistics the backward reads."""
 import os
 
 import pytest
@@ -40,11 +40,8 @@ def _inputs(B, S, nq, nkv, seed, amp=1.0, spike=False):
 
 def _both(q, k, v, km):
     o_new, ctx_new = hip.attn_fwd(q, k, v, causal=True, key_mask=km)
-    os.environ["UR_ATTN_C128"] = "0"
-    try:
+    with hip.attn_mode_set(hip.ATTN_MODE_C128, 0):
         o_old, ctx_old = hip.attn_fwd(q, k, v, causal=True, key_mask=km)
-    finally:
-        del os.environ["UR_ATTN_C128"]
     torch.cuda.synchronize()
     return o_new, ctx_new, o_old, ctx_old
 
@@ -112,7 +109,7 @@ def test_bitwise_reproducible():
 @pytest.mark.parametrize("S,B,mask", [(2048, 2, "none"), (1024, 4, "left"), (512, 8, "none")])
 def test_persistent_dkv_walk_equals_one_workgroup_per_key_block(S, B, mask, monkeypatch):
     """The dK/dV kernel's persistent walk (8 x U workgroups, the key block rotating with the step) computes every (batch, kv head,
-    key block) exactly as the one-workgroup-per-block launch does: dk, dv bit for bit (UR_ATTN_DKV_PERSIST=0 switches it off).  Shapes
+    key block) exactly as the one-workgroup-per-block launch does: dk, dv bit for bit (ur_attn_mode(UR_ATTN_MODE_DKV_PERSIST, 0) switches it off).  Shapes
     whose sweep divides evenly over 256 CUs: 16 (batch, kv head) groups x 16 / 8 / 4 key blocks."""
     nq, nkv = 16, 8 if S != 512 else 8
     q, k, v = _inputs(B, S, nq, nkv, 50 + S)
@@ -124,8 +121,8 @@ def test_persistent_dkv_walk_equals_one_workgroup_per_key_block(S, B, mask, monk
     o, ctx = hip.attn_fwd(q, k, v, causal=True, key_mask=km)
     dout = torch.randn(B, S, nq, 128, generator=torch.Generator().manual_seed(3)).to(DEV).to(torch.bfloat16)
     dq1, dk1, dv1 = hip.attn_bwd(ctx, dout)
-    monkeypatch.setenv("UR_ATTN_DKV_PERSIST", "0")
-    dq0, dk0, dv0 = hip.attn_bwd(ctx, dout)
+    with hip.attn_mode_set(hip.ATTN_MODE_DKV_PERSIST, 0):
+        dq0, dk0, dv0 = hip.attn_bwd(ctx, dout)
     torch.cuda.synchronize()
     assert torch.equal(dk1, dk0) and torch.equal(dv1, dv0) and torch.equal(dq1, dq0)
     assert dk1.float().abs().max() > 0

@@ -231,44 +231,6 @@ def test_gate_up_projection_with_paired_swiglu_epilogue(lora):
     assert torch.equal(act1, act0)
 
 
-# ---- the wave-specialised 128 x 256 kernel (csrc/gemm_ws.hip; lab switch ur_gemm_persistent_mode(2), not a default path) ----
-def _ws(fn):
-    prev = hip.gemm_persistent_mode(2)
-    try:
-        out = fn()
-        torch.cuda.synchronize()
-    finally:
-        hip.gemm_persistent_mode(prev)
-    return out
-
-
-# 264 x 16 tiles of 128 x 256 on 256 workgroups: 16 or 17 tiles each (the stash hand-over, the epilogue waves one tile behind, the
-# tail after the MFMA waves have left); K = 1024 is the shortest eligible stream (an epilogue step every phase pair), 1536 = three phases per step
-@pytest.mark.parametrize("M,N,K", [(8192, 4096, 1536), (33792, 4096, 1024), (8192, 4096, 3072)])
-def test_wave_specialised_plain_is_exact(M, N, K):
-    Rm, Sm = _ints((M, K), seed=91), _ints((N, K), seed=92)
-    R, S = _bf(Rm), _bf(Sm)
-    ref = ((Rm.to(DEV).double() @ Sm.to(DEV).double().t()) / 8).to(torch.bfloat16)
-    out = _ws(lambda: hip.gemm(R, S, alpha=0.125))
-    assert torch.equal(out, ref), f"{(out.float() - ref.float()).abs().max().item()}"
-
-
-def test_wave_specialised_swiglu_backward_equals_the_unfused_pair():
-    """Its epilogue waves see d(act) rounded to bf16 (the LDS stash), i.e. exactly what ur_gemm + ur_swiglu_bwd compute
-    (modeling_qwen3.py:81-83 backward); the persistent kernel's register epilogue uses the unrounded f32 value."""
-    M, I, K = 16384, 3072, 1024
-    R, W, gu = _randn((M, K), 93), _randn((I, K), 94, 0.05), _randn((M, 2 * I), 95)
-    dgu = torch.full_like(gu, float("nan"))
-    _ws(lambda: hip.gemm(R, W, swiglu_bwd=(gu, dgu)))
-    prev = hip.gemm_persistent_mode(1)
-    try:
-        ref = hip.swiglu_bwd(hip.gemm(R, W), gu, I)
-        torch.cuda.synchronize()
-    finally:
-        hip.gemm_persistent_mode(prev)
-    assert torch.equal(dgu, ref)
-
-
 # ---- seeded sweep over shapes, row strides and epilogue combinations: persistent == generic, bit for bit ----
 # (round 5 re-mapped which output columns a wave owns and how its epilogue addresses every operand; the cases above pin each epilogue at
 # one or two shapes, this one walks odd tile counts, K tile counts of both parities, strided views of every operand and the combinations)

@@ -372,8 +372,8 @@ def test_right_padded_key_tail_is_skipped_without_changing_a_bit(Sq, Sk, p_drop,
     assert torch.equal(o[sel], o2[sel]) and torch.equal(dq[sel], dq2[sel]) and torch.equal(dk[sel], dk2[sel]) and torch.equal(dv[sel], dv2[sel])
     # the few-query kernel against the generic one, bit for bit (same arithmetic, the generic kernel sweeps everything)
     if Sq <= 64 and Sk >= 256:
-        monkeypatch.setenv("UR_ATTN_FEWQ", "0")
-        o3, dq3, dk3, dv3 = run(k, v)
+        with hip.attn_mode_set(hip.ATTN_MODE_FEWQ, 0):
+            o3, dq3, dk3, dv3 = run(k, v)
         assert torch.equal(dk, dk3) and torch.equal(dv, dv3) and torch.equal(dq, dq3)
 
 

@@ -116,7 +116,9 @@ MODULE_SWITCHES = {
 }
 # switches read on every call (Python layer and library)
 ENV_SWITCHES = ["UNIREC_BITS_T=0", "UNIREC_BITS_ONE_EVENT=1", "UNIREC_PAD_ATT=0", "UNIREC_ROPE_BWD_FUSED=0", "UNIREC_ROPE_K_FUSED=0",
-                "UNIREC_FUSE_QK_ROPE_OFF_AND_ROPE_BWD_FUSED=1", "UR_ATTN_C128=0", "UR_ATTN_DKV_PERSIST=0", "UR_ATTN_TINY=0"]
+                "UNIREC_FUSE_QK_ROPE_OFF_AND_ROPE_BWD_FUSED=1"]
+# kernel-selection words of the library (ur_attn_mode; it reads no environment variable)
+ATTN_MODES = {"ur_attn_mode(C128, 0)": (1, 0), "ur_attn_mode(DKV_PERSIST, 0)": (2, 0), "ur_attn_mode(TINY, 0)": (0, 0)}
 
 
 @pytest.mark.parametrize("name", list(MODULE_SWITCHES))
@@ -142,12 +144,21 @@ def test_call_time_switch_flipped_alone(name, monkeypatch):
     _product_step_meets_the_oracle(name)
 
 
+@pytest.mark.parametrize("name", list(ATTN_MODES))
+def test_attention_mode_flipped_alone(name):
+    from unirec_amd import hip
+    key, val = ATTN_MODES[name]
+    with hip.attn_mode_set(key, val):
+        _product_step_meets_the_oracle(name)
+    assert hip.attn_mode(key, -2) == (3 if key == 0 else 1)
+
+
 def test_recompute_mlp_and_the_generic_gemm():
     from unirec_amd import _lib
     _product_step_meets_the_oracle("recompute_mlp", recompute_mlp=True)
     lib = _lib.load()
     prev = lib.ur_gemm_persistent_mode(0)
     try:
-        _product_step_meets_the_oracle("UR_GEMM_PERSISTENT=0")
+        _product_step_meets_the_oracle("ur_gemm_persistent_mode(0)")
     finally:
         lib.ur_gemm_persistent_mode(prev)

@@ -89,9 +89,9 @@ def xattn(args):
         t = timeit(lambda: hip.attn_fwd(q, kv[:, :, 0], kv[:, :, 1], causal=False, key_mask=km, dropout_p=pd, seed=3), args.iters)
         print(f"xattn fwd p={pd}: {t:.3f} ms")
         for sw in ("0", "1"):
-            os.environ["UR_ATTN_FEWQ"] = sw
-            t = timeit(lambda: hip.attn_bwd(ctx, dout, dk=dkv[:, :, 0], dv=dkv[:, :, 1]), args.iters)
-            print(f"xattn bwd (dq + dkv) p={pd} UR_ATTN_FEWQ={sw}: {t:.3f} ms")
+            with hip.attn_mode_set(hip.ATTN_MODE_FEWQ, int(sw)):
+                t = timeit(lambda: hip.attn_bwd(ctx, dout, dk=dkv[:, :, 0], dv=dkv[:, :, 1]), args.iters)
+            print(f"xattn bwd (dq + dkv) p={pd} ur_attn_mode(FEWQ, {sw}): {t:.3f} ms")
 
 
 def gemm_merge(args):

@@ -10,6 +10,8 @@ g = torch.Generator().manual_seed(0)
 qkv = torch.randn(B, S, (nq + 2 * nkv) * hd, generator=g).cuda().to(torch.bfloat16)
 q = qkv[..., :nq * hd].view(B, S, nq, hd); k = qkv[..., nq * hd:(nq + nkv) * hd].view(B, S, nkv, hd); v = qkv[..., (nq + nkv) * hd:].view(B, S, nkv, hd)
 dout = torch.randn(B, S, nq, hd, generator=g).cuda().to(torch.bfloat16)
+if os.environ.get("DKV_PERSIST") == "0":
+    hip.attn_mode(hip.ATTN_MODE_DKV_PERSIST, 0)
 o, ctx = hip.attn_fwd(q, k, v, causal=True)
 for _ in range(3):
     hip.attn_bwd(ctx, dout)
@@ -28,7 +30,7 @@ for i, nm in enumerate(names):
     print(f"  {nm:90s} {a[:, :, i].mean():10.0f}  ({100 * a[:, :, i].mean() / tot.mean():4.1f} %)  per block {a[:, :, i].sum() / nb.sum():8.0f}")
 for w in range(4):
     print(f"  wave {w}: loop {a[:, w, 1].mean():.0f}  draw (waits for the slowest wave) {a[:, w, 2].mean():.0f}")
-if os.environ.get("UR_ATTN_DKV_PERSIST") == "0":
+if os.environ.get("DKV_PERSIST") == "0":      # (this tool's own switch: it sets ur_attn_mode(UR_ATTN_MODE_DKV_PERSIST, 0) before the launches)
     # one record per key block: the generated loop's own accumulators (words 8..13: ring wait cycles / count, body cycles / count)
     r = np.frombuffer(buf, np.uint32).reshape(8192, 4, 32).astype(np.float64)
     ok = r[:, :, 6] == 0xD0C5

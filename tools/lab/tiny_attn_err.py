@@ -30,7 +30,7 @@ for (Sq, Sk, selfattn) in ((2, 2, True), (2, 14, False), (4, 4, True)):
     dout = torch.randn(B, Sq, nh, 64, generator=g).cuda().bfloat16()
     want = ref(q, k, v, dout)
     for sw in ("0", "1"):
-        os.environ["UR_ATTN_TINY"] = sw
+        hip.attn_mode(hip.ATTN_MODE_TINY, 3 if sw == "1" else 0)
         o, ctx = hip.attn_fwd(q, k, v, causal=False)
         dq, dk, dv = hip.attn_bwd(ctx, dout)
         torch.cuda.synchronize()

@@ -29,7 +29,8 @@ for seed in (11, 22, 33, 44, 55, 66):
     t = lambda a: torch.from_numpy(a).cuda()
     line = f"seed {seed}:"
     for sw in ("0", "1"):
-        os.environ["UR_ATTN_TINY"] = sw
+        from unirec_amd import hip
+        hip.attn_mode(hip.ATTN_MODE_TINY, 3 if sw == "1" else 0)
         m, qf = _build_joint(case, use_lora=False)
         loss = InfoNCELoss()(m(t(ids), t(am), t(hfe), t(ham)), t(pos), t(neg), t(nmask))
         loss.backward()

@@ -2202,13 +2202,12 @@ __global__ __launch_bounds__(256) void attn_tiny_bwd_kernel(AttnP p) {
       *reinterpret_cast<uint2*>(p.dq + ((long)t.b * p.Sq + qi) * p.lddq + e0) = make_uint2(pack_bf2(dq[qi][0], dq[qi][1]), pack_bf2(dq[qi][2], dq[qi][3]));
 }
 
-// lab / test switch (read on every call): UR_ATTN_TINY=0 keeps tiny shapes on the MFMA kernels (f / b: tiny forward /
-// backward only)
-inline bool tiny_enabled(bool bwd) {
-  const char* e = getenv("UR_ATTN_TINY");
-  if (!e) return true;
-  return e[0] == '1' || (e[0] == 'f' && !bwd) || (e[0] == 'b' && bwd);
-}
+// Kernel-selection switches of the attention entry points: process-wide words set through the C ABI (ur_attn_mode, include/unirec_hip.h) --
+// the library reads no environment variable.  Every alternative is a complete, tested path (bit-identity / oracle tests flip them).
+std::atomic<int> g_attn_mode[UR_ATTN_MODE_COUNT] = {{3}, {1}, {1}, {1}};      // TINY: bit 0 forward, bit 1 backward; C128, DKV_PERSIST, FEWQ: 0 / 1
+inline int attn_mode(int key) { return g_attn_mode[key].load(std::memory_order_relaxed); }
+// UR_ATTN_MODE_TINY = 0 keeps tiny shapes on the MFMA kernels (1 / 2: tiny forward / backward only)
+inline bool tiny_enabled(bool bwd) { return (attn_mode(UR_ATTN_MODE_TINY) & (bwd ? 2 : 1)) != 0; }
 inline bool tiny_shape(const AttnP& p, int hd, bool causal, bool bwd) {
   return hd == 64 && !causal && p.rep == 1 && p.Sq <= 4 && p.Sk <= TK && tiny_enabled(bwd);
 }
@@ -3083,10 +3082,10 @@ int fill(AttnP& p, const ur_attn_args* a) {
 inline bool c128_bwd_ok(const AttnP& p);
 // CUs of the current device (persistent grids), cached per device
 inline int device_cu_count() { return ur_device_cu_count(); }
-// test / lab switch, read on every call: UR_ATTN_C128=0 sends the causal head_dim-128 forward back to attn_fwd_kernel
-inline bool fwd_c128_enabled() { const char* e = getenv("UR_ATTN_C128"); return !(e && e[0] == '0'); }
-// test / lab switch, read on every call: UR_ATTN_DKV_PERSIST=0 launches one workgroup per key block
-inline bool dkv_persist_enabled() { const char* e = getenv("UR_ATTN_DKV_PERSIST"); return !(e && e[0] == '0'); }
+// UR_ATTN_MODE_C128 = 0 sends the causal head_dim-128 launches back to the compiler-scheduled kernels
+inline bool fwd_c128_enabled() { return attn_mode(UR_ATTN_MODE_C128) != 0; }
+// UR_ATTN_MODE_DKV_PERSIST = 0 launches one workgroup per key block
+inline bool dkv_persist_enabled() { return attn_mode(UR_ATTN_MODE_DKV_PERSIST) != 0; }
 inline bool fwd_gq2_enabled() { static const bool on = ur_lab_int("UR_FWD_GQ2", 0) == 1; return on; }
 template <int HD, bool CAUSAL, int NW>
 int launch_fwd(const AttnP& p, hipStream_t st) {
@@ -3143,9 +3142,8 @@ int launch_dq(const AttnP& p, hipStream_t st) {
   UR_CHECK_LAUNCH("ur_attn_bwd(dq)");
   return 0;
 }
-// lab / test switch: UR_ATTN_FEWQ=0 sends few-query shapes back to attn_bwd_dkv_kernel (read on every call so one
-// test process can compare the two kernels bit for bit)
-inline bool fewq_enabled() { const char* e = getenv("UR_ATTN_FEWQ"); return !(e && e[0] == '0'); }
+// UR_ATTN_MODE_FEWQ = 0 sends few-query shapes back to attn_bwd_dkv_kernel (one test process compares the two kernels bit for bit)
+inline bool fewq_enabled() { return attn_mode(UR_ATTN_MODE_FEWQ) != 0; }
 
 template <int HD, bool CAUSAL, int NW>
 int launch_dkv(const AttnP& p, hipStream_t st) {
@@ -3153,6 +3151,7 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
     // few queries, many keys: one workgroup per (batch, head) pair -- or per chunk of its key blocks while the pairs
     // alone do not fill the chip (>= 8 key blocks, i.e. two per wave, per workgroup)
     constexpr int SMF = 2 * Cfg<64>::TILE + 5 * KT * (int)sizeof(float) + 16 + 4 * 2 * 64 * (int)sizeof(float) + 256;      // + flag + the waves' column sums + one liveness byte per key block
+    static_assert(MAX_KTILES * KT / 32 <= 256, "attn_bwd_dkv_fewq_kernel: one liveness byte per 32-key block in a 256-byte LDS tail (ur_attn caps Sk at MAX_KTILES * KT)");
     const int nblk = ur_cdiv(p.Sk, 32), pairs = p.nq * p.B;
     int nchunk = std::max(1, std::min(ur_cdiv(4096, pairs), nblk / 8));
     if (p.colsum_part != nullptr) nchunk = 1;          // the column sums leave as ONE partial per (batch, head): one workgroup per pair
@@ -3194,7 +3193,7 @@ int launch_dkv(const AttnP& p, hipStream_t st) {
 inline int pick_nw(int S) { return S <= 32 ? 1 : (S <= 64 ? 2 : 4); }
 // the shapes whose dK/dV run on attn_bwd_dkv_fewq_kernel (the only kernel that can also emit the column sums of dK | dV)
 inline bool fewq_shape(const AttnP& p, int hd, bool causal) {
-  return hd == 64 && !causal && pick_nw(p.Sk) == 4 && p.rep == 1 && p.Sq <= KT && p.Sk >= 256 && fewq_enabled();
+  return hd == 64 && !causal && pick_nw(p.Sk) == 4 && p.rep == 1 && p.Sq <= KT && p.Sk >= 256 && p.Sk <= MAX_KTILES * KT && fewq_enabled();
 }
 inline bool c128_bwd_ok(const AttnP& p) {
   return p.Sq == p.Sk && (p.Sk % 128) == 0 && p.Sk >= 128 && p.Sk <= c128::MAX_SK && fwd_c128_enabled() && (long)p.nq * p.B * 8 < (1L << 24) &&
@@ -3245,6 +3244,14 @@ extern "C" int64_t ur_attn_bwd_kv_colsum_floats(const ur_attn_args* a) {
   if (!a || fill(p, a) != 0 || a->B <= 0) return 0;
   if (tiny_shape(p, a->head_dim, a->causal != 0, true) || !fewq_shape(p, a->head_dim, a->causal != 0)) return 0;
   return 2 * (int64_t)a->B * a->nq * a->head_dim;
+}
+
+extern "C" int ur_attn_mode(int key, int value) {
+  if (key < 0 || key >= UR_ATTN_MODE_COUNT) return -1;
+  static const int dflt[UR_ATTN_MODE_COUNT] = {3, 1, 1, 1};
+  const int hi = key == UR_ATTN_MODE_TINY ? 3 : 1;
+  if (value == -2) return g_attn_mode[key].load(std::memory_order_relaxed);                     // query only
+  return g_attn_mode[key].exchange(value < 0 || value > hi ? dflt[key] : value);
 }
 
 extern "C" int64_t ur_attn_bwd_workspace_floats(int32_t B, int32_t nq, int32_t Sq) {

@@ -97,7 +97,7 @@ __device__ __forceinline__ void swap16f(float& a, float& b) {
 bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf32);
 int gemm_pers_launch(GemmP p, hipStream_t st);
 
-// gemm_ws.hip: wave-specialised 128x256 kernel (the epilogue of a tile beside the next tile's K loop); a subset of the persistent kernel's launches
+// tools/lab/gemm_ws.hip (lab builds, -DUR_LAB=1): wave-specialised 128x256 kernel (the epilogue of a tile beside the next tile's K loop); a subset of the persistent kernel's launches
 bool gemm_ws_eligible(const GemmP& p);
 int gemm_ws_launch(GemmP p, hipStream_t st);
 

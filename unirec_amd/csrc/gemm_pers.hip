@@ -871,12 +871,11 @@ int launch_pers(const GemmP& p, hipStream_t st) {
 
 namespace urgemm {
 
-static std::atomic<int> g_pers_mode{-1};     // -1 = not set: UR_GEMM_PERSISTENT (default 1); 0 = generic kernel only (A/B runs, bit-identity tests)
+static std::atomic<int> g_pers_mode{-1};     // -1 = not set: the default (1); 0 = generic kernel only (A/B runs, bit-identity tests)
 
 bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf32) {
-  static const int env_mode = [] { const char* e = getenv("UR_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
   const int set = g_pers_mode.load(std::memory_order_relaxed);
-  const int mode = set >= 0 ? set : env_mode;
+  const int mode = set >= 0 ? set : 1;
   if (!mode || !rk || !sk || outf32 || splits > 1) return false;
   if ((p.M % BM) || (p.N % BN) || (p.K % BK) || p.K < 4 * BK) return false;
   static const int min_tiles = ur_lab_int("UR_PERS_MIN_TILES", 128);      // lab; default 128: half a round already gains from the register epilogue (C2 item stage 21.66 -> 21.05 ms; 256 and 512 equal within noise, user stage unchanged)
@@ -916,9 +915,10 @@ bool gemm_pers_eligible(const GemmP& p, int splits, bool rk, bool sk, bool outf3
 
 int gemm_pers_launch(GemmP p, hipStream_t st) {
   {
-    static const int env_mode = [] { const char* e = getenv("UR_GEMM_PERSISTENT"); return e ? atoi(e) : 1; }();
+#if UR_LAB      // lab builds only (tools/lab/gemm_ws.hip linked in by tools/lab/gemm_ws_build.sh): the wave-specialised 128 x 256 kernel of round 5
     const int set = g_pers_mode.load(std::memory_order_relaxed);
-    if ((set >= 0 ? set : env_mode) == 2 && gemm_ws_eligible(p)) return gemm_ws_launch(p, st);      // gemm_ws.hip
+    if (set == 2 && gemm_ws_eligible(p)) return gemm_ws_launch(p, st);
+#endif
   }
   p.gm = p.M / BM; p.gn = p.N / BN;
   p.gcw = 0;

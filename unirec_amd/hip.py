@@ -278,6 +278,33 @@ def qknorm_rope_bwd_roped_k(dk_out, k_r, rstd, h0, kw, cos, sin, dk_raw, S, nkv,
     return dk_raw
 
 
+ATTN_MODE_TINY, ATTN_MODE_C128, ATTN_MODE_DKV_PERSIST, ATTN_MODE_FEWQ = 0, 1, 2, 3      # include/unirec_hip.h: UR_ATTN_MODE_*
+
+
+def attn_mode(key, value):
+    """Kernel selection of the attention entry points (ur_attn_mode, include/unirec_hip.h): sets the process-wide word `key` and returns
+    the previous value; value -1 = default, -2 = query only.  The library reads no environment variable."""
+    prev = int(_lib.load().ur_attn_mode(int(key), int(value)))
+    if prev < 0:
+        raise ValueError(f"ur_attn_mode: unknown key {key}")
+    return prev
+
+
+class attn_mode_set:
+    """with hip.attn_mode_set(hip.ATTN_MODE_C128, 0): ...   -- the word is restored on exit (tests, A/B timing)"""
+
+    def __init__(self, key, value):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        self.prev = attn_mode(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        attn_mode(self.key, self.prev)
+        return False
+
+
 def gemm_persistent_mode(mode):
     """0 = generic GEMM kernel only, 1 = persistent kernel where eligible, -1 = default; returns the previous setting
     (ur_gemm_persistent_mode, include/unirec_hip.h)."""
