@@ -24,6 +24,7 @@ from attn_fwd import flatten, _tag, s_m0_add, ACC_ROW
 from attn_dq import s_mov_vcc, ds_read_b64, v_readfirstlane
 import balance
 
+PACKED = os.environ.get("UR_ASMGEN_PACKED", "0") == "1"        # round 6 LAB switch, off (see attn_dq.py PACKED): packed-f32 multiplies in the vector stream
 BALANCE = os.environ.get("UR_ASMGEN_BALANCE", "1") == "1"      # round 6: dependency-aware re-placement of the side instructions (balance.py)
 
 LEAD = int(os.environ.get("UR_DKV_LEAD", "6"))      # transposed fragments: MFMA slots between a read and its use (their ring has 8 slots: < 8)
@@ -259,7 +260,11 @@ def soft_events(half, G0):
     ev = []
     for r in range(16):
         pos = G0 + (3 * r) // 4
-        ev += [(pos, 0, v_exp_f32(S_(half, r), S_(half, r))), (pos + 1, 1, v_mul_f32(DP(half, r), DP(half, r), S_(half, r)))]
+        ev.append((pos, 0, v_exp_f32(S_(half, r), S_(half, r))))
+        if not PACKED:
+            ev.append((pos + 1, 1, v_mul_f32(DP(half, r), DP(half, r), S_(half, r))))
+        elif r % 2 == 1:        # round 6: dS of two scores by one packed-f32 multiply
+            ev.append((pos + 1, 1, v_pk_mul_f32(DP(half, r - 1), DP(half, r - 1), S_(half, r - 1))))
     for s2 in range(2):
         for j in range(4):
             r0 = 8 * s2 + 2 * j
@@ -439,7 +444,7 @@ def build_program(with_dma_prologue=True):
                 s_add_i32(HRS, HRS, Lit(1)), label("SAMEHEAD_%d" % p)]
         seq += stamp_acc(2)
         if BALANCE:
-            seq = balance.balance(flatten(seq), entry_lgkm=entry_pending())
+            seq = balance.balance(flatten(seq), entry_lgkm=entry_pending(), name="dkv")
         fixed, _ = fix_hazards(seq, entry_lgkm=entry_pending())
         bodies[name] = fixed
         P.add(label(name), fixed, s_add_i32(IT, IT, Lit(1)), s_cmp("ge", IT, NTOT), s_cbranch_scc(1, "EXIT"))

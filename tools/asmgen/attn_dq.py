@@ -24,6 +24,7 @@ import isa
 from attn_fwd import (flatten, _tag, s_m0_add, s_andn2_b64, KSLOT, VSLOT, VBASE_LDS, ACC_ROW)
 
 LEADK, LEADV, LEADT = 6, 6, 8
+PACKED = os.environ.get("UR_ASMGEN_PACKED", "0") == "1"        # round 6 LAB switch, off: packed-f32 subtracts / multiplies in the vector stream.  Correct in the emulator and on the hardware where the generator places them, but re-placed by balance.py the dQ kernel's LAST body became NONDETERMINISTIC on the MI355X (a high-half-broadcast v_pk_add_f32 directly ahead of an MFMA; docs/lab_notes.md 14.2): not shipped
 BALANCE = os.environ.get("UR_ASMGEN_BALANCE", "1") == "1"      # round 6: dependency-aware re-placement of the side instructions (balance.py)
 WORDS_LDS = 131072
 LDS_BYTES = WORDS_LDS + 64 * 8
@@ -239,7 +240,13 @@ def vec_events(sub, G0, skip_qb0):
             if skip_qb0 and qb == 0:
                 continue
             s, d, pos = S_(sub, qb, r), DP(sub, qb, r), start(2 * r + qb)
-            ev += [(pos, 0, v_sub_f32(s, s, LSE2(qb))), (pos, 1, v_sub_f32(d, d, DELTA(qb))), (pos + 1, 2, v_exp_f32(s, s)), (pos + 2, 3, v_mul_f32(d, d, s))]
+            if not PACKED:
+                ev += [(pos, 0, v_sub_f32(s, s, LSE2(qb))), (pos, 1, v_sub_f32(d, d, DELTA(qb))), (pos + 1, 2, v_exp_f32(s, s)), (pos + 2, 3, v_mul_f32(d, d, s))]
+            elif r % 2 == 0:
+                # round 6: two scores per subtract / multiply (packed f32; the row constant is one register broadcast to both halves)
+                pos1 = start(2 * (r + 1) + qb)
+                ev += [(pos, 0, v_pk_sub_f32_bcast(s, s, LSE2(qb))), (pos, 1, v_pk_sub_f32_bcast(d, d, DELTA(qb))), (pos + 1, 2, v_exp_f32(s, s)),
+                       (pos1 + 1, 2, v_exp_f32(s + 1, s + 1)), (pos1 + 2, 3, v_pk_mul_f32(d, d, s))]
     for qb in range(2):
         if skip_qb0 and qb == 0:
             continue
@@ -409,7 +416,7 @@ def build_program(with_dma_prologue=True):
         seq += stamp_acc({"PRO": 2, "PROL": 2}.get(name, 6 if last else 4))
         if BALANCE:
             import balance
-            seq = balance.balance(flatten(seq), entry_lgkm=entry_pending() if kind == "steady" else (), temps={TMPA})
+            seq = balance.balance(flatten(seq), entry_lgkm=entry_pending() if kind == "steady" else (), temps={TMPA}, name="dq_" + name.split("_")[0])
         fixed, _ = fix_hazards(seq, entry_lgkm=entry_pending() if kind == "steady" else ())
         bodies[name] = fixed
         return fixed

@@ -573,7 +573,7 @@ def build_program(with_dma_prologue=True):
         seq += stamp_acc({"PRO": 2, "PROL": 2}.get(name, 6 if last else 4))
         if BALANCE:
             import balance
-            seq = balance.balance(flatten(seq), entry_lgkm=entry_pending() if kind == "steady" else (), temps={TMPA})
+            seq = balance.balance(flatten(seq), entry_lgkm=entry_pending() if kind == "steady" else (), temps={TMPA}, name="fwd")
         fixed, _ = fix_hazards(seq, entry_lgkm=entry_pending() if kind == "steady" else ())
         bodies[name] = fixed
         return fixed

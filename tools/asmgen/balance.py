@@ -85,8 +85,15 @@ def _units(seq, temps):
     return unit
 
 
-def balance(seq, entry_lgkm=(), budget=32, min_lead=5, reach=12, temps=(), max_moves=400, verbose=False, frozen_tags=("max",)):
+def balance(seq, entry_lgkm=(), budget=32, min_lead=5, reach=12, temps=(), max_moves=400, verbose=False, frozen_tags=("max",), name=""):
     """seq: straight-line body (MFMAs + side instructions, before fix_hazards).  Returns the re-placed list (same instructions)."""
+    import os
+    # lab: bisecting a schedule on the hardware (name = generator, or generator_BODY: the longest match wins)
+    for key in ("UR_BALANCE_MAX_MOVES_" + name.upper(), "UR_BALANCE_MAX_MOVES_" + name.upper().split("_")[0], "UR_BALANCE_MAX_MOVES"):
+        if key in os.environ:
+            max_moves = int(os.environ[key])
+            break
+    fill_m0 = os.environ.get("UR_BALANCE_FILL_M0", "1") == "1"
     temps = set(temps) | {isa.M0}
     seq = list(seq)
 
@@ -156,7 +163,7 @@ def balance(seq, entry_lgkm=(), budget=32, min_lead=5, reach=12, temps=(), max_m
     k = 0
     while k + 1 < len(seq):
         x, y = seq[k], seq[k + 1]
-        if isa.M0 in x.wr and y.kind == "vmem" and isa.M0 in y.rd:
+        if fill_m0 and isa.M0 in x.wr and y.kind == "vmem" and isa.M0 in y.rd:
             nxt = seq[k + 2] if k + 2 < len(seq) else None
             prv = seq[k - 1] if k > 0 else None
             ok = lambda z, *others: z is not None and z.kind in ("lds", "valu", "trans", "salu") and not _is_fence(z) and z.tag not in frozen_tags and \

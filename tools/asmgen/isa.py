@@ -186,6 +186,33 @@ def v_and_b32(d, x, y):
     return valu2("v_and_b32", d, x, y, lambda p, q: p & q)
 
 
+def v_pk_mul_f32(d, x, y):
+    """packed f32: (d, d+1) = (x, x+1) * (y, y+1) -- two products per lane at the issue cost of one (round 6: halves the multiply /
+    subtract instructions of the backward loops' vector streams).  d, x, y: EVEN register ids (64-bit pairs)."""
+    assert d % 2 == 0 and x % 2 == 0 and y % 2 == 0, (d, x, y)
+
+    def fn(w):
+        lo = (_f32(w.R[x]) * _f32(w.R[y])).astype(np.float32)
+        hi = (_f32(w.R[x + 1]) * _f32(w.R[y + 1])).astype(np.float32)
+        w.R[d], w.R[d + 1] = _u32(lo), _u32(hi)
+    return I("v_pk_mul_f32 %s, %s, %s" % (rrange(d, 2), rrange(x, 2), rrange(y, 2)), "valu", (x, x + 1, y, y + 1), (d, d + 1), fn, 4)
+
+
+def v_pk_sub_f32_bcast(d, x, y):
+    """packed f32: (d, d+1) = (x, x+1) - y broadcast: y is ONE register (either half of an even-aligned pair), subtracted from both
+    halves (v_pk_add_f32 with neg_lo / neg_hi on the second source and op_sel / op_sel_hi picking y's half for both results)"""
+    assert d % 2 == 0 and x % 2 == 0, (d, x)
+    base, half = y & ~1, y & 1
+
+    def fn(w):
+        lo = (_f32(w.R[x]) - _f32(w.R[y])).astype(np.float32)
+        hi = (_f32(w.R[x + 1]) - _f32(w.R[y])).astype(np.float32)
+        w.R[d], w.R[d + 1] = _u32(lo), _u32(hi)
+    mods = "op_sel:[0,1] op_sel_hi:[1,1]" if half else "op_sel_hi:[1,0]"
+    return I("v_pk_add_f32 %s, %s, %s %s neg_lo:[0,1] neg_hi:[0,1]" % (rrange(d, 2), rrange(x, 2), rrange(base, 2), mods), "valu",
+             (x, x + 1, y), (d, d + 1), fn, 4)
+
+
 def v_max3_f32(d, x, y, z):
     def fn(w):
         w.R[d] = _u32(np.fmax(np.fmax(_f32(_opd(w, x)), _f32(_opd(w, y))), _f32(_opd(w, z))).astype(np.float32))
