@@ -50,3 +50,20 @@ def test_stage_line_contract(workload, unit):
     _common(d)
     assert d["unit"] == unit and d["config"]["workload"] == workload
     assert d["cpu_baseline"]["unit"] == unit and d["cpu_baseline"]["value"] > 0
+
+
+def test_item_c1_line_contract():
+    """BASELINE configs[0] (C1): eval forward + reconstruction metrics on the GPU, launch by launch and as one hipGraph replay, beside the
+    oracle's CPU figure (round 6: every BASELINE config has a number in the driver's line -- `stages.item_c1`)."""
+    d = _run(["--workload", "item_c1", "--cpu-budget", "10"])
+    assert d["unit"] == "items/sec" and d["value"] > 0 and d["config"]["workload"] == "item_c1" and d["config"]["per_gpu_batch"] == 16
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    lat = d["latency_us"]
+    assert lat["launch_by_launch"] > 0
+    g = d["hip_graph"]
+    if g["captured"]:
+        assert g["bit_identical_to_the_launch_by_launch_call"] and lat["hip_graph"] > 0
+    assert 0.0 < d["config"]["eval_mse"] < 10.0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "items/sec" and c["value"] > 0

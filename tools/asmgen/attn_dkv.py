@@ -337,8 +337,9 @@ def build_body(p, tag, cnt):
     ev = [(pos, o, i) for pos, o, i in soft_events(0, GXB + SOFT0)] + [(pos, o, i) for pos, o, i in soft_events(1, GYA + SOFT0)]
     for pos, o, i in sorted(ev, key=lambda t: (t[0], t[1])):
         put(pos, _tag([i], "soft")[0])
-    put(GXB + 1, _tag(diag_block(0, tag, cnt), "max"))
-    put(GYA + 1, _tag(diag_block(1, tag, cnt), "max"))
+    if "diag" not in ABLATE:
+        put(GXB + 1, _tag(diag_block(0, tag, cnt), "max"))
+        put(GYA + 1, _tag(diag_block(1, tag, cnt), "max"))
     seq = []
     for g in range(NG):
         seq.append(mf[g])

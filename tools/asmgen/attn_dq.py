@@ -196,7 +196,7 @@ def mask_block(sub, skip_qb0, diag, tag, cnt):
             if not (skip_qb0 and qb == 0):
                 blk.append(v_cndmask_b32(S_(sub, qb, r), NEGINF, S_(sub, qb, r), VCC))
     out.append([s_bitcmp1_b64(MASKBITS, IT)] + cond_block(s_cbranch_scc(0, lbl), blk, label(lbl)))
-    if diag:
+    if diag and "diag" not in ABLATE:
         qb = sub
         for r in range(16):
             out += [v_cmp_i32("ge", VCC, DIAGX, Lit(ACC_ROW[r])), v_cndmask_b32(S_(sub, qb, r), NEGINF, S_(sub, qb, r), VCC)]
