@@ -378,9 +378,6 @@ struct RmsLoraP {
   const uint8_t* bits; long bits_ld, bits_stride;
   bf16_t* P; long ldp; float alpha;
 };
-#ifndef UR_RMS_NT_STORE
-#define UR_RMS_NT_STORE 0
-#endif
 template <int NAD, bool MASKED>
 __global__ __launch_bounds__(256, 2) void rms_lora_kernel(RmsLoraP p) {
   constexpr int D = 1024, KC = 128, NC = D / 32;
@@ -470,7 +467,7 @@ _Pragma("unroll") \
 _Pragma("unroll") \
       for (int e = 0; e < 4; ++e) hw[e] = pack_bf2(wv[2 * e] * (bf_lo(wd[e]) * rs), wv[2 * e + 1] * (bf_hi(wd[e]) * rs)); \
       const uint4 hq = make_uint4(hw[0], hw[1], hw[2], hw[3]); \
-      if (mok) { if (UR_RMS_NT_STORE) __builtin_nontemporal_store(u32x4_t{hq.x, hq.y, hq.z, hq.w}, reinterpret_cast<u32x4_t*>(hrow + 32 * c)); else *reinterpret_cast<uint4*>(hrow + 32 * c) = hq; } \
+      if (mok) *reinterpret_cast<uint4*>(hrow + 32 * c) = hq; \
 _Pragma("unroll") \
       for (int a = 0; a < NAD; ++a) { \
         const int row = a * 16 + l15, ch = 4 * (sx & 1) + g; \
