@@ -98,3 +98,46 @@ def test_joint_c4_exact_architecture_matches_the_reference():
                     assert_close(gk, g["grad/" + k], joint_tol, "grad/" + k)
     print(f"  worst relative error of an adapter gradient's NORM over 28 x 7 x 2 adapters: {worst:.3e}")
     assert named["layers.0.self_attn.q_proj.weight"].grad is None      # base weights stay frozen
+
+
+@pytest.mark.parametrize("kind", ["item", "user"])
+def test_weight_gradients_on_the_side_stream_are_bit_identical(kind, monkeypatch):
+    """Round 6: the Q-Formers' token reductions dW = dY^T X and bias column sums run on a side stream beside the dX chain
+    (unirec_amd/qformer.py:_DW_SIDE).  Same kernels, same arithmetic: every gradient equals the single-stream run bit for bit, also when the
+    step is repeated (the second step reuses memory the first one's side-stream work read)."""
+    import unirec_amd.qformer as qformer
+    from unirec_amd.losses import mse_loss
+
+    def run(side):
+        monkeypatch.setattr(qformer, "_DW_SIDE", side)
+        torch.manual_seed(7)
+        if kind == "item":
+            from unirec_amd.qformer_utils import QFormerForItemRepresentation
+            m = QFormerForItemRepresentation(hidden_size=256, num_hidden_layers=4, num_attention_heads=4, intermediate_size=1024, num_query_tokens=32,
+                                             field_embedding_dim=256, num_fields=14, dropout=0.2).to(DEV).train()
+            g = torch.Generator().manual_seed(3)
+            x = torch.randn(192, 14, 256, generator=g).to(DEV)
+            mk = (torch.rand(192, 14, generator=g) < 0.8).long(); mk[:, 0] = 1
+            mk = mk.to(DEV)
+            fwd = lambda: m(x, mk)["query_outputs"].float().pow(2).mean() + m(x, mk)["reconstructed_fields"].float().pow(2).mean()
+        else:
+            from unirec_amd.user_qformer import UserQFormer
+            m = UserQFormer(hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512, num_query_tokens=64, input_embedding_dim=256,
+                            num_item_tokens_to_predict=4, dropout=0.1).to(DEV).train()
+            g = torch.Generator().manual_seed(4)
+            x = torch.randn(24, 320, 256, generator=g).to(DEV)
+            mask = (torch.arange(320)[None, :] < torch.randint(160, 321, (24,), generator=g)[:, None]).float().to(DEV)
+            tgt = torch.randn(24, 4, 256, generator=g).to(DEV)
+            fwd = lambda: mse_loss(m(x, mask), tgt)
+        outs = []
+        for _ in range(2):
+            m.zero_grad(set_to_none=True)
+            fwd().backward()
+            torch.cuda.synchronize()
+            outs.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        return outs
+    a, b = run(True), run(False)
+    for step in range(2):
+        assert a[step].keys() == b[step].keys() and len(a[step]) > 20
+        for n in a[step]:
+            assert torch.equal(a[step][n], b[step][n]), (kind, step, n)

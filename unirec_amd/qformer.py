@@ -115,6 +115,20 @@ class _EncoderParams(nn.Module):
 
 _KV_COLSUM = os.environ.get("UNIREC_KV_COLSUM", "1") != "0"     # test / lab: 0 = the K | V bias gradients by a column-sum pass over dK | dV again
 _USE_WT = os.environ.get("UNIREC_QF_WT", "1") != "0"     # lab: 0 = dX products read the [out, in] weights as K-strided operands again
+# round 6: the weight gradients dW = dY^T X (token reductions, split-K) and the bias column sums of the backward are issued on a SIDE stream:
+# they hang off the dX chain (nothing in the backward reads them) and neither they nor the dX products fill 256 CUs at the Q-Formers' row counts
+# (item Q-Former of the joint step: 6400 rows = 100 output tiles), so the two streams' kernels run beside each other.  Same kernels, same
+# arithmetic: results bit-identical (tests/test_gpu_r6_parity.py).  0 = everything on the caller's stream, as before.
+_DW_SIDE = os.environ.get("UNIREC_QF_DW_STREAM", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
 _DEAD_RE = re.compile(r"(^|\.)layer\.\d+\.(intermediate\.dense|output\.dense|output\.LayerNorm)\.")
 
 
@@ -505,10 +519,34 @@ class BertModel(nn.Module):
                 return hip.gemm(dy, wt[key], **kw)
             return hip.gemm(dy, pack.fused16(list(names)) if len(names) > 1 else pack.w16(names[0]), s_kcontig=False, **kw)
 
+        side = _side_stream(dout.device) if (_DW_SIDE and dout.is_cuda) else None
+        main = torch.cuda.current_stream(dout.device) if side is not None else None
+        if side is not None:
+            side.wait_stream(main)         # (the first use: everything the caller has queued so far, incl. the zeroing of the gradient buffers)
+
+        def off_chain(fn, *tensors):
+            """run fn() on the side stream behind what the main stream has queued so far (its inputs `tensors` were produced there)"""
+            if side is None:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            for t in tensors:              # the caching allocator must not hand their memory to the main stream before the side stream is done
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                return fn()
+
+        def join():
+            if side is not None:
+                main.wait_stream(side)
+
         def dW(dy, xin, names):
             """grad of an [out,in] weight (or several adjacent ones): dY^T X, token reduction split over CUs."""
             out = pack.fusedg(names) if len(names) > 1 else pack.g32(names[0])
-            hip.gemm(dy, xin, r_kcontig=False, s_kcontig=False, out=out, split_k=_split_k_for(out.shape[0], out.shape[1], dy.shape[0]))
+            off_chain(lambda: hip.gemm(dy, xin, r_kcontig=False, s_kcontig=False, out=out, split_k=_split_k_for(out.shape[0], out.shape[1], dy.shape[0])), dy, xin)
+
+        def colsum(x, out):
+            off_chain(lambda: hip.colsum(x, out=out), x)
 
         kvw, kvb = self._cross_kv_names(pre)
         ncross = len(kvw) // 2
@@ -527,7 +565,7 @@ class BertModel(nn.Module):
                                          pack.g32(f2 + "LayerNorm.bias"), dbias=pack.g32(f2 + "dense.bias"), p_pre=p_h, seed_pre=s_h3, drop_row0=row0)
             dW(dy3, hbuf, [f2 + "dense.weight"])
             du = dX(dy3, [f2 + "dense.weight"], gelu_grad_aux=u)
-            hip.colsum(du, out=pack.g32(f1 + "bias"))
+            colsum(du, pack.g32(f1 + "bias"))
             dW(du, xc, [f1 + "weight"])
             dx = dX(du, [f1 + "weight"], residual=dz3)
             # ---- cross attention
@@ -552,7 +590,7 @@ class BertModel(nn.Module):
                     kv_colsum_fused = False
                 hip.attn_bwd(actx2, dctx2.view(B, Qn, nh, dh), dq=dqc.view(B, Qn, nh, dh), dk=dkv5[:, :, 0], dv=dkv5[:, :, 1], kv_colsum=cs)
                 dW(dqc, x1, [c + "self.query.weight"])
-                hip.colsum(dqc, out=pack.g32(c + "self.query.bias"))
+                colsum(dqc, pack.g32(c + "self.query.bias"))
                 dx = dX(dqc, [c + "self.query.weight"], residual=dz2)
             # ---- self attention
             a = lp + "attention."
@@ -567,20 +605,22 @@ class BertModel(nn.Module):
             hip.attn_bwd(actx, dctx.view(B, Qn, nh, dh), dq=d5[:, :, 0], dk=d5[:, :, 1], dv=d5[:, :, 2])
             names = [a + "self.query.weight", a + "self.key.weight", a + "self.value.weight"]
             dW(dqkv, x0, names)
-            hip.colsum(dqkv, out=pack.fusedg([a + "self.query.bias", a + "self.key.bias", a + "self.value.bias"]))
+            colsum(dqkv, pack.fusedg([a + "self.query.bias", a + "self.key.bias", a + "self.value.bias"]))
             dx = dX(dqkv, names, residual=dz1)
             L.clear()
             S["layers"][i].clear()
             if self.grad_ready_hook is not None:      # dp.GradBuckets: layer i's gradients are final
+                join()                                # (... once the side stream's token reductions of this layer have run)
                 self.grad_ready_hook(i)
         # ---- the cross-attention K | V projections of all layers: one token reduction, one bias sum (and one dX for the encoder states)
         if ncross:
             dW(dkv_all, enc16, kvw)
             if kv_colsum_fused is not True:
-                hip.colsum(dkv_all, out=pack.fusedg(kvb))
+                colsum(dkv_all, pack.fusedg(kvb))
             if enc_needs_grad:
                 d_enc = dX(dkv_all, kvw)
             if self.grad_ready_hook is not None:
+                join()
                 self.grad_ready_hook(-2)              # the hoisted K | V gradients of every layer are final (their own bucket: dp.bucket_hook)
         # ---- embeddings LayerNorm; gradient of the batch-broadcast query table reduces over B
         z0, mean0, rstd0, s0 = S["emb"]
@@ -599,6 +639,7 @@ class BertModel(nn.Module):
             d_qe = hip.batch_reduce(dz0, M // rows, rows, H).view(1, Qn, H)
         if d_enc is not None:
             d_enc = hip.cast_bf16_to_f32(d_enc).view(B, T, -1)
+        join()                                        # every gradient of this backward is on the caller's stream from here on
         pack.publish_grads(touched)
         if self.grad_ready_hook is not None:
             self.grad_ready_hook(-1)                  # query table + embedding LayerNorm
