@@ -848,12 +848,12 @@ def measure_joint(args, rank, world, device, side_steps=3):
         # largest launch of the family, the merged gate|up forward (M=131072, N=6144, K=1024).
         traffic, tnote = None, "no PMC summary found"
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r5_gemm_pmc.json")))["launches"]["gate|up fwd"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r6_gemm_pmc.json")))["launches"]["gate|up fwd"]
             if B * args.seq == pm["M"]:
                 traffic = pm["hbm_bytes"]
                 tnote = (f"gate|up forward launch (N=6144, K=1024): fabric reads {pm['fabric_read_bytes']} (x{pm['read_ratio']} of A+W; FETCH_SIZE "
                          f"counts Infinity-Cache hits too) + writes {pm['write_bytes']} vs algorithmic {pm['algorithmic_bytes']} (x{pm['ratio']}); "
-                         f"profiles/r5_gemm_pmc.json")
+                         f"profiles/r6_gemm_pmc.json")
         except Exception:
             pass
         roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4),
