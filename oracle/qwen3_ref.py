@@ -92,8 +92,10 @@ def masked_softmax(scores, ok, fully_masked):
     Rows with at least one allowed key are identical under both."""
     if fully_masked == "uniform":
         return torch.softmax(scores + torch.where(ok, 0.0, torch.finfo(torch.float32).min), dim=-1)
-    w = torch.softmax(scores.masked_fill(~ok, float("-inf")), dim=-1)
-    return torch.where(ok.any(dim=-1, keepdim=True), w, torch.zeros_like(w))
+    # (the scores are this call's own temporary: masked in place, and the fully masked rows zeroed by ONE masked_fill -- at S 2048 every
+    # [B, heads, S, S] temporary is 0.27 GB per sequence and the page faults of fresh ones were two thirds of the oracle's forward time)
+    w = torch.softmax(scores.masked_fill_(~ok, float("-inf")), dim=-1)
+    return w.masked_fill(~ok.any(dim=-1, keepdim=True), 0.0)
 
 
 def decoder_layer(P, pre, x, cos, sin, ok, cfg: Qwen3Cfg, fully_masked="zero", masks=None):
@@ -114,7 +116,7 @@ def decoder_layer(P, pre, x, cos, sin, ok, cfg: Qwen3Cfg, fully_masked="zero", m
     rep = nq // nkv
     k = k[:, :, None].expand(B, nkv, rep, S, hd).reshape(B, nq, S, hd)      # repeat_kv :173-182
     v = v[:, :, None].expand(B, nkv, rep, S, hd).reshape(B, nq, S, hd)
-    w = masked_softmax(q @ k.transpose(2, 3) * (hd ** -0.5), ok, fully_masked)
+    w = masked_softmax((q @ k.transpose(2, 3)).mul_(hd ** -0.5), ok, fully_masked)
     a = (w @ v).transpose(1, 2).reshape(B, S, nq * hd)
     x = x + lora_linear(P, pre + "self_attn.o_proj", a, cfg, masks)
     h = rms_norm(x, P[pre + "post_attention_layernorm.weight"], cfg.rms_norm_eps)
@@ -124,15 +126,22 @@ def decoder_layer(P, pre, x, cos, sin, ok, cfg: Qwen3Cfg, fully_masked="zero", m
     return x
 
 
-def qwen3_forward(P, cfg: Qwen3Cfg, inputs_embeds, attention_mask=None, prefix="", fully_masked="zero", lora_masks=None):
+def qwen3_forward(P, cfg: Qwen3Cfg, inputs_embeds, attention_mask=None, prefix="", fully_masked="zero", lora_masks=None, checkpoint_layers=False):
     """Qwen3Model.forward on inputs_embeds, modeling_qwen3.py:367-425 -> last_hidden_state
-    (== hidden_states[-1], i.e. AFTER the final norm; SURVEY §3.3 [probe])."""
+    (== hidden_states[-1], i.e. AFTER the final norm; SURVEY §3.3 [probe]).
+    checkpoint_layers (tests at the full depth x length only): every decoder layer is re-run in the backward instead of keeping its S x S
+    probabilities (0.5 GB per layer and sequence at S 2048) -- the same arithmetic in the same order, identical results, a third more
+    compute and far less memory churn."""
     B, S, _ = inputs_embeds.shape
     cos, sin = rope_cos_sin(S, cfg.head_dim, cfg.rope_theta)
     ok = attention_allowed(attention_mask, S)
     x = inputs_embeds
     for i in range(cfg.num_hidden_layers):
-        x = decoder_layer(P, f"{prefix}layers.{i}.", x, cos, sin, ok, cfg, fully_masked, lora_masks)
+        if checkpoint_layers:
+            from torch.utils.checkpoint import checkpoint
+            x = checkpoint(lambda xi, i=i: decoder_layer(P, f"{prefix}layers.{i}.", xi, cos, sin, ok, cfg, fully_masked, lora_masks), x, use_reentrant=False)
+        else:
+            x = decoder_layer(P, f"{prefix}layers.{i}.", x, cos, sin, ok, cfg, fully_masked, lora_masks)
     return rms_norm(x, P[prefix + "norm.weight"], cfg.rms_norm_eps)
 
 
@@ -149,13 +158,13 @@ def inject_tokens(text_embeds, input_ids, item_tokens, first_special_id):
 
 
 def joint_forward(P, cfg: Qwen3Cfg, input_ids, attention_mask, item_tokens, first_special_id, prefix="",
-                  fully_masked="zero", lora_masks=None):
+                  fully_masked="zero", lora_masks=None, checkpoint_layers=False):
     """MultiModalQwenEmbedding.forward after the Q-Former call (:143,160-181):
     embed -> inject -> Qwen3(+LoRA) -> mean over ALL S positions."""
     text = P[prefix + "embed_tokens.weight"][input_ids]
     if item_tokens is not None:
         text = inject_tokens(text, input_ids, item_tokens, first_special_id)
-    h = qwen3_forward(P, cfg, text, attention_mask, prefix, fully_masked, lora_masks)
+    h = qwen3_forward(P, cfg, text, attention_mask, prefix, fully_masked, lora_masks, checkpoint_layers)
     return h.mean(dim=1)
 
 

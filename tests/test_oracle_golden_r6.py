@@ -29,7 +29,8 @@ def oracle_joint_c4(case):
     B, hist = case["B"], case["hist"]
     out = R.item_qformer_forward(PQ, cfg, torch.from_numpy(hfe).view(B * hist, c["F"], c["E"]), torch.from_numpy(ham).view(B * hist, c["F"]))
     toks = out["query_outputs"].view(B, hist, c["Q"], c["H"])
-    user = Q.joint_forward(PW, qc, torch.from_numpy(ids), torch.from_numpy(am), toks, case["first_special_id"], fully_masked="zero")
+    user = Q.joint_forward(PW, qc, torch.from_numpy(ids), torch.from_numpy(am), toks, case["first_special_id"], fully_masked="zero",
+                           checkpoint_layers=True)          # (the same arithmetic; 28 layers x 0.5 GB of saved probabilities would cost more time than the extra forward)
     loss = Q.infonce_loss(user, torch.from_numpy(pos), torch.from_numpy(neg), torch.from_numpy(nmask))
     _, rank = Q.mrr_ranks(user.detach(), torch.from_numpy(pos), torch.from_numpy(neg))
     loss.backward()
