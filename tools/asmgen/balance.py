@@ -94,6 +94,9 @@ def balance(seq, entry_lgkm=(), budget=32, min_lead=5, reach=12, temps=(), max_m
             max_moves = int(os.environ[key])
             break
     fill_m0 = os.environ.get("UR_BALANCE_FILL_M0", "1") == "1"
+    budget = int(os.environ.get("UR_BALANCE_BUDGET", budget))              # lab
+    min_lead = int(os.environ.get("UR_BALANCE_MIN_LEAD", min_lead))        # lab
+    reach = int(os.environ.get("UR_BALANCE_REACH", reach))                 # lab
     temps = set(temps) | {isa.M0}
     seq = list(seq)
 
