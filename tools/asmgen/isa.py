@@ -840,9 +840,13 @@ def fix_hazards(seq, entry_lgkm=()):
     out = []
     saved = None
 
+    import os
+    _abl = set(os.environ.get("UR_ASMGEN_ABLATE", "").split(","))       # lab, timing only (results WRONG): "lgkm" drops the counted LDS waits, "nop" the s_nops
+
     def wait_keep(keep):
         wi = s_waitcnt(lgkmcnt=min(keep, 15))
-        out.append(wi)
+        if "lgkm" not in _abl:
+            out.append(wi)
         track(t, wi)
         del q[:len(q) - min(keep, 15)]
 
@@ -875,7 +879,8 @@ def fix_hazards(seq, entry_lgkm=()):
         while n > 0:
             m = min(n, 8)
             ni = s_nop(m - 1)
-            out.append(ni)
+            if "nop" not in _abl:
+                out.append(ni)
             track(t, ni)
             n -= m
         if k == "lds":
