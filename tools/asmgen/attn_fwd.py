@@ -338,7 +338,7 @@ def pv_block(sub, skip_qb0):
             for qb in range(2):
                 out.append(None if (skip_qb0 and qb == 0) else v_mfma_32x32x16_bf16(O_(qb, dt), VF(4 * s2 + dt), P_(sub, qb, s2), O_(qb, dt)))
         for qb in range(2):
-            out.append(None if (skip_qb0 and qb == 0) else v_mfma_32x32x16_bf16(LA(qb), ONES(), P_(sub, qb, s2), LA(qb)))
+            out.append(None if ((skip_qb0 and qb == 0) or "rowsum" in os.environ.get("UR_ASMGEN_ABLATE", "")) else v_mfma_32x32x16_bf16(LA(qb), ONES(), P_(sub, qb, s2), LA(qb)))
     return out
 
 
