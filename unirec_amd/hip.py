@@ -75,8 +75,10 @@ def _nb(*ts):
 
 
 def workspace(nbytes, device, tag="default"):
-    """Grow-only scratch buffer per (device, tag); owned by the caller side (torch allocator)."""
-    key = (device, tag)
+    """Grow-only scratch buffer per (device, tag, STREAM); owned by the caller side (torch allocator).  Per stream since round 6: launches of
+    one family run on two streams at once (the Q-Formers' weight-gradient reductions on their side stream beside the dX chain), and a scratch
+    buffer shared across streams would be a race (the C3 full-size determinism test caught exactly that)."""
+    key = (device, tag, _stream() if device.type == "cuda" else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
