@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--recompute-mlp", action="store_true",
                     help="drop gate|up and act after each layer's forward and rebuild them in the backward (memory for time: "
                          "the C5 shape --user-tokens --hist 100 --seq 4096 --batch 64 then runs as ONE launch)")
+    ap.add_argument("--recompute-mlp-layers", type=int, default=0,
+                    help="like --recompute-mlp for decoder layers 0 .. N-1 only (the C5 line keeps as many layers' gate|up / act as 288 GB allow)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--comm-bf16", action="store_true",
                     help="multi-GPU, opt-in: the item Q-Former's gradient buckets cross xGMI as bf16 (dp.GradBuckets wire_dtype); default f32")
@@ -656,9 +658,18 @@ def main():
             # BASELINE configs[4] (C5): the C4 step with hist 100, S 4096, pool 10000 and the User Q-Former's 64 tokens (U4), B 64 as ONE launch
             # (recompute_mlp keeps it inside 288 GB); 1 warm-up + 2 timed steps, its own roofline / attention / cpu_baseline on a bounded sample
             torch.cuda.reset_peak_memory_stats()
-            ca = argparse.Namespace(**{**vars(args), "hist": 100, "seq": 4096, "pool": 10000, "user_tokens": True, "recompute_mlp": True, "steps": 2, "warmup": 1,
-                                       "micro_batches": 1, "cpu_budget": args.c5_cpu_budget, "cpu_runs": 1})
-            so = measure_joint(ca, rank, world, device, side_steps=1)
+            # gate|up / act of the LAST 10 layers are kept (4.8 GB each at 262144 tokens: ~250 GB of 288), the first 18 rebuilt in the backward;
+            # should the allocator refuse, the line falls back to rebuilding all 28 (201.8 GB) and says so in config.recompute_mlp
+            ca = argparse.Namespace(**{**vars(args), "hist": 100, "seq": 4096, "pool": 10000, "user_tokens": True, "recompute_mlp": False, "recompute_mlp_layers": 18,
+                                       "steps": 2, "warmup": 1, "micro_batches": 1, "cpu_budget": args.c5_cpu_budget, "cpu_runs": 1})
+            try:
+                so = measure_joint(ca, rank, world, device, side_steps=1)
+            except torch.cuda.OutOfMemoryError:
+                if world > 1:
+                    raise                      # (ranks must not diverge: a multi-rank run states its own budget)
+                gc.collect(); torch.cuda.empty_cache()
+                ca.recompute_mlp, ca.recompute_mlp_layers = True, 0
+                so = measure_joint(ca, rank, world, device, side_steps=1)
             if rank == 0 and so:
                 stages["joint_c5"] = {k: so[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "step_tflops_per_gpu", "loss", "max_mem_gb", "config", "roofline", "attention", "comm",
                                                          "cpu_baseline") if k in so}
@@ -687,6 +698,8 @@ def measure_joint(args, rank, world, device, side_steps=3):
     loss_fn = InfoNCELoss(0.07)
     qw = model.base_model
     qw.recompute_mlp = bool(args.recompute_mlp) or qw.recompute_mlp
+    if getattr(args, "recompute_mlp_layers", 0) > 0 and not args.recompute_mlp:
+        qw.recompute_mlp = int(args.recompute_mlp_layers)
     dp.set_dp_rank(rank, model, qf)                # dropout / LoRA-dropout masks keyed on the global sample index (same seeds on every rank)
     qpack, lpack = qf._ensure_pack(device), qw._ensure_pack(device)
     packs = [qpack, lpack]
@@ -904,7 +917,7 @@ def measure_joint(args, rank, world, device, side_steps=3):
                                       f"Qwen3-0.6B-shaped({cfg.num_hidden_layers}L)+LoRA r16 -> mean-pool -> InfoNCE pool {args.pool}; "
                                       f"fwd+bwd+allreduce+AdamW", "per_gpu_batch": B, "global_batch": B * world, "seq_len": args.seq,
                           "hist": args.hist, "pool": args.pool, "dropout": 0.0 if args.no_dropout else 0.2, "lora_dropout": 0.0 if args.no_dropout else args.lora_dropout,
-                          "micro_batches": nmb, "recompute_mlp": bool(qw.recompute_mlp), "parallelism": f"dp{world}", "random_init": True},
+                          "micro_batches": nmb, "recompute_mlp": (qw.recompute_mlp if isinstance(qw.recompute_mlp, bool) else f"layers 0..{int(qw.recompute_mlp) - 1}"), "parallelism": f"dp{world}", "random_init": True},
                "step_tflops_per_gpu": round(fl / (dt / args.steps) / 1e12, 1), "loss": round(lossv, 4),
                "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 1), "roofline": roof, "attention": attn, "comm": {**_comm_info(world), **comm_extra}, "param_checksum": checksum}
         if world == 1 and not args.no_cpu_baseline:

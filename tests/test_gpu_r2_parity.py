@@ -226,6 +226,10 @@ def test_recompute_mlp_switch_is_bit_identical_and_frees_the_mlp_activations(tok
         assert torch.equal(g0[n], g1[n]), n
     M, I = B * S, cfg.intermediate_size
     assert peak0 - peak1 >= (L - 2) * M * 3 * I * 2, (peak0, peak1)          # L - 1 layers' worth less, give or take where the peak falls
+    # round 6: recompute_mlp = k rebuilds layers 0 .. k - 1 only (bench.py's C5 line keeps as many layers as 288 GB allow)
+    p2, g2, _ = run(2)
+    assert seen["big"] == 2 * (L - 2) and [bool(k) for k in seen["kinds"]] == [True, True, False], seen
+    assert torch.equal(p0, p2) and all(torch.equal(g0[n], g2[n]) for n in g0)
 
 
 def test_user_qformer_mid_size_matches_reference():

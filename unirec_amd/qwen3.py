@@ -653,7 +653,8 @@ class Qwen3LoRAModel(nn.Module):
             else:
                 x3 = hip.gemm(act, fl["d"], residual=x2)
             L.update(rstd1=rstd1, qkv=qkv, actx=actx, att=att2, x2=x2, rstd2=rstd2, gu=gu, act=act)      # (qkv is None under the fused q/k-norm + RoPE epilogue)
-            if self.recompute_mlp and keep:
+            # (recompute_mlp = True: every layer; an int k: layers 0 .. k - 1 only -- as much memory as the shape needs, no more recomputation than that)
+            if self.recompute_mlp and keep and (self.recompute_mlp is True or i < int(self.recompute_mlp)):
                 # memory for time: gate|up and act (2 x [M, 3I] bf16 over the stack: 67 GB at C4) are dropped and rebuilt in the
                 # backward by the very launch that made them (bit-identical: same kernel, same operands).
                 how = "pair" if (pack is not None and pair) else ("merged" if (pack is not None and bc_gu is not None and not fused) else ("plain" if pack is None else None))
