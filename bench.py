@@ -658,9 +658,9 @@ def main():
             # BASELINE configs[4] (C5): the C4 step with hist 100, S 4096, pool 10000 and the User Q-Former's 64 tokens (U4), B 64 as ONE launch
             # (recompute_mlp keeps it inside 288 GB); 1 warm-up + 2 timed steps, its own roofline / attention / cpu_baseline on a bounded sample
             torch.cuda.reset_peak_memory_stats()
-            # gate|up / act of the LAST 10 layers are kept (4.8 GB each at 262144 tokens: ~250 GB of 288), the first 18 rebuilt in the backward;
+            # gate|up / act of the LAST 14 layers are kept (4.8 GB each at 262144 tokens: ~262 GB of 288), the first 14 rebuilt in the backward;
             # should the allocator refuse, the line falls back to rebuilding all 28 (201.8 GB) and says so in config.recompute_mlp
-            ca = argparse.Namespace(**{**vars(args), "hist": 100, "seq": 4096, "pool": 10000, "user_tokens": True, "recompute_mlp": False, "recompute_mlp_layers": 18,
+            ca = argparse.Namespace(**{**vars(args), "hist": 100, "seq": 4096, "pool": 10000, "user_tokens": True, "recompute_mlp": False, "recompute_mlp_layers": 14,
                                        "steps": 2, "warmup": 1, "micro_batches": 1, "cpu_budget": args.c5_cpu_budget, "cpu_runs": 1})
             try:
                 so = measure_joint(ca, rank, world, device, side_steps=1)
