@@ -875,6 +875,7 @@ def measure_joint(args, rank, world, device, side_steps=3):
                                            "frac": round(e1_fl / max(e1_ms, 1e-9) / 1e9 / 2500.0, 4),
                                            "note": "gemm_pers_kernel<1, 2>: the down-projection dX launch that carries the SwiGLU backward in its epilogue (inside `frac` since round 5)"},
                 "frac_without_swiglu_backward": round((tot_fl - x1_fl) / max(tot_ms - x1_ms, 1e-9) / 1e9 / 2500.0, 4),
+                "frac_definition": "rounds 5+: every 256x256 K-contiguous projection launch INCLUDING the one that carries the SwiGLU backward (EPI 1); compare with BENCH_r01..r04 through frac_without_swiglu_backward",
                 "hbm_bound_families": streams, "kernel": "gemm_pers_kernel<EPI 0|1|2|3|4|5, MODE> (every launch of the C4 step since the gate|up dX launch moved to it; other shapes: gemm_kernel<true,true,false,256,256,2,4,0>) (K-contiguous 256x256 projection GEMM: forward + "
                           "frozen-weight dX incl. the launch that carries the SwiGLU backward; the persistent kernel takes the launches csrc/gemm_pers.hip:gemm_pers_eligible "
                           "accepts; launches with a q/k-norm + RoPE, SwiGLU-forward or SwiGLU-backward epilogue are counted with their GEMM FLOPs only)",
