@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 10
+#define UR_ABI_VERSION 11
 
 int ur_version(void);
 const char* ur_last_error(void);
@@ -196,12 +196,17 @@ int ur_layernorm_fwd(const void* y, int32_t y_rows, const void* residual, const 
 /* Backward.  dz [M,H] bf16 = gradient w.r.t. z (the residual branch); dy [M,H] bf16 = dz with the
  * pre-dropout mask applied (may alias dz when p_pre == 0; may be NULL when not needed).
  * dgamma, dbeta [H] f32 are OVERWRITTEN; dbias [H] f32 (column sum of dy, i.e. the gradient of the
- * preceding dense bias) is written when non-NULL.  workspace: ur_layernorm_bwd_workspace_bytes(H). */
+ * preceding dense bias) is written when non-NULL.  workspace: ur_layernorm_bwd_workspace_bytes(H).
+ * dgamma == NULL (round 6): the call stops at the per-block partial sums in `workspace` and the caller finishes them with
+ * ur_layernorm_bwd_reduce(workspace, M, H, ...) -- on ANY stream ordered behind this call: the three parameter gradients hang off the
+ * backward's dX chain (unirec_amd/qformer.py runs the reduction on its side stream beside the next layer's products).  The workspace then
+ * belongs to that pending reduction until it has run. */
 int64_t ur_layernorm_bwd_workspace_bytes(int32_t H);
 int ur_layernorm_bwd(const void* dout, const void* z, const float* mean, const float* rstd, const float* gamma,
                      void* dz, void* dy, float* dgamma, float* dbeta, float* dbias, int32_t M, int32_t H,
                      float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post, int64_t drop_row0,
                      void* workspace, int64_t workspace_bytes, void* stream);
+int ur_layernorm_bwd_reduce(const void* workspace, int32_t M, int32_t H, float* dgamma, float* dbeta, float* dbias, void* stream);
 
 /* out[r][h] (f32, overwritten) = sum_{b<nb} in[(b*rows + r)][h]   (bf16 in).  Used for the
  * gradient of the batch-broadcast query_embeddings (models/qformer_utils.py:39) and, with rows=1,

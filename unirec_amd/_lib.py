@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UNIREC_HIP_LIB selects another build of the SAME library (kernel A/B experiments); there is still no fallback.
 LIB_PATH = os.environ.get("UNIREC_HIP_LIB") or os.path.join(_HERE, "lib", "libunirec_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_void_p, c_int, c_i64, c_u64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
@@ -107,6 +107,7 @@ SIGNATURES = {
     "ur_layernorm_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_int, c_int, c_float, c_float, c_u64, c_float, c_u64, c_i64, c_void_p]),
     "ur_layernorm_bwd_workspace_bytes": (c_i64, [c_int]),
+    "ur_layernorm_bwd_reduce": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ur_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_int, c_int, c_float, c_u64, c_float, c_u64, c_i64, c_void_p, c_i64, c_void_p]),
     "ur_batch_reduce": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_i64, c_void_p]),

@@ -397,7 +397,7 @@ extern "C" int ur_layernorm_bwd(const void* dout, const void* z, const float* me
                                 int32_t M, int32_t H, float p_pre, uint64_t seed_pre, float p_post, uint64_t seed_post,
                                 int64_t drop_row0, void* workspace, int64_t workspace_bytes, void* stream) {
   UR_REQUIRE(M >= 0 && H > 0 && (H % 8) == 0 && H <= 2048, "ur_layernorm_bwd: need H %% 8 == 0 and H <= 2048 (H=%d)", H);
-  UR_REQUIRE(dout && z && mean && rstd && gamma && dz && dgamma && dbeta, "ur_layernorm_bwd: null argument");
+  UR_REQUIRE(dout && z && mean && rstd && gamma && dz && ((dgamma && dbeta) || (!dgamma && !dbeta)), "ur_layernorm_bwd: null argument");
   UR_REQUIRE(workspace && workspace_bytes >= ur_layernorm_bwd_workspace_bytes(H), "ur_layernorm_bwd: workspace too small");
   UR_REQUIRE(UR_ALIGNED16(dout) && UR_ALIGNED16(z) && UR_ALIGNED16(dz) && UR_ALIGNED16(gamma) && (!dy || UR_ALIGNED16(dy)),
              "ur_layernorm_bwd: 16-byte alignment");
@@ -409,10 +409,20 @@ extern "C" int ur_layernorm_bwd(const void* dout, const void* z, const float* me
   UR_NCH_DISPATCH(H, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(grid), dim3(256), 0, st, (const bf16_t*)dout,
                                         (const bf16_t*)z, mean, rstd, gamma, (bf16_t*)dz, (bf16_t*)dy, part, M, H, pre, post));
   UR_CHECK_LAUNCH("ur_layernorm_bwd");
+  if (!dgamma) return 0;            // partial sums only: ur_layernorm_bwd_reduce finishes them (on a stream of the caller's choice)
   const int ncols = 3 * H;
   hipLaunchKernelGGL(colpart_reduce_kernel, dim3(ur_cdiv(ncols, 64)), dim3(1024), 0, st, (const float*)part,
                      grid, ncols, dgamma, dbeta, dbias, H);
   UR_CHECK_LAUNCH("ur_layernorm_bwd(reduce)");
+  return 0;
+}
+
+extern "C" int ur_layernorm_bwd_reduce(const void* workspace, int32_t M, int32_t H, float* dgamma, float* dbeta, float* dbias, void* stream) {
+  UR_REQUIRE(M >= 0 && H > 0 && (H % 8) == 0 && H <= 2048 && workspace && dgamma && dbeta, "ur_layernorm_bwd_reduce: bad argument");
+  const int ncols = 3 * H;
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(ur_cdiv(ncols, 64)), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace,
+                     row_grid(M, LN_BWD_BLOCKS), ncols, dgamma, dbeta, dbias, H);
+  UR_CHECK_LAUNCH("ur_layernorm_bwd_reduce");
   return 0;
 }
 

@@ -485,13 +485,26 @@ def layernorm_fwd(y, gamma, beta, eps, residual=None, save_z=True, p_pre=0.0, se
 
 
 def layernorm_bwd(dout, z, mean, rstd, gamma, dgamma, dbeta, dbias=None, p_pre=0.0, seed_pre=0, p_post=0.0, seed_post=0,
-                  need_dy=True, drop_row0=0):
-    """Returns (dz, dy); dgamma/dbeta/dbias (f32 [H]) are overwritten in place."""
+                  need_dy=True, drop_row0=0, defer_reduce=False):
+    """Returns (dz, dy); dgamma/dbeta/dbias (f32 [H]) are overwritten in place.
+    defer_reduce=True: returns (dz, dy, finish) -- the call stops at the per-block partial sums (a scratch tensor of its own) and
+    finish() launches their reduction into dgamma / dbeta / dbias on the stream that is current WHEN IT IS CALLED (ordering against this
+    call is the caller's: qformer.py runs it on its side stream behind an event)."""
     lib = _lib.load()
     M, H = z.shape
     dz = torch.empty_like(z)
     dy = dz if (p_pre == 0.0 or not need_dy) else torch.empty_like(z)
     wsb = lib.ur_layernorm_bwd_workspace_bytes(H)
+    if defer_reduce:
+        ws = torch.empty(int(wsb), dtype=torch.uint8, device=z.device)
+        check(lib.ur_layernorm_bwd(dout.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                   dz.data_ptr(), dy.data_ptr() if need_dy else 0, 0, 0, 0,
+                                   M, H, p_pre, seed_pre, p_post, seed_post, int(drop_row0), ws.data_ptr(), wsb, _stream()), "ur_layernorm_bwd")
+
+        def finish():
+            check(lib.ur_layernorm_bwd_reduce(ws.data_ptr(), M, H, dgamma.data_ptr(), dbeta.data_ptr(), _p(dbias), _stream()), "ur_layernorm_bwd_reduce")
+        finish.scratch = ws
+        return dz, dy, finish
     ws = workspace(wsb, z.device, "ln")
     check(lib.ur_layernorm_bwd(dout.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
                                dz.data_ptr(), dy.data_ptr() if need_dy else 0, dgamma.data_ptr(), dbeta.data_ptr(), _p(dbias),

@@ -120,6 +120,7 @@ _USE_WT = os.environ.get("UNIREC_QF_WT", "1") != "0"     # lab: 0 = dX products 
 # (item Q-Former of the joint step: 6400 rows = 100 output tiles), so the two streams' kernels run beside each other.  Same kernels, same
 # arithmetic: results bit-identical (tests/test_gpu_r6_parity.py).  0 = everything on the caller's stream, as before.
 _DW_SIDE = os.environ.get("UNIREC_QF_DW_STREAM", "1") != "0"
+_DW_SIDE_MAX_ROWS = 16384
 _side_streams = {}
 
 
@@ -519,7 +520,9 @@ class BertModel(nn.Module):
                 return hip.gemm(dy, wt[key], **kw)
             return hip.gemm(dy, pack.fused16(list(names)) if len(names) > 1 else pack.w16(names[0]), s_kcontig=False, **kw)
 
-        side = _side_stream(dout.device) if (_DW_SIDE and dout.is_cuda) else None
+        # (only where the launches leave CUs idle: at 32768 rows -- the user Q-Former of C3 -- both streams' kernels fill the chip, nothing is gained,
+        # and the caching allocator's bookkeeping for tensors used on two streams stalls the host now and then: 49.9 ms -> 50.2-59.8 ms per step)
+        side = _side_stream(dout.device) if (_DW_SIDE and dout.is_cuda and M <= _DW_SIDE_MAX_ROWS) else None
         main = torch.cuda.current_stream(dout.device) if side is not None else None
         if side is not None:
             side.wait_stream(main)         # (the first use: everything the caller has queued so far, incl. the zeroing of the gradient buffers)
@@ -548,6 +551,14 @@ class BertModel(nn.Module):
         def colsum(x, out):
             off_chain(lambda: hip.colsum(x, out=out), x)
 
+        def ln_bwd(*a, **kw):
+            """hip.layernorm_bwd with the reduction of its per-block partial sums (dgamma, dbeta, dbias: parameter gradients only) on the side stream"""
+            if side is None:
+                return hip.layernorm_bwd(*a, **kw)
+            dz_, dy_, finish = hip.layernorm_bwd(*a, defer_reduce=True, **kw)
+            off_chain(finish, finish.scratch)
+            return dz_, dy_
+
         kvw, kvb = self._cross_kv_names(pre)
         ncross = len(kvw) // 2
         dkv_all = torch.empty_like(S["kv_all"]) if ncross else None          # every layer's dK | dV, reduced by ONE launch after the loop
@@ -561,7 +572,7 @@ class BertModel(nn.Module):
             # ---- FFN
             xc, u, hbuf, z3, m3, r3, s_h3 = L["ffn"]
             f1, f2 = lp + "intermediate_query.dense.", lp + "output_query."
-            dz3, dy3 = hip.layernorm_bwd(dx, z3, m3, r3, pack.w32(f2 + "LayerNorm.weight"), pack.g32(f2 + "LayerNorm.weight"),
+            dz3, dy3 = ln_bwd(dx, z3, m3, r3, pack.w32(f2 + "LayerNorm.weight"), pack.g32(f2 + "LayerNorm.weight"),
                                          pack.g32(f2 + "LayerNorm.bias"), dbias=pack.g32(f2 + "dense.bias"), p_pre=p_h, seed_pre=s_h3, drop_row0=row0)
             dW(dy3, hbuf, [f2 + "dense.weight"])
             du = dX(dy3, [f2 + "dense.weight"], gelu_grad_aux=u)
@@ -572,7 +583,7 @@ class BertModel(nn.Module):
             if lyr.has_cross_attention:
                 c = lp + "crossattention."
                 x1, qc, jc, actx2, ctx2, z2, m2, r2, s_h2 = L["cross"]
-                dz2, dy2 = hip.layernorm_bwd(dx, z2, m2, r2, pack.w32(c + "output.LayerNorm.weight"),
+                dz2, dy2 = ln_bwd(dx, z2, m2, r2, pack.w32(c + "output.LayerNorm.weight"),
                                              pack.g32(c + "output.LayerNorm.weight"), pack.g32(c + "output.LayerNorm.bias"),
                                              dbias=pack.g32(c + "output.dense.bias"), p_pre=p_h, seed_pre=s_h2, drop_row0=row0)
                 dW(dy2, ctx2.view(M, H), [c + "output.dense.weight"])
@@ -595,7 +606,7 @@ class BertModel(nn.Module):
             # ---- self attention
             a = lp + "attention."
             x0, qkv, actx, ctx_o, z1, m1, r1, s_h = L["self"]
-            dz1, dy1 = hip.layernorm_bwd(dx, z1, m1, r1, pack.w32(a + "output.LayerNorm.weight"),
+            dz1, dy1 = ln_bwd(dx, z1, m1, r1, pack.w32(a + "output.LayerNorm.weight"),
                                          pack.g32(a + "output.LayerNorm.weight"), pack.g32(a + "output.LayerNorm.bias"),
                                          dbias=pack.g32(a + "output.dense.bias"), p_pre=p_h, seed_pre=s_h, drop_row0=row0)
             dW(dy1, ctx_o.view(M, H), [a + "output.dense.weight"])
