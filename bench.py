@@ -662,11 +662,14 @@ def main():
             # should the allocator refuse, the line falls back to rebuilding all 28 (201.8 GB) and says so in config.recompute_mlp
             ca = argparse.Namespace(**{**vars(args), "hist": 100, "seq": 4096, "pool": 10000, "user_tokens": True, "recompute_mlp": False, "recompute_mlp_layers": int(os.environ.get("UNIREC_BENCH_C5_REBUILD_LAYERS", "14")),
                                        "steps": 2, "warmup": 1, "micro_batches": 1, "cpu_budget": args.c5_cpu_budget, "cpu_runs": 1})
+            refused = False
             try:
                 so = measure_joint(ca, rank, world, device, side_steps=1)
             except torch.cuda.OutOfMemoryError:
                 if world > 1:
                     raise                      # (ranks must not diverge: a multi-rank run states its own budget)
+                refused = True                 # (retry OUTSIDE the handler: the exception's traceback keeps the failed attempt's model and activations alive)
+            if refused:
                 gc.collect(); torch.cuda.empty_cache()
                 ca.recompute_mlp, ca.recompute_mlp_layers = True, 0
                 so = measure_joint(ca, rank, world, device, side_steps=1)
