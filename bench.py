@@ -670,7 +670,7 @@ def main():
                     raise                      # (ranks must not diverge: a multi-rank run states its own budget)
                 refused = True                 # (retry OUTSIDE the handler: the exception's traceback keeps the failed attempt's model and activations alive)
             if refused:
-                gc.collect(); torch.cuda.empty_cache()
+                gc.collect(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
                 ca.recompute_mlp, ca.recompute_mlp_layers = True, 0
                 so = measure_joint(ca, rank, world, device, side_steps=1)
             if rank == 0 and so:
