@@ -556,9 +556,9 @@ def measure_item_c1(args, rank, world, device, g):
         call()
     dt, sums = timed(call, reps)
     graph = {"captured": False}
-    try:                         # one hipGraph replay per call
+    try:                         # one hipGraph replay per call (stream capture on a side stream; allocations come from the graph's private pool)
         if world > 1:            # (a process group's watchdog thread may touch the device during a global-mode capture: the single-rank line carries the graph number)
-            raise RuntimeError("hipGraph capture is measured on the single-rank line only") (stream capture on a side stream; allocations come from the graph's private pool)
+            raise RuntimeError("hipGraph capture is measured on the single-rank line only")
         gr = torch.cuda.CUDAGraph()
         st = torch.cuda.Stream()
         st.wait_stream(torch.cuda.current_stream())
