@@ -585,7 +585,7 @@ def measure_item_c1(args, rank, world, device, g):
     roof = {"bound": "hbm", "achieved": round(nbytes / best / 1e9, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(nbytes / best / 1e9 / 8000.0, 6), "traffic": None,
             "note": f"latency-bound: {nbytes / 1e6:.2f} MB of weights + inputs per call; the call is a chain of ~40 dependent launches over 64 query rows, not a stream"}
     out = {"metric": "items/sec item Q-Former eval forward + reconstruction metrics (C1: L2 Q4 H256 nh4 I1024 F8 E256, batch 16; evaluate_item_qformer.py path)",
-           "value": round(B / best, 1), "unit": "items/sec", "n_gpus": 1, "steps": reps, "warmup": 10, "ms_per_step": round(best * 1e3, 4),
+           "value": round(world * B / best, 1), "unit": "items/sec", "n_gpus": world, "steps": reps, "warmup": 10, "ms_per_step": round(best * 1e3, 4),
            "latency_us": {"launch_by_launch": round(dt * 1e6, 1), "hip_graph": graph.get("latency_us")}, "hip_graph": graph,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "item_c1", "per_gpu_batch": B, "mode": "eval (dropout off)", "eval_mse": round(sums[0] / max(sums[1], 1.0), 6), "eval_cos_mean": round(sums[2] / max(sums[1], 1.0), 6)},
