@@ -662,7 +662,7 @@ def main():
             torch.cuda.reset_peak_memory_stats()
             # gate|up / act of the LAST 14 layers are kept (4.8 GB each at 262144 tokens: ~262 GB of 288), the first 14 rebuilt in the backward;
             # should the allocator refuse, the line falls back to rebuilding all 28 (201.8 GB) and says so in config.recompute_mlp
-            ca = argparse.Namespace(**{**vars(args), "hist": 100, "seq": 4096, "pool": 10000, "user_tokens": True, "recompute_mlp": False, "recompute_mlp_layers": int(os.environ.get("UNIREC_BENCH_C5_REBUILD_LAYERS", "14")),
+            ca = argparse.Namespace(**{**vars(args), "hist": 100, "seq": 4096, "pool": 10000, "user_tokens": True, "recompute_mlp": False, "recompute_mlp_layers": int(os.environ.get("UNIREC_BENCH_C5_REBUILD_LAYERS", "14" if world == 1 else "20")),      # (multi-rank: room for the communicator's buffers; no fallback there)
                                        "steps": 2, "warmup": 1, "micro_batches": 1, "cpu_budget": args.c5_cpu_budget, "cpu_runs": 1})
             refused = False
             try:
