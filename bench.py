@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--stage-steps", type=int, default=10)
     ap.add_argument("--no-c5-stage", dest="c5_stage", action="store_false",
                     help="joint workload: skip the C5 line (hist 100, S 4096, pool 10000, user tokens, B 64; 1 warm-up + 2 steps) that follows the stages")
+    ap.add_argument("--c5-stage-multi", action="store_true",
+                    help="run the C5 line on a multi-rank launch as well (default: single-GPU runs only -- it fills 260 of 288 GB per rank, and a rank "
+                         "that runs out of memory there would take the headline line of the scaling run with it)")
     ap.add_argument("--c5-cpu-budget", type=float, default=45.0, help="seconds of oracle work the C5 cpu_baseline leg may start")
     ap.add_argument("--cpu-runs", type=int, default=3, help="(internal) timed repeats of the cpu_baseline leg after its warm-up (0: the cold run is the sample)")
     ap.add_argument("--stage-cpu-budget", type=float, default=25.0, help="seconds of oracle work per stage cpu_baseline leg")
@@ -656,7 +659,7 @@ def main():
                 if "cpu_baseline" in so:
                     stages[key]["cpu_baseline"] = so["cpu_baseline"]
             gc.collect(); torch.cuda.empty_cache()
-        if args.c5_stage:
+        if args.c5_stage and (world == 1 or args.c5_stage_multi):
             # BASELINE configs[4] (C5): the C4 step with hist 100, S 4096, pool 10000 and the User Q-Former's 64 tokens (U4), B 64 as ONE launch
             # (recompute_mlp keeps it inside 288 GB); 1 warm-up + 2 timed steps, its own roofline / attention / cpu_baseline on a bounded sample
             torch.cuda.reset_peak_memory_stats()
