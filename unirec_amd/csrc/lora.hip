@@ -67,6 +67,21 @@ __device__ __forceinline__ int f64sw(int r) { return ((r >> 1) & 1) | (((r >> 3)
 // {0..3, 8..11} + 4 (32-lane groups, banks mod 256 B: rows of one parity need distinct pair positions -> bit 3 of the row
 // moves the pair index by 2).  The f64sw form left the writes 4-way conflicted (PMC: 66 % of the kernel's LDS cycles).
 __device__ __forceinline__ int sw16(int r) { return (r & 7) ^ ((r & 8) >> 1); }
+// The RING kernels' image of the same tile has no LDS write instruction (LDS-DMA pieces land contiguously; the swizzle is applied on the
+// source side), and two kinds of read: ds_read_b128 of a row's 16-byte chunk (4 s2 + g) by lanes (row l15, group g) -- the hardware serves
+// that instruction in four 16-lane groups, {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS table): rows
+// {0-3, 12-15} at chunk c beside rows {4-11} at chunk c ^ 1, banks mod 256 B = two rows -- and the transposed reads above.  Under sw16 the
+// row reads are 2-way conflicted (rows 0 / 12, 2 / 14, 4 / 8, 6 / 10 share a chunk position: PMC, 36-50 % of these kernels' LDS cycles).
+// swr = the f64sw PAIR swizzle written as a chunk swizzle serves both: transposed reads need rows {0, 2, 8, 10} (and {4, 6, 12, 14}) on
+// four different chunk pairs, row reads need the chunk positions of rows {0, 2, 12, 14} and (1 ^ those of) rows {4, 6, 8, 10} all different:
+// positions (0, 2, 0, 2, 4, 6, 4, 6) for rows (0, 2, 4, .. 14); odd rows alike in the other half of the banks.
+#ifndef UR_RING_SWR
+#define UR_RING_SWR 1        // lab: 0 = sw16 in the ring kernels (round 5)
+#endif
+__device__ __forceinline__ int swr(int r) { return UR_RING_SWR ? ((((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2)) : sw16(r); }
+// (ring kernels, [tokens][16] tiles of 32-byte rows: transposed reads of rows {0-3, 8-11} + 4 by a 32-lane group need rows r and r + 8 in
+// different halves of the 256 bytes of banks: LDS row slot s holds source row vrow(s), an involution)
+__device__ __forceinline__ int vrow(int s) { return UR_RING_SWR ? (s ^ (((s >> 3) & 1) << 2)) : s; }
 
 // ---- dropped-flag bit planes ---------------------------------------------------------------------
 // thread <-> (row m, group q of 32 columns): one 32-bit word per adapter plane.  Every element draws a 15-bit value u;
@@ -247,7 +262,7 @@ __global__ __launch_bounds__(256, 4) void lora_project_kernel(ProjP p) {
 
 // ---- the column reduction of ONE adapter with X streamed through an LDS-DMA ring ------------------------------------------------
 // grid: x = block of 256 tokens, y = entry (widths multiples of 64).  The block walks the entry's columns in chunks of 64: a stage =
-// the [256 x 64] piece of X (32 KiB, rows of 128 bytes, chunks swizzled by sw16 on the source side), the [16 x 64] chunk of U and
+// the [256 x 64] piece of X (32 KiB, rows of 128 bytes, chunks swizzled by swr on the source side), the [16 x 64] chunk of U and
 // -- MASKED -- the 8 flag bytes of each row, fetched by global_load_lds three stages ahead (96 KiB in flight per CU); one barrier
 // per stage; wave w consumes tokens 64 w .. + 63 as MFMA column operands (the layout of lora_bgrad_ring_kernel's tb product).
 constexpr int P2_NST = 4, P2_XS = 256 * 128, P2_STAGE = P2_XS + 2048 + 2048, P2_SMEM = P2_NST * P2_STAGE;
@@ -267,8 +282,8 @@ __global__ __launch_bounds__(256) void lora_project_ring_kernel(ProjP p) {
 
   // ---- producer ----
   const int prow = lane >> 3, wpar = wave & 1;
-  // X piece = rows 8 piece .. + 7 (piece = 4 i + wave): sw16(row) = prow ^ 4 (wave & 1)
-  const int schunk = (lane & 7) ^ prow ^ (4 * wpar);
+  // X piece = rows 8 piece .. + 7 (piece = 4 i + wave): row = 8 (wave & 1) + prow (mod 16) for the swizzle
+  const int schunk = (lane & 7) ^ swr(8 * wpar + prow);
   const uint32_t xlane = (uint32_t)((prow * p.ldx + schunk * 8) * 2);
   const uint32_t ulane = (uint32_t)((prow * p.ldu[y] + schunk * 8) * 2);
   const uint32_t blane = (uint32_t)((lane >> 1) * p.bits_ld + 4 * (lane & 1));
@@ -313,7 +328,7 @@ __global__ __launch_bounds__(256) void lora_project_ring_kernel(ProjP p) {
   for (int rb = 0; rb < 4; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int npro = min(P2_NST - 1, nch);
   for (int c = 0; c < npro; ++c) issue(c);
-  const int swl = sw16(l15);
+  const int swl = swr(l15);
   const uint32_t xrd = (uint32_t)((64 * wave + l15) * 128), urd = (uint32_t)(P2_XS + l15 * 128), brd = (uint32_t)(P2_XS + 2048 + (64 * wave + l15) * 8 + g);
   for (int c = 0; c < nch; ++c) {
     const int later = min(nch, c + P2_NST - 1) - (c + 1);
@@ -764,7 +779,7 @@ __global__ __launch_bounds__(256) void lora_reduce_ring_kernel(RedP p) {
   // source chunk ((pos >> 1) ^ f64sw) << 1 | (pos & 1)
   const int fsw = ((prow >> 1) & 1) | (wpar << 1);
   const uint32_t xlane = (uint32_t)((prow * p.ldx + ((((pos >> 1) ^ fsw) << 1) | (pos & 1)) * 8) * 2);
-  const uint32_t vlane = (uint32_t)(((lane >> 1) * p.ldv + 8 * (lane & 1)) * 2);
+  const uint32_t vlane = (uint32_t)((vrow(lane >> 1) * p.ldv + 8 * (lane & 1)) * 2);         // LDS row slot lane >> 1 of the wave's 32-row piece
   const int am = wave < NAD ? wave : NAD - 1;             // this wave's flag piece (waves >= NAD repeat the last adapter's: same bytes)
   const uint32_t mlane = (uint32_t)(((lane >> 4) * p.bt_ld + 4 * (lane & 15)) * 4);
   auto issue = [&](int s) {
@@ -793,12 +808,13 @@ __global__ __launch_bounds__(256) void lora_reduce_ring_kernel(RedP p) {
   const int npro = min(R2_NST - 1, nst);
   for (int s = 0; s < npro; ++s) issue(s);
   // lane constants of the consumer: transposed reads of step ks at rows ka = 32 ks + 8 g + q (+ 4)
-  uint32_t xo[4], vo[4];
+  uint32_t xo[4], vo[4], vo4[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     const int ka = 32 * ks + 8 * g + q;
     xo[ks] = (uint32_t)(ka * 128 + ((wave ^ f64sw(ka)) << 5) + pp * 8);
-    vo[ks] = (uint32_t)(R2_XS + ka * 32 + pp * 8);
+    vo[ks] = (uint32_t)(R2_XS + vrow(ka) * 32 + pp * 8);
+    vo4[ks] = (uint32_t)(R2_XS + vrow(ka + 4) * 32 + pp * 8);
   }
   const uint32_t mo = (uint32_t)(R2_XS + NAD * R2_VS + (16 * wave + l15) * 4);
 
@@ -818,7 +834,7 @@ __global__ __launch_bounds__(256) void lora_reduce_ring_kernel(RedP p) {
       bf16x8 xf, vf[NAD];
       if constexpr (NAD == 1) {
         bf16x8 f[2];
-        const uint32_t a[2] = {sb + xo[ks], sb + vo[ks]}, b[2] = {sb + xo[ks] + 4 * 128, sb + vo[ks] + 4 * 32};
+        const uint32_t a[2] = {sb + xo[ks], sb + vo[ks]}, b[2] = {sb + xo[ks] + 4 * 128, sb + vo4[ks]};
         tr_read(f, a, b);
         xf = f[0]; vf[0] = f[1];
       } else {
@@ -826,14 +842,14 @@ __global__ __launch_bounds__(256) void lora_reduce_ring_kernel(RedP p) {
         uint32_t a[4], b[4];
         a[0] = sb + xo[ks]; b[0] = a[0] + 4 * 128;
 #pragma unroll
-        for (int i = 1; i < 4; ++i) { const int ad = i - 1 < NAD ? i - 1 : NAD - 1; a[i] = sb + vo[ks] + ad * R2_VS; b[i] = a[i] + 4 * 32; }
+        for (int i = 1; i < 4; ++i) { const int ad = i - 1 < NAD ? i - 1 : NAD - 1; a[i] = sb + vo[ks] + ad * R2_VS; b[i] = sb + vo4[ks] + ad * R2_VS; }
         tr_read(f, a, b);
         xf = f[0];
 #pragma unroll
         for (int ad = 0; ad < NAD && ad < 3; ++ad) vf[ad] = f[1 + ad];
         if constexpr (NAD == 4) {
           bf16x8 f2[2];
-          const uint32_t a2[2] = {sb + vo[ks] + 3 * R2_VS, sb + vo[ks] + 3 * R2_VS}, b2[2] = {a2[0] + 4 * 32, a2[0] + 4 * 32};
+          const uint32_t a2[2] = {sb + vo[ks] + 3 * R2_VS, sb + vo[ks] + 3 * R2_VS}, b2[2] = {sb + vo4[ks] + 3 * R2_VS, sb + vo4[ks] + 3 * R2_VS};
           tr_read(f2, a2, b2);
           vf[3] = f2[0];
         }
@@ -1079,7 +1095,7 @@ __global__ __launch_bounds__(256, 2) void lora_bgrad_kernel(BgradP p) {
 // ---- the same products with dy streamed through an LDS-DMA ring ------------------------------------------------------------
 // grid: x = block of 512 tokens, y = adapter entry (every width a multiple of 64).  The block's stream is a sequence of stages
 // (column chunk c, token tile t): [256 tokens x 64 columns] of dy (32 KiB, rows of 128 bytes, 16-byte chunks swizzled by
-// sw16) + the [16 x 64] chunk of B^T, fetched by global_load_lds three stages ahead of their use (no registers, no LDS write
+// swr) + the [16 x 64] chunk of B^T, fetched by global_load_lds three stages ahead of their use (no registers, no LDS write
 // instructions; 96 KiB in flight per CU).  One barrier per stage makes the tile visible to the four waves, which then split it
 // TWO ways: tokens for tb (wave w: tokens 64 w .. + 63 of the tile as MFMA column operands, all 64 columns), columns for dB
 // (wave w: columns 16 w .. + 15 as hardware-transposed operands, all 256 tokens) -- the dB partial of a column is complete
@@ -1107,10 +1123,11 @@ __global__ __launch_bounds__(256) void lora_bgrad_ring_kernel(BgradP p) {
 
   // ---- producer: this wave's 8 pieces (8 rows x 128 B each) of a stage's dy tile + one piece of its B^T chunk ----
   // every address = uniform base (scalar registers) + ONE 32-bit lane offset; only the launch's last token block clamps rows per lane
-  const int prow = lane >> 3;                                 // row within a piece; rows 8 i .. of the tile: sw16(row) = prow ^ 4 (i & 1)
+  const int prow = lane >> 3;                                 // row within a piece; rows 8 piece .. of the tile (piece = 4 i + wave): swizzle row 8 (wave & 1) + prow
   const int wpar = wave & 1;
-  const uint32_t xlane = (uint32_t)((prow * p.ldx + (((lane & 7) ^ prow ^ (4 * wpar)) * 8)) * 2);
-  const uint32_t ulane = (uint32_t)((prow * p.ldu[e] + (((lane & 7) ^ prow ^ (4 * wpar)) * 8)) * 2);
+  const int schunk = (lane & 7) ^ swr(8 * wpar + prow);
+  const uint32_t xlane = (uint32_t)((prow * p.ldx + schunk * 8) * 2);
+  const uint32_t ulane = (uint32_t)((prow * p.ldu[e] + schunk * 8) * 2);
   const char* ubase = reinterpret_cast<const char*>(p.U[e] + (long)(8 * wpar) * p.ldu[e]);
   const bool full = tok0 + B2_TOK <= p.M;                     // uniform
   // (every block walks the column chunks in the same order: a token's tb must not depend on where its row sits in the batch -- the
@@ -1130,7 +1147,7 @@ __global__ __launch_bounds__(256) void lora_bgrad_ring_kernel(BgradP p) {
       for (int i = 0; i < 8; ++i) {
         const int piece = 4 * i + wave;
         const int m = min(tok0 + t * B2_TILE + 8 * piece + prow, p.M - 1);
-        const char* src = reinterpret_cast<const char*>(p.X + (long)m * p.ldx + col0 + 64 * c + (((lane & 7) ^ prow ^ (4 * wpar)) * 8));
+        const char* src = reinterpret_cast<const char*>(p.X + (long)m * p.ldx + col0 + 64 * c + schunk * 8);
         __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(st + piece * 1024), 16, 0, UR_RING_AUX);
       }
     }
@@ -1174,14 +1191,14 @@ __global__ __launch_bounds__(256) void lora_bgrad_ring_kernel(BgradP p) {
     for (int rb = 0; rb < 4; ++rb) tb[t][rb] = f32x4{0.f, 0.f, 0.f, 0.f};
   float* slab = p.slabs + (long)blockIdx.x * p.total + p.goff[e];
   // lane constants of the consumers
-  const uint32_t xrd0 = (uint32_t)((64 * wave + l15) * 128);             // row of row block 0; chunk position (4 s2 + g) ^ sw16(l15)
-  const int swl = sw16(l15);
+  const uint32_t xrd0 = (uint32_t)((64 * wave + l15) * 128);             // row of row block 0; chunk position (4 s2 + g) ^ swr(l15)
+  const int swl = swr(l15);
   uint32_t tra[8], trb[8];                                                // transposed reads of k-step k: rows 32 k + 8 g + q (+ 4)
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const int ka = 32 * k + 8 * g + q, swk = sw16(ka), c0 = 2 * wave + (pp >> 1);
-    tra[k] = (uint32_t)(ka * 128 + ((pp & 1) << 3) + ((c0 ^ swk) << 4));
-    trb[k] = (uint32_t)((ka + 4) * 128 + ((pp & 1) << 3) + ((c0 ^ swk ^ 4) << 4));
+    const int ka = 32 * k + 8 * g + q, c0 = 2 * wave + (pp >> 1);
+    tra[k] = (uint32_t)(ka * 128 + ((pp & 1) << 3) + ((c0 ^ swr(ka)) << 4));
+    trb[k] = (uint32_t)((ka + 4) * 128 + ((pp & 1) << 3) + ((c0 ^ swr(ka + 4)) << 4));
   }
 
   int s = 0;
