@@ -265,7 +265,10 @@ __global__ __launch_bounds__(256, 4) void lora_project_kernel(ProjP p) {
 // the [256 x 64] piece of X (32 KiB, rows of 128 bytes, chunks swizzled by swr on the source side), the [16 x 64] chunk of U and
 // -- MASKED -- the 8 flag bytes of each row, fetched by global_load_lds three stages ahead (96 KiB in flight per CU); one barrier
 // per stage; wave w consumes tokens 64 w .. + 63 as MFMA column operands (the layout of lora_bgrad_ring_kernel's tb product).
-constexpr int P2_NST = 4, P2_XS = 256 * 128, P2_STAGE = P2_XS + 2048 + 2048, P2_SMEM = P2_NST * P2_STAGE;
+#ifndef UR_P2_NST
+#define UR_P2_NST 4          // lab: ring depth of lora_project_ring_kernel (2 = one stage in flight, two workgroups per CU)
+#endif
+constexpr int P2_NST = UR_P2_NST, P2_XS = 256 * 128, P2_STAGE = P2_XS + 2048 + 2048, P2_SMEM = P2_NST * P2_STAGE;
 template <bool MASKED>
 __global__ __launch_bounds__(256) void lora_project_ring_kernel(ProjP p) {
   typedef __attribute__((address_space(3))) void lds_void;
@@ -754,7 +757,10 @@ __global__ __launch_bounds__(256) void lora_reduce_kernel(RedP p) {
 constexpr int R2_TOK = 128, R2_XS = R2_TOK * 128, R2_VS = R2_TOK * 32;
 // ring depth: 4 stages and one workgroup per CU for a single adapter; two or more adapters (their flag expansion and MFMA chains make the
 // consumer the longer side) run 2 stages and TWO workgroups per CU, one's loads under the other's chains (measured: 104 -> 86 us for 3 adapters)
-constexpr int r2_nst(int nad) { return nad == 1 ? 4 : 2; }
+#ifndef UR_R2_NST1
+#define UR_R2_NST1 4         // lab: ring depth of the single-adapter launch
+#endif
+constexpr int r2_nst(int nad) { return nad == 1 ? UR_R2_NST1 : 2; }
 template <int NAD, bool MASKED> constexpr int r2_stage() { return R2_XS + NAD * R2_VS + (MASKED ? NAD * 1024 : 0); }
 template <int NAD, bool MASKED>
 __global__ __launch_bounds__(256) void lora_reduce_ring_kernel(RedP p) {
@@ -1444,7 +1450,7 @@ static inline int lora_reduce_splits(const ur_lora_args* a) {
   const int tiles = ur_cdiv(a->M, 128);
   // ~8 blocks per CU for the register-staged kernel; the ring kernel runs one workgroup per CU: 2 rounds of them
   // ring: two rounds of the workgroups a CU holds (one for a single adapter, two otherwise), never a partial third
-  const long ring_wg = (a->shared && a->nad > 1 ? 4L : 2L) * ur_device_cu_count();
+  const long ring_wg = ((a->shared && a->nad > 1) || r2_nst(1) == 2 ? 4L : 2L) * ur_device_cu_count();
   long want = lora_reduce_ring_ok(a) ? ring_wg / colblocks : (2048L + colblocks - 1) / colblocks;
   if (want < 1) want = 1;
   if (want > tiles) want = tiles;
