@@ -431,6 +431,9 @@ def measure_stage(args, rank, world, device):
         lens = torch.randint(T // 2, T + 1, (B,), generator=g)
         mask = (torch.arange(T)[None, :] < lens[:, None]).float().to(device)
         x = x * mask[..., None].to(torch.bfloat16)
+        # fraction of the T keys a launch actually sweeps (ragged histories: the forward / dQ kernels stop at the last 64-key tile that holds a
+        # valid key, the few-query dK/dV kernel skips 32-key blocks without one) -- `GB_per_s_swept` of the cross-attention entries below
+        swept_frac = float((((lens + 63) // 64) * 64).clamp(max=T).double().mean() / T)
         tgt = (torch.randn(B, 32, 1024, generator=g) * 0.8).to(device)
         dp.set_dp_rank(rank, m)                # dropout masks keyed on the global sample index: same seeds, counters offset by rank * B
         pack = m._ensure_pack(device)
@@ -509,6 +512,9 @@ def measure_stage(args, rank, world, device):
             nbytes = kvb if kind == "fwd" else 3.0 * kvb   # bwd: K | V twice + dK | dV once (the masked key tail is not read: an upper bound)
             attn_shapes[f"{kind}_q{aSq}_k{aSk}"] = {"launches_per_step": n // max(1, min(nprof, 3)), "avg_launch_us": round(ms / n * 1e3, 1),
                                                     "GB_per_s_upper": round(nbytes / (ms / n) / 1e6, 1)}
+            if args.workload == "user" and aSk == T:      # the ragged cross-attention: bytes of the key tiles the kernels sweep (valid histories, mean swept_frac of T)
+                attn_shapes[f"{kind}_q{aSq}_k{aSk}"].update({"GB_per_s_swept": round(nbytes * swept_frac / (ms / n) / 1e6, 1), "swept_frac": round(swept_frac, 4),
+                                                           "hbm_fraction_swept": round(nbytes * swept_frac / (ms / n) / 1e6 / 8000.0, 4)})
         roof["attention_by_shape"] = attn_shapes
         out = {"metric": metric, "value": round(world * B * args.steps / dt, 2), "unit": unit, "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "host_issue_ms_per_step": round(t_host / args.steps * 1e3, 2),
