@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define UR_ABI_VERSION 11
+#define UR_ABI_VERSION 12
 
 int ur_version(void);
 const char* ur_last_error(void);
@@ -111,6 +111,14 @@ int ur_gemm_qkrope_supported(const ur_gemm_args* a);
 int ur_qkrope_perm(int c);
 int64_t ur_gemm_workspace_bytes(const ur_gemm_args* a);
 int ur_gemm(const ur_gemm_args* a, void* workspace, int64_t workspace_bytes, void* stream);
+/* `count` (1..8) independent products of ONE kind in one grid: K-strided ("token-major") bf16 operands, f32 output, the same K,
+ * split_k and alpha, no epilogue -- the weight gradients dW = dY^T X of the Linear layers of one Q-Former layer (autograd of
+ * nn.Linear under /root/reference/models/qformer.py:56-92 attention projections, :238-275 feed-forward; the reference issues one
+ * addmm per weight).  Alone none of those [out, in] = [768..3072, 768..3072] products over 8192 tokens fills the chip without
+ * slicing the token axis into pieces too short for a tile; together they are one round of 256 x 256 tiles.  Results per product
+ * equal ur_gemm's for the same tile size and split (same order of summation).  Workspace: ur_gemm_grouped_workspace_bytes. */
+int64_t ur_gemm_grouped_workspace_bytes(const ur_gemm_args* a, int32_t count);
+int ur_gemm_grouped(const ur_gemm_args* a, int32_t count, void* workspace, int64_t workspace_bytes, void* stream);
 /* Launches with K-contiguous operands, bf16 output, M, N multiples of 256, K a multiple of 64 (>= 256), >= 128 output tiles and
  * a plain / bias / residual / masked-LoRA / SwiGLU-backward epilogue run on the persistent kernel (csrc/gemm_pers.hip: one
  * workgroup per CU walks its tiles, the LDS-DMA ring never drains, epilogue from registers) -- bit-identical to the generic

@@ -114,6 +114,7 @@ MODULE_SWITCHES = {
     "UNIREC_QF_WT=0": [("qformer", "_USE_WT", False)],
     "UNIREC_KV_COLSUM=0": [("qformer", "_KV_COLSUM", False)],
     "UNIREC_QF_DW_STREAM=0": [("qformer", "_DW_SIDE", False)],
+    "UNIREC_QF_DW_GROUPED=0": [("qformer", "_DW_GROUPED", False)],
 }
 # switches read on every call (Python layer and library)
 ENV_SWITCHES = ["UNIREC_BITS_T=0", "UNIREC_BITS_ONE_EVENT=1", "UNIREC_PAD_ATT=0", "UNIREC_ROPE_BWD_FUSED=0", "UNIREC_ROPE_K_FUSED=0",

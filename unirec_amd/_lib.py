@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # UNIREC_HIP_LIB selects another build of the SAME library (kernel A/B experiments); there is still no fallback.
 LIB_PATH = os.environ.get("UNIREC_HIP_LIB") or os.path.join(_HERE, "lib", "libunirec_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_void_p, c_int, c_i64, c_u64, c_float = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_float
 
@@ -88,6 +88,8 @@ SIGNATURES = {
     "ur_comm_destroy": (c_int, [c_void_p]),
     "ur_gemm_workspace_bytes": (c_i64, [ctypes.POINTER(GemmArgs)]),
     "ur_gemm": (c_int, [ctypes.POINTER(GemmArgs), c_void_p, c_i64, c_void_p]),
+    "ur_gemm_grouped_workspace_bytes": (c_i64, [ctypes.POINTER(GemmArgs), c_int]),
+    "ur_gemm_grouped": (c_int, [ctypes.POINTER(GemmArgs), c_int, c_void_p, c_i64, c_void_p]),
     "ur_gemm_persistent_mode": (c_int, [c_int]),
     "ur_attn_mode": (c_int, [c_int, c_int]),
     "ur_gemm_qkrope_supported": (c_int, [ctypes.POINTER(GemmArgs)]),

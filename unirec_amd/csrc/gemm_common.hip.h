@@ -26,6 +26,16 @@ struct GemmP {
   bf16_t* sp_act; long sp_ldact; int sp_I;
 };
 
+// grouped launches (gemm.hip: gemm_grouped_kernel): what differs between the groups of one grid
+constexpr int UR_GEMM_MAX_GROUPS = 8;
+struct GemmGroupSlot {
+  const bf16_t* R; const bf16_t* S; void* C;
+  long ldr, lds, ldc, slab_stride;
+  int M, N, gm, gn;
+  int wg0, pad_;        // first workgroup of the group's run
+};
+struct GemmGroups { int n, pad_; GemmGroupSlot g[UR_GEMM_MAX_GROUPS]; };
+
 __device__ __forceinline__ const char* uniform_ptr(const char* p) {
   const uint64_t v = reinterpret_cast<uint64_t>(p);
   uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));

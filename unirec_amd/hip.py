@@ -202,6 +202,50 @@ def swiglu_pair_rows(I):
     return torch.cat([t, t + I], dim=1).reshape(-1)
 
 
+GEMM_MAX_GROUPS = 8
+
+
+def gemm_grouped(products, split_k=1):
+    """ur_gemm_grouped: products = [(R [K, M], S [K, N], out f32 [M, N]), ...] (1..8 token-major pairs: out_i = R_i^T S_i over the shared
+    token axis K) as ONE launch -- the weight gradients of one Q-Former layer.  Every out_i is written (split_k > 1: through the
+    per-stream workspace and one grouped reduction)."""
+    lib = _lib.load()
+    n = len(products)
+    if not 1 <= n <= GEMM_MAX_GROUPS:
+        raise ValueError(f"gemm_grouped: 1 .. {GEMM_MAX_GROUPS} products per launch (got {n})")
+    arr = (GemmArgs * n)()
+    for a, (R, S, out) in zip(arr, products):
+        for t_, nm in ((R, "R"), (S, "S")):
+            if t_.dtype != BF16 or not t_.is_cuda or t_.dim() != 2 or t_.stride(1) != 1:
+                raise ValueError(f"gemm_grouped: {nm} must be a 2-D bf16 device tensor with unit inner stride")
+        if R.shape[0] != S.shape[0]:
+            raise ValueError(f"gemm_grouped: token counts differ ({R.shape[0]} vs {S.shape[0]})")
+        _need(out, F32, "out")
+        if out.dim() != 2 or tuple(out.shape) != (R.shape[1], S.shape[1]) or out.stride(1) != 1:
+            raise ValueError(f"gemm_grouped: out must be f32 [{R.shape[1]}, {S.shape[1]}], got {tuple(out.shape)}")
+        a.R, a.ldr, a.r_kcontig = R.data_ptr(), R.stride(0), 0
+        a.S, a.lds, a.s_kcontig = S.data_ptr(), S.stride(0), 0
+        a.K, a.M, a.N, a.alpha = R.shape[0], R.shape[1], S.shape[1], 1.0
+        a.C, a.ldc, a.c_f32 = out.data_ptr(), out.stride(0), 1
+        a.split_k = int(split_k)
+    ws, wsb = 0, 0
+    if split_k > 1:
+        wsb = lib.ur_gemm_grouped_workspace_bytes(arr, n)
+        ws = workspace(wsb, products[0][0].device, "gemm_grouped").data_ptr()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ur_gemm_grouped(arr, n, ws, wsb, _stream()), "ur_gemm_grouped")
+        e1.record()
+        # (one entry for the launch: M = the products' output rows summed at the widest N -- FLOP-exact only for equal N; see flops below)
+        fl = sum(2.0 * R.shape[0] * R.shape[1] * S.shape[1] for R, S, _ in products)
+        K = products[0][0].shape[0]
+        N = max(S.shape[1] for _, S, _ in products)
+        PROFILE.append((e0, e1, 0, 0, 1, int(round(fl / (2.0 * K * N))), N, K, int(split_k), 0))
+        return
+    check(lib.ur_gemm_grouped(arr, n, ws, wsb, _stream()), "ur_gemm_grouped")
+
+
 def gemm_swiglu_paired_supported(M, I, K, K2, device):
     """True when the merged gate|up projection of these sizes can carry the SwiGLU forward in its epilogue."""
     lib = _lib.load()

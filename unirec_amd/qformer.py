@@ -121,6 +121,7 @@ _USE_WT = os.environ.get("UNIREC_QF_WT", "1") != "0"     # lab: 0 = dX products 
 # arithmetic: results bit-identical (tests/test_gpu_r6_parity.py).  0 = everything on the caller's stream, as before.
 _DW_SIDE = os.environ.get("UNIREC_QF_DW_STREAM", "1") != "0"
 _DW_SIDE_MAX_ROWS = 16384
+_DW_GROUPED = os.environ.get("UNIREC_QF_DW_GROUPED", "1") != "0"
 _side_streams = {}
 
 
@@ -540,13 +541,33 @@ class BertModel(nn.Module):
                 return fn()
 
         def join():
+            flush_dW()
             if side is not None:
                 main.wait_stream(side)
 
         def dW(dy, xin, names):
             """grad of an [out,in] weight (or several adjacent ones): dY^T X, token reduction split over CUs."""
             out = pack.fusedg(names) if len(names) > 1 else pack.g32(names[0])
+            if grouped is not None and dy.shape[0] == M and dy.shape[1] % 8 == 0 and xin.shape[1] % 8 == 0 and dy.stride(0) % 8 == 0 and xin.stride(0) % 8 == 0:
+                grouped.append((dy, xin, out.view(dy.shape[1], xin.shape[1])))        # leaves with the layer's other weight gradients: flush_dW()
+                if len(grouped) == hip.GEMM_MAX_GROUPS:
+                    flush_dW()
+                return
             off_chain(lambda: hip.gemm(dy, xin, r_kcontig=False, s_kcontig=False, out=out, split_k=_split_k_for(out.shape[0], out.shape[1], dy.shape[0])), dy, xin)
+
+        # The weight gradients of ONE layer as one grouped launch (ur_gemm_grouped): 5-7 products of 9-36 big tiles each over the same tokens.
+        # Alone each needs 7-14 token slices to fill the chip (K tiles too short to pay for a tile's prologue, and a split-K reduction launch each);
+        # together they are one round of 256 x 256 tiles at split 1-2.  UNIREC_QF_DW_GROUPED=0: one ur_gemm per weight, as before.
+        grouped = [] if (_DW_GROUPED and dout.is_cuda and M >= 256) else None
+
+        def flush_dW():
+            if not grouped:
+                return
+            prods = list(grouped)
+            del grouped[:]
+            t256 = sum(-(-o.shape[0] // 256) * -(-o.shape[1] // 256) for _, _, o in prods)
+            sp = max(1, min(256 // max(t256, 1), M // 2048))          # at most one round of big tiles, never fewer than 32 K tiles per slice
+            off_chain(lambda: hip.gemm_grouped(prods, split_k=sp), *[t for d_, x_, _ in prods for t in (d_, x_)])
 
         def colsum(x, out):
             off_chain(lambda: hip.colsum(x, out=out), x)
@@ -620,6 +641,7 @@ class BertModel(nn.Module):
             dx = dX(dqkv, names, residual=dz1)
             L.clear()
             S["layers"][i].clear()
+            flush_dW()                                # the layer's weight gradients: one grouped launch (beside the next layer's dX chain)
             if self.grad_ready_hook is not None:      # dp.GradBuckets: layer i's gradients are final
                 join()                                # (... once the side stream's token reductions of this layer have run)
                 self.grad_ready_hook(i)
