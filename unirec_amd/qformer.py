@@ -120,7 +120,7 @@ _USE_WT = os.environ.get("UNIREC_QF_WT", "1") != "0"     # lab: 0 = dX products 
 # (item Q-Former of the joint step: 6400 rows = 100 output tiles), so the two streams' kernels run beside each other.  Same kernels, same
 # arithmetic: results bit-identical (tests/test_gpu_r6_parity.py).  0 = everything on the caller's stream, as before.
 _DW_SIDE = os.environ.get("UNIREC_QF_DW_STREAM", "1") != "0"
-_DW_SIDE_MAX_ROWS = 16384
+_DW_SIDE_MAX_ROWS = 65536       # (beyond: the inputs held until the join are whole gigabytes; C3 runs 32768 rows)
 _DW_GROUPED = os.environ.get("UNIREC_QF_DW_GROUPED", "1") != "0"
 _side_streams = {}
 
@@ -521,10 +521,10 @@ class BertModel(nn.Module):
                 return hip.gemm(dy, wt[key], **kw)
             return hip.gemm(dy, pack.fused16(list(names)) if len(names) > 1 else pack.w16(names[0]), s_kcontig=False, **kw)
 
-        # (only where the launches leave CUs idle: at 32768 rows -- the user Q-Former of C3 -- both streams' kernels fill the chip, nothing is gained,
-        # and the caching allocator's bookkeeping for tensors used on two streams stalls the host now and then: 49.9 ms -> 50.2-59.8 ms per step)
+        # (at 32768 rows -- the user Q-Former of C3 -- both streams' kernels fill the chip: 50.7-51.0 -> 50.4 ms per step, no more)
         side = _side_stream(dout.device) if (_DW_SIDE and dout.is_cuda and M <= _DW_SIDE_MAX_ROWS) else None
         main = torch.cuda.current_stream(dout.device) if side is not None else None
+        held = []
         if side is not None:
             side.wait_stream(main)         # (the first use: everything the caller has queued so far, incl. the zeroing of the gradient buffers)
 
@@ -535,8 +535,10 @@ class BertModel(nn.Module):
             ev = torch.cuda.Event()
             ev.record(main)
             side.wait_event(ev)
-            for t in tensors:              # the caching allocator must not hand their memory to the main stream before the side stream is done
-                t.record_stream(side)
+            # The caching allocator must not hand the inputs' memory to the main stream before the side stream is done with it: they are kept
+            # alive until the next join() (after which the main stream is behind the side stream).  tensor.record_stream() instead makes the
+            # allocator poll an event per block at every later allocation: at 32768 rows (C3) the host then stalled for up to 400 ms per step.
+            held.extend(tensors)
             with torch.cuda.stream(side):
                 return fn()
 
@@ -544,6 +546,7 @@ class BertModel(nn.Module):
             flush_dW()
             if side is not None:
                 main.wait_stream(side)
+                del held[:]
 
         def dW(dy, xin, names):
             """grad of an [out,in] weight (or several adjacent ones): dY^T X, token reduction split over CUs."""
