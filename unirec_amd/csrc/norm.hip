@@ -358,7 +358,10 @@ __global__ __launch_bounds__(256) void rms_bwd_kernel(const bf16_t* __restrict__
 
 inline int nch_for(int H) { int c = ur_cdiv(H, 512); return c <= 1 ? 1 : (c <= 2 ? 2 : 4); }
 inline int row_grid(int M, int cap) { int g = ur_cdiv(M, ROWS_PER_BLOCK); return g < cap ? (g > 0 ? g : 1) : cap; }
-constexpr int LN_BWD_BLOCKS = 512;   // partial rows of the column sums = blocks (ln_bwd_kernel folds its four waves)
+#ifndef UR_LN_BWD_BLOCKS
+#define UR_LN_BWD_BLOCKS 512
+#endif
+constexpr int LN_BWD_BLOCKS = UR_LN_BWD_BLOCKS;   // partial rows of the column sums = blocks (ln_bwd_kernel folds its four waves)
 
 }  // namespace
 
